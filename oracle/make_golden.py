@@ -1,0 +1,117 @@
+"""Generate tests/golden/* by running the REFERENCE's own host code -- TEST
+INFRASTRUCTURE, build-container only (needs /root/reference; never runs on the
+GPU box).  Usage:  python oracle/make_golden.py [--ref /root/reference]
+
+What the reference can pin (it has no tests and TensorFlow cannot run here):
+  * scoring_*.npz   -- data_utils.getSortedResults / computeTopK_* outputs
+                       (data_utils.py:263-304) and the Evaluator.eval batching
+                       (sse_evaluator.py:103-113), on seeded inputs;
+  * prep_qna.json   -- data_utils.prepare_raw_data on rawdata-qna: vocabulary,
+                       sample raw lines and the token-id rows the reference
+                       produced (data_utils.py:115-213), which pin pad_tokens and
+                       the drop-in tokenizer;
+  * prep_crosslingual.json -- same on a sample of rawdata-crosslingual.
+"""
+import argparse
+import contextlib
+import io
+import json
+import math
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def import_reference(ref):
+    sys.path.insert(0, os.path.join(HERE, "ref_shim"))
+    sys.path.insert(0, ref)
+    import data_utils  # noqa: E402  (the reference's module)
+    import text_encoder  # noqa: E402
+    import tokenizer  # noqa: E402
+    return data_utils, text_encoder, tokenizer
+
+
+def golden_scoring(data_utils):
+    rng = np.random.RandomState(1234)
+    for name, (Q, N, S) in {"small": (7, 23, 8), "eval": (1300, 211, 16)}.items():
+        src = rng.standard_normal((Q, S)).astype(np.float32)
+        src /= np.linalg.norm(src, axis=1, keepdims=True)
+        tgt32 = rng.standard_normal((N, S)).astype(np.float32)
+        tgt32 /= np.linalg.norm(tgt32, axis=1, keepdims=True)
+        # the reference re-parses the index from decimal text (sse_evaluator.py:87)
+        tgt = np.array([[float(str(v)) for v in row] for row in tgt32])
+        labels = [sorted(set(rng.randint(0, N, size=rng.randint(1, 4)).tolist())) for _ in range(Q)]
+        scores = np.dot(src, tgt.T)                                    # sse_evaluator.py:110
+        ranked_score, ranked_idx = data_utils.getSortedResults(scores)  # :111
+        accs_tight = [data_utils.computeTopK_TightVersion_accuracy(k, labels, ranked_idx) for k in (1, 3, 10)]
+        accs_loose = [data_utils.computeTopK_accuracy(k, labels, ranked_idx) for k in (1, 3, 10)]
+        # Evaluator.eval batching (sse_evaluator.py:103-113)
+        eval_acc = []
+        for n in (1, 3, 10):
+            bs, batchacc = 600, []
+            for b in range(math.ceil(Q / bs)):
+                d = np.dot(src[b * bs:(b + 1) * bs], tgt.T)
+                _, ridx = data_utils.getSortedResults(d)
+                batchacc.append(data_utils.computeTopK_TightVersion_accuracy(n, labels[b * bs:(b + 1) * bs], ridx))
+            eval_acc.append(np.mean(batchacc))
+        lab = np.full((Q, 3), -1, np.int64)
+        for i, l in enumerate(labels):
+            lab[i, :len(l)] = l
+        np.savez_compressed(os.path.join(OUT, "scoring_%s.npz" % name), src=src, tgt32=tgt32, tgt64=tgt,
+                            labels=lab, ranked_score=ranked_score[:, :16], ranked_idx=ranked_idx[:, :16],
+                            accs_tight=np.array(accs_tight), accs_loose=np.array(accs_loose),
+                            eval_acc=np.array(eval_acc))
+        print("scoring_%s: top1 %.4f eval_acc %s" % (name, accs_tight[0], eval_acc))
+
+
+def golden_prep(data_utils, ref, task, vocab_size, max_seq_length, n_sample):
+    with tempfile.TemporaryDirectory() as work:
+        with contextlib.redirect_stdout(io.StringIO()):
+            encoder, train, evalc, full_tgt, id_name = data_utils.prepare_raw_data(
+                os.path.join(ref, "rawdata-" + task), work, vocab_size, max_seq_length)
+        vocab = open(os.path.join(work, "vocabulary.txt"), encoding="utf-8").read()
+        pairs = [l.rstrip("\n") for l in open(os.path.join(work, "TrainPairs"), encoding="utf-8")]
+        targets = [l.rstrip("\n") for l in open(os.path.join(work, "targetIDs"), encoding="utf-8")]
+    rng = np.random.RandomState(7)
+    # TrainPairs lines map 1:1 onto `train` only while no line is skipped; keep
+    # the raw source text by re-encoding through the reference encoder instead.
+    pick_p = sorted(rng.choice(len(pairs), size=min(n_sample, len(pairs)), replace=False).tolist())
+    pick_t = sorted(rng.choice(len(targets), size=min(n_sample, len(targets)), replace=False).tolist())
+    src_cases = []
+    for i in pick_p:
+        info = pairs[i].strip().split("\t")
+        if len(info) != 2:
+            continue
+        src_cases.append({"text": info[0], "tokens": encoder.encode(info[0].lower())})
+    tgt_cases = []
+    for i in pick_t:
+        seq, tid = targets[i].strip().split("\t")
+        tgt_cases.append({"text": seq, "id": tid, "padded": full_tgt[tid]})
+    out = {"task": task, "vocab_size_flag": vocab_size, "max_seq_length": max_seq_length,
+           "encoder_vocab_size": encoder.vocab_size, "n_train": len(train), "n_eval": len(evalc),
+           "n_targets": len(full_tgt), "vocabulary_txt": vocab, "src_cases": src_cases, "tgt_cases": tgt_cases,
+           "train_head": [[t, ids] for t, ids in train[:5]]}
+    with open(os.path.join(OUT, "prep_%s.json" % task), "w", encoding="utf-8") as f:
+        json.dump(out, f, ensure_ascii=False)
+    print("prep_%s: vocab %d, %d train, %d targets" % (task, encoder.vocab_size, len(train), len(full_tgt)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    data_utils, text_encoder, tokenizer = import_reference(args.ref)
+    assert tokenizer.encode(u"Dude - that's so cool.") == [u"Dude", u" - ", u"that", u"'", u"s", u"so", u"cool", u"."]
+    golden_scoring(data_utils)
+    golden_prep(data_utils, args.ref, "qna", 8000, 1000, 40)            # makefile:17
+    golden_prep(data_utils, args.ref, "crosslingual", 32000, 50, 120)    # makefile:42
+
+
+if __name__ == "__main__":
+    main()
