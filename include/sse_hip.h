@@ -1,0 +1,133 @@
+/*
+ * sse_hip.h -- C ABI of libsse_hip.so, the MI355X (gfx950) implementation of
+ * the Sequence-Semantic-Embedding hot path.
+ *
+ * The reference (eBay/Sequence-Semantic-Embedding, pure Python on TensorFlow
+ * 1.x) has no FFI; its de-facto boundary for this path is the `SSEModel`
+ * object plus `tf.Session.run(fetches, feed_dict)`.  Each entry point below
+ * names the reference call it replaces (file:line in the reference tree).
+ * The ctypes binding a maintainer adds on the reference side is shown in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error;
+ *     sse_last_error(h) (or sse_last_error(NULL) for sse_create failures)
+ *     returns a NUL-terminated message owned by the library;
+ *   - "host" pointers are caller-owned numpy-style buffers, read/written only
+ *     during the call; "dev" pointers are HIP device pointers on the handle's
+ *     device, `stream` is a hipStream_t passed as void* (NULL = null stream);
+ *   - token ids are row-major int32 [B,T] (sse_model.py:408-409,419-421,430,439),
+ *     encodings row-major float32 [B,S];
+ *   - a handle may be used from several threads for encode/score (calls are
+ *     serialised internally, like tf.Session.run in webserver.py:108);
+ *     sse_train_step is exclusive.
+ */
+#ifndef SSE_HIP_H
+#define SSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sse_handle sse_handle;
+
+/* network_mode values (sse_model.py:167-177) */
+enum {
+  SSE_MODE_DUAL_ENCODER = 0,        /* 'dual-encoder'        sse_model.py:236 */
+  SSE_MODE_SHARED_ENCODER = 1,      /* 'shared-encoder'      sse_model.py:258 */
+  SSE_MODE_SOURCE_ENCODER_ONLY = 2, /* 'source-encoder-only' sse_model.py:217 */
+  SSE_MODE_SOURCE_ONLY_CNN = 3      /* 'source_only_cnn'     sse_model.py:179 */
+};
+enum { SSE_SIDE_SOURCE = 0, SSE_SIDE_TARGET = 1 };
+
+/* modelParams of SSEModel.__init__ (sse_model.py:94-126) */
+typedef struct sse_config {
+  int32_t network_mode;
+  int32_t vocab_size;        /* V */
+  int32_t embedding_size;    /* E */
+  int32_t encoding_size;     /* S */
+  int32_t src_cell_size;     /* H source */
+  int32_t tgt_cell_size;     /* H target (ignored in shared-encoder, sse_model.py:269) */
+  int32_t max_seq_length;    /* T */
+  int32_t target_space_size; /* N targets (source-encoder-only / cnn modes) */
+  int32_t device;            /* HIP device ordinal */
+  float learning_rate;               /* sse_model.py:122 */
+  float learning_rate_decay_factor;  /* sse_model.py:124 */
+} sse_config;
+
+/* SSEModel(modelParams) -- sse_model.py:94; sse_train.py:109 */
+int sse_create(const sse_config *cfg, sse_handle **out);
+void sse_destroy(sse_handle *h);
+const char *sse_last_error(sse_handle *h);
+
+/* Variables, addressed by their TF names ('word_embedding',
+ * 'source_encoder/rnn/basic_lstm_cell/kernel', '.../bias', 'source_encoder/src_M',
+ * ..., and '<name>/Adagrad' for the optimizer slots).  Replaces
+ * saver.restore / saver.save (sse_model.py:138,379-386; sse_train.py:110-113). */
+int sse_num_variables(sse_handle *h);
+int sse_variable_info(sse_handle *h, int index, const char **name, int64_t *count, int32_t *rows, int32_t *cols);
+int sse_set_variable(sse_handle *h, const char *name, const float *host, int64_t count);
+int sse_get_variable(sse_handle *h, const char *name, float *host, int64_t count);
+
+/* session.run([model.norm_src_seq_embedding | model.src_seq_embedding |
+ * model.norm_tgt_seq_embedding], feed) -- sse_evaluator.py:107-109,
+ * sse_index.py:90-92, sse_demo.py:121-125.  side: SSE_SIDE_*.  normalize=1
+ * gives the l2-normalised encoding (sse_model.py:282-283). */
+int sse_encode(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int32_t T,
+               int32_t normalize, float *out_host);
+int sse_encode_dev(sse_handle *h, int side, const int32_t *ids_dev, int32_t B, int32_t T,
+                   int32_t normalize, float *out_dev, void *stream);
+
+/* tf.nn.l2_normalize(x, dim=-1) on device rows (sse_model.py:282-283). */
+int sse_l2_normalize_dev(sse_handle *h, const float *x_dev, float *out_dev, int64_t rows, int32_t cols,
+                         void *stream);
+
+/* The target index (Evaluator.__init__ builds it from targetEncodingIndex.tsv,
+ * sse_evaluator.py:80-92; sse_demo.py:79-90).  Rows are uploaded once and stay
+ * resident.  *_f64 keeps the float64 values the reference parses from text for
+ * the exact re-scoring pass; id_base is added to row numbers in results (row
+ * shards of one index).  sse_index_set_dev adopts rows already on
+ * the device (copied). */
+int sse_index_upload(sse_handle *h, const float *rows_host, int64_t N, int32_t S, int64_t id_base);
+int sse_index_upload_f64(sse_handle *h, const double *rows_host, int64_t N, int32_t S, int64_t id_base);
+int sse_index_set_dev(sse_handle *h, const float *rows_dev, int64_t N, int32_t S, int64_t id_base,
+                      void *stream);
+
+/* np.dot(srcEnc, tgtEnc.T) + data_utils.getSortedResults, first k columns only
+ * (sse_evaluator.py:110-112, data_utils.py:263-267, sse_demo.py:126-129).
+ * Scores are float64 like the reference's; ties rank the lower row id first.
+ * out_scores [Q,k] float64, out_ids [Q,k] int64. */
+int sse_score_topk(sse_handle *h, const float *q_host, int32_t Q, int32_t k, double *out_scores,
+                   int64_t *out_ids);
+int sse_score_topk_dev(sse_handle *h, const float *q_dev, int32_t Q, int32_t k, double *out_scores_dev,
+                       int64_t *out_ids_dev, void *stream);
+
+/* k-way merge of P per-shard top-k lists per query (after the RCCL all-gather
+ * of SURVEY 8e): in_* are [P,Q,k] (shard-major), out_* [Q,k]; same order rule. */
+int sse_merge_topk_dev(sse_handle *h, const double *in_scores_dev, const int64_t *in_ids_dev, int32_t P,
+                       int32_t Q, int32_t k, double *out_scores_dev, int64_t *out_ids_dev, void *stream);
+
+/* session.run([model.train, model.loss, model.train_acc], feed) --
+ * sse_train.py:170-172; loss/acc are evaluated before the update.  labels
+ * float32 [B] (sse_model.py:420). */
+int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tgt_ids_host,
+                   const float *labels_host, int32_t B, int32_t T, float *loss, float *train_acc);
+/* model.learning_rate.eval(), model.global_step.eval(), learning_rate_decay_op
+ * (sse_train.py:181,200; sse_model.py:122-125) */
+int sse_get_learning_rate(sse_handle *h, float *lr);
+int sse_set_learning_rate(sse_handle *h, float lr);
+int sse_decay_learning_rate(sse_handle *h);
+int sse_get_global_step(sse_handle *h, int64_t *step);
+int sse_set_global_step(sse_handle *h, int64_t step);
+
+/* Timing helper for bench.py: HIP events recorded on `stream`. */
+int sse_timer_start(sse_handle *h, void *stream);
+int sse_timer_stop_ms(sse_handle *h, void *stream, float *ms);
+int sse_synchronize(sse_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSE_HIP_H */

@@ -1,0 +1,228 @@
+"""ctypes binding of libsse_hip.so (C ABI in include/sse_hip.h).
+
+There is NO CPU fallback: if the library is missing or no HIP device is
+visible, loading / handle creation raises.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsse_hip.so")
+
+MODE_IDS = {"dual-encoder": 0, "shared-encoder": 1, "source-encoder-only": 2, "source_only_cnn": 3}
+SIDE_SOURCE, SIDE_TARGET = 0, 1
+
+
+class SSEConfig(C.Structure):
+    _fields_ = [("network_mode", C.c_int32), ("vocab_size", C.c_int32), ("embedding_size", C.c_int32),
+                ("encoding_size", C.c_int32), ("src_cell_size", C.c_int32), ("tgt_cell_size", C.c_int32),
+                ("max_seq_length", C.c_int32), ("target_space_size", C.c_int32), ("device", C.c_int32),
+                ("learning_rate", C.c_float), ("learning_rate_decay_factor", C.c_float)]
+
+
+# every symbol declared in include/sse_hip.h: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "sse_create": (C.c_int, [C.POINTER(SSEConfig), C.POINTER(_P)]),
+    "sse_destroy": (None, [_P]),
+    "sse_last_error": (C.c_char_p, [_P]),
+    "sse_num_variables": (C.c_int, [_P]),
+    "sse_variable_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "sse_set_variable": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
+    "sse_get_variable": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
+    "sse_encode": (C.c_int, [_P, C.c_int, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "sse_encode_dev": (C.c_int, [_P, C.c_int, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "sse_l2_normalize_dev": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P]),
+    "sse_index_upload": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int64]),
+    "sse_index_upload_f64": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int64]),
+    "sse_index_set_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int64, _P]),
+    "sse_score_topk": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
+    "sse_score_topk_dev": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "sse_merge_topk_dev": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "sse_train_step": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "sse_get_learning_rate": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "sse_set_learning_rate": (C.c_int, [_P, C.c_float]),
+    "sse_decay_learning_rate": (C.c_int, [_P]),
+    "sse_get_global_step": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "sse_set_global_step": (C.c_int, [_P, C.c_int64]),
+    "sse_timer_start": (C.c_int, [_P, _P]),
+    "sse_timer_stop_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
+    "sse_synchronize": (C.c_int, [_P]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen libsse_hip.so (once).  When torch is importable it is imported
+    FIRST so that both share one HIP runtime (torch bundles its own
+    libamdhip64.so.7; two copies in one process cannot share device memory)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libsse_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)")
+    if "torch" not in sys.modules and os.environ.get("SSE_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class SSEError(RuntimeError):
+    pass
+
+
+class Handle(object):
+    """Owner of one `sse_handle*`."""
+
+    def __init__(self, cfg):
+        self.lib = load_library()
+        self._h = C.c_void_p()
+        rc = self.lib.sse_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            raise SSEError(self.lib.sse_last_error(None).decode())
+        self.cfg = cfg
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.sse_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != 0:
+            raise SSEError(self.lib.sse_last_error(self._h).decode())
+
+    # -- variables ---------------------------------------------------------
+    def variables(self):
+        out = []
+        name, cnt, r, c = C.c_char_p(), C.c_int64(), C.c_int32(), C.c_int32()
+        for i in range(self.lib.sse_num_variables(self._h)):
+            self.check(self.lib.sse_variable_info(self._h, i, C.byref(name), C.byref(cnt), C.byref(r), C.byref(c)))
+            out.append((name.value.decode(), int(cnt.value), int(r.value), int(c.value)))
+        return out
+
+    def set_variable(self, name, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float32)
+        self.check(self.lib.sse_set_variable(self._h, name.encode(), _ptr(a), a.size))
+
+    def get_variable(self, name, count):
+        a = np.empty(count, np.float32)
+        self.check(self.lib.sse_get_variable(self._h, name.encode(), _ptr(a), a.size))
+        return a
+
+    # -- encode ------------------------------------------------------------
+    def encode(self, side, ids, normalize=True):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        if ids.ndim != 2:
+            raise ValueError("ids must be [B,T]")
+        B, T = ids.shape
+        out = np.empty((B, self.cfg.encoding_size), np.float32)
+        self.check(self.lib.sse_encode(self._h, side, _ptr(ids), B, T, 1 if normalize else 0, _ptr(out)))
+        return out
+
+    def encode_dev(self, side, ids_ptr, B, T, normalize, out_ptr, stream=0):
+        self.check(self.lib.sse_encode_dev(self._h, side, ids_ptr, B, T, 1 if normalize else 0, out_ptr, stream))
+
+    def l2_normalize_dev(self, x_ptr, out_ptr, rows, cols, stream=0):
+        self.check(self.lib.sse_l2_normalize_dev(self._h, x_ptr, out_ptr, rows, cols, stream))
+
+    # -- index / scoring -----------------------------------------------------
+    def index_upload(self, rows, id_base=0):
+        rows = np.ascontiguousarray(rows)
+        if rows.ndim != 2:
+            raise ValueError("index rows must be [N,S]")
+        N, S = rows.shape
+        if rows.dtype == np.float64:
+            self.check(self.lib.sse_index_upload_f64(self._h, _ptr(rows), N, S, id_base))
+        else:
+            rows = np.ascontiguousarray(rows, dtype=np.float32)
+            self.check(self.lib.sse_index_upload(self._h, _ptr(rows), N, S, id_base))
+
+    def index_set_dev(self, rows_ptr, N, S, id_base=0, stream=0):
+        self.check(self.lib.sse_index_set_dev(self._h, rows_ptr, N, S, id_base, stream))
+
+    def score_topk(self, queries, k):
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim != 2:
+            raise ValueError("queries must be [Q,S]")
+        Q = q.shape[0]
+        scores = np.empty((Q, k), np.float64)
+        ids = np.empty((Q, k), np.int64)
+        self.check(self.lib.sse_score_topk(self._h, _ptr(q), Q, k, _ptr(scores), _ptr(ids)))
+        return scores, ids
+
+    def score_topk_dev(self, q_ptr, Q, k, scores_ptr, ids_ptr, stream=0):
+        self.check(self.lib.sse_score_topk_dev(self._h, q_ptr, Q, k, scores_ptr, ids_ptr, stream))
+
+    def merge_topk_dev(self, in_s, in_i, P, Q, k, out_s, out_i, stream=0):
+        self.check(self.lib.sse_merge_topk_dev(self._h, in_s, in_i, P, Q, k, out_s, out_i, stream))
+
+    # -- training ------------------------------------------------------------
+    def train_step(self, src_ids, tgt_ids, labels):
+        s = np.ascontiguousarray(src_ids, dtype=np.int32)
+        t = np.ascontiguousarray(tgt_ids, dtype=np.int32)
+        z = np.ascontiguousarray(labels, dtype=np.float32)
+        if s.shape != t.shape or s.ndim != 2 or z.shape != (s.shape[0],):
+            raise ValueError("train batch shapes: src/tgt [B,T], labels [B]")
+        loss, acc = C.c_float(), C.c_float()
+        self.check(self.lib.sse_train_step(self._h, _ptr(s), _ptr(t), _ptr(z), s.shape[0], s.shape[1],
+                                           C.byref(loss), C.byref(acc)))
+        return float(loss.value), float(acc.value)
+
+    @property
+    def learning_rate(self):
+        v = C.c_float()
+        self.check(self.lib.sse_get_learning_rate(self._h, C.byref(v)))
+        return float(v.value)
+
+    @learning_rate.setter
+    def learning_rate(self, lr):
+        self.check(self.lib.sse_set_learning_rate(self._h, float(lr)))
+
+    def decay_learning_rate(self):
+        self.check(self.lib.sse_decay_learning_rate(self._h))
+
+    @property
+    def global_step(self):
+        v = C.c_int64()
+        self.check(self.lib.sse_get_global_step(self._h, C.byref(v)))
+        return int(v.value)
+
+    @global_step.setter
+    def global_step(self, step):
+        self.check(self.lib.sse_set_global_step(self._h, int(step)))
+
+    # -- timing --------------------------------------------------------------
+    def timer_start(self, stream=0):
+        self.check(self.lib.sse_timer_start(self._h, stream))
+
+    def timer_stop_ms(self, stream=0):
+        v = C.c_float()
+        self.check(self.lib.sse_timer_stop_ms(self._h, stream, C.byref(v)))
+        return float(v.value)
+
+    def synchronize(self):
+        self.check(self.lib.sse_synchronize(self._h))

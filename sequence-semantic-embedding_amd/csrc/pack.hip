@@ -1,0 +1,212 @@
+// Layout and elementwise helper kernels (HBM-bound): frag32 packing of row-major
+// matrices, f64->f32 conversion, row L2-normalise (tf.nn.l2_normalize,
+// sse_model.py:282-283).
+#include "sse_kernels.h"
+
+// rows [R][C] -> frag32 [RT][KG][256]; one thread per output float4
+// (lane = half*32 + r, 4 consecutive k) -> coalesced 1 KiB stores per wave.
+__global__ void pack_rows_kernel(const float *__restrict__ rows, int64_t R, int C, int KG, int64_t total4,
+                                 f32x4 *__restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(i & 63);
+    const int64_t blk = i >> 6;
+    const int kg = (int)(blk % KG);
+    const int64_t rt = blk / KG;
+    const int64_t r = rt * 32 + (l & 31);
+    const int k0 = kg * 8 + (l >> 5) * 4;
+    f32x4 v = {0, 0, 0, 0};
+    if (r < R) {
+      const float *src = rows + (size_t)r * C + k0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (k0 + e < C) v[e] = src[e];
+    }
+    out[i] = v;
+  }
+}
+
+hipError_t launch_pack_rows(const float *rows, int64_t R, int C, float *out, hipStream_t stream) {
+  const int KG = (C + 7) / 8;
+  const int64_t RT = (R + 31) / 32;
+  const int64_t total4 = RT * KG * 64;
+  if (total4 == 0) return hipSuccess;
+  const int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+  hipLaunchKernelGGL(pack_rows_kernel, dim3(grid), dim3(256), 0, stream, rows, R, C, KG, total4,
+                     reinterpret_cast<f32x4 *>(out));
+  return hipGetLastError();
+}
+
+__global__ void f64_to_f32_kernel(const double *__restrict__ in, float *__restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (float)in[i];
+}
+
+hipError_t launch_f64_to_f32(const double *in, float *out, int64_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  hipLaunchKernelGGL(f64_to_f32_kernel, dim3(grid), dim3(256), 0, stream, in, out, n);
+  return hipGetLastError();
+}
+
+// one wave per row: x * rsqrt(max(sum(x^2), 1e-12))
+__global__ void l2_normalize_kernel(const float *__restrict__ x, float *__restrict__ out, int64_t rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave0; r < rows; r += nwaves) {
+    const float *src = x + (size_t)r * cols;
+    float ss = 0.0f;
+    for (int c = lane; c < cols; c += 64) ss += src[c] * src[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float sc = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+    for (int c = lane; c < cols; c += 64) out[(size_t)r * cols + c] = src[c] * sc;
+  }
+}
+
+hipError_t launch_l2_normalize(const float *x, float *out, int64_t rows, int cols, hipStream_t stream) {
+  if (rows == 0) return hipSuccess;
+  const int64_t blocks = (rows + 3) / 4;
+  hipLaunchKernelGGL(l2_normalize_kernel, dim3((int)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream, x, out,
+                     rows, cols);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Weight re-layouts for the LSTM forward kernel (run whenever variables change).
+
+// BasicLSTMCell kernel [(E+H)][4H] (TF 1.x: rows [x | h], columns [i | j | f | o])
+// -> Wp[wn][u][kg][gate][256]: for hidden-unit block ub = wn*UB + u the four gate
+// tiles of one k-group are contiguous (4 KiB), k = [x padded to Ep | h padded to Hp].
+__global__ void pack_lstm_kernel_k(const float *__restrict__ K, int E, int H, int Ep, int Hp, int UB,
+                                   int64_t total4, f32x4 *__restrict__ out) {
+  const int KG = (Ep + Hp) / 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(i & 63);
+    int64_t blk = i >> 6;
+    const int g = (int)(blk & 3);
+    blk >>= 2;
+    const int kg = (int)(blk % KG);
+    const int ub = (int)(blk / KG);  // = wn*UB + u
+    const int unit = ub * 32 + (l & 31);
+    f32x4 v = {0, 0, 0, 0};
+    if (unit < H) {
+      const int col = g * H + unit;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kk = kg * 8 + (l >> 5) * 4 + e;
+        int row = -1;
+        if (kk < Ep) {
+          if (kk < E) row = kk;
+        } else if (kk - Ep < H) {
+          row = E + (kk - Ep);
+        }
+        if (row >= 0) v[e] = K[(size_t)row * 4 * H + col];
+      }
+    }
+    out[i] = v;
+  }
+  (void)UB;
+}
+
+// bias [4H] -> [Hp/32][4][32]; forget_bias = 1.0 folded into the f block
+// (BasicLSTMCell adds it at run time, it is not stored in the variable).
+__global__ void pack_lstm_bias_k(const float *__restrict__ b, int H, int Hp, float *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Hp * 4) return;
+  const int r = i & 31, g = (i >> 5) & 3, ub = i >> 7;
+  const int unit = ub * 32 + r;
+  float v = (unit < H) ? b[g * H + unit] : 0.0f;
+  if (g == 2) v += 1.0f;
+  out[i] = v;
+}
+
+// X[K][N] row-major -> frag32 with rows = n (columns of X), k = rows of X, zero padded to KGp groups
+__global__ void pack_kn_kernel_k(const float *__restrict__ X, int K, int N, int KGp, int64_t total4,
+                                 f32x4 *__restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(i & 63);
+    const int64_t blk = i >> 6;
+    const int kg = (int)(blk % KGp);
+    const int nt = (int)(blk / KGp);
+    const int n = nt * 32 + (l & 31);
+    f32x4 v = {0, 0, 0, 0};
+    if (n < N) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = kg * 8 + (l >> 5) * 4 + e;
+        if (k < K) v[e] = X[(size_t)k * N + n];
+      }
+    }
+    out[i] = v;
+  }
+}
+
+__global__ void pad_rows_kernel_k(const float *__restrict__ in, int64_t R, int C, int Cp, float *__restrict__ out) {
+  const int64_t total = R * Cp;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cp);
+    const int64_t r = i / Cp;
+    out[i] = (c < C) ? in[r * C + c] : 0.0f;
+  }
+}
+
+static inline int grid_for(int64_t n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
+
+hipError_t launch_pack_lstm(const float *K, const float *b, int E, int H, int Ep, int Hp, int UB, float *Wp,
+                            float *biasp, hipStream_t stream) {
+  const int KG = (Ep + Hp) / 8;
+  const int64_t total4 = (int64_t)(Hp / 32) * KG * 4 * 64;
+  hipLaunchKernelGGL(pack_lstm_kernel_k, dim3(grid_for(total4)), dim3(256), 0, stream, K, E, H, Ep, Hp, UB, total4,
+                     reinterpret_cast<f32x4 *>(Wp));
+  hipLaunchKernelGGL(pack_lstm_bias_k, dim3((Hp * 4 + 255) / 256), dim3(256), 0, stream, b, H, Hp, biasp);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_kn(const float *X, int K, int N, int KGp, float *out, hipStream_t stream) {
+  const int64_t total4 = (int64_t)((N + 31) / 32) * KGp * 64;
+  hipLaunchKernelGGL(pack_kn_kernel_k, dim3(grid_for(total4)), dim3(256), 0, stream, X, K, N, KGp, total4,
+                     reinterpret_cast<f32x4 *>(out));
+  return hipGetLastError();
+}
+
+hipError_t launch_pad_rows(const float *in, int64_t R, int C, int Cp, float *out, hipStream_t stream) {
+  hipLaunchKernelGGL(pad_rows_kernel_k, dim3(grid_for(R * Cp)), dim3(256), 0, stream, in, R, C, Cp, out);
+  return hipGetLastError();
+}
+
+// max over rows of sum(x^2) (float bits are order-preserving for non-negative values)
+__global__ void row_norm2_max_kernel_k(const float *__restrict__ x, int64_t rows, int cols, unsigned *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  float best = 0.0f;
+  for (int64_t r = wave0; r < rows; r += nwaves) {
+    float ss = 0.0f;
+    for (int c = lane; c < cols; c += 64) ss += x[(size_t)r * cols + c] * x[(size_t)r * cols + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    best = fmaxf(best, ss);
+  }
+  if (lane == 0) atomicMax(out, __float_as_uint(best));
+}
+
+hipError_t launch_row_norm2_max(const float *x, int64_t rows, int cols, float *out_bits, hipStream_t stream) {
+  if (rows == 0) return hipSuccess;
+  const int64_t blocks = (rows + 3) / 4;
+  hipLaunchKernelGGL(row_norm2_max_kernel_k, dim3((int)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, x, rows,
+                     cols, reinterpret_cast<unsigned *>(out_bits));
+  return hipGetLastError();
+}
+
+__global__ void fill_kernel_k(float *p, int64_t n, float v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+hipError_t launch_fill(float *p, int64_t n, float v, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(fill_kernel_k, dim3(grid_for(n)), dim3(256), 0, stream, p, n, v);
+  return hipGetLastError();
+}

@@ -1,0 +1,430 @@
+// Query x index cosine scoring with fused top-k for gfx950 (MI355X).
+//
+// Replaces np.dot(sourceEncodings, targetEncodings.T) + getSortedResults
+// (sse_evaluator.py:110-111, data_utils.py:263-267, sse_demo.py:126-127): the
+// reference materialises the [Q,N] float64 score matrix and fully argsorts each
+// row although only the first <= 10 columns are consumed
+// (sse_evaluator.py:95,112; sse_demo.py:128-129).  Here:
+//   1. score_topk_kernel: [N,S] x [S,Q] on v_mfma_f32_32x32x2_f32 (exact fp32),
+//      index rows as the MFMA M dimension so that every lane owns ONE query
+//      column and keeps a private sorted top-KC list in registers; the [Q,N]
+//      matrix is never written.
+//   2. rescore_kernel: the union of the per-lane lists is re-scored exactly in
+//      float64 (the reference's arithmetic), ordered (score desc, row id asc),
+//      and CERTIFIED: if a row outside the candidate set could still reach the
+//      exact top-k (fp32 bound), the query is flagged and
+//   3. exact_topk_kernel recomputes flagged queries by float64 brute force.
+#include "sse_kernels.h"
+
+#define SC_THREADS 256
+#define SC_KC 16
+#define NEG_INF (-__builtin_inff())
+
+// ---------------------------------------------------------------------------
+template <int KC>
+__device__ __forceinline__ void list_insert(float (&ls)[KC], int (&li)[KC], float s, int id, bool take) {
+  // bubble (s,id) down a descending list; lanes with take == false keep their list
+#pragma unroll
+  for (int i = 0; i < KC; ++i) {
+    const bool gt = take && (s > ls[i]);
+    const float tv = ls[i];
+    const int ti = li[i];
+    ls[i] = gt ? s : tv;
+    li[i] = gt ? id : ti;
+    s = gt ? tv : s;
+    id = gt ? ti : id;
+  }
+}
+
+template <int KC>
+__global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // query block [4][KG][256]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int KG = a.KG;
+
+  // XCD-aware decode: workgroups of one XCD (blockIdx % 8) sweep the same index
+  // range so that the range is fetched into that XCD's L2 once.
+  int split, qb;
+  {
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    if (a.NSPLIT <= 8) {
+      const int per = 8 / a.NSPLIT;
+      split = xcd / per;
+      qb = j * per + xcd % per;
+    } else {
+      const int m = a.NSPLIT >> 3;
+      split = xcd + 8 * (j % m);
+      qb = j / m;
+    }
+  }
+  const int QB = (a.QT + 3) >> 2;
+  if (qb >= QB) return;
+
+  // stage the 128-query block (already frag32-packed) into LDS
+  {
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(a.qp) + (size_t)qb * 4 * KG * 64;
+    f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
+    const int valid = min(4, a.QT - qb * 4) * KG * 64;
+    for (int i = tid; i < 4 * KG * 64; i += SC_THREADS) dst[i] = (i < valid) ? src[i] : f32x4{0, 0, 0, 0};
+  }
+  __syncthreads();
+
+  float ls[4][KC];
+  int li[4][KC];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {
+      ls[q][i] = NEG_INF;
+      li[q][i] = -1;
+    }
+
+  const int tps = (a.NT + a.NSPLIT - 1) / a.NSPLIT;  // n-tiles per split
+  const int t0 = split * tps, t1 = min(a.NT, t0 + tps);
+  const float *qs = smem + lane * 4;
+
+  for (int base = t0 + w * 2; base < t1; base += 8) {
+    const bool validB = (base + 1) < t1;
+    const float *pa = a.idxp + (size_t)base * KG * 256 + lane * 4;
+    const float *pb = validB ? pa + (size_t)KG * 256 : pa;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int na = 0; na < 2; ++na)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[na][q][r] = 0.0f;
+
+    f32x4 a0 = *reinterpret_cast<const f32x4 *>(pa);
+    f32x4 a1 = *reinterpret_cast<const f32x4 *>(pb);
+    for (int kg = 0; kg < KG; ++kg) {
+      const int kn = (kg + 1 < KG) ? kg + 1 : kg;
+      const f32x4 n0 = *reinterpret_cast<const f32x4 *>(pa + kn * 256);
+      const f32x4 n1 = *reinterpret_cast<const f32x4 *>(pb + kn * 256);
+      f32x4 b[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG + kg) * 256);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b[q][e], acc[0][q], 0, 0, 0);
+          acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b[q][e], acc[1][q], 0, 0, 0);
+        }
+      a0 = n0;
+      a1 = n1;
+    }
+
+    // fused top-k: lane owns query column (lane & 31) of each q-tile and sees
+    // 16 index rows per n-tile, in increasing row order (ties keep the lower row)
+#pragma unroll
+    for (int na = 0; na < 2; ++na) {
+      if (na == 1 && !validB) break;
+      const int nrow0 = (base + na) * 32;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = nrow0 + mfma_row(r, lane);
+          const float s = (n < a.N) ? acc[na][q][r] : NEG_INF;
+          const bool take = s > ls[q][KC - 1];
+          if (__any(take)) list_insert<KC>(ls[q], li[q], s, n, take);
+        }
+      }
+    }
+  }
+
+  // partial lists -> global: candidate slot (split, wave, lane half)
+  const int slot = (split * 4 + w) * 2 + (lane >> 5);
+  const int nslots = a.NSPLIT * 8;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int query = (qb * 4 + q) * 32 + (lane & 31);
+    if (query < a.Q) {
+      float *ps = a.part_scores + ((size_t)query * nslots + slot) * KC;
+      int32_t *pi = a.part_ids + ((size_t)query * nslots + slot) * KC;
+#pragma unroll
+      for (int i = 0; i < KC; i += 4) {
+        *reinterpret_cast<f32x4 *>(ps + i) = f32x4{ls[q][i], ls[q][i + 1], ls[q][i + 2], ls[q][i + 3]};
+        *reinterpret_cast<int4 *>(pi + i) = int4{li[q][i], li[q][i + 1], li[q][i + 2], li[q][i + 3]};
+      }
+    }
+  }
+}
+
+hipError_t launch_score_topk(const ScoreArgs &a, hipStream_t stream) {
+  if (a.KC != SC_KC) return hipErrorInvalidValue;
+  const size_t lds = (size_t)4 * a.KG * 256 * sizeof(float);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  const int QB = (a.QT + 3) / 4;
+  int grid;
+  if (a.NSPLIT <= 8) {
+    const int per = 8 / a.NSPLIT;
+    grid = (QB + per - 1) / per * 8;
+  } else {
+    grid = QB * a.NSPLIT;
+  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(score_topk_kernel<SC_KC>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(score_topk_kernel<SC_KC>, dim3(grid), dim3(SC_THREADS), lds, stream, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// exact float64 score of query row q against index row n (frag32-packed f32 rows
+// or row-major f64 rows), computed by one wave; result valid in every lane.
+__device__ __forceinline__ double wave_exact_dot(const float *qrow, const float *idxp, const double *idx64,
+                                                 int64_t n, int S, int KG, int lane) {
+  double acc = 0.0;
+  if (idx64) {
+    const double *row = idx64 + (size_t)n * S;
+    for (int d = lane; d < S; d += 64) acc += (double)qrow[d] * row[d];
+  } else {
+    const float *blk = idxp + (size_t)(n >> 5) * KG * 256;
+    const int r = (int)(n & 31);
+    for (int j = lane; j < KG * 2; j += 64) {  // j = kg*2 + half -> 4 consecutive dims
+      const int kg = j >> 1, half = j & 1;
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(blk + kg * 256 + (half * 32 + r) * 4);
+      const int d0 = kg * 8 + half * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (d0 + e < S) acc += (double)qrow[d0 + e] * (double)v[e];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  return acc;
+}
+
+__device__ __forceinline__ bool before(double sa, int64_t ia, double sb, int64_t ib) {
+  return (sa > sb) || (sa == sb && ia < ib);  // score descending, then lower row id
+}
+
+// One 256-thread workgroup per query.  NC candidates (f32 score, local row id).
+#define RS_THREADS 256
+#define RS_MAXWIN 256
+__global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
+  __shared__ float s_thr[RS_THREADS / 64];
+  __shared__ int s_cnt;
+  __shared__ int s_win[RS_MAXWIN];
+  __shared__ double s_ex[RS_MAXWIN];
+  __shared__ float s_m[RS_THREADS / 64];
+  __shared__ double s_qn[RS_THREADS / 64];
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float *ps = a.part_scores + (size_t)q * a.NC;
+  const int32_t *pi = a.part_ids + (size_t)q * a.NC;
+  const float *qrow = a.q + (size_t)q * a.S;
+  const int KG = (a.S + 7) / 8;
+
+  // |q| for the fp32 error bound eps_q = eps * |q|
+  {
+    double v = 0.0;
+    for (int d = tid; d < a.S; d += RS_THREADS) v += (double)qrow[d] * qrow[d];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) s_qn[w] = v;
+  }
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  const float eps_q = a.eps * (float)sqrt(s_qn[0] + s_qn[1] + s_qn[2] + s_qn[3]);
+
+  // k-th largest fp32 candidate score: each thread ranks its candidates by counting
+  // (NC is a few hundred; O(NC^2/256) compares per thread)
+  float kth = NEG_INF;
+  for (int c = tid; c < a.NC; c += RS_THREADS) {
+    const int id = pi[c];
+    if (id < 0) continue;
+    const float s = ps[c];
+    int rank = 0;
+    for (int j = 0; j < a.NC; ++j) {
+      const int idj = pi[j];
+      if (idj < 0) continue;
+      const float sj = ps[j];
+      rank += (sj > s) || (sj == s && idj < id);
+    }
+    if (rank == a.k - 1) kth = s;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) kth = fmaxf(kth, __shfl_xor(kth, o));
+  if (lane == 0) s_thr[w] = kth;
+  __syncthreads();
+  kth = fmaxf(fmaxf(s_thr[0], s_thr[1]), fmaxf(s_thr[2], s_thr[3]));
+
+  // window: candidates whose fp32 score is within 2*eps of the k-th (the only ones
+  // that can be in the exact top-k); largest slot minimum M over full slots
+  float mmax = NEG_INF;
+  const int KCc = SC_KC;
+  for (int c = tid; c < a.NC; c += RS_THREADS) {
+    const int id = pi[c];
+    if (id < 0) continue;
+    const float s = ps[c];
+    if (s >= kth - 2.0f * eps_q) {
+      const int p = atomicAdd(&s_cnt, 1);
+      if (p < RS_MAXWIN) s_win[p] = c;
+    }
+    if ((c % KCc) == KCc - 1) mmax = fmaxf(mmax, s);  // slot is full: rows outside it score <= s
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mmax = fmaxf(mmax, __shfl_xor(mmax, o));
+  if (lane == 0) s_m[w] = mmax;
+  __syncthreads();
+  mmax = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+  const int nwin_all = s_cnt;
+  const int nwin = min(nwin_all, RS_MAXWIN);
+
+  // exact float64 re-score of the window, one wave per candidate
+  for (int i = w; i < nwin; i += RS_THREADS / 64) {
+    const double ex = wave_exact_dot(qrow, a.idx32, a.idx64, pi[s_win[i]], a.S, KG, lane);
+    if (lane == 0) s_ex[i] = ex;
+  }
+  __syncthreads();
+
+  // rank the window exactly; emit the first k
+  double theta = -__builtin_inf();
+  for (int i = tid; i < nwin; i += RS_THREADS) {
+    const double s = s_ex[i];
+    const int64_t id = pi[s_win[i]];
+    int rank = 0;
+    for (int j = 0; j < nwin; ++j) rank += before(s_ex[j], (int64_t)pi[s_win[j]], s, id);
+    if (rank < a.k) {
+      a.out_scores[(size_t)q * a.k + rank] = s;
+      a.out_ids[(size_t)q * a.k + rank] = a.id_base + id;
+    }
+    if (rank == a.k - 1) theta = s;
+  }
+  // certificate: every row outside the candidate set has fp32 score <= mmax, hence
+  // exact score <= mmax + eps_q; it cannot displace the exact k-th if that is < theta.
+  {
+    double t = theta;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t = fmax(t, __shfl_xor(t, o));
+    __syncthreads();
+    if (lane == 0) s_ex[w] = t;
+    __syncthreads();
+    if (tid == 0) {
+      t = fmax(fmax(s_ex[0], s_ex[1]), fmax(s_ex[2], s_ex[3]));
+      const bool ok = (nwin_all <= RS_MAXWIN) && (nwin >= a.k) && ((double)mmax + (double)eps_q < t);
+      a.cert[q] = ok ? 1 : 0;
+    }
+  }
+}
+
+hipError_t launch_rescore(const RescoreArgs &a, hipStream_t stream) {
+  hipLaunchKernelGGL(rescore_kernel, dim3(a.Q), dim3(RS_THREADS), 0, stream, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// float64 brute force for queries whose certificate failed (cert[q] == 0), or
+// for every query when cert == nullptr.  One workgroup per query; each thread
+// keeps a top-k list (k <= 16) over rows n = tid (mod 256); then a serial merge.
+#define EX_THREADS 256
+struct ExactArgs {
+  const float *q;
+  const float *idxp;
+  const double *idx64;
+  const int32_t *cert;
+  double *out_scores;
+  int64_t *out_ids;
+  int64_t id_base, N;
+  int32_t Q, S, k;
+};
+
+__global__ __launch_bounds__(EX_THREADS) void exact_topk_kernel(ExactArgs a) {
+  __shared__ double s_sc[EX_THREADS / 64][SC_KC];
+  __shared__ int64_t s_id[EX_THREADS / 64][SC_KC];
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (a.cert && a.cert[q]) return;
+  const float *qrow = a.q + (size_t)q * a.S;
+  const int KG = (a.S + 7) / 8;
+  double ls[SC_KC];
+  int64_t li[SC_KC];
+#pragma unroll
+  for (int i = 0; i < SC_KC; ++i) {
+    ls[i] = -__builtin_inf();
+    li[i] = -1;
+  }
+  // every wave scans rows n = w, w+4, ...; the dot is wave-cooperative, the list is
+  // replicated in all lanes of the wave
+  for (int64_t n = w; n < a.N; n += EX_THREADS / 64) {
+    double s = wave_exact_dot(qrow, a.idxp, a.idx64, n, a.S, KG, lane);
+    if (s > ls[SC_KC - 1]) {
+      int64_t id = n;
+#pragma unroll
+      for (int i = 0; i < SC_KC; ++i) {
+        const bool gt = s > ls[i];
+        const double tv = ls[i];
+        const int64_t ti = li[i];
+        ls[i] = gt ? s : tv;
+        li[i] = gt ? id : ti;
+        s = gt ? tv : s;
+        id = gt ? ti : id;
+      }
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < SC_KC; ++i) {
+      s_sc[w][i] = ls[i];
+      s_id[w][i] = li[i];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int pos[EX_THREADS / 64] = {0, 0, 0, 0};
+    for (int o = 0; o < a.k; ++o) {
+      int best = -1;
+      for (int p = 0; p < EX_THREADS / 64; ++p) {
+        if (pos[p] >= SC_KC || s_id[p][pos[p]] < 0) continue;
+        if (best < 0 || before(s_sc[p][pos[p]], s_id[p][pos[p]], s_sc[best][pos[best]], s_id[best][pos[best]])) best = p;
+      }
+      a.out_scores[(size_t)q * a.k + o] = s_sc[best][pos[best]];
+      a.out_ids[(size_t)q * a.k + o] = a.id_base + s_id[best][pos[best]];
+      ++pos[best];
+    }
+  }
+}
+
+hipError_t launch_exact_topk(const float *q, const float *idxp, const double *idx64, const int32_t *cert,
+                             double *out_scores, int64_t *out_ids, int64_t id_base, int64_t N, int Q, int S,
+                             int k, hipStream_t stream) {
+  ExactArgs a{q, idxp, idx64, cert, out_scores, out_ids, id_base, N, Q, S, k};
+  hipLaunchKernelGGL(exact_topk_kernel, dim3(Q), dim3(EX_THREADS), 0, stream, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// k-way merge of P sorted lists per query: in [P][Q][k] -> out [Q][k].
+__global__ void merge_topk_kernel(const double *in_s, const int64_t *in_i, int P, int Q, int k, double *out_s,
+                                  int64_t *out_i) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= Q) return;
+  // rank of element (p,j) in the merged order = #elements before it; lists are
+  // sorted, so count with a scan over the other lists (P*k is small)
+  for (int p = 0; p < P; ++p)
+    for (int j = 0; j < k; ++j) {
+      const double s = in_s[((size_t)p * Q + q) * k + j];
+      const int64_t id = in_i[((size_t)p * Q + q) * k + j];
+      int rank = j;
+      for (int p2 = 0; p2 < P && rank < k; ++p2) {
+        if (p2 == p) continue;
+        for (int j2 = 0; j2 < k; ++j2) {
+          const double s2 = in_s[((size_t)p2 * Q + q) * k + j2];
+          const int64_t id2 = in_i[((size_t)p2 * Q + q) * k + j2];
+          if (before(s2, id2, s, id)) ++rank; else break;
+        }
+      }
+      if (rank < k) {
+        out_s[(size_t)q * k + rank] = s;
+        out_i[(size_t)q * k + rank] = id;
+      }
+    }
+}
+
+hipError_t launch_merge_topk(const double *in_s, const int64_t *in_i, int P, int Q, int k, double *out_s,
+                             int64_t *out_i, hipStream_t stream) {
+  hipLaunchKernelGGL(merge_topk_kernel, dim3((Q + 127) / 128), dim3(128), 0, stream, in_s, in_i, P, Q, k, out_s,
+                     out_i);
+  return hipGetLastError();
+}

@@ -1,0 +1,606 @@
+// C-ABI layer of libsse_hip.so (see include/sse_hip.h): handle, variables,
+// lazy weight re-layout, scratch management, kernel orchestration.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/sse_hip.h"
+#include "sse_kernels.h"
+#include "train.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Variable {
+  std::string name;
+  int rows = 0, cols = 0;  // logical 2-D view (count = rows*cols)
+  int64_t count = 0;
+  float *dev = nullptr;     // master copy, row-major, TF shape
+  float *slot = nullptr;    // '<name>/Adagrad' accumulator
+};
+
+struct Encoder {
+  int kernel = -1, bias = -1, proj = -1;  // variable indices
+  int H = 0, Hp = 0, UB = 0, KGx = 0, KGh = 0, Ep = 0;
+  float *Wp = nullptr, *biasp = nullptr, *Mp = nullptr;
+  int shares_lstm_with = -1;  // shared-encoder: target reuses the source LSTM packing
+};
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct sse_handle {
+  sse_config cfg;
+  std::mutex mu;
+  std::string err;
+  std::vector<Variable> vars;
+  Encoder enc[2];
+  bool packed_dirty = true;
+  float *emb_pad = nullptr;  // [V][Ep]
+  int32_t *err_flag = nullptr;
+  // index
+  float *idxp = nullptr;
+  double *idx64 = nullptr;
+  int64_t idx_N = 0, idx_base = 0;
+  int idx_S = 0;
+  float idx_norm_max = 1.0f;
+  // scratch
+  DevBuf s_ids, s_out, s_q, s_qp, s_ps, s_pi, s_cert, s_os, s_oi, s_tmp, s_tmp2;
+  // training
+  float lr = 0.9f;
+  int64_t global_step = 0;
+  TrainState *train = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int fail(sse_handle *h, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf; else g_create_error = buf;
+  return 1;
+}
+
+#define HIPCHECK(h, expr)                                                                         \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) return fail(h, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+int reserve(sse_handle *h, DevBuf &b, size_t bytes) {
+  if (bytes <= b.cap) return 0;
+  if (b.p) HIPCHECK(h, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  const size_t cap = bytes + bytes / 4 + 256;
+  HIPCHECK(h, hipMalloc(&b.p, cap));
+  b.cap = cap;
+  return 0;
+}
+
+int add_var(sse_handle *h, const std::string &name, int rows, int cols) {
+  Variable v;
+  v.name = name;
+  v.rows = rows;
+  v.cols = cols;
+  v.count = (int64_t)rows * cols;
+  h->vars.push_back(v);
+  return (int)h->vars.size() - 1;
+}
+
+int find_var(sse_handle *h, const char *name, bool *is_slot) {
+  std::string n(name);
+  *is_slot = false;
+  const std::string suffix = "/Adagrad";
+  if (n.size() > suffix.size() && n.compare(n.size() - suffix.size(), suffix.size(), suffix) == 0) {
+    n.resize(n.size() - suffix.size());
+    *is_slot = true;
+  }
+  for (size_t i = 0; i < h->vars.size(); ++i)
+    if (h->vars[i].name == n) return (int)i;
+  return -1;
+}
+
+int setup_encoder(sse_handle *h, Encoder &e, const std::string &scope, const std::string &proj, int H, int proj_rows) {
+  const sse_config &c = h->cfg;
+  e.H = H;
+  e.kernel = add_var(h, scope + "/rnn/basic_lstm_cell/kernel", c.embedding_size + H, 4 * H);
+  e.bias = add_var(h, scope + "/rnn/basic_lstm_cell/bias", 1, 4 * H);
+  e.proj = add_var(h, proj, proj_rows, c.encoding_size);
+  return 0;
+}
+
+int geometry(sse_handle *h, Encoder &e) {
+  const sse_config &c = h->cfg;
+  if (e.H <= 0) return 0;
+  if (e.H > 256) return fail(h, "LSTM cell size %d > 256 is not supported by the gfx950 kernel yet", e.H);
+  e.Hp = e.H <= 128 ? 128 : 256;
+  e.UB = e.Hp / 128;
+  e.Ep = round_up(c.embedding_size, 8);
+  e.KGx = e.Ep / 8;
+  e.KGh = e.Hp / 8;
+  if (lstm_fwd_lds_bytes(e.KGx, e.KGh) > 160 * 1024)
+    return fail(h, "embedding_size %d too large for the LSTM kernel's LDS tile", c.embedding_size);
+  if (c.encoding_size > 512) return fail(h, "encoding_size %d > 512 not supported", c.encoding_size);
+  return 0;
+}
+
+// (re)build the kernel-facing layouts from the master variables
+int ensure_packed(sse_handle *h, hipStream_t st) {
+  if (!h->packed_dirty) return 0;
+  const sse_config &c = h->cfg;
+  const int Ep = round_up(c.embedding_size, 8);
+  if (!h->emb_pad) HIPCHECK(h, hipMalloc((void **)&h->emb_pad, (size_t)c.vocab_size * Ep * sizeof(float)));
+  HIPCHECK(h, launch_pad_rows(h->vars[0].dev, c.vocab_size, c.embedding_size, Ep, h->emb_pad, st));
+  for (int s = 0; s < 2; ++s) {
+    Encoder &e = h->enc[s];
+    if (e.H <= 0 || e.kernel < 0) continue;
+    const int KG = e.KGx + e.KGh;
+    if (e.shares_lstm_with < 0) {
+      if (!e.Wp) HIPCHECK(h, hipMalloc((void **)&e.Wp, (size_t)(e.Hp / 32) * KG * 4 * 256 * sizeof(float)));
+      if (!e.biasp) HIPCHECK(h, hipMalloc((void **)&e.biasp, (size_t)e.Hp * 4 * sizeof(float)));
+      HIPCHECK(h, launch_pack_lstm(h->vars[e.kernel].dev, h->vars[e.bias].dev, c.embedding_size, e.H, e.Ep, e.Hp, e.UB,
+                                   e.Wp, e.biasp, st));
+    } else {
+      e.Wp = h->enc[e.shares_lstm_with].Wp;
+      e.biasp = h->enc[e.shares_lstm_with].biasp;
+    }
+    const int NTS = (c.encoding_size + 31) / 32;
+    if (!e.Mp) HIPCHECK(h, hipMalloc((void **)&e.Mp, (size_t)NTS * e.KGh * 256 * sizeof(float)));
+    HIPCHECK(h, launch_pack_kn(h->vars[e.proj].dev, e.H, c.encoding_size, e.KGh, e.Mp, st));
+  }
+  h->packed_dirty = false;
+  return 0;
+}
+
+int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T, int normalize, float *out,
+                      hipStream_t st) {
+  const sse_config &c = h->cfg;
+  if (side != SSE_SIDE_SOURCE && side != SSE_SIDE_TARGET) return fail(h, "side must be 0 (source) or 1 (target)");
+  if (B < 0 || T < 1) return fail(h, "bad batch shape B=%d T=%d", B, T);
+  if (B == 0) return 0;
+  if (c.network_mode == SSE_MODE_SOURCE_ONLY_CNN) return fail(h, "source_only_cnn encoder: not built yet");
+  Encoder &e = h->enc[side];
+  if (e.kernel < 0) return fail(h, "network mode has no %s sequence encoder (sse_model.py:231-233)", side ? "target" : "source");
+  if (ensure_packed(h, st)) return 1;
+  LstmFwdArgs a;
+  a.ids = ids;
+  a.emb = h->emb_pad;
+  a.Wp = e.Wp;
+  a.bias = e.biasp;
+  a.Mp = e.Mp;
+  a.out = out;
+  a.err = h->err_flag;
+  a.B = B;
+  a.T = T;
+  a.V = c.vocab_size;
+  a.Ep = e.Ep;
+  a.KGx = e.KGx;
+  a.KGh = e.KGh;
+  a.S = c.encoding_size;
+  a.NTS = (c.encoding_size + 31) / 32;
+  a.normalize = normalize ? 1 : 0;
+  HIPCHECK(h, launch_lstm_fwd(a, e.Hp, st));
+  return 0;
+}
+
+int check_err_flag(sse_handle *h, hipStream_t st) {
+  int32_t flag = 0;
+  HIPCHECK(h, hipMemcpyAsync(&flag, h->err_flag, sizeof flag, hipMemcpyDeviceToHost, st));
+  HIPCHECK(h, hipStreamSynchronize(st));
+  if (flag) {
+    HIPCHECK(h, hipMemsetAsync(h->err_flag, 0, sizeof(int32_t), st));
+    if (flag & 1) return fail(h, "token id out of range [0, %d) (tf.gather would raise; sse_model.py:163-164)", h->cfg.vocab_size);
+    return fail(h, "device error flag 0x%x", flag);
+  }
+  return 0;
+}
+
+int index_from_dev_rows(sse_handle *h, const float *rows_dev, int64_t N, int S, int64_t id_base, hipStream_t st) {
+  if (N <= 0 || S <= 0) return fail(h, "empty index");
+  if (S > 320) return fail(h, "index dimension %d > 320 not supported by the scoring kernel", S);
+  if (N > (int64_t)2147483000) return fail(h, "index shard too large for int32 row ids");
+  const int KG = (S + 7) / 8;
+  const int64_t NT = (N + 31) / 32;
+  if (h->idxp) HIPCHECK(h, hipFree(h->idxp));
+  h->idxp = nullptr;
+  HIPCHECK(h, hipMalloc((void **)&h->idxp, (size_t)NT * KG * 256 * sizeof(float)));
+  HIPCHECK(h, launch_pack_rows(rows_dev, N, S, h->idxp, st));
+  if (reserve(h, h->s_tmp2, 16)) return 1;
+  HIPCHECK(h, hipMemsetAsync(h->s_tmp2.p, 0, 4, st));
+  HIPCHECK(h, launch_row_norm2_max(rows_dev, N, S, (float *)h->s_tmp2.p, st));
+  float n2 = 0;
+  HIPCHECK(h, hipMemcpyAsync(&n2, h->s_tmp2.p, 4, hipMemcpyDeviceToHost, st));
+  HIPCHECK(h, hipStreamSynchronize(st));
+  h->idx_norm_max = std::sqrt(n2);
+  h->idx_N = N;
+  h->idx_S = S;
+  h->idx_base = id_base;
+  return 0;
+}
+
+int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s, int64_t *out_i, hipStream_t st) {
+  if (!h->idxp) return fail(h, "no index uploaded");
+  if (Q < 0) return fail(h, "bad Q");
+  if (Q == 0) return 0;
+  if (k < 1 || k > h->idx_N) return fail(h, "k=%d must be in [1, N=%lld]", k, (long long)h->idx_N);
+  if (k > 16) return fail(h, "k=%d > 16 not supported by the fused top-k kernel yet", k);
+  const int S = h->idx_S, KG = (S + 7) / 8;
+  const int QT = (Q + 31) / 32, QB = (QT + 3) / 4;
+  const int64_t NT = (h->idx_N + 31) / 32;
+  // splits of the index range: enough workgroups to fill 256 CUs, >= 8 n-tiles per split,
+  // <= 16 splits (candidate lists stay small)
+  int nsplit = 1;
+  while (nsplit < 16 && QB * nsplit < 256 && NT / (nsplit * 2) >= 8) nsplit *= 2;
+  const int NC = nsplit * 8 * 16;
+  if (reserve(h, h->s_qp, (size_t)QB * 4 * KG * 256 * sizeof(float))) return 1;
+  if (reserve(h, h->s_ps, (size_t)Q * NC * sizeof(float))) return 1;
+  if (reserve(h, h->s_pi, (size_t)Q * NC * sizeof(int32_t))) return 1;
+  if (reserve(h, h->s_cert, (size_t)Q * sizeof(int32_t))) return 1;
+  HIPCHECK(h, launch_pack_rows(q, Q, S, (float *)h->s_qp.p, st));
+  ScoreArgs a;
+  a.idxp = h->idxp;
+  a.qp = (const float *)h->s_qp.p;
+  a.part_scores = (float *)h->s_ps.p;
+  a.part_ids = (int32_t *)h->s_pi.p;
+  a.N = h->idx_N;
+  a.Q = Q;
+  a.KG = KG;
+  a.NT = (int)NT;
+  a.QT = QT;
+  a.NSPLIT = nsplit;
+  a.KC = 16;
+  HIPCHECK(h, launch_score_topk(a, st));
+  RescoreArgs r;
+  r.q = q;
+  r.idx32 = h->idxp;
+  r.idx64 = h->idx64;
+  r.part_scores = a.part_scores;
+  r.part_ids = a.part_ids;
+  r.out_scores = out_s;
+  r.out_ids = out_i;
+  r.cert = (int32_t *)h->s_cert.p;
+  r.id_base = h->idx_base;
+  r.N = h->idx_N;
+  r.Q = Q;
+  r.S = S;
+  r.NC = NC;
+  r.k = k;
+  // |fp32 fma-chain dot - exact| <= S * 2^-24 * |q||t| (+ the f32 rounding of f64 rows); use 2x margin
+  r.eps = (float)(2.0 * (S + 2) * 5.97e-8 * h->idx_norm_max);
+  HIPCHECK(h, launch_rescore(r, st));
+  HIPCHECK(h, launch_exact_topk(q, h->idxp, h->idx64, r.cert, out_s, out_i, h->idx_base, h->idx_N, Q, S, k, st));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *sse_last_error(sse_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int sse_create(const sse_config *cfg, sse_handle **out) {
+  if (!cfg || !out) return fail(nullptr, "sse_create: null argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, "no HIP device available");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, "device %d out of range (have %d)", cfg->device, ndev);
+  if (cfg->vocab_size < 2 || cfg->embedding_size < 1 || cfg->encoding_size < 1)
+    return fail(nullptr, "bad model sizes V=%d E=%d S=%d", cfg->vocab_size, cfg->embedding_size, cfg->encoding_size);
+  sse_handle *h = new sse_handle();
+  h->cfg = *cfg;
+  h->lr = cfg->learning_rate;
+#define CREATE_FAIL(...)        \
+  do {                          \
+    fail(nullptr, __VA_ARGS__); \
+    sse_destroy(h);             \
+    return 1;                   \
+  } while (0)
+  if (hipSetDevice(cfg->device) != hipSuccess) CREATE_FAIL("hipSetDevice(%d) failed", cfg->device);
+  add_var(h, "word_embedding", cfg->vocab_size, cfg->embedding_size);
+  switch (cfg->network_mode) {
+    case SSE_MODE_DUAL_ENCODER:
+      setup_encoder(h, h->enc[0], "source_encoder", "source_encoder/src_M", cfg->src_cell_size, cfg->src_cell_size);
+      setup_encoder(h, h->enc[1], "target_encoder", "target_encoder/tgt_M", cfg->tgt_cell_size, cfg->tgt_cell_size);
+      break;
+    case SSE_MODE_SHARED_ENCODER:
+      setup_encoder(h, h->enc[0], "shared_encoder", "shared_encoder/src_M", cfg->src_cell_size, cfg->src_cell_size);
+      h->enc[1] = h->enc[0];
+      h->enc[1].proj = add_var(h, "shared_encoder/tgt_M", cfg->src_cell_size, cfg->encoding_size);
+      h->enc[1].shares_lstm_with = 0;
+      break;
+    case SSE_MODE_SOURCE_ENCODER_ONLY:
+      setup_encoder(h, h->enc[0], "source_only_encoder", "source_only_encoder/src_M", cfg->src_cell_size, cfg->src_cell_size);
+      add_var(h, "target_embedding/tgt_seq_embedding", cfg->target_space_size, cfg->encoding_size);
+      break;
+    case SSE_MODE_SOURCE_ONLY_CNN: {
+      static const int fs[4] = {2, 3, 4, 5}, nf[4] = {256, 128, 128, 64};
+      for (int i = 0; i < 4; ++i) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "source_only_cnn/conv-maxpool-%d/W", fs[i]);
+        add_var(h, nm, fs[i] * cfg->embedding_size, nf[i]);
+        snprintf(nm, sizeof nm, "source_only_cnn/conv-maxpool-%d/b", fs[i]);
+        add_var(h, nm, 1, nf[i]);
+      }
+      add_var(h, "source_only_cnn/src_M", 576, cfg->encoding_size);
+      add_var(h, "target_embedding/tgt_seq_embedding", cfg->target_space_size, cfg->encoding_size);
+      break;
+    }
+    default:
+      CREATE_FAIL("Unsupported network mode %d (sse_model.py:175-177)", cfg->network_mode);
+  }
+  for (int s = 0; s < 2; ++s)
+    if (h->enc[s].kernel >= 0 && geometry(h, h->enc[s])) {
+      g_create_error = h->err;
+      sse_destroy(h);
+      return 1;
+    }
+  for (auto &v : h->vars) {
+    if (hipMalloc((void **)&v.dev, v.count * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&v.slot, v.count * sizeof(float)) != hipSuccess)
+      CREATE_FAIL("hipMalloc failed for variable %s", v.name.c_str());
+    hipMemset(v.dev, 0, v.count * sizeof(float));
+    launch_fill(v.slot, v.count, 0.1f, nullptr);  // AdagradOptimizer initial_accumulator_value
+  }
+  if (hipMalloc((void **)&h->err_flag, sizeof(int32_t)) != hipSuccess) CREATE_FAIL("hipMalloc failed");
+  hipMemset(h->err_flag, 0, sizeof(int32_t));
+  hipEventCreate(&h->ev0);
+  hipEventCreate(&h->ev1);
+  if (hipDeviceSynchronize() != hipSuccess) CREATE_FAIL("device initialisation failed");
+#undef CREATE_FAIL
+  *out = h;
+  return 0;
+}
+
+void sse_destroy(sse_handle *h) {
+  if (!h) return;
+  hipSetDevice(h->cfg.device);
+  hipDeviceSynchronize();
+  for (auto &v : h->vars) {
+    if (v.dev) hipFree(v.dev);
+    if (v.slot) hipFree(v.slot);
+  }
+  for (int s = 0; s < 2; ++s) {
+    Encoder &e = h->enc[s];
+    if (e.shares_lstm_with < 0) {
+      if (e.Wp) hipFree(e.Wp);
+      if (e.biasp) hipFree(e.biasp);
+    }
+    if (e.Mp) hipFree(e.Mp);
+  }
+  if (h->emb_pad) hipFree(h->emb_pad);
+  if (h->err_flag) hipFree(h->err_flag);
+  if (h->idxp) hipFree(h->idxp);
+  if (h->idx64) hipFree(h->idx64);
+  DevBuf *bufs[] = {&h->s_ids, &h->s_out, &h->s_q, &h->s_qp, &h->s_ps, &h->s_pi, &h->s_cert, &h->s_os, &h->s_oi, &h->s_tmp, &h->s_tmp2};
+  for (DevBuf *b : bufs)
+    if (b->p) hipFree(b->p);
+  if (h->train) train_state_free(h->train);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  delete h;
+}
+
+int sse_num_variables(sse_handle *h) { return h ? (int)h->vars.size() : 0; }
+
+int sse_variable_info(sse_handle *h, int index, const char **name, int64_t *count, int32_t *rows, int32_t *cols) {
+  if (!h) return 1;
+  if (index < 0 || index >= (int)h->vars.size()) return fail(h, "variable index %d out of range", index);
+  const Variable &v = h->vars[index];
+  if (name) *name = v.name.c_str();
+  if (count) *count = v.count;
+  if (rows) *rows = v.rows;
+  if (cols) *cols = v.cols;
+  return 0;
+}
+
+int sse_set_variable(sse_handle *h, const char *name, const float *host, int64_t count) {
+  if (!h || !name || !host) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  bool slot;
+  const int i = find_var(h, name, &slot);
+  if (i < 0) return fail(h, "unknown variable '%s'", name);
+  if (count != h->vars[i].count) return fail(h, "variable '%s' has %lld elements, got %lld", name, (long long)h->vars[i].count, (long long)count);
+  HIPCHECK(h, hipMemcpy(slot ? h->vars[i].slot : h->vars[i].dev, host, count * sizeof(float), hipMemcpyHostToDevice));
+  if (!slot) h->packed_dirty = true;
+  return 0;
+}
+
+int sse_get_variable(sse_handle *h, const char *name, float *host, int64_t count) {
+  if (!h || !name || !host) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  bool slot;
+  const int i = find_var(h, name, &slot);
+  if (i < 0) return fail(h, "unknown variable '%s'", name);
+  if (count != h->vars[i].count) return fail(h, "variable '%s' has %lld elements, got %lld", name, (long long)h->vars[i].count, (long long)count);
+  HIPCHECK(h, hipDeviceSynchronize());
+  HIPCHECK(h, hipMemcpy(host, slot ? h->vars[i].slot : h->vars[i].dev, count * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int sse_encode_dev(sse_handle *h, int side, const int32_t *ids_dev, int32_t B, int32_t T, int32_t normalize,
+                   float *out_dev, void *stream) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  return encode_dev_locked(h, side, ids_dev, B, T, normalize, out_dev, (hipStream_t)stream);
+}
+
+int sse_encode(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int32_t T, int32_t normalize,
+               float *out_host) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  if (B == 0) return 0;
+  if (B < 0 || T < 1 || !ids_host || !out_host) return fail(h, "bad arguments to sse_encode");
+  const size_t S = h->cfg.encoding_size;
+  if (reserve(h, h->s_ids, (size_t)B * T * sizeof(int32_t))) return 1;
+  if (reserve(h, h->s_out, (size_t)B * S * sizeof(float))) return 1;
+  hipStream_t st = nullptr;
+  HIPCHECK(h, hipMemcpyAsync(h->s_ids.p, ids_host, (size_t)B * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  if (encode_dev_locked(h, side, (const int32_t *)h->s_ids.p, B, T, normalize, (float *)h->s_out.p, st)) return 1;
+  if (check_err_flag(h, st)) return 1;
+  HIPCHECK(h, hipMemcpy(out_host, h->s_out.p, (size_t)B * S * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int sse_l2_normalize_dev(sse_handle *h, const float *x_dev, float *out_dev, int64_t rows, int32_t cols, void *stream) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  HIPCHECK(h, launch_l2_normalize(x_dev, out_dev, rows, cols, (hipStream_t)stream));
+  return 0;
+}
+
+int sse_index_set_dev(sse_handle *h, const float *rows_dev, int64_t N, int32_t S, int64_t id_base, void *stream) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  if (h->idx64) {
+    HIPCHECK(h, hipFree(h->idx64));
+    h->idx64 = nullptr;
+  }
+  return index_from_dev_rows(h, rows_dev, N, S, id_base, (hipStream_t)stream);
+}
+
+int sse_index_upload(sse_handle *h, const float *rows_host, int64_t N, int32_t S, int64_t id_base) {
+  if (!h || !rows_host) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  if (N <= 0 || S <= 0) return fail(h, "empty index");
+  if (reserve(h, h->s_tmp, (size_t)N * S * sizeof(float))) return 1;
+  HIPCHECK(h, hipMemcpy(h->s_tmp.p, rows_host, (size_t)N * S * sizeof(float), hipMemcpyHostToDevice));
+  if (h->idx64) {
+    HIPCHECK(h, hipFree(h->idx64));
+    h->idx64 = nullptr;
+  }
+  return index_from_dev_rows(h, (const float *)h->s_tmp.p, N, S, id_base, nullptr);
+}
+
+int sse_index_upload_f64(sse_handle *h, const double *rows_host, int64_t N, int32_t S, int64_t id_base) {
+  if (!h || !rows_host) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  if (N <= 0 || S <= 0) return fail(h, "empty index");
+  if (h->idx64) {
+    HIPCHECK(h, hipFree(h->idx64));
+    h->idx64 = nullptr;
+  }
+  HIPCHECK(h, hipMalloc((void **)&h->idx64, (size_t)N * S * sizeof(double)));
+  HIPCHECK(h, hipMemcpy(h->idx64, rows_host, (size_t)N * S * sizeof(double), hipMemcpyHostToDevice));
+  if (reserve(h, h->s_tmp, (size_t)N * S * sizeof(float))) return 1;
+  HIPCHECK(h, launch_f64_to_f32(h->idx64, (float *)h->s_tmp.p, N * S, nullptr));
+  return index_from_dev_rows(h, (const float *)h->s_tmp.p, N, S, id_base, nullptr);
+}
+
+int sse_score_topk_dev(sse_handle *h, const float *q_dev, int32_t Q, int32_t k, double *out_scores_dev,
+                       int64_t *out_ids_dev, void *stream) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  return score_dev_locked(h, q_dev, Q, k, out_scores_dev, out_ids_dev, (hipStream_t)stream);
+}
+
+int sse_score_topk(sse_handle *h, const float *q_host, int32_t Q, int32_t k, double *out_scores, int64_t *out_ids) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  if (Q == 0) return 0;
+  if (Q < 0 || !q_host || !out_scores || !out_ids) return fail(h, "bad arguments to sse_score_topk");
+  if (!h->idxp) return fail(h, "no index uploaded");
+  const size_t S = h->idx_S;
+  if (reserve(h, h->s_q, (size_t)Q * S * sizeof(float))) return 1;
+  if (reserve(h, h->s_os, (size_t)Q * k * sizeof(double))) return 1;
+  if (reserve(h, h->s_oi, (size_t)Q * k * sizeof(int64_t))) return 1;
+  HIPCHECK(h, hipMemcpy(h->s_q.p, q_host, (size_t)Q * S * sizeof(float), hipMemcpyHostToDevice));
+  if (score_dev_locked(h, (const float *)h->s_q.p, Q, k, (double *)h->s_os.p, (int64_t *)h->s_oi.p, nullptr)) return 1;
+  HIPCHECK(h, hipMemcpy(out_scores, h->s_os.p, (size_t)Q * k * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHECK(h, hipMemcpy(out_ids, h->s_oi.p, (size_t)Q * k * sizeof(int64_t), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int sse_merge_topk_dev(sse_handle *h, const double *in_scores_dev, const int64_t *in_ids_dev, int32_t P, int32_t Q,
+                       int32_t k, double *out_scores_dev, int64_t *out_ids_dev, void *stream) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  if (P < 1 || Q < 0 || k < 1) return fail(h, "bad arguments to sse_merge_topk_dev");
+  if (Q == 0) return 0;
+  HIPCHECK(h, launch_merge_topk(in_scores_dev, in_ids_dev, P, Q, k, out_scores_dev, out_ids_dev, (hipStream_t)stream));
+  return 0;
+}
+
+int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tgt_ids_host, const float *labels_host,
+                   int32_t B, int32_t T, float *loss, float *train_acc) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  (void)src_ids_host; (void)tgt_ids_host; (void)labels_host; (void)B; (void)T; (void)loss; (void)train_acc;
+  return fail(h, "sse_train_step: training kernels not built yet");
+}
+
+int sse_get_learning_rate(sse_handle *h, float *lr) {
+  if (!h || !lr) return 1;
+  *lr = h->lr;
+  return 0;
+}
+int sse_set_learning_rate(sse_handle *h, float lr) {
+  if (!h) return 1;
+  h->lr = lr;
+  return 0;
+}
+int sse_decay_learning_rate(sse_handle *h) {
+  if (!h) return 1;
+  // learning_rate.assign(max(lr * decay, 1e-3)), float32 (sse_model.py:123-124)
+  h->lr = fmaxf(h->lr * h->cfg.learning_rate_decay_factor, 1e-3f);
+  return 0;
+}
+int sse_get_global_step(sse_handle *h, int64_t *step) {
+  if (!h || !step) return 1;
+  *step = h->global_step;
+  return 0;
+}
+int sse_set_global_step(sse_handle *h, int64_t step) {
+  if (!h) return 1;
+  h->global_step = step;
+  return 0;
+}
+
+int sse_timer_start(sse_handle *h, void *stream) {
+  if (!h) return 1;
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  HIPCHECK(h, hipEventRecord(h->ev0, (hipStream_t)stream));
+  return 0;
+}
+int sse_timer_stop_ms(sse_handle *h, void *stream, float *ms) {
+  if (!h || !ms) return 1;
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  HIPCHECK(h, hipEventRecord(h->ev1, (hipStream_t)stream));
+  HIPCHECK(h, hipEventSynchronize(h->ev1));
+  HIPCHECK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return 0;
+}
+int sse_synchronize(sse_handle *h) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  HIPCHECK(h, hipDeviceSynchronize());
+  return check_err_flag(h, nullptr);
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// Internal declarations shared by the gfx950 kernels and the C-ABI layer.
+// Not part of the public interface (that is include/sse_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------
+// MFMA fragment packing ("frag32" layout), used for every operand of
+// v_mfma_f32_32x32x2_f32 in this library.
+//
+// A matrix X[R][K] (R = the MFMA's 32-wide M or N dimension, K = reduction) is
+// stored as blocks of 32 rows x 8 k = 256 floats = 1 KiB:
+//     Xp[(rt * KG + kg) * 256 + lane * 4 + e],   rt = r / 32, kg = k / 8,
+//     lane = ((k % 8) / 4) * 32 + (r % 32),      e = k % 4.
+// Lane l of a wave reads ONE float4 at block + 4*l (a fully coalesced 1 KiB
+// wave access, or a conflict-free ds_read_b128) and uses component e as the
+// MFMA operand of sub-step e: A[i = l&31][kk = l>>5] (or B[kk][j = l&31]) =
+// X[rt*32 + (l&31)][kg*8 + (l>>5)*4 + e].  Both operands permute k the same
+// way, so four MFMAs cover k = kg*8 .. kg*8+7 exactly.
+// ---------------------------------------------------------------------------
+__host__ __device__ static inline int frag32_off(int r_in_tile, int k_in_group) {
+  return ((((k_in_group >> 2) << 5) + r_in_tile) << 2) + (k_in_group & 3);
+}
+
+// C/D layout of the 32x32 MFMA: acc[reg] holds row mfma_row(reg, lane), column lane & 31.
+__device__ static inline int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ------------------------------ LSTM forward -------------------------------
+struct LstmFwdArgs {
+  const int32_t *ids;   // [B][T]
+  const float *emb;     // [V][Ep] zero-padded word_embedding
+  const float *Wp;      // packed kernel, see pack_lstm_kernel()
+  const float *bias;    // [Hp/32][4][32], forget bias folded into the f block
+  const float *Mp;      // packed projection [Sp/32][KGh][256]
+  float *out;           // [B][S]
+  int32_t *err;         // bit 0: token id out of range
+  int32_t B, T, V, Ep, KGx, KGh, S, NTS, normalize;
+};
+// Hp = 128 * UB hidden units; 512 threads; dynamic LDS = lstm_fwd_lds_bytes()
+size_t lstm_fwd_lds_bytes(int KGx, int KGh);
+hipError_t launch_lstm_fwd(const LstmFwdArgs &a, int Hp, hipStream_t stream);
+
+// ------------------------------ scoring ------------------------------------
+struct ScoreArgs {
+  const float *idxp;     // packed index  [NT][KG][256]  (frag32, rows = targets)
+  const float *qp;       // packed queries [QT][KG][256] (frag32, rows = queries)
+  float *part_scores;    // [Q][NSPLIT][KC] per-split candidate scores (f32)
+  int32_t *part_ids;     // [Q][NSPLIT][KC] row numbers local to this index (or -1)
+  int64_t N;             // index rows
+  int32_t Q, KG, NT, QT, NSPLIT, KC;
+};
+hipError_t launch_score_topk(const ScoreArgs &a, hipStream_t stream);
+
+struct RescoreArgs {
+  const float *q;          // [Q][S] f32 row-major queries
+  const float *idx32;      // [N][S] f32 rows (used when idx64 == nullptr)
+  const double *idx64;     // [N][S] f64 rows or nullptr
+  const float *part_scores;
+  const int32_t *part_ids;
+  double *out_scores;      // [Q][k]
+  int64_t *out_ids;        // [Q][k]
+  int32_t *cert;           // [Q] 1 = the f32 candidate set provably contains the exact top-k
+  int64_t id_base, N;
+  int32_t Q, S, NC, k;     // NC = NSPLIT*KC candidates per query
+  float eps;               // bound on |f32 score - exact score|
+};
+hipError_t launch_rescore(const RescoreArgs &a, hipStream_t stream);
+
+hipError_t launch_merge_topk(const double *in_s, const int64_t *in_i, int P, int Q, int k, double *out_s,
+                             int64_t *out_i, hipStream_t stream);
+
+// ------------------------------ packing / misc -----------------------------
+// rows [R][C] f32 row-major -> frag32 [ceil(R/32)][ceil(C/8)][256], zero padded
+hipError_t launch_pack_rows(const float *rows, int64_t R, int C, float *out, hipStream_t stream);
+hipError_t launch_f64_to_f32(const double *in, float *out, int64_t n, hipStream_t stream);
+hipError_t launch_l2_normalize(const float *x, float *out, int64_t rows, int cols, hipStream_t stream);
+
+hipError_t launch_pack_lstm(const float *K, const float *b, int E, int H, int Ep, int Hp, int UB, float *Wp,
+                            float *biasp, hipStream_t stream);
+hipError_t launch_pack_kn(const float *X, int K, int N, int KGp, float *out, hipStream_t stream);
+hipError_t launch_pad_rows(const float *in, int64_t R, int C, int Cp, float *out, hipStream_t stream);
+hipError_t launch_row_norm2_max(const float *x, int64_t rows, int cols, float *out_bits, hipStream_t stream);
+hipError_t launch_fill(float *p, int64_t n, float v, hipStream_t stream);
+hipError_t launch_exact_topk(const float *q, const float *idxp, const double *idx64, const int32_t *cert,
+                             double *out_scores, int64_t *out_ids, int64_t id_base, int64_t N, int Q, int S,
+                             int k, hipStream_t stream);
