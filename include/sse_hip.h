@@ -122,9 +122,13 @@ int sse_decay_learning_rate(sse_handle *h);
 int sse_get_global_step(sse_handle *h, int64_t *step);
 int sse_set_global_step(sse_handle *h, int64_t step);
 
-/* Timing helper for bench.py: HIP events recorded on `stream`. */
-int sse_timer_start(sse_handle *h, void *stream);
-int sse_timer_stop_ms(sse_handle *h, void *stream, float *ms);
+/* Timing helper for bench.py: HIP events recorded on the stream the kernels are
+ * launched on.  sse_timer_record stamps event `slot` (0..255); sse_timer_elapsed_ms
+ * waits for event `b` and returns the time from event `a` to event `b`. */
+int sse_timer_record(sse_handle *h, int32_t slot, void *stream);
+int sse_timer_elapsed_ms(sse_handle *h, int32_t a, int32_t b, float *ms);
+/* hipDeviceSynchronize + report deferred device-side errors (e.g. an id out of
+ * range seen by an asynchronous sse_encode_dev). */
 int sse_synchronize(sse_handle *h);
 
 #ifdef __cplusplus

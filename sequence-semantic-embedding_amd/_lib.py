@@ -49,8 +49,8 @@ SYMBOLS = {
     "sse_decay_learning_rate": (C.c_int, [_P]),
     "sse_get_global_step": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "sse_set_global_step": (C.c_int, [_P, C.c_int64]),
-    "sse_timer_start": (C.c_int, [_P, _P]),
-    "sse_timer_stop_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
+    "sse_timer_record": (C.c_int, [_P, C.c_int32, _P]),
+    "sse_timer_elapsed_ms": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
     "sse_synchronize": (C.c_int, [_P]),
 }
 
@@ -216,12 +216,12 @@ class Handle(object):
         self.check(self.lib.sse_set_global_step(self._h, int(step)))
 
     # -- timing --------------------------------------------------------------
-    def timer_start(self, stream=0):
-        self.check(self.lib.sse_timer_start(self._h, stream))
+    def timer_record(self, slot, stream=0):
+        self.check(self.lib.sse_timer_record(self._h, slot, stream))
 
-    def timer_stop_ms(self, stream=0):
+    def timer_elapsed_ms(self, a, b):
         v = C.c_float()
-        self.check(self.lib.sse_timer_stop_ms(self._h, stream, C.byref(v)))
+        self.check(self.lib.sse_timer_elapsed_ms(self._h, a, b, C.byref(v)))
         return float(v.value)
 
     def synchronize(self):

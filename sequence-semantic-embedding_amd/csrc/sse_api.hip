@@ -59,7 +59,7 @@ struct sse_handle {
   float lr = 0.9f;
   int64_t global_step = 0;
   TrainState *train = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> events;
 };
 
 namespace {
@@ -357,8 +357,6 @@ int sse_create(const sse_config *cfg, sse_handle **out) {
   }
   if (hipMalloc((void **)&h->err_flag, sizeof(int32_t)) != hipSuccess) CREATE_FAIL("hipMalloc failed");
   hipMemset(h->err_flag, 0, sizeof(int32_t));
-  hipEventCreate(&h->ev0);
-  hipEventCreate(&h->ev1);
   if (hipDeviceSynchronize() != hipSuccess) CREATE_FAIL("device initialisation failed");
 #undef CREATE_FAIL
   *out = h;
@@ -389,8 +387,8 @@ void sse_destroy(sse_handle *h) {
   for (DevBuf *b : bufs)
     if (b->p) hipFree(b->p);
   if (h->train) train_state_free(h->train);
-  if (h->ev0) hipEventDestroy(h->ev0);
-  if (h->ev1) hipEventDestroy(h->ev1);
+  for (hipEvent_t e : h->events)
+    if (e) (void)hipEventDestroy(e);
   delete h;
 }
 
@@ -581,18 +579,22 @@ int sse_set_global_step(sse_handle *h, int64_t step) {
   return 0;
 }
 
-int sse_timer_start(sse_handle *h, void *stream) {
+int sse_timer_record(sse_handle *h, int32_t slot, void *stream) {
   if (!h) return 1;
+  if (slot < 0 || slot >= 256) return fail(h, "timer slot %d out of range [0,256)", slot);
   HIPCHECK(h, hipSetDevice(h->cfg.device));
-  HIPCHECK(h, hipEventRecord(h->ev0, (hipStream_t)stream));
+  if ((int)h->events.size() <= slot) h->events.resize(slot + 1, nullptr);
+  if (!h->events[slot]) HIPCHECK(h, hipEventCreate(&h->events[slot]));
+  HIPCHECK(h, hipEventRecord(h->events[slot], (hipStream_t)stream));
   return 0;
 }
-int sse_timer_stop_ms(sse_handle *h, void *stream, float *ms) {
+int sse_timer_elapsed_ms(sse_handle *h, int32_t a, int32_t b, float *ms) {
   if (!h || !ms) return 1;
+  if (a < 0 || b < 0 || a >= (int)h->events.size() || b >= (int)h->events.size() || !h->events[a] || !h->events[b])
+    return fail(h, "timer slots %d/%d were not recorded", a, b);
   HIPCHECK(h, hipSetDevice(h->cfg.device));
-  HIPCHECK(h, hipEventRecord(h->ev1, (hipStream_t)stream));
-  HIPCHECK(h, hipEventSynchronize(h->ev1));
-  HIPCHECK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+  HIPCHECK(h, hipEventSynchronize(h->events[b]));
+  HIPCHECK(h, hipEventElapsedTime(ms, h->events[a], h->events[b]));
   return 0;
 }
 int sse_synchronize(sse_handle *h) {
