@@ -26,7 +26,7 @@ size_t lstm_fwd_lds_bytes(int KGx, int KGh) {
 __device__ __forceinline__ float fast_sigmoid(float x) { return __fdividef(1.0f, 1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - __fdividef(2.0f, 1.0f + __expf(2.0f * x)); }
 
-template <int UB>
+template <int UB, bool TRAIN>
 __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -101,6 +101,30 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
 
     const float *xa = xbuf + (size_t)(((t & 1) * 2 + wm) * KGx) * 256 + lane * 4;
     const float *ha = hbuf + (size_t)(wm * KGh) * 256 + lane * 4;
+
+    if constexpr (TRAIN) {
+      // A-tape for the weight-gradient GEMM: [x_t | h_{t-1}] of this tile, stored as
+      // frag32 blocks with rows = k' (x: 0..63, h: 64 + unit) and reduction index
+      // r = (t*NT32 + tile32)*32 + b, i.e. AT[(r/8)*KT + k'/32][256].
+      const int KT = 2 + KGh / 4;
+      const int nf4 = (64 + KGh * 8) * 16;  // float4s per step: k' count x 16 groups of 4 rows
+      for (int i = tid; i < nf4; i += LSTM_THREADS) {
+        const int kp = i % (64 + KGh * 8), b4 = i / (64 + KGh * 8);  // b4: rows 4*b4 .. 4*b4+3 of the 64
+        const int mt = b4 >> 3, bl = (b4 & 7) * 4;
+        f32x4 v = {0, 0, 0, 0};
+        if (kp >= 64) {
+          const int unit = kp - 64;
+          const float *src = hbuf + (size_t)(mt * KGh + (unit >> 3)) * 256 + ((((unit >> 2) & 1) * 32 + bl) << 2) + (unit & 3);
+          v = f32x4{src[0], src[4], src[8], src[12]};
+        } else if (kp < KGx * 8) {
+          const float *src = xbuf + (size_t)(((t & 1) * 2 + mt) * KGx + (kp >> 3)) * 256 + ((((kp >> 2) & 1) * 32 + bl) << 2) + (kp & 3);
+          v = f32x4{src[0], src[4], src[8], src[12]};
+        }
+        const size_t rg = ((size_t)t * (gridDim.x * 2) + blockIdx.x * 2 + mt) * 4 + (bl >> 3);
+        float *dst = a.tape_a + (rg * KT + (kp >> 5)) * 256 + ((((bl >> 2) & 1) * 32 + (kp & 31)) << 2);
+        *reinterpret_cast<f32x4 *>(dst) = v;
+      }
+    }
     const int kend = (t == 0) ? KGx : KG;  // h_0 = 0: skip the recurrent part of step 0
 
     f32x16 hnew[UB];
@@ -138,6 +162,15 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
         const float cn = c[u][r] * sf + si * tj;
         c[u][r] = cn;
         hnew[u][r] = fast_tanh(cn) * so;
+        if constexpr (TRAIN) {
+          // gate tape in accumulator layout: [t][tile32][wn][u][q][reg][lane], q = si,tj,sf,so,c
+          float *tp = a.tape_g + ((((size_t)t * (gridDim.x * 2) + blockIdx.x * 2 + wm) * 4 + wn) * UB + u) * 5 * 1024 + r * 64 + lane;
+          tp[0] = si;
+          tp[1024] = tj;
+          tp[2048] = sf;
+          tp[3072] = so;
+          tp[4096] = cn;
+        }
       }
     }
 
@@ -159,6 +192,16 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       for (int r = 0; r < 16; ++r) dst[(half * 32 + mfma_row(r, lane)) * 4] = hnew[u][r];
     }
     __syncthreads();  // h_t visible
+  }
+
+  if constexpr (TRAIN) {
+    // h_T, row-major [Bp][Hp], for dM = h_T^T . d(out)
+    const int Hp = KGh * 8;
+    for (int i = tid; i < LSTM_BM * Hp; i += LSTM_THREADS) {
+      const int unit = i % Hp, b = i / Hp;
+      a.h_last[(size_t)(b0 + b) * Hp + unit] =
+          hbuf[(size_t)((b >> 5) * KGh + (unit >> 3)) * 256 + ((((unit >> 2) & 1) * 32 + (b & 31)) << 2) + (unit & 3)];
+    }
   }
 
   // --- projection  out = h_T . M   (+ optional l2_normalize), N tiles nt = wn, wn+4, ...
@@ -222,22 +265,20 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   }
 }
 
+template <int UB, bool TRAIN>
+static hipError_t launch_one(const LstmFwdArgs &a, size_t lds, dim3 grid, dim3 block, hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_kernel<UB, TRAIN>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((lstm_fwd_kernel<UB, TRAIN>), grid, block, lds, stream, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_lstm_fwd(const LstmFwdArgs &a, int Hp, hipStream_t stream) {
   const size_t lds = lstm_fwd_lds_bytes(a.KGx, a.KGh);
   const dim3 grid((a.B + LSTM_BM - 1) / LSTM_BM), block(LSTM_THREADS);
-  hipError_t e;
-  if (Hp == 128) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_kernel<1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(lstm_fwd_kernel<1>, grid, block, lds, stream, a);
-  } else if (Hp == 256) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_kernel<2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(lstm_fwd_kernel<2>, grid, block, lds, stream, a);
-  } else {
-    return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
+  const bool train = a.tape_g != nullptr;
+  if (Hp == 128) return train ? launch_one<1, true>(a, lds, grid, block, stream) : launch_one<1, false>(a, lds, grid, block, stream);
+  if (Hp == 256) return train ? launch_one<2, true>(a, lds, grid, block, stream) : launch_one<2, false>(a, lds, grid, block, stream);
+  return hipErrorInvalidValue;
 }

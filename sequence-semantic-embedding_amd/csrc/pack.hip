@@ -210,3 +210,36 @@ hipError_t launch_fill(float *p, int64_t n, float v, hipStream_t stream) {
   hipLaunchKernelGGL(fill_kernel_k, dim3(grid_for(n)), dim3(256), 0, stream, p, n, v);
   return hipGetLastError();
 }
+
+// Transposed slices of the LSTM kernel for the backward GEMMs:
+// out = frag32(rows = i in [0, RT*32), red = n in [0, 4*Hp)),
+// value = K[row0 + i][g*H + unit] for i < nrows, unit < H, with n = g*Hp + unit (gate-major, padded)
+__global__ void pack_kT_kernel_k(const float *__restrict__ K, int row0, int nrows, int H, int Hp, int64_t total4,
+                                 f32x4 *__restrict__ out) {
+  const int KGn = Hp / 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(i & 63);
+    const int64_t blk = i >> 6;
+    const int kg = (int)(blk % KGn);
+    const int rt = (int)(blk / KGn);
+    const int row = rt * 32 + (l & 31);
+    f32x4 v = {0, 0, 0, 0};
+    if (row < nrows) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = kg * 8 + (l >> 5) * 4 + e;
+        const int g = n / Hp, unit = n % Hp;
+        if (unit < H) v[e] = K[(size_t)(row0 + row) * 4 * H + g * H + unit];
+      }
+    }
+    out[i] = v;
+  }
+}
+
+hipError_t launch_pack_kT(const float *K, int row0, int nrows, int RT, int H, int Hp, float *out, hipStream_t stream) {
+  const int64_t total4 = (int64_t)RT * (Hp / 2) * 64;
+  hipLaunchKernelGGL(pack_kT_kernel_k, dim3(grid_for(total4)), dim3(256), 0, stream, K, row0, nrows, H, Hp, total4,
+                     reinterpret_cast<f32x4 *>(out));
+  return hipGetLastError();
+}

@@ -22,6 +22,7 @@ struct Variable {
   int64_t count = 0;
   float *dev = nullptr;     // master copy, row-major, TF shape
   float *slot = nullptr;    // '<name>/Adagrad' accumulator
+  float *grad = nullptr;    // gradient of the current step (allocated by the first train step)
 };
 
 struct Encoder {
@@ -34,6 +35,14 @@ struct Encoder {
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
+};
+
+// device buffers of the training path, grown on demand
+struct TrainState {
+  DevBuf ids[2], labels, raw[2], draw[2], tape_g[2], tape_a[2], h_last[2], dh_last, dg_a, dg_b, db_part, dk_part,
+      sq_part, norm_part, row_loss, row_acc, scal;
+  float *KhT[2] = {nullptr, nullptr}, *KxT[2] = {nullptr, nullptr};
+  bool packed_dirty = true;
 };
 
 }  // namespace
@@ -370,6 +379,7 @@ void sse_destroy(sse_handle *h) {
   for (auto &v : h->vars) {
     if (v.dev) hipFree(v.dev);
     if (v.slot) hipFree(v.slot);
+    if (v.grad) hipFree(v.grad);
   }
   for (int s = 0; s < 2; ++s) {
     Encoder &e = h->enc[s];
@@ -386,7 +396,19 @@ void sse_destroy(sse_handle *h) {
   DevBuf *bufs[] = {&h->s_ids, &h->s_out, &h->s_q, &h->s_qp, &h->s_ps, &h->s_pi, &h->s_cert, &h->s_os, &h->s_oi, &h->s_tmp, &h->s_tmp2};
   for (DevBuf *b : bufs)
     if (b->p) hipFree(b->p);
-  if (h->train) train_state_free(h->train);
+  if (h->train) {
+    TrainState *t = h->train;
+    DevBuf *tb[] = {&t->ids[0], &t->ids[1], &t->labels, &t->raw[0], &t->raw[1], &t->draw[0], &t->draw[1], &t->tape_g[0],
+                    &t->tape_g[1], &t->tape_a[0], &t->tape_a[1], &t->h_last[0], &t->h_last[1], &t->dh_last, &t->dg_a,
+                    &t->dg_b, &t->db_part, &t->dk_part, &t->sq_part, &t->norm_part, &t->row_loss, &t->row_acc, &t->scal};
+    for (DevBuf *b : tb)
+      if (b->p) (void)hipFree(b->p);
+    for (int s = 0; s < 2; ++s) {
+      if (t->KhT[s] && (s == 0 || t->KhT[s] != t->KhT[0])) (void)hipFree(t->KhT[s]);
+      if (t->KxT[s] && (s == 0 || t->KxT[s] != t->KxT[0])) (void)hipFree(t->KxT[s]);
+    }
+    delete t;
+  }
   for (hipEvent_t e : h->events)
     if (e) (void)hipEventDestroy(e);
   delete h;
@@ -414,7 +436,10 @@ int sse_set_variable(sse_handle *h, const char *name, const float *host, int64_t
   if (i < 0) return fail(h, "unknown variable '%s'", name);
   if (count != h->vars[i].count) return fail(h, "variable '%s' has %lld elements, got %lld", name, (long long)h->vars[i].count, (long long)count);
   HIPCHECK(h, hipMemcpy(slot ? h->vars[i].slot : h->vars[i].dev, host, count * sizeof(float), hipMemcpyHostToDevice));
-  if (!slot) h->packed_dirty = true;
+  if (!slot) {
+    h->packed_dirty = true;
+    if (h->train) h->train->packed_dirty = true;
+  }
   return 0;
 }
 
@@ -548,8 +573,141 @@ int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tg
   if (!h) return 1;
   std::lock_guard<std::mutex> lk(h->mu);
   HIPCHECK(h, hipSetDevice(h->cfg.device));
-  (void)src_ids_host; (void)tgt_ids_host; (void)labels_host; (void)B; (void)T; (void)loss; (void)train_acc;
-  return fail(h, "sse_train_step: training kernels not built yet");
+  const sse_config &c = h->cfg;
+  if (c.network_mode != SSE_MODE_DUAL_ENCODER && c.network_mode != SSE_MODE_SHARED_ENCODER)
+    return fail(h, "train step: the reference loss is ill-shaped for this network mode (sse_model.py:233,290)");
+  if (B < 1 || T < 1 || !src_ids_host || !tgt_ids_host || !labels_host || !loss || !train_acc)
+    return fail(h, "bad arguments to sse_train_step");
+  hipStream_t st = nullptr;
+  if (!h->train) h->train = new TrainState();
+  TrainState &ts = *h->train;
+  const int E = c.embedding_size, S = c.encoding_size, V = c.vocab_size;
+  const int Bp = round_up(B, 64), NT32 = Bp / 32;
+  const bool shared = c.network_mode == SSE_MODE_SHARED_ENCODER;
+  for (auto &v : h->vars)
+    if (!v.grad) HIPCHECK(h, hipMalloc((void **)&v.grad, v.count * sizeof(float)));
+
+  if (ensure_packed(h, st)) return 1;
+  // transposed kernel slices for the backward GEMMs
+  if (ts.packed_dirty) {
+    for (int s = 0; s < 2; ++s) {
+      Encoder &e = h->enc[s];
+      if (e.shares_lstm_with >= 0) {
+        ts.KhT[s] = ts.KhT[e.shares_lstm_with];
+        ts.KxT[s] = ts.KxT[e.shares_lstm_with];
+        continue;
+      }
+      if (!ts.KhT[s]) HIPCHECK(h, hipMalloc((void **)&ts.KhT[s], (size_t)(e.Hp / 32) * (e.Hp / 2) * 256 * sizeof(float)));
+      if (!ts.KxT[s]) HIPCHECK(h, hipMalloc((void **)&ts.KxT[s], (size_t)2 * (e.Hp / 2) * 256 * sizeof(float)));
+      HIPCHECK(h, launch_pack_kT(h->vars[e.kernel].dev, E, e.H, e.Hp / 32, e.H, e.Hp, ts.KhT[s], st));
+      HIPCHECK(h, launch_pack_kT(h->vars[e.kernel].dev, 0, E, 2, e.H, e.Hp, ts.KxT[s], st));
+    }
+    ts.packed_dirty = false;
+  }
+  if (E > 64) return fail(h, "train step: embedding_size %d > 64 not supported yet", E);
+
+  // ---- inputs
+  const int32_t *ids_host[2] = {src_ids_host, tgt_ids_host};
+  for (int s = 0; s < 2; ++s) {
+    if (reserve(h, ts.ids[s], (size_t)B * T * sizeof(int32_t))) return 1;
+    HIPCHECK(h, hipMemcpyAsync(ts.ids[s].p, ids_host[s], (size_t)B * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  }
+  if (reserve(h, ts.labels, (size_t)B * sizeof(float))) return 1;
+  HIPCHECK(h, hipMemcpyAsync(ts.labels.p, labels_host, (size_t)B * sizeof(float), hipMemcpyHostToDevice, st));
+
+  // ---- forward with tapes (un-normalised encodings; the loss kernel normalises)
+  for (int s = 0; s < 2; ++s) {
+    Encoder &e = h->enc[s];
+    const int KT = 2 + e.Hp / 32;
+    if (reserve(h, ts.raw[s], (size_t)Bp * S * sizeof(float))) return 1;
+    if (reserve(h, ts.draw[s], (size_t)Bp * S * sizeof(float))) return 1;
+    if (reserve(h, ts.tape_g[s], (size_t)T * NT32 * 4 * e.UB * 5 * 1024 * sizeof(float))) return 1;
+    if (reserve(h, ts.tape_a[s], (size_t)T * NT32 * 4 * KT * 256 * sizeof(float))) return 1;
+    if (reserve(h, ts.h_last[s], (size_t)Bp * e.Hp * sizeof(float))) return 1;
+    LstmFwdArgs a;
+    a.ids = (const int32_t *)ts.ids[s].p;
+    a.emb = h->emb_pad;
+    a.Wp = e.Wp;
+    a.bias = e.biasp;
+    a.Mp = e.Mp;
+    a.out = (float *)ts.raw[s].p;
+    a.err = h->err_flag;
+    a.B = B;
+    a.T = T;
+    a.V = V;
+    a.Ep = e.Ep;
+    a.KGx = e.KGx;
+    a.KGh = e.KGh;
+    a.S = S;
+    a.NTS = (S + 31) / 32;
+    a.normalize = 0;
+    a.tape_g = (float *)ts.tape_g[s].p;
+    a.tape_a = (float *)ts.tape_a[s].p;
+    a.h_last = (float *)ts.h_last[s].p;
+    HIPCHECK(h, launch_lstm_fwd(a, e.Hp, st));
+  }
+  if (check_err_flag(h, st)) return 1;
+
+  // ---- loss, train accuracy, d(raw encodings)
+  if (reserve(h, ts.row_loss, (size_t)B * sizeof(float))) return 1;
+  if (reserve(h, ts.row_acc, (size_t)B * sizeof(float))) return 1;
+  if (reserve(h, ts.scal, 4 * sizeof(float))) return 1;
+  float *scal = (float *)ts.scal.p;  // [0] gnorm [1] clip scale [2] loss [3] acc
+  HIPCHECK(h, launch_loss((const float *)ts.raw[0].p, (const float *)ts.raw[1].p, (const float *)ts.labels.p,
+                          (float *)ts.draw[0].p, (float *)ts.draw[1].p, (float *)ts.row_loss.p, (float *)ts.row_acc.p,
+                          scal + 2, B, Bp, S, st));
+
+  // ---- backward
+  Variable &emb = h->vars[0];
+  HIPCHECK(h, hipMemsetAsync(emb.grad, 0, emb.count * sizeof(float), st));
+  const int NORM_BLOCKS = 64;
+  int nparts = 0;
+  if (reserve(h, ts.sq_part, (size_t)2 * T * NT32 * sizeof(float))) return 1;
+  for (int s = 0; s < 2; ++s) {
+    Encoder &e = h->enc[s];
+    const int Hp = e.Hp, KGn = Hp / 2, NTn = Hp / 8, KT = 2 + Hp / 32, RG = T * NT32 * 4;
+    const int SL = dk_slices(RG);
+    if (reserve(h, ts.dh_last, (size_t)Bp * Hp * sizeof(float))) return 1;
+    if (reserve(h, ts.dg_a, (size_t)T * NT32 * KGn * 256 * sizeof(float))) return 1;
+    if (reserve(h, ts.dg_b, (size_t)RG * NTn * 256 * sizeof(float))) return 1;
+    if (reserve(h, ts.db_part, (size_t)NT32 * 4 * Hp * sizeof(float))) return 1;
+    if (reserve(h, ts.dk_part, (size_t)SL * KT * 32 * NTn * 32 * sizeof(float))) return 1;
+    HIPCHECK(h, launch_proj_bwd((const float *)ts.h_last[s].p, (const float *)ts.draw[s].p, h->vars[e.proj].dev, Bp, e.H, Hp,
+                                S, h->vars[e.proj].grad, (float *)ts.dh_last.p, st));
+    HIPCHECK(h, launch_lstm_bwd((const float *)ts.tape_g[s].p, (const float *)ts.dh_last.p, ts.KhT[s], (float *)ts.dg_a.p,
+                                (float *)ts.dg_b.p, (float *)ts.db_part.p, T, NT32, Hp, st));
+    const int accumulate = (shared && s == 1) ? 1 : 0;
+    HIPCHECK(h, launch_dk((const float *)ts.tape_a[s].p, (const float *)ts.dg_b.p, (float *)ts.dk_part.p, RG, KT, NTn, SL, E,
+                          e.H, Hp, accumulate, h->vars[e.kernel].grad, st));
+    HIPCHECK(h, launch_db_reduce((const float *)ts.db_part.p, NT32, e.H, Hp, accumulate, h->vars[e.bias].grad, st));
+    HIPCHECK(h, launch_dx((const float *)ts.dg_a.p, ts.KxT[s], (const int32_t *)ts.ids[s].p, emb.grad,
+                          (float *)ts.sq_part.p + (size_t)s * T * NT32, T, NT32, KGn, B, E, V, st));
+  }
+
+  // ---- global norm over the dense gradients + the raw (un-deduplicated) embedding slices
+  if (reserve(h, ts.norm_part, (size_t)(h->vars.size() * NORM_BLOCKS + 2 * T * NT32) * sizeof(float))) return 1;
+  float *np_ = (float *)ts.norm_part.p;
+  for (size_t i = 1; i < h->vars.size(); ++i) {
+    Variable &v = h->vars[i];
+    HIPCHECK(h, launch_sumsq(v.grad, v.count, np_ + nparts, NORM_BLOCKS, st));
+    nparts += NORM_BLOCKS;
+  }
+  HIPCHECK(h, hipMemcpyAsync(np_ + nparts, ts.sq_part.p, (size_t)2 * T * NT32 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  nparts += 2 * T * NT32;
+  HIPCHECK(h, launch_clip_scale(np_, nparts, 5.0f /* max_gradient_norm, sse_model.py:117 */, scal, st));
+
+  // ---- Adagrad (dense for every tensor; rows of word_embedding with zero gradient are unchanged)
+  for (auto &v : h->vars) HIPCHECK(h, launch_adagrad(v.dev, v.slot, v.grad, scal, h->lr, v.count, st));
+  h->global_step += 1;
+  h->packed_dirty = true;
+  ts.packed_dirty = true;
+
+  float out[4];
+  HIPCHECK(h, hipMemcpyAsync(out, scal, sizeof out, hipMemcpyDeviceToHost, st));
+  HIPCHECK(h, hipStreamSynchronize(st));
+  *loss = out[2];
+  *train_acc = out[3];
+  return 0;
 }
 
 int sse_get_learning_rate(sse_handle *h, float *lr) {

@@ -1,4 +1,22 @@
-// Training-path state (loss, BPTT, clip, Adagrad) -- see train.hip.
+// Training-path launchers (train.hip) and the per-handle training state.
 #pragma once
-struct TrainState;
-void train_state_free(TrainState *t);
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+hipError_t launch_loss(const float *src_raw, const float *tgt_raw, const float *labels, float *d_src, float *d_tgt,
+                       float *row_loss, float *row_acc, float *out2, int B, int Bp, int S, hipStream_t st);
+hipError_t launch_proj_bwd(const float *hT, const float *d, const float *M, int Bp, int H, int Hp, int S, float *dM,
+                           float *dh, hipStream_t st);
+hipError_t launch_lstm_bwd(const float *tape_g, const float *dh_last, const float *KhT, float *dg_a, float *dg_b,
+                           float *db_part, int T, int NT32, int Hp, hipStream_t st);
+int dk_slices(int RG);
+hipError_t launch_dk(const float *tape_a, const float *dg_b, float *part, int RG, int KT, int NTn, int SL, int E, int H,
+                     int Hp, int accumulate, float *dK, hipStream_t st);
+hipError_t launch_db_reduce(const float *db_part, int NT32, int H, int Hp, int accumulate, float *db, hipStream_t st);
+hipError_t launch_dx(const float *dg_a, const float *KxT, const int32_t *ids, float *d_emb, float *sq_part, int T,
+                     int NT32, int KGn, int B, int E, int V, hipStream_t st);
+hipError_t launch_sumsq(const float *g, int64_t n, float *part, int nblocks, hipStream_t st);
+hipError_t launch_clip_scale(const float *part, int n, float clip, float *scal, hipStream_t st);
+hipError_t launch_adagrad(float *w, float *accum, const float *grad, const float *scal, float lr, int64_t n,
+                          hipStream_t st);
+hipError_t launch_pack_kT(const float *K, int row0, int nrows, int RT, int H, int Hp, float *out, hipStream_t stream);

@@ -1,4 +1,522 @@
-// Training kernels: placeholder until the backward path lands.
+// Training kernels for gfx950: pairwise cosine loss, BPTT through the LSTM
+// encoders, gradient global norm + clip, Adagrad.  Together with the TRAIN
+// instantiation of lstm_fwd_kernel they replace
+//   session.run([model.train, model.loss, model.train_acc], feed)   (sse_train.py:170-172)
+// i.e. sse_model.py:279-302 (_def_loss) and :355-364 (_def_optimize:
+// tf.gradients -> clip_by_global_norm(5.0) -> AdagradOptimizer.apply_gradients).
+//
+// Tapes written by the forward pass (layouts in sse_kernels.h / lstm_fwd.hip):
+//   tape_g  gate activations + c per step, accumulator layout (lane-private)
+//   tape_a  [x_t | h_{t-1}]  as frag32(rows = k', red = r)
+// Buffers produced here:
+//   dg_a    d(pre-activation gates) as frag32(rows = b, red = n): A operand of
+//           the recurrent GEMM dh = dg . Kh^T and of dX = dg . Kx^T
+//   dg_b    the same values as frag32(rows = n, red = r): B operand of
+//           dK = A^T . dG
 #include "train.h"
-struct TrainState { int unused; };
-void train_state_free(TrainState *t) { delete t; }
+
+#include "sse_kernels.h"
+
+#define BW_THREADS 256
+
+__device__ __forceinline__ float fast_tanh_t(float x) { return 1.0f - __fdividef(2.0f, 1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ float fast_sigmoid_t(float x) { return __fdividef(1.0f, 1.0f + __expf(-x)); }
+
+// ---------------------------------------------------------------------------
+// Loss: one wave per pair row.  sse_model.py:282-283,290,298,302.
+struct LossArgs {
+  const float *src_raw, *tgt_raw;  // [B][S] un-normalised encodings
+  const float *labels;             // [B]
+  float *d_src, *d_tgt;            // [Bp][S] gradients w.r.t. the raw encodings (rows >= B zeroed)
+  float *row_loss, *row_acc;       // [B]
+  int32_t B, Bp, S;
+};
+
+__global__ void loss_kernel(LossArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= a.Bp) return;
+  float *ds = a.d_src + (size_t)row * a.S, *dt = a.d_tgt + (size_t)row * a.S;
+  if (row >= a.B) {
+    for (int d = lane; d < a.S; d += 64) {
+      ds[d] = 0.0f;
+      dt[d] = 0.0f;
+    }
+    return;
+  }
+  const float *s = a.src_raw + (size_t)row * a.S, *t = a.tgt_raw + (size_t)row * a.S;
+  float ss = 0.0f, tt = 0.0f, st = 0.0f;
+  for (int d = lane; d < a.S; d += 64) {
+    const float x = s[d], y = t[d];
+    ss += x * x;
+    tt += y * y;
+    st += x * y;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ss += __shfl_xor(ss, o);
+    tt += __shfl_xor(tt, o);
+    st += __shfl_xor(st, o);
+  }
+  const float rs = 1.0f / sqrtf(fmaxf(ss, 1e-12f)), rt = 1.0f / sqrtf(fmaxf(tt, 1e-12f));
+  const float cosv = st * rs * rt;           // reduce_sum(ns * nt)
+  const float x = 64.0f * cosv;
+  const float z = a.labels[row];
+  const float sg = fast_sigmoid_t(x);
+  if (lane == 0) {
+    // weighted_cross_entropy_with_logits, pos_weight = 1
+    a.row_loss[row] = (1.0f - z) * x + log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.0f);
+    a.row_acc[row] = z * floorf(sg + 0.1f) + (1.0f - z) * floorf(1.1f - sg);
+  }
+  const float dcos = 64.0f * (sg - z) / (float)a.B;
+  // l2_normalize backward: d raw = r * (dn - n * (n . dn)), dn_s = dcos * nt; the max(., eps)
+  // clamp passes no gradient to the norm when sum(x^2) < eps
+  const bool cs = ss < 1e-12f, ct = tt < 1e-12f;
+  for (int d = lane; d < a.S; d += 64) {
+    const float ns = s[d] * rs, nt = t[d] * rt;
+    ds[d] = rs * dcos * (nt - (cs ? 0.0f : ns * cosv));
+    dt[d] = rt * dcos * (ns - (ct ? 0.0f : nt * cosv));
+  }
+}
+
+// mean over rows, fixed order (deterministic); out[0] = loss, out[1] = train_acc
+__global__ void loss_reduce_kernel(const float *row_loss, const float *row_acc, int B, float *out) {
+  __shared__ float sl[256], sa[256];
+  float l = 0.0f, c = 0.0f;
+  for (int i = threadIdx.x; i < B; i += 256) {
+    l += row_loss[i];
+    c += row_acc[i];
+  }
+  sl[threadIdx.x] = l;
+  sa[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      sl[threadIdx.x] += sl[threadIdx.x + o];
+      sa[threadIdx.x] += sa[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = sl[0] / (float)B;
+    out[1] = sa[0] / (float)B;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Projection backward: dM[j][s] = sum_b hT[b][j] * d[b][s];  dh[b][j] = sum_s d[b][s] * M[j][s]
+__global__ void proj_bwd_dm_kernel(const float *hT, const float *d, int Bp, int H, int Hp, int S, float *dM) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H * S) return;
+  const int s = i % S, j = i / S;
+  float acc = 0.0f;
+  for (int b = 0; b < Bp; ++b) acc += hT[(size_t)b * Hp + j] * d[(size_t)b * S + s];
+  dM[i] = acc;
+}
+
+__global__ void proj_bwd_dh_kernel(const float *d, const float *M, int Bp, int H, int Hp, int S, float *dh) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Bp * Hp) return;
+  const int j = i % Hp, b = i / Hp;
+  float acc = 0.0f;
+  if (j < H)
+    for (int s = 0; s < S; ++s) acc += d[(size_t)b * S + s] * M[(size_t)j * S + s];
+  dh[i] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// Sequential BPTT over one 32-row tile: 4 waves, wave wn owns hidden units
+// [wn*UB*32, (wn+1)*UB*32) exactly as in the forward kernel, so the gate tape
+// is read back lane-privately and dc / dh stay in registers across steps.
+struct LstmBwdArgs {
+  const float *tape_g;  // forward gate tape
+  const float *dh_last; // [Bp][Hp]
+  const float *KhT;     // frag32(rows = j (Hp), red = n (4Hp)):  Kh^T
+  float *dg_a;          // [T][NT32][KGn][256]
+  float *dg_b;          // [(T*NT32*4)][NTn][256]
+  float *db_part;       // [NT32][4*Hp] per-tile bias-gradient partials
+  int32_t T, NT32, Hp;
+};
+
+template <int UB>
+__global__ __launch_bounds__(BW_THREADS) void lstm_bwd_kernel(LstmBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float dgs[];  // [KGn][256]: dg tile, frag32(rows = b, red = n)
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int tile = blockIdx.x, Hp = a.Hp, KGn = Hp / 2, NTn = Hp / 8, T = a.T;
+  const int half = lane >> 5;
+
+  f32x16 dh[UB], dc[UB];
+  float dbacc[UB][4];
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    const int unit = (wn * UB + u) * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dh[u][r] = a.dh_last[(size_t)(tile * 32 + mfma_row(r, lane)) * Hp + unit];
+      dc[u][r] = 0.0f;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dbacc[u][g] = 0.0f;
+  }
+
+  for (int t = T - 1; t >= 0; --t) {
+    // ---- elementwise gate backward, results into the LDS dg tile
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const float *tp = a.tape_g + ((((size_t)t * a.NT32 + tile) * 4 + wn) * UB + u) * 5 * 1024 + lane;
+      const float *tprev = a.tape_g + ((((size_t)(t > 0 ? t - 1 : 0) * a.NT32 + tile) * 4 + wn) * UB + u) * 5 * 1024 + 4096 + lane;
+      const int unit = (wn * UB + u) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float si = tp[r * 64], tj = tp[1024 + r * 64], sf = tp[2048 + r * 64], so = tp[3072 + r * 64];
+        const float cn = tp[4096 + r * 64];
+        const float cprev = (t > 0) ? tprev[r * 64] : 0.0f;
+        const float tc = fast_tanh_t(cn);
+        const float dhv = dh[u][r];
+        const float dov = dhv * tc;
+        const float dcv = dc[u][r] + dhv * so * (1.0f - tc * tc);
+        const float g_i = dcv * tj * si * (1.0f - si);
+        const float g_j = dcv * si * (1.0f - tj * tj);
+        const float g_f = dcv * cprev * sf * (1.0f - sf);
+        const float g_o = dov * so * (1.0f - so);
+        dc[u][r] = dcv * sf;
+        dbacc[u][0] += g_i;
+        dbacc[u][1] += g_j;
+        dbacc[u][2] += g_f;
+        dbacc[u][3] += g_o;
+        const int b = mfma_row(r, lane);
+        // element (b, n = g*Hp + unit) -> dgs[n/8][((n%8)/4*32 + b)*4 + n%4]; Hp % 8 == 0 so n%8 == unit%8
+        float *dst = dgs + (size_t)(unit >> 3) * 256 + ((((unit >> 2) & 1) * 32 + b) << 2) + (unit & 3);
+        dst[(size_t)(0 * Hp / 8) * 256] = g_i;
+        dst[(size_t)(1 * Hp / 8) * 256] = g_j;
+        dst[(size_t)(2 * Hp / 8) * 256] = g_f;
+        dst[(size_t)(3 * Hp / 8) * 256] = g_o;
+      }
+    }
+    __syncthreads();
+
+    // ---- dump the tile: linear copy (A-operand layout) and transposed (B-operand layout)
+    {
+      f32x4 *ga = reinterpret_cast<f32x4 *>(a.dg_a + ((size_t)t * a.NT32 + tile) * KGn * 256);
+      const f32x4 *ls = reinterpret_cast<const f32x4 *>(dgs);
+      for (int i = tid; i < KGn * 64; i += BW_THREADS) ga[i] = ls[i];
+      // (n, 4 consecutive rows) -> one float4 of block (rg, n/32)
+      const size_t rg0 = ((size_t)t * a.NT32 + tile) * 4;
+      for (int i = tid; i < 4 * Hp * 8; i += BW_THREADS) {
+        const int n = i % (4 * Hp), b4 = i / (4 * Hp);  // rows 4*b4 .. 4*b4+3
+        const int bl = b4 * 4;
+        const float *src = dgs + (size_t)(n >> 3) * 256 + ((((n >> 2) & 1) * 32 + bl) << 2) + (n & 3);
+        const f32x4 v = {src[0], src[4], src[8], src[12]};
+        float *dst = a.dg_b + ((rg0 + (bl >> 3)) * NTn + (n >> 5)) * 256 + ((((bl >> 2) & 1) * 32 + (n & 31)) << 2);
+        *reinterpret_cast<f32x4 *>(dst) = v;
+      }
+    }
+
+    // ---- recurrent GEMM: dh_{t-1}[b][j] = sum_n dg[b][n] * Kh[j][n]
+    if (t > 0) {
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[u][r] = 0.0f;
+      const float *la = dgs + lane * 4;
+      const float *kb = a.KhT + (size_t)(wn * UB) * KGn * 256 + lane * 4;
+      f32x4 bcur[UB], bnxt[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) bcur[u] = *reinterpret_cast<const f32x4 *>(kb + (size_t)u * KGn * 256);
+      for (int kg = 0; kg < KGn; ++kg) {
+        const int kn = (kg + 1 < KGn) ? kg + 1 : kg;
+#pragma unroll
+        for (int u = 0; u < UB; ++u) bnxt[u] = *reinterpret_cast<const f32x4 *>(kb + ((size_t)u * KGn + kn) * 256);
+        const f32x4 a4 = *reinterpret_cast<const f32x4 *>(la + kg * 256);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int u = 0; u < UB; ++u) dh[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], bcur[u][e], dh[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < UB; ++u) bcur[u] = bnxt[u];
+      }
+    }
+    __syncthreads();
+  }
+
+  // bias-gradient partials of this tile (sum over its 32 rows and all steps)
+#pragma unroll
+  for (int u = 0; u < UB; ++u)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float v = dbacc[u][g];
+      v += __shfl_xor(v, 32);
+      if (half == 0) a.db_part[(size_t)tile * 4 * Hp + g * Hp + (wn * UB + u) * 32 + lane] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// dK partials: out[slice][k'][n] = sum_{r in slice} A[r][k'] * dG[r][n]
+// wave tile = 2 k'-tiles x 4 n-tiles; workgroup = 4 waves covering 4 consecutive
+// n-quads; grid = (NTn/16 * KT/2, slices).
+struct DkArgs {
+  const float *tape_a;  // [(RG)][KT][256]
+  const float *dg_b;    // [(RG)][NTn][256]
+  float *part;          // [SL][KT*32][NTn*32]
+  int32_t RG, KT, NTn, SL;
+};
+
+__global__ __launch_bounds__(256) void dk_gemm_kernel(DkArgs a) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nquads = a.NTn / 4;               // n-quads in total
+  const int nqg = (nquads + 3) / 4;           // groups of 4 quads (one per wave)
+  const int kpair = blockIdx.x / nqg, qg = blockIdx.x % nqg;
+  const int quad = qg * 4 + w;
+  const int slice = blockIdx.y;
+  const int per = (a.RG + a.SL - 1) / a.SL;
+  const int rg0 = slice * per, rg1 = min(a.RG, rg0 + per);
+  const bool active = quad < nquads;
+  const int kt0 = kpair * 2;
+  const bool k1 = (kt0 + 1) < a.KT;
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  if (active) {
+    for (int rg = rg0; rg < rg1; ++rg) {
+      const float *pa = a.tape_a + ((size_t)rg * a.KT + kt0) * 256 + lane * 4;
+      const float *pb = a.dg_b + ((size_t)rg * a.NTn + quad * 4) * 256 + lane * 4;
+      const f32x4 a0 = *reinterpret_cast<const f32x4 *>(pa);
+      const f32x4 a1 = k1 ? *reinterpret_cast<const f32x4 *>(pa + 256) : f32x4{0, 0, 0, 0};
+      f32x4 b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f32x4 *>(pb + j * 256);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b[j][e], acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b[j][e], acc[1][j], 0, 0, 0);
+        }
+    }
+    const int ldn = a.NTn * 32;
+    float *out = a.part + (size_t)slice * a.KT * 32 * ldn;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i == 1 && !k1) break;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          out[(size_t)((kt0 + i) * 32 + mfma_row(r, lane)) * ldn + (quad * 4 + j) * 32 + (lane & 31)] = acc[i][j][r];
+    }
+  }
+}
+
+// sum the slices and write/accumulate into the variable-shaped gradient dK [(E+H)][4H]
+__global__ void dk_reduce_kernel(const float *part, int SL, int KT, int NTn, int E, int H, int Hp, int accumulate,
+                                 float *dK) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int rows = E + H, cols = 4 * H;
+  if (i >= rows * cols) return;
+  const int col = i % cols, row = i / cols;
+  const int kp = (row < E) ? row : 64 + (row - E);
+  const int g = col / H, unit = col % H;
+  const int n = g * Hp + unit;
+  const size_t ldn = (size_t)NTn * 32, plane = (size_t)KT * 32 * ldn;
+  float acc = 0.0f;
+  for (int s = 0; s < SL; ++s) acc += part[s * plane + (size_t)kp * ldn + n];
+  dK[i] = accumulate ? dK[i] + acc : acc;
+}
+
+__global__ void db_reduce_kernel(const float *db_part, int NT32, int H, int Hp, int accumulate, float *db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * H) return;
+  const int g = i / H, unit = i % H;
+  float acc = 0.0f;
+  for (int t = 0; t < NT32; ++t) acc += db_part[(size_t)t * 4 * Hp + g * Hp + unit];
+  db[i] = accumulate ? db[i] + acc : acc;
+}
+
+// ---------------------------------------------------------------------------
+// dX[r][e] = sum_n dg[r][n] * Kx[e][n]; scatter-add into the dense embedding
+// gradient (duplicate ids summed, as TF's sparse Adagrad does) and accumulate
+// sum(dx^2) over OCCURRENCES (tf.global_norm takes IndexedSlices.values raw).
+struct DxArgs {
+  const float *dg_a;   // [T][NT32][KGn][256]
+  const float *KxT;    // frag32(rows = e (64), red = n): Kx^T, 2 tiles
+  const int32_t *ids;  // [B][T]
+  float *d_emb;        // [V][E] zero-initialised
+  float *sq_part;      // [T*NT32] partial sums of dx^2
+  int32_t T, NT32, KGn, B, E, V;
+};
+
+__global__ __launch_bounds__(64) void dx_kernel(DxArgs a) {
+  const int lane = threadIdx.x;
+  const int t = blockIdx.x / a.NT32, tile = blockIdx.x % a.NT32;
+  const float *pa = a.dg_a + (size_t)blockIdx.x * a.KGn * 256 + lane * 4;
+  const float *pb = a.KxT + lane * 4;
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+  for (int kg = 0; kg < a.KGn; ++kg) {
+    const f32x4 a4 = *reinterpret_cast<const f32x4 *>(pa + kg * 256);
+    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(pb + kg * 256);
+    const f32x4 b1 = *reinterpret_cast<const f32x4 *>(pb + (size_t)(a.KGn + kg) * 256);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b0[e], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b1[e], acc[1], 0, 0, 0);
+    }
+  }
+  float sq = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int b = tile * 32 + mfma_row(r, lane);
+    if (b < a.B) {
+      const int id = a.ids[(size_t)b * a.T + t];
+      if (id >= 0 && id < a.V) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int e = j * 32 + (lane & 31);
+          if (e < a.E) {
+            const float v = acc[j][r];
+            sq += v * v;
+            atomicAdd(a.d_emb + (size_t)id * a.E + e, v);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  if (lane == 0) a.sq_part[blockIdx.x] = sq;
+}
+
+// ---------------------------------------------------------------------------
+// global norm + clip scale + Adagrad
+__global__ void sumsq_kernel(const float *g, int64_t n, float *part /*[gridDim.x]*/) {
+  __shared__ float sh[256];
+  float acc = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += g[i] * g[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+// scal[0] = global norm, scal[1] = clip scale = clip * min(1/norm, 1/clip)
+__global__ void clip_scale_kernel(const float *part, int n, float clip, float *scal) {
+  __shared__ double sh[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += (double)part[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float gn = (float)sqrt(sh[0]);
+    scal[0] = gn;
+    scal[1] = (gn > 0.0f) ? clip * fminf(1.0f / gn, 1.0f / clip) : 1.0f;
+  }
+}
+
+// acc += g^2 ; w -= lr * g / sqrt(acc)   with g = scale * grad  (TF ApplyAdagrad)
+__global__ void adagrad_kernel(float *w, float *accum, const float *grad, const float *scal, float lr, int64_t n) {
+  const float sc = scal[1];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float g = grad[i] * sc;
+    const float ac = accum[i] + g * g;
+    accum[i] = ac;
+    w[i] -= lr * g / sqrtf(ac);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host-side launchers
+static inline int gridn(int64_t n, int cap = 4096) { return (int)((n + 255) / 256 < cap ? (n + 255) / 256 : cap); }
+
+hipError_t launch_loss(const float *src_raw, const float *tgt_raw, const float *labels, float *d_src, float *d_tgt,
+                       float *row_loss, float *row_acc, float *out2, int B, int Bp, int S, hipStream_t st) {
+  LossArgs a{src_raw, tgt_raw, labels, d_src, d_tgt, row_loss, row_acc, B, Bp, S};
+  hipLaunchKernelGGL(loss_kernel, dim3((Bp + 3) / 4), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, row_loss, row_acc, B, out2);
+  return hipGetLastError();
+}
+
+hipError_t launch_proj_bwd(const float *hT, const float *d, const float *M, int Bp, int H, int Hp, int S, float *dM,
+                           float *dh, hipStream_t st) {
+  hipLaunchKernelGGL(proj_bwd_dm_kernel, dim3((H * S + 255) / 256), dim3(256), 0, st, hT, d, Bp, H, Hp, S, dM);
+  hipLaunchKernelGGL(proj_bwd_dh_kernel, dim3((Bp * Hp + 255) / 256), dim3(256), 0, st, d, M, Bp, H, Hp, S, dh);
+  return hipGetLastError();
+}
+
+hipError_t launch_lstm_bwd(const float *tape_g, const float *dh_last, const float *KhT, float *dg_a, float *dg_b,
+                           float *db_part, int T, int NT32, int Hp, hipStream_t st) {
+  LstmBwdArgs a{tape_g, dh_last, KhT, dg_a, dg_b, db_part, T, NT32, Hp};
+  const size_t lds = (size_t)(Hp / 2) * 256 * sizeof(float);
+  hipError_t e;
+  if (Hp == 128) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(lstm_bwd_kernel<1>, dim3(NT32), dim3(BW_THREADS), lds, st, a);
+  } else if (Hp == 256) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(lstm_bwd_kernel<2>, dim3(NT32), dim3(BW_THREADS), lds, st, a);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+int dk_slices(int RG) {
+  int sl = RG / 16;  // >= 16 r-groups (128 rows) per slice
+  if (sl < 1) sl = 1;
+  if (sl > 24) sl = 24;
+  return sl;
+}
+
+hipError_t launch_dk(const float *tape_a, const float *dg_b, float *part, int RG, int KT, int NTn, int SL, int E, int H,
+                     int Hp, int accumulate, float *dK, hipStream_t st) {
+  DkArgs a{tape_a, dg_b, part, RG, KT, NTn, SL};
+  const int nqg = (NTn / 4 + 3) / 4, kpairs = (KT + 1) / 2;
+  hipLaunchKernelGGL(dk_gemm_kernel, dim3(nqg * kpairs, SL), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(dk_reduce_kernel, dim3(((E + H) * 4 * H + 255) / 256), dim3(256), 0, st, part, SL, KT, NTn, E, H, Hp,
+                     accumulate, dK);
+  return hipGetLastError();
+}
+
+hipError_t launch_db_reduce(const float *db_part, int NT32, int H, int Hp, int accumulate, float *db, hipStream_t st) {
+  hipLaunchKernelGGL(db_reduce_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, st, db_part, NT32, H, Hp, accumulate, db);
+  return hipGetLastError();
+}
+
+hipError_t launch_dx(const float *dg_a, const float *KxT, const int32_t *ids, float *d_emb, float *sq_part, int T,
+                     int NT32, int KGn, int B, int E, int V, hipStream_t st) {
+  DxArgs a{dg_a, KxT, ids, d_emb, sq_part, T, NT32, KGn, B, E, V};
+  hipLaunchKernelGGL(dx_kernel, dim3(T * NT32), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_sumsq(const float *g, int64_t n, float *part, int nblocks, hipStream_t st) {
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks), dim3(256), 0, st, g, n, part);
+  return hipGetLastError();
+}
+
+hipError_t launch_clip_scale(const float *part, int n, float clip, float *scal, hipStream_t st) {
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(256), 0, st, part, n, clip, scal);
+  return hipGetLastError();
+}
+
+hipError_t launch_adagrad(float *w, float *accum, const float *grad, const float *scal, float lr, int64_t n,
+                          hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(adagrad_kernel, dim3(gridn(n)), dim3(256), 0, st, w, accum, grad, scal, lr, n);
+  return hipGetLastError();
+}

@@ -1,0 +1,123 @@
+"""Parity of the HIP training step (loss, BPTT, clip_by_global_norm, Adagrad;
+through the C ABI) against the CPU oracle's restatement of
+sse_model.py:279-302,355-364.  Tolerances: loss/acc 1e-5 relative; updated
+variables and Adagrad slots 2e-4 absolute after one step (fp32, different
+summation orders), drift stays below 2e-3 after several steps."""
+import numpy as np
+import pytest
+
+from oracle import sse_oracle as O
+from tests.util import make_pair, model_params, random_ids
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(rng, B, T, V, pad_frac=0.6):
+    src = random_ids(rng, B // 2, T, V, pad_frac)
+    src = np.repeat(src, 2, axis=0)                       # data.py:95-115: each source appears twice (pos, neg)
+    tgt = random_ids(rng, B, T, V, pad_frac)
+    labels = np.tile(np.array([1.0, 0.0], np.float32), B // 2)
+    return src, tgt, labels
+
+
+CASES = [
+    ("dual-encoder", 400, 50, 256, 256, 256, 32, 128),
+    ("shared-encoder", 300, 40, 96, 96, 50, 50, 64),
+    ("dual-encoder", 90, 30, 64, 128, 64, 6, 10),
+    ("shared-encoder", 60, 8, 32, 32, 16, 3, 2),
+]
+
+
+@pytest.mark.parametrize("mode,V,E,Hs,Ht,S,T,B", CASES)
+def test_one_train_step_matches_oracle(mode, V, E, Hs, Ht, S, T, B):
+    params = model_params(mode, V, E, Hs, Ht, S, T, lr=0.9)
+    m, p = make_pair(params, seed=3)
+    st = O.new_optimizer_state(p)
+    rng = np.random.RandomState(11)
+    src, tgt, z = _batch(rng, B, T, V)
+    want_loss, want_acc = O.train_step(p, st, params, src, tgt, z, 0.9)
+    loss, acc = m.train_step(src, tgt, z)
+    assert loss == pytest.approx(float(want_loss), rel=1e-5, abs=1e-6)
+    assert acc == pytest.approx(float(want_acc), abs=1e-6)
+    got = m.get_variables(with_slots=True)
+    for name, w in p.items():
+        assert np.abs(got[name].reshape(w.shape) - w).max() < 2e-4, name
+        assert np.abs(got[name + "/Adagrad"].reshape(w.shape) - st[name]).max() < 2e-4, name + "/Adagrad"
+    assert m.handle.global_step == 1
+
+
+def test_several_steps_track_oracle_and_loss_falls():
+    params = model_params("dual-encoder", 200, 50, 96, 96, 64, 12, lr=0.5)
+    m, p = make_pair(params, seed=5)
+    m.handle.learning_rate = 0.5
+    st = O.new_optimizer_state(p)
+    rng = np.random.RandomState(2)
+    src, tgt, z = _batch(rng, 32, 12, 200)
+    got_losses, want_losses = [], []
+    for _ in range(8):
+        want_losses.append(float(O.train_step(p, st, params, src, tgt, z, 0.5)[0]))
+        got_losses.append(m.train_step(src, tgt, z)[0])
+    assert got_losses[-1] < got_losses[0]
+    assert np.allclose(got_losses, want_losses, rtol=2e-3, atol=2e-4)
+    got = m.get_variables()
+    for name, w in p.items():
+        assert np.abs(got[name].reshape(w.shape) - w).max() < 2e-3, name
+    # encoders see the updated weights (re-layout after the step)
+    ids = random_ids(rng, 5, 12, 200)
+    assert np.abs(m.encode_source(ids) - O.encode(p, params, "src", ids)).max() < 1e-3
+
+
+def test_clip_engages_and_untouched_embedding_rows_stay():
+    params = model_params("dual-encoder", 500, 20, 32, 32, 16, 5, lr=0.9)
+    m, p = make_pair(params, seed=7)
+    for k in p:                                            # large weights -> large gradients -> clipping active
+        if k.endswith("_M"):
+            p[k] = (p[k] * 30).astype(np.float32)
+    m.set_variables(p)
+    st = O.new_optimizer_state(p)
+    rng = np.random.RandomState(1)
+    src, tgt, z = _batch(rng, 16, 5, 40)                   # only ids < 40 are touched
+    _, _, grads = O.gradients(p, params, src, tgt, z)
+    assert O.global_norm(grads) > 5.0
+    before = p["word_embedding"].copy()
+    O.train_step(p, st, params, src, tgt, z, 0.9)
+    m.train_step(src, tgt, z)
+    got = m.get_variables(with_slots=True)
+    assert np.array_equal(got["word_embedding"][40:], before[40:])
+    assert np.all(got["word_embedding/Adagrad"][40:] == np.float32(0.1))
+    for name, w in p.items():
+        assert np.abs(got[name].reshape(w.shape) - w).max() < 5e-4, name
+
+
+def test_session_run_train_contract_and_lr_decay():
+    import sse_amd
+    params = model_params("shared-encoder", 80, 16, 32, 32, 24, 6, lr=0.9)
+    m, p = make_pair(params)
+    sess = sse_amd.Session(m)
+    rng = np.random.RandomState(0)
+    src, tgt, z = _batch(rng, 8, 6, 80)
+    d = m.get_train_feed_dict(src.tolist(), tgt.tolist(), z.tolist())
+    _, summary, step_loss, step_acc = sess.run([m.train, m.add_summaries(), m.loss, m.train_acc], feed_dict=d)
+    want_loss, want_acc = O.train_step(p, O.new_optimizer_state(p), params, src, tgt, z, 0.9)
+    assert step_loss == pytest.approx(float(want_loss), rel=1e-5)
+    assert m.global_step.eval() == 1 and m.learning_rate.eval() == pytest.approx(0.9)
+    sess.run(m.learning_rate_decay_op)
+    assert m.learning_rate.eval() == pytest.approx(float(O.decayed_learning_rate(0.9, 0.99)))
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    import sse_amd
+    params = model_params("dual-encoder", 60, 8, 32, 32, 16, 4)
+    m, p = make_pair(params)
+    rng = np.random.RandomState(0)
+    src, tgt, z = _batch(rng, 4, 4, 60)
+    m.train_step(src, tgt, z)
+    path = m.save(None, str(tmp_path / "SSE-LSTM.ckpt-BestEver"))
+    assert sse_amd.get_checkpoint_state(str(tmp_path)) == path
+    m2 = sse_amd.SSEModel(params)
+    m2.saver.restore(None, path)
+    a, b = m.get_variables(with_slots=True), m2.get_variables(with_slots=True)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert m2.handle.global_step == 1
+    ids = random_ids(rng, 3, 4, 60)
+    assert np.array_equal(m.encode_target(ids), m2.encode_target(ids))
