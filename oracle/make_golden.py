@@ -75,6 +75,10 @@ def golden_prep(data_utils, ref, task, vocab_size, max_seq_length, n_sample):
             encoder, train, evalc, full_tgt, id_name = data_utils.prepare_raw_data(
                 os.path.join(ref, "rawdata-" + task), work, vocab_size, max_seq_length)
         vocab = open(os.path.join(work, "vocabulary.txt"), encoding="utf-8").read()
+        token_counts = None
+        if task == "qna":      # small enough to pin the vocabulary BUILD as well (data_utils.py:178-179)
+            import tokenizer
+            token_counts = dict(tokenizer.corpus_token_counts(work + "/*.Corpus", 1000000, split_on_newlines=True))
         pairs = [l.rstrip("\n") for l in open(os.path.join(work, "TrainPairs"), encoding="utf-8")]
         targets = [l.rstrip("\n") for l in open(os.path.join(work, "targetIDs"), encoding="utf-8")]
     rng = np.random.RandomState(7)
@@ -92,10 +96,33 @@ def golden_prep(data_utils, ref, task, vocab_size, max_seq_length, n_sample):
     for i in pick_t:
         seq, tid = targets[i].strip().split("\t")
         tgt_cases.append({"text": seq, "id": tid, "padded": full_tgt[tid]})
+    if task == "crosslingual":
+        # real-data parity fixture: token-id rows of 600 eval sources and a
+        # slice of the index = all their positives + 1500 other targets
+        pick = sorted(rng.choice(len(evalc), size=600, replace=False).tolist())
+        need = []
+        for i in pick:
+            for t in evalc[i][1]:
+                if t not in need:
+                    need.append(t)
+        others = [t for t in full_tgt if t not in set(need)]
+        extra = [others[j] for j in rng.choice(len(others), size=1500, replace=False)]
+        tids = need + extra
+        order = rng.permutation(len(tids))
+        tids = [tids[j] for j in order]
+        row_of = {t: r for r, t in enumerate(tids)}
+        lab = np.full((600, 8), -1, np.int32)
+        for r, i in enumerate(pick):
+            rows = [row_of[t] for t in evalc[i][1]][:8]
+            lab[r, :len(rows)] = rows
+        np.savez_compressed(os.path.join(OUT, "crosslingual_ids.npz"),
+                            src_ids=np.array([evalc[i][0] for i in pick], np.int32),
+                            tgt_ids=np.array([full_tgt[t] for t in tids], np.int32), labels=lab,
+                            vocab_size=np.int32(encoder.vocab_size))
     out = {"task": task, "vocab_size_flag": vocab_size, "max_seq_length": max_seq_length,
            "encoder_vocab_size": encoder.vocab_size, "n_train": len(train), "n_eval": len(evalc),
            "n_targets": len(full_tgt), "vocabulary_txt": vocab, "src_cases": src_cases, "tgt_cases": tgt_cases,
-           "train_head": [[t, ids] for t, ids in train[:5]]}
+           "train_head": [[t, ids] for t, ids in train[:5]], "token_counts": token_counts}
     with open(os.path.join(OUT, "prep_%s.json" % task), "w", encoding="utf-8") as f:
         json.dump(out, f, ensure_ascii=False)
     print("prep_%s: vocab %d, %d train, %d targets" % (task, encoder.vocab_size, len(train), len(full_tgt)))

@@ -1,0 +1,77 @@
+"""Top-n evaluation against the target index (reference `sse_evaluator.py:61-114`,
+`data_utils.py:263-304`).  The index is uploaded to the GPU once; per batch of
+600 sources the encoder output is scored with the fused cosine top-k kernel
+instead of np.dot + a full argsort.  The reported numbers keep the reference's
+definition: "tight" accuracy per batch, batch accuracies averaged UNWEIGHTED,
+for n in (1, 3, 10).  Unlike the reference, sources are encoded and ranked
+once, not once per n -- the numbers are identical."""
+import codecs
+import math
+
+import numpy as np
+
+
+def load_index_file(path):
+    """Parse targetEncodingIndex.tsv as Evaluator.__init__ does (sse_evaluator.py:80-92):
+    lines without exactly 3 fields are skipped; float() per component -> float64."""
+    ids, names, enc, id_map = [], [], [], {}
+    for line in codecs.open(path, "r", "utf-8").readlines():
+        info = line.strip().split("\t")
+        if len(info) != 3:
+            print("Error in targetIndexFile! %s" % line)
+            continue
+        id_map[info[0]] = len(ids)
+        ids.append(info[0])
+        names.append(info[1])
+        enc.append([float(f) for f in info[2].strip().split(",")])
+    return ids, names, np.array(enc), id_map
+
+
+def topk_tight_accuracy(topk, labels, ranked_idx):
+    """computeTopK_TightVersion_accuracy (data_utils.py:270-286)."""
+    assert len(labels) == len(ranked_idx)
+    k = min(topk, ranked_idx.shape[1])
+    total = 0.0
+    for i in range(ranked_idx.shape[0]):
+        head = ranked_idx[i][:k]
+        total += sum(1.0 for lab in labels[i] if lab in head) / len(labels[i])
+    return total / float(ranked_idx.shape[0])
+
+
+def topk_accuracy(topk, labels, ranked_idx):
+    """computeTopK_accuracy (data_utils.py:289-304)."""
+    assert len(labels) == len(ranked_idx)
+    k = min(topk, ranked_idx.shape[1])
+    hit = sum(1.0 for i in range(ranked_idx.shape[0]) if any(lab in ranked_idx[i][:k] for lab in labels[i]))
+    return hit / float(ranked_idx.shape[0])
+
+
+class Evaluator(object):
+    def __init__(self, model, eval_corpus, tgtIndexFile, session):
+        self.model = model
+        self.session = session
+        self.srcSeq_batch = [entry[0] for entry in eval_corpus]
+        self.targetIDs, _, self.targetEncodings, self.idLabelMap = load_index_file(tgtIndexFile)
+        self.eval_Labels = [[self.idLabelMap[t] for t in entry[1]] for entry in eval_corpus]
+        model.handle.index_upload(self.targetEncodings)         # float64 rows, resident on the GPU
+
+    def ranked(self, k=10, batch=600):
+        """Top-k row indices per eval source, in batches of 600 (sse_evaluator.py:104-111)."""
+        k = min(k, len(self.targetIDs))
+        out = []
+        for b in range(int(math.ceil(len(self.srcSeq_batch) / float(batch)))):
+            feed = self.model.get_source_encoding_feed_dict(self.srcSeq_batch[b * batch:(b + 1) * batch])
+            enc = np.vstack(self.session.run([self.model.norm_src_seq_embedding], feed_dict=feed))
+            _, idx = self.model.handle.score_topk(enc, k)
+            out.append(idx)
+        return out
+
+    def eval(self, top_n=(1, 3, 10), batch=600):
+        self.model.set_forward_only(True)
+        per_batch = self.ranked(max(top_n), batch)
+        acc = []
+        for n in top_n:
+            accs = [topk_tight_accuracy(n, self.eval_Labels[b * batch:(b + 1) * batch], idx)
+                    for b, idx in enumerate(per_batch)]
+            acc.append(np.mean(accs))
+        return acc

@@ -1,0 +1,114 @@
+"""End-to-end drop-in check on the GPU: the sse_train / sse_index / sse_demo
+command lines on a seeded stand-in for the (missing) rawdata-classification set,
+file formats of the reference, and the evaluator numbers against the oracle's
+restatement of Evaluator.eval on identical weights; plus real-data parity on a
+slice of rawdata-crosslingual (token ids produced by the reference's own
+data_utils, tests/golden/crosslingual_ids.npz)."""
+import importlib.util
+import io
+import os
+
+import numpy as np
+import pytest
+
+from oracle import sse_oracle as O
+from tests.util import make_pair, model_params
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _standin(tmp, **kw):
+    spec = importlib.util.spec_from_file_location("standin", os.path.join(ROOT, "tools", "make_standin_dataset.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    raw = os.path.join(tmp, "rawdata-classification")
+    mod.write_tar(mod.generate(**kw), raw)
+    return raw
+
+
+def test_train_index_eval_demo_cli(tmp_path):
+    import sse_amd
+    from sse_amd import sse_data, sse_demo, sse_evaluator, sse_index, sse_train
+    tmp = str(tmp_path)
+    raw = _standin(tmp, n_targets=37, n_train=600, n_eval=90, n_vocab=400, seed=1)
+    mdir = os.path.join(tmp, "models-classification")
+    import logging
+    sse_train.main(["--task_type=classification", "--data_dir=" + raw, "--model_dir=" + mdir, "--max_epoc=1",
+                    "--steps_per_checkpoint=10", "--batch_size=16", "--network_mode=shared-encoder",
+                    "--src_cell_size=128", "--vocab_size=600", "--max_seq_length=24", "--seed=0", "--max_steps=25",
+                    "--learning_rate=0.3"])
+    logging.getLogger("").handlers.clear()
+    for name in ("vocabulary.txt", "modelConfig.param", "compressed", "encoded.FullTargetSpace",
+                 "targetEncodingIndex.tsv", "TrainingLog.txt", "checkpoint", "SSE-LSTM.ckpt-BestEver.npz",
+                 "SSE-LSTM.ckpt-epoch-0.npz"):
+        assert os.path.exists(os.path.join(mdir, name)), name
+    log = open(os.path.join(mdir, "TrainingLog.txt")).read()
+    assert "train_binary_acc" in log and "top 1/3/10 accuracies" in log
+
+    # the trained model, reloaded the way sse_index / sse_demo do
+    cfg = sse_data.load_model_configs(mdir)
+    model = sse_amd.SSEModel(cfg)
+    model.saver.restore(None, sse_amd.get_checkpoint_state(mdir))
+    p = model.get_variables()
+    ocfg = dict(cfg, vocab_size=int(cfg["vocab_size"]), embedding_size=int(cfg["embedding_size"]),
+                encoding_size=int(cfg["encoding_size"]), src_cell_size=int(cfg["src_cell_size"]),
+                tgt_cell_size=int(cfg["tgt_cell_size"]))
+
+    # sse_index CLI rewrites the index from the checkpoint; rows == oracle encodings of the padded targets
+    sse_index.main(["--idx_model_dir=" + mdir])
+    lines = open(os.path.join(mdir, "targetEncodingIndex.tsv"), encoding="utf-8").readlines()
+    ids, sents, enc = O.parse_index_lines(lines)
+    assert len(ids) == 37 and enc.shape == (37, int(cfg["encoding_size"]))
+    data = sse_data.Data(mdir, raw, 600, 24, log=lambda *a: None)
+    tgt_rows = np.array([data.encodedFullTargetSpace[t] for t in ids], np.int32)
+    want = O.encode(p, ocfg, "tgt", tgt_rows)
+    assert np.abs(enc - want).max() < 1e-4
+    assert lines[0].split("\t")[1] == open(os.path.join(mdir, "targetIDs"), encoding="utf-8").readline().split("\t")[0]
+
+    # Evaluator numbers == the oracle's restatement of sse_evaluator.py:95-114 on the same index file
+    ev = sse_evaluator.Evaluator(model, data.rawEvalCorpus, os.path.join(mdir, "targetEncodingIndex.tsv"),
+                                 sse_amd.Session(model))
+    got = ev.eval()
+    src_rows = np.array([e[0] for e in data.rawEvalCorpus], np.int32)
+    src_enc = O.encode(p, ocfg, "src", src_rows)
+    labels = [[ids.index(t) for t in e[1]] for e in data.rawEvalCorpus]
+    want_acc = O.evaluator_accuracy(src_enc, enc, labels)
+    assert got == pytest.approx(want_acc, abs=1e-12)
+
+    # sse_demo: un-normalised source encoding x index, top-N printed (sse_demo.py:121-134)
+    out = io.StringIO()
+    f = sse_demo.FLAGS.parse(["--model_dir=" + mdir])
+    query = open(os.path.join(mdir, "EvalPairs"), encoding="utf-8").readline().split("\t")[0]
+    sse_demo.demo(f, 5, stdin=io.StringIO(query + "\nexit\n"), out=out)
+    text = out.getvalue()
+    assert "Top 5 Prediction results are:" in text and text.count("top") >= 5
+    q_ids = np.array([sse_amd.sse_text.pad_tokens(data.encoder.encode(query.lower()), 24)], np.int32)
+    raw_enc = O.encode(p, ocfg, "src", q_ids, normalize=False)
+    wsc, wids = O.topk(O.scores_f64(raw_enc, enc), 5)
+    assert ("top1:  %s , %f" % (ids[wids[0][0]], wsc[0][0])) in text
+
+
+def test_crosslingual_real_data_slice_matches_oracle():
+    """SURVEY 8d C3 on real token ids: encode 4868 targets (index) and 600 queries with
+    the dual-encoder H=S=256 T=50 model, score, rank: cosine |d| <= 1e-4, top-10 ids and
+    the top-1/3/10 accuracies identical to the oracle."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "crosslingual_ids.npz"))
+    V = int(z["vocab_size"])
+    params = model_params("dual-encoder", V, 50, 256, 256, 256, 50)
+    m, p = make_pair(params, seed=8)
+    tgt = m.encode_target(z["tgt_ids"])
+    src = m.encode_source(z["src_ids"])
+    want_t = O.encode(p, params, "tgt", z["tgt_ids"][:256])
+    want_s = O.encode(p, params, "src", z["src_ids"][:256])
+    assert np.abs(tgt[:256] - want_t).max() < 1e-4 and np.abs(src[:256] - want_s).max() < 1e-4
+    # index hand-off through decimal text, as the reference does (sse_index.py:93-95 -> sse_evaluator.py:87)
+    _, _, idx64 = O.parse_index_lines([O.format_index_line("t%d" % i, "x", v) for i, v in enumerate(tgt)])
+    m.handle.index_upload(idx64)
+    sc, ids = m.handle.score_topk(src, 10)
+    wsc, wids = O.topk(O.scores_f64(src, idx64), 10)
+    assert np.array_equal(ids, wids) and np.abs(sc - wsc).max() < 1e-12
+    labels = [[int(v) for v in row if v >= 0] for row in z["labels"]]
+    from sse_amd import sse_evaluator
+    for n in (1, 3, 10):
+        assert sse_evaluator.topk_tight_accuracy(n, labels, ids) == O.topk_tight_accuracy(n, labels, wids)
