@@ -227,24 +227,13 @@ def main():
         noise = torch.randn((Q, S), generator=gq, device=dev)
         mine = torch.arange(Q, device=dev)[torch.arange(Q, device=dev) % world == rank]
         shard[mine] = torch.nn.functional.normalize(q[mine] + 0.1 * noise[mine], dim=1)   # planted: query j -> shard j%world, row j
-        h.index_set_dev(shard.data_ptr(), Ns, S, id_base=rank * Ns)
+        sharded = sse_amd.ShardedIndex(h, rank, world, Ns * world)
+        sharded.set_local_rows(shard)
         del shard
-        ls = torch.empty((Q, k), dtype=torch.float64, device=dev)
-        li = torch.empty((Q, k), dtype=torch.int64, device=dev)
-        gs = torch.empty((world, Q, k), dtype=torch.float64, device=dev)
-        gi = torch.empty((world, Q, k), dtype=torch.int64, device=dev)
-        fs = torch.empty((Q, k), dtype=torch.float64, device=dev)
-        fi = torch.empty((Q, k), dtype=torch.int64, device=dev)
+        state = {}
 
         def score_step():
-            h.score_topk_dev(q.data_ptr(), Q, k, ls.data_ptr(), li.data_ptr())
-            if world > 1:
-                dist.all_gather_into_tensor(gs, ls)
-                dist.all_gather_into_tensor(gi, li)
-                h.merge_topk_dev(gs.data_ptr(), gi.data_ptr(), world, Q, k, fs.data_ptr(), fi.data_ptr())
-            else:
-                fs.copy_(ls)
-                fi.copy_(li)
+            state["s"], state["i"] = sharded.score_topk(q, k)
 
         score_step()
         barrier()
@@ -258,7 +247,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             sdt = float(t.item())
         jj = torch.arange(Q, device=dev)
-        planted_ok = float((fi[:, 0] == (jj % world) * Ns + jj).double().mean().item())
+        planted_ok = float((state["i"][:, 0] == (jj % world) * Ns + jj).double().mean().item())
         scoring = {"scores_per_s": Q * Ns * world / sdt, "ms_per_pass": sdt * 1e3, "queries": Q,
                    "index_rows_total": Ns * world, "index_rows_per_gpu": Ns, "S": S, "k": k,
                    "collective": "rccl all_gather of per-shard top-k + k-way merge" if world > 1 else "none (1 shard)",

@@ -1,0 +1,77 @@
+"""Row-sharded target index over the GPUs of one node (BASELINE
+configs[3]): rank g holds rows [g*N/P, (g+1)*N/P), queries are replicated, every
+rank computes its shard's top-k with GLOBAL row ids, one all-gather (RCCL over
+xGMI when the process group is `nccl`) exchanges the [Q,k] (float64 score,
+int64 id) lists -- 16*Q*k bytes per rank -- and a k-way merge with the same
+order rule (score desc, row id asc) yields exactly the unsharded result.
+
+The reference has no distributed code at all; this is the one real exchange
+step of the hot path.  torch / torch.distributed are plumbing only.
+"""
+
+
+def shard_bounds(n_rows, world):
+    """Contiguous, balanced row ranges: [(start, end)] * world; sizes differ by <= 1."""
+    base, extra = divmod(int(n_rows), int(world))
+    out, start = [], 0
+    for r in range(world):
+        size = base + (1 if r < extra else 0)
+        out.append((start, start + size))
+        start += size
+    return out
+
+
+def all_gather_topk(local_scores, local_ids, group=None):
+    """All-gather the per-shard lists.  local_* are [Q,k] tensors (CUDA with the
+    nccl backend, CPU with gloo); returns ([P,Q,k] scores, [P,Q,k] ids), shard-major."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    gs = torch.empty((world,) + tuple(local_scores.shape), dtype=local_scores.dtype, device=local_scores.device)
+    gi = torch.empty((world,) + tuple(local_ids.shape), dtype=local_ids.dtype, device=local_ids.device)
+    if world == 1:
+        gs[0].copy_(local_scores)
+        gi[0].copy_(local_ids)
+        return gs, gi
+    if local_scores.is_cuda:
+        dist.all_gather_into_tensor(gs, local_scores.contiguous(), group=group)
+        dist.all_gather_into_tensor(gi, local_ids.contiguous(), group=group)
+    else:                                   # gloo: list form
+        dist.all_gather(list(gs.unbind(0)), local_scores.contiguous(), group=group)
+        dist.all_gather(list(gi.unbind(0)), local_ids.contiguous(), group=group)
+    return gs, gi
+
+
+class ShardedIndex(object):
+    """One rank's view of the sharded index.  `handle` is an sse_amd Handle."""
+
+    def __init__(self, handle, rank, world, n_total, group=None):
+        self.handle, self.rank, self.world, self.group = handle, int(rank), int(world), group
+        self.n_total = int(n_total)
+        self.start, self.end = shard_bounds(n_total, world)[rank]
+
+    def set_local_rows(self, rows):
+        """rows: CUDA float32 tensor [end-start, S] -- this rank's shard, already on its GPU."""
+        if rows.shape[0] != self.end - self.start:
+            raise ValueError("shard of rank %d must have %d rows, got %d" % (self.rank, self.end - self.start, rows.shape[0]))
+        self.handle.index_set_dev(rows.data_ptr(), rows.shape[0], rows.shape[1], id_base=self.start)
+
+    def score_topk(self, queries, k):
+        """queries: CUDA float32 [Q,S] (identical on every rank).  Returns the global
+        top-k (scores float64 [Q,k], row ids int64 [Q,k]) on every rank."""
+        import torch
+        Q = queries.shape[0]
+        ls = torch.empty((Q, k), dtype=torch.float64, device=queries.device)
+        li = torch.empty((Q, k), dtype=torch.int64, device=queries.device)
+        self.handle.score_topk_dev(queries.data_ptr(), Q, k, ls.data_ptr(), li.data_ptr())
+        if self.world == 1:
+            return ls, li
+        gs, gi = all_gather_topk(ls, li, self.group)
+        fs, fi = torch.empty_like(ls), torch.empty_like(li)
+        self.handle.merge_topk_dev(gs.data_ptr(), gi.data_ptr(), self.world, Q, k, fs.data_ptr(), fi.data_ptr())
+        return fs, fi
+
+
+def split_rows(n_rows, rank, world):
+    """Independent units (sequences to encode): the slice of [0, n_rows) rank handles; no collective."""
+    return shard_bounds(n_rows, world)[rank]
