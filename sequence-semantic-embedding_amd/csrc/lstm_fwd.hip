@@ -6,35 +6,106 @@
 // :245/:254/:267/:275 (projection) and :282-283 (l2_normalize).
 //
 // Design (DESIGN.md "K2"): one 512-thread workgroup owns 64 sequences for all
-// T steps.  h lives in LDS in MFMA A-fragment order, c in registers, the
-// per-step gate GEMM [64,(Ep+Hp)] x [(Ep+Hp),4Hp] runs on
-// v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF chip peak).  The kernel matrix is
-// pre-packed so every B operand is one coalesced 1 KiB wave load from L2; the
-// gate non-linearities are applied straight on the accumulators.
-// Wave w: wn = w & 3 picks the hidden-unit range, wm = w >> 2 the 32-row half
-// (waves w and w+4 share a SIMD and the same weights -> L1 reuse).
+// T steps.  h lives in LDS in MFMA A-fragment order (double-buffered: one
+// barrier per step), c in registers, the per-step gate GEMM
+// [64,(Ep+Hp)] x [(Ep+Hp),4Hp] runs on v_mfma_f32_32x32x2_f32 (exact fp32,
+// 157 TF chip peak).  The kernel matrix is pre-packed so every B operand is one
+// coalesced 1 KiB wave load from L2; gate non-linearities are applied straight
+// on the accumulators.
+//
+// Wave decomposition (template MT = M-tiles per wave):
+//   MT = 2 (Hp = 256): wave w owns hidden units [32w, 32w+32) for ALL 64 rows --
+//       every weight tile is loaded by exactly one wave per CU and feeds two
+//       MFMAs (both row halves): 16 MFMAs per (2 global loads + 2 LDS reads).
+//   MT = 1 (Hp = 128): wave w: units [32(w&3), +32), row half w>>2.
+// Per unit block the four gates are computed in two passes (i,j then f,o) so
+// that only 2*MT accumulators are live.
 #include "sse_kernels.h"
 
 #define LSTM_THREADS 512
 #define LSTM_BM 64
 
+// LDS: xbuf[XD ? 2 : 1][2 mt][KGx][256] + hbuf[2 bufs][2 mt][KGh][256] + red[64][4].
+// h is double-buffered (step t reads buffer t&1, writes (t+1)&1: one barrier per
+// step); x is double-buffered too when it fits in the 160 KiB (XD).
+bool lstm_fwd_x_double(int KGx, int KGh) { return (size_t)(4 * KGx + 4 * KGh + 1) * 1024 <= 160 * 1024; }
 size_t lstm_fwd_lds_bytes(int KGx, int KGh) {
-  // xbuf[2 bufs][2 mt][KGx][256] + hbuf[2 mt][KGh][256] + red[64][4]
-  return (size_t)(2 * 2 * KGx + 2 * KGh) * 256 * sizeof(float) + 64 * 4 * sizeof(float);
+  const int xb = lstm_fwd_x_double(KGx, KGh) ? 2 : 1;
+  return (size_t)(xb * 2 * KGx + 4 * KGh) * 256 * sizeof(float) + 64 * 4 * sizeof(float);
 }
 
-__device__ __forceinline__ float fast_sigmoid(float x) { return __fdividef(1.0f, 1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - __fdividef(2.0f, 1.0f + __expf(2.0f * x)); }
+// v_exp_f32 (2^x) + v_rcp_f32 (1 ulp); plain `/` or __fdividef would expand to the ~10-instruction IEEE division
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504089f * x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008178f * x)); }
 
-template <int UB, bool TRAIN>
+// One GEMM pass of a wave: two gate tiles (B operands at wp and wp+256 floats, k-group
+// stride 1024 floats) times MT row tiles, over k-groups [0, kend).  A fragments come from
+// the x tile (kg < KGx) or the h tile.  Hand software-pipelined with two named operand
+// sets (no register copies): the operands of k-group kg+1 are in flight while kg's
+// 8*MT MFMAs issue.
+template <int MT>
+__device__ __forceinline__ void gemm_pass(const float *__restrict__ wp, const float *const (&xa)[MT],
+                                          const float *const (&ha)[MT], int KGx, int kend, f32x16 (&acc)[MT][2]) {
+  auto a_frag = [&](int m, int kg) -> f32x4 {
+    return *reinterpret_cast<const f32x4 *>(kg < KGx ? xa[m] + kg * 256 : ha[m] + (kg - KGx) * 256);
+  };
+  f32x4 p0 = *reinterpret_cast<const f32x4 *>(wp), p1 = *reinterpret_cast<const f32x4 *>(wp + 256);
+  f32x4 q0, q1, a0[MT], a1[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) a0[m] = a_frag(m, 0);
+  int kg = 0;
+  for (; kg + 1 < kend; kg += 2) {
+    q0 = *reinterpret_cast<const f32x4 *>(wp + (size_t)(kg + 1) * 1024);
+    q1 = *reinterpret_cast<const f32x4 *>(wp + (size_t)(kg + 1) * 1024 + 256);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a1[m] = a_frag(m, kg + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][e], p0[e], acc[m][0], 0, 0, 0);
+        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][e], p1[e], acc[m][1], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    const int k2 = (kg + 2 < kend) ? kg + 2 : kg;  // clamped: harmless reload on the last pair
+    p0 = *reinterpret_cast<const f32x4 *>(wp + (size_t)k2 * 1024);
+    p1 = *reinterpret_cast<const f32x4 *>(wp + (size_t)k2 * 1024 + 256);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a0[m] = a_frag(m, k2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m][e], q0[e], acc[m][0], 0, 0, 0);
+        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m][e], q1[e], acc[m][1], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (kg < kend) {  // odd k-group count: operands of the last group are already loaded
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][e], p0[e], acc[m][0], 0, 0, 0);
+        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][e], p1[e], acc[m][1], 0, 0, 0);
+      }
+  }
+}
+
+template <int MT, bool TRAIN>
 __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wn = w & 3, wm = w >> 2;
+  // unit block owned by this wave, and its first row tile
+  const int ub = (MT == 2) ? w : (w & 3);
+  const int mt0 = (MT == 2) ? 0 : (w >> 2);
   const int KGx = a.KGx, KGh = a.KGh, KG = KGx + KGh, T = a.T;
-  float *xbuf = smem;                      // [2][2][KGx][256]
-  float *hbuf = smem + 4 * KGx * 256;      // [2][KGh][256]
-  float *red = hbuf + 2 * KGh * 256;       // [64][4]
+  const int XD = a.xdouble;                            // x tile double-buffered?
+  float *xbuf = smem;                                  // [XD ? 2 : 1][2][KGx][256]
+  float *hbuf0 = smem + (XD ? 4 : 2) * KGx * 256;      // [2 bufs][2][KGh][256]
+  float *red = hbuf0 + 4 * KGh * 256;                  // [64][4]
   const int b0 = blockIdx.x * LSTM_BM;
 
   // --- x gather assignment: 8 threads per sequence row, 8 floats (one k-group) each
@@ -50,12 +121,12 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
     return id;
   };
   auto x_store = [&](int buf, int kg, f32x4 lo, f32x4 hi) {
-    float *dst = xbuf + ((size_t)((buf * 2 + (xr >> 5)) * KGx + kg)) * 256;
+    float *dst = xbuf + ((size_t)(((XD ? buf : 0) * 2 + (xr >> 5)) * KGx + kg)) * 256;
     *reinterpret_cast<f32x4 *>(dst + (xr & 31) * 4) = lo;         // k%8 in 0..3 -> lane half 0
     *reinterpret_cast<f32x4 *>(dst + (32 + (xr & 31)) * 4) = hi;  // k%8 in 4..7 -> lane half 1
   };
 
-  // --- prologue: x_0 -> xbuf[0], h_0 = 0
+  // --- prologue: x_0 -> x buffer 0, h_0 = 0
   {
     const int id = fetch_id(0);
     const float *src = a.emb + (size_t)id * a.Ep;
@@ -64,29 +135,30 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       f32x4 hi = *reinterpret_cast<const f32x4 *>(src + kg * 8 + 4);
       x_store(0, kg, lo, hi);
     }
-    for (int i = tid; i < 2 * KGh * 64; i += LSTM_THREADS) reinterpret_cast<f32x4 *>(hbuf)[i] = f32x4{0, 0, 0, 0};
+    for (int i = tid; i < 2 * KGh * 64; i += LSTM_THREADS) reinterpret_cast<f32x4 *>(hbuf0)[i] = f32x4{0, 0, 0, 0};
   }
 
-  float bias[UB][4];
+  float bias[4];
 #pragma unroll
-  for (int u = 0; u < UB; ++u)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bias[u][g] = a.bias[((wn * UB + u) * 4 + g) * 32 + (lane & 31)];
+  for (int g = 0; g < 4; ++g) bias[g] = a.bias[(ub * 4 + g) * 32 + (lane & 31)];
 
-  f32x16 c[UB];
+  f32x16 c[MT];
 #pragma unroll
-  for (int u = 0; u < UB; ++u)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) c[u][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) c[m][r] = 0.0f;
 
   __syncthreads();
 
-  // weights of this wave: Wp[wn][u][kg][gate][256]
-  const float *wbase = a.Wp + (size_t)wn * UB * KG * 1024 + lane * 4;
+  // weights of this wave's unit block: Wp[ub][kg][gate][256]
+  const float *wp = a.Wp + (size_t)ub * KG * 1024 + lane * 4;
+  const int unit = ub * 32 + (lane & 31);
+  const int hoff = (unit >> 3) * 256 + ((((unit >> 2) & 1) * 32) << 2) + (unit & 3);  // h element (row 0, k = unit) in a row tile
+  const int NT32 = gridDim.x * 2;
 
   for (int t = 0; t < T; ++t) {
     // prefetch the embedding rows of step t+1 into registers (one k-group per
-    // thread covers E <= 64; wider embeddings loop below after the GEMM)
+    // thread covers E <= 64; wider embeddings are completed after the GEMM)
     const bool have_next = (t + 1) < T;
     int nid = 0;
     f32x4 nlo = {0, 0, 0, 0}, nhi = {0, 0, 0, 0};
@@ -99,114 +171,138 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       }
     }
 
-    const float *xa = xbuf + (size_t)(((t & 1) * 2 + wm) * KGx) * 256 + lane * 4;
-    const float *ha = hbuf + (size_t)(wm * KGh) * 256 + lane * 4;
+    const float *hbuf = hbuf0 + (size_t)(t & 1) * 2 * KGh * 256;   // h_{t-1}
+    float *hnext = hbuf0 + (size_t)((t + 1) & 1) * 2 * KGh * 256;  // h_t goes here
+    const float *xcur = xbuf + (size_t)((XD ? (t & 1) : 0) * 2 * KGx) * 256;
+    const float *xa[MT], *ha[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      xa[m] = xcur + (size_t)((mt0 + m) * KGx) * 256 + lane * 4;
+      ha[m] = hbuf + (size_t)((mt0 + m) * KGh) * 256 + lane * 4;
+    }
 
     if constexpr (TRAIN) {
       // A-tape for the weight-gradient GEMM: [x_t | h_{t-1}] of this tile, stored as
       // frag32 blocks with rows = k' (x: 0..63, h: 64 + unit) and reduction index
       // r = (t*NT32 + tile32)*32 + b, i.e. AT[(r/8)*KT + k'/32][256].
       const int KT = 2 + KGh / 4;
-      const int nf4 = (64 + KGh * 8) * 16;  // float4s per step: k' count x 16 groups of 4 rows
-      for (int i = tid; i < nf4; i += LSTM_THREADS) {
-        const int kp = i % (64 + KGh * 8), b4 = i / (64 + KGh * 8);  // b4: rows 4*b4 .. 4*b4+3 of the 64
+      const int nk = 64 + KGh * 8;
+      for (int i = tid; i < nk * 16; i += LSTM_THREADS) {
+        const int kp = i % nk, b4 = i / nk;  // b4: rows 4*b4 .. 4*b4+3 of the 64
         const int mt = b4 >> 3, bl = (b4 & 7) * 4;
         f32x4 v = {0, 0, 0, 0};
         if (kp >= 64) {
-          const int unit = kp - 64;
-          const float *src = hbuf + (size_t)(mt * KGh + (unit >> 3)) * 256 + ((((unit >> 2) & 1) * 32 + bl) << 2) + (unit & 3);
+          const int un = kp - 64;
+          const float *src = hbuf + (size_t)(mt * KGh + (un >> 3)) * 256 + ((((un >> 2) & 1) * 32 + bl) << 2) + (un & 3);
           v = f32x4{src[0], src[4], src[8], src[12]};
         } else if (kp < KGx * 8) {
-          const float *src = xbuf + (size_t)(((t & 1) * 2 + mt) * KGx + (kp >> 3)) * 256 + ((((kp >> 2) & 1) * 32 + bl) << 2) + (kp & 3);
+          const float *src = xcur + (size_t)(mt * KGx + (kp >> 3)) * 256 + ((((kp >> 2) & 1) * 32 + bl) << 2) + (kp & 3);
           v = f32x4{src[0], src[4], src[8], src[12]};
         }
-        const size_t rg = ((size_t)t * (gridDim.x * 2) + blockIdx.x * 2 + mt) * 4 + (bl >> 3);
+        const size_t rg = ((size_t)t * NT32 + blockIdx.x * 2 + mt) * 4 + (bl >> 3);
         float *dst = a.tape_a + (rg * KT + (kp >> 5)) * 256 + ((((bl >> 2) & 1) * 32 + (kp & 31)) << 2);
         *reinterpret_cast<f32x4 *>(dst) = v;
       }
     }
     const int kend = (t == 0) ? KGx : KG;  // h_0 = 0: skip the recurrent part of step 0
 
-    f32x16 hnew[UB];
+    // gate tape, accumulator layout: [t][tile32][unit block][q][reg][lane], q = si,tj,sf,so,c
+    float *tp[MT];
+    if constexpr (TRAIN) {
 #pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      f32x16 acc[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][r] = bias[u][g];
+      for (int m = 0; m < MT; ++m)
+        tp[m] = a.tape_g + (((size_t)t * NT32 + blockIdx.x * 2 + mt0 + m) * (KGh / 4) + ub) * 5 * 1024 + lane;
+    }
 
-      const float *wp = wbase + (size_t)u * KG * 1024;
-      f32x4 bcur[4], bnxt[4];
+    // pass A: gates i, j  ->  pij = sigmoid(i) * tanh(j)      (BasicLSTMCell, TF 1.x)
+    f32x16 g[MT][2], pij[MT];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) bcur[g] = *reinterpret_cast<const f32x4 *>(wp + g * 256);
-      for (int kg = 0; kg < kend; ++kg) {
-        const int kn = (kg + 1 < kend) ? kg + 1 : kg;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bnxt[g] = *reinterpret_cast<const f32x4 *>(wp + (size_t)kn * 1024 + g * 256);
-        const f32x4 a4 = *reinterpret_cast<const f32x4 *>(kg < KGx ? xa + kg * 256 : ha + (kg - KGx) * 256);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], bcur[g][e], acc[g], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bcur[g] = bnxt[g];
-      }
-      // gates: acc[0]=i acc[1]=j acc[2]=f(+1 folded) acc[3]=o   (BasicLSTMCell, TF 1.x)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float si = fast_sigmoid(acc[0][r]);
-        const float tj = fast_tanh(acc[1][r]);
-        const float sf = fast_sigmoid(acc[2][r]);
-        const float so = fast_sigmoid(acc[3][r]);
-        const float cn = c[u][r] * sf + si * tj;
-        c[u][r] = cn;
-        hnew[u][r] = fast_tanh(cn) * so;
+        g[m][0][r] = bias[0];
+        g[m][1][r] = bias[1];
+      }
+    gemm_pass<MT>(wp, xa, ha, KGx, kend, g);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float si = fast_sigmoid(g[m][0][r]);
+        const float tj = fast_tanh(g[m][1][r]);
+        pij[m][r] = si * tj;
         if constexpr (TRAIN) {
-          // gate tape in accumulator layout: [t][tile32][wn][u][q][reg][lane], q = si,tj,sf,so,c
-          float *tp = a.tape_g + ((((size_t)t * (gridDim.x * 2) + blockIdx.x * 2 + wm) * 4 + wn) * UB + u) * 5 * 1024 + r * 64 + lane;
-          tp[0] = si;
-          tp[1024] = tj;
-          tp[2048] = sf;
-          tp[3072] = so;
-          tp[4096] = cn;
+          tp[m][r * 64] = si;
+          tp[m][1024 + r * 64] = tj;
+        }
+      }
+    // pass B: gates f (+1 folded into the bias), o -> c' = c*sigmoid(f) + pij ; h' = tanh(c')*sigmoid(o)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        g[m][0][r] = bias[2];
+        g[m][1][r] = bias[3];
+      }
+    gemm_pass<MT>(wp + 512, xa, ha, KGx, kend, g);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float *hdst = hnext + (size_t)((mt0 + m) * KGh) * 256 + hoff;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float sf = fast_sigmoid(g[m][0][r]);
+        const float so = fast_sigmoid(g[m][1][r]);
+        const float cn = c[m][r] * sf + pij[m][r];
+        c[m][r] = cn;
+        hdst[mfma_row(r, lane) << 2] = fast_tanh(cn) * so;  // h_t -> the other h buffer, A-fragment order
+        if constexpr (TRAIN) {
+          tp[m][2048 + r * 64] = sf;
+          tp[m][3072 + r * 64] = so;
+          tp[m][4096 + r * 64] = cn;
         }
       }
     }
 
-    // stage x_{t+1} (its buffer was last read in step t-1)
-    if (have_next) {
-      if (xq < KGx) x_store((t + 1) & 1, xq, nlo, nhi);
-      for (int kg = xq + 8; kg < KGx; kg += 8) {
-        const float *src = a.emb + (size_t)nid * a.Ep + kg * 8;
-        x_store((t + 1) & 1, kg, *reinterpret_cast<const f32x4 *>(src), *reinterpret_cast<const f32x4 *>(src + 4));
+    // stage x_{t+1}: with a double-buffered x tile its buffer was last read in step
+    // t-1; with a single buffer it must wait until every wave finished step t
+    if (XD) {
+      if (have_next) {
+        if (xq < KGx) x_store((t + 1) & 1, xq, nlo, nhi);
+        for (int kg = xq + 8; kg < KGx; kg += 8) {
+          const float *src = a.emb + (size_t)nid * a.Ep + kg * 8;
+          x_store((t + 1) & 1, kg, *reinterpret_cast<const f32x4 *>(src), *reinterpret_cast<const f32x4 *>(src + 4));
+        }
       }
+      __syncthreads();  // h_t complete and visible; h_{t-1} / x_t no longer needed
+    } else {
+      __syncthreads();
+      if (have_next) {
+        if (xq < KGx) x_store(0, xq, nlo, nhi);
+        for (int kg = xq + 8; kg < KGx; kg += 8) {
+          const float *src = a.emb + (size_t)nid * a.Ep + kg * 8;
+          x_store(0, kg, *reinterpret_cast<const f32x4 *>(src), *reinterpret_cast<const f32x4 *>(src + 4));
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();  // every wave is done reading h_{t-1}
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int unit = (wn * UB + u) * 32 + (lane & 31);
-      float *dst = hbuf + (size_t)(wm * KGh + (unit >> 3)) * 256 + (unit & 3);
-      const int half = (unit >> 2) & 1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dst[(half * 32 + mfma_row(r, lane)) * 4] = hnew[u][r];
-    }
-    __syncthreads();  // h_t visible
   }
+  const float *hbuf = hbuf0 + (size_t)(T & 1) * 2 * KGh * 256;  // h_T
 
   if constexpr (TRAIN) {
     // h_T, row-major [Bp][Hp], for dM = h_T^T . d(out)
     const int Hp = KGh * 8;
     for (int i = tid; i < LSTM_BM * Hp; i += LSTM_THREADS) {
-      const int unit = i % Hp, b = i / Hp;
-      a.h_last[(size_t)(b0 + b) * Hp + unit] =
-          hbuf[(size_t)((b >> 5) * KGh + (unit >> 3)) * 256 + ((((unit >> 2) & 1) * 32 + (b & 31)) << 2) + (unit & 3)];
+      const int un = i % Hp, b = i / Hp;
+      a.h_last[(size_t)(b0 + b) * Hp + un] =
+          hbuf[(size_t)((b >> 5) * KGh + (un >> 3)) * 256 + ((((un >> 2) & 1) * 32 + (b & 31)) << 2) + (un & 3)];
     }
   }
 
-  // --- projection  out = h_T . M   (+ optional l2_normalize), N tiles nt = wn, wn+4, ...
+  // --- projection  out = h_T . M   (+ optional l2_normalize): wave w -> row tile w>>2,
+  // N tiles nt = (w&3), (w&3)+4, ...
+  const int wn = w & 3, wm = w >> 2;
   constexpr int PT = 4;  // up to Sp = 512
-  const float *ha = hbuf + (size_t)(wm * KGh) * 256 + lane * 4;
+  const float *hp = hbuf + (size_t)(wm * KGh) * 256 + lane * 4;
   f32x16 pacc[PT];
   float ss[16];
 #pragma unroll
@@ -219,7 +315,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
     if (nt < a.NTS) {
       const float *mp = a.Mp + (size_t)nt * KGh * 256 + lane * 4;
       for (int kg = 0; kg < KGh; ++kg) {
-        const f32x4 a4 = *reinterpret_cast<const f32x4 *>(ha + kg * 256);
+        const f32x4 a4 = *reinterpret_cast<const f32x4 *>(hp + kg * 256);
         const f32x4 b4 = *reinterpret_cast<const f32x4 *>(mp + kg * 256);
 #pragma unroll
         for (int e = 0; e < 4; ++e) pacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], pacc[i], 0, 0, 0);
@@ -265,19 +361,22 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   }
 }
 
-template <int UB, bool TRAIN>
+template <int MT, bool TRAIN>
 static hipError_t launch_one(const LstmFwdArgs &a, size_t lds, dim3 grid, dim3 block, hipStream_t stream) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_kernel<UB, TRAIN>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_kernel<MT, TRAIN>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((lstm_fwd_kernel<UB, TRAIN>), grid, block, lds, stream, a);
+  hipLaunchKernelGGL((lstm_fwd_kernel<MT, TRAIN>), grid, block, lds, stream, a);
   return hipGetLastError();
 }
 
-hipError_t launch_lstm_fwd(const LstmFwdArgs &a, int Hp, hipStream_t stream) {
+hipError_t launch_lstm_fwd(const LstmFwdArgs &a_in, int Hp, hipStream_t stream) {
+  LstmFwdArgs a = a_in;
+  a.xdouble = lstm_fwd_x_double(a.KGx, a.KGh) ? 1 : 0;
   const size_t lds = lstm_fwd_lds_bytes(a.KGx, a.KGh);
   const dim3 grid((a.B + LSTM_BM - 1) / LSTM_BM), block(LSTM_THREADS);
   const bool train = a.tape_g != nullptr;
+  // Hp = 128: 4 unit blocks x 2 row halves over the 8 waves; Hp = 256: 8 unit blocks, both halves per wave
   if (Hp == 128) return train ? launch_one<1, true>(a, lds, grid, block, stream) : launch_one<1, false>(a, lds, grid, block, stream);
   if (Hp == 256) return train ? launch_one<2, true>(a, lds, grid, block, stream) : launch_one<2, false>(a, lds, grid, block, stream);
   return hipErrorInvalidValue;

@@ -95,24 +95,51 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[na][q][r] = 0.0f;
 
-    f32x4 a0 = *reinterpret_cast<const f32x4 *>(pa);
-    f32x4 a1 = *reinterpret_cast<const f32x4 *>(pb);
-    for (int kg = 0; kg < KG; ++kg) {
-      const int kn = (kg + 1 < KG) ? kg + 1 : kg;
-      const f32x4 n0 = *reinterpret_cast<const f32x4 *>(pa + kn * 256);
-      const f32x4 n1 = *reinterpret_cast<const f32x4 *>(pb + kn * 256);
-      f32x4 b[4];
+    // k-loop, hand software-pipelined with two named operand sets (X / Y): index
+    // fragments of k-group kg+1 (global) and query fragments (LDS) are in flight
+    // while kg's 32 MFMAs issue; no register copies.
+    f32x4 ax0 = *reinterpret_cast<const f32x4 *>(pa), ax1 = *reinterpret_cast<const f32x4 *>(pb);
+    f32x4 bx[4], by[4], ay0, ay1;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG + kg) * 256);
+    for (int q = 0; q < 4; ++q) bx[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG) * 256);
+    int kg = 0;
+    for (; kg + 1 < KG; kg += 2) {
+      ay0 = *reinterpret_cast<const f32x4 *>(pa + (kg + 1) * 256);
+      ay1 = *reinterpret_cast<const f32x4 *>(pb + (kg + 1) * 256);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) by[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG + kg + 1) * 256);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b[q][e], acc[0][q], 0, 0, 0);
-          acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b[q][e], acc[1][q], 0, 0, 0);
+          acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax0[e], bx[q][e], acc[0][q], 0, 0, 0);
+          acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax1[e], bx[q][e], acc[1][q], 0, 0, 0);
         }
-      a0 = n0;
-      a1 = n1;
+      __builtin_amdgcn_sched_barrier(0);
+      const int k2 = (kg + 2 < KG) ? kg + 2 : kg;
+      ax0 = *reinterpret_cast<const f32x4 *>(pa + k2 * 256);
+      ax1 = *reinterpret_cast<const f32x4 *>(pb + k2 * 256);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bx[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG + k2) * 256);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay0[e], by[q][e], acc[0][q], 0, 0, 0);
+          acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay1[e], by[q][e], acc[1][q], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kg < KG) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax0[e], bx[q][e], acc[0][q], 0, 0, 0);
+          acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax1[e], bx[q][e], acc[1][q], 0, 0, 0);
+        }
     }
 
     // fused top-k: lane owns query column (lane & 31) of each q-tile and sees

@@ -40,6 +40,7 @@ struct LstmFwdArgs {
   float *out;           // [B][S]
   int32_t *err;         // bit 0: token id out of range
   int32_t B, T, V, Ep, KGx, KGh, S, NTS, normalize;
+  int32_t xdouble = 1;  // set by launch_lstm_fwd from lstm_fwd_x_double()
   // training only (nullptr for inference): tapes consumed by the backward kernels
   float *tape_g = nullptr;  // [T][NT32][4][UB][5][16][64] gate activations + c, accumulator layout
   float *tape_a = nullptr;  // [(T*NT32*4)][KT][256]  [x_t | h_{t-1}] as frag32(rows = k', red = r)
@@ -47,6 +48,7 @@ struct LstmFwdArgs {
 };
 // Hp = 128 * UB hidden units; 512 threads; dynamic LDS = lstm_fwd_lds_bytes()
 size_t lstm_fwd_lds_bytes(int KGx, int KGh);
+bool lstm_fwd_x_double(int KGx, int KGh);
 hipError_t launch_lstm_fwd(const LstmFwdArgs &a, int Hp, hipStream_t stream);
 
 // ------------------------------ scoring ------------------------------------

@@ -19,8 +19,8 @@
 
 #define BW_THREADS 256
 
-__device__ __forceinline__ float fast_tanh_t(float x) { return 1.0f - __fdividef(2.0f, 1.0f + __expf(2.0f * x)); }
-__device__ __forceinline__ float fast_sigmoid_t(float x) { return __fdividef(1.0f, 1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh_t(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008178f * x)); }
+__device__ __forceinline__ float fast_sigmoid_t(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504089f * x)); }
 
 // ---------------------------------------------------------------------------
 // Loss: one wave per pair row.  sse_model.py:282-283,290,298,302.
@@ -220,20 +220,30 @@ __global__ __launch_bounds__(BW_THREADS) void lstm_bwd_kernel(LstmBwdArgs a) {
         for (int r = 0; r < 16; ++r) dh[u][r] = 0.0f;
       const float *la = dgs + lane * 4;
       const float *kb = a.KhT + (size_t)(wn * UB) * KGn * 256 + lane * 4;
-      f32x4 bcur[UB], bnxt[UB];
+      f32x4 b0[UB], b1[UB];
 #pragma unroll
-      for (int u = 0; u < UB; ++u) bcur[u] = *reinterpret_cast<const f32x4 *>(kb + (size_t)u * KGn * 256);
-      for (int kg = 0; kg < KGn; ++kg) {
-        const int kn = (kg + 1 < KGn) ? kg + 1 : kg;
+      for (int u = 0; u < UB; ++u) b0[u] = *reinterpret_cast<const f32x4 *>(kb + (size_t)u * KGn * 256);
+      f32x4 a0 = *reinterpret_cast<const f32x4 *>(la);
+      for (int kg = 0; kg < KGn; kg += 2) {  // KGn is even (Hp/2)
 #pragma unroll
-        for (int u = 0; u < UB; ++u) bnxt[u] = *reinterpret_cast<const f32x4 *>(kb + ((size_t)u * KGn + kn) * 256);
-        const f32x4 a4 = *reinterpret_cast<const f32x4 *>(la + kg * 256);
+        for (int u = 0; u < UB; ++u) b1[u] = *reinterpret_cast<const f32x4 *>(kb + ((size_t)u * KGn + kg + 1) * 256);
+        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(la + (kg + 1) * 256);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int u = 0; u < UB; ++u) dh[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], bcur[u][e], dh[u], 0, 0, 0);
+          for (int u = 0; u < UB; ++u) dh[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[u][e], dh[u], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int k2 = (kg + 2 < KGn) ? kg + 2 : kg;
 #pragma unroll
-        for (int u = 0; u < UB; ++u) bcur[u] = bnxt[u];
+        for (int u = 0; u < UB; ++u) b0[u] = *reinterpret_cast<const f32x4 *>(kb + ((size_t)u * KGn + k2) * 256);
+        a0 = *reinterpret_cast<const f32x4 *>(la + k2 * 256);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int u = 0; u < UB; ++u) dh[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[u][e], dh[u], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();
