@@ -55,6 +55,9 @@ struct sse_handle {
   Encoder enc[2];
   bool packed_dirty = true;
   float *emb_pad = nullptr;  // [V][Ep]
+  // source_only_cnn
+  int cnn_W[4] = {-1, -1, -1, -1}, cnn_b[4] = {-1, -1, -1, -1}, cnn_M = -1, tgt_table = -1;
+  float *cnn_Wc = nullptr, *cnn_bias = nullptr, *cnn_Mp = nullptr;
   int32_t *err_flag = nullptr;
   // index
   float *idxp = nullptr;
@@ -63,7 +66,7 @@ struct sse_handle {
   int idx_S = 0;
   float idx_norm_max = 1.0f;
   // scratch
-  DevBuf s_ids, s_out, s_q, s_qp, s_ps, s_pi, s_cert, s_os, s_oi, s_tmp, s_tmp2;
+  DevBuf s_ids, s_out, s_q, s_qp, s_ps, s_pi, s_cert, s_os, s_oi, s_tmp, s_tmp2, s_feat;
   // training
   float lr = 0.9f;
   int64_t global_step = 0;
@@ -171,6 +174,22 @@ int ensure_packed(sse_handle *h, hipStream_t st) {
     if (!e.Mp) HIPCHECK(h, hipMalloc((void **)&e.Mp, (size_t)NTS * e.KGh * 256 * sizeof(float)));
     HIPCHECK(h, launch_pack_kn(h->vars[e.proj].dev, e.H, c.encoding_size, e.KGh, e.Mp, st));
   }
+  if (c.network_mode == SSE_MODE_SOURCE_ONLY_CNN) {
+    if (c.encoding_size > 512) return fail(h, "encoding_size %d > 512 not supported", c.encoding_size);
+    if (!h->cnn_Wc) HIPCHECK(h, hipMalloc((void **)&h->cnn_Wc, cnn_packed_weight_floats(Ep) * sizeof(float)));
+    if (!h->cnn_bias) HIPCHECK(h, hipMalloc((void **)&h->cnn_bias, 576 * sizeof(float)));
+    const int NTS = (c.encoding_size + 31) / 32;
+    if (!h->cnn_Mp) HIPCHECK(h, hipMalloc((void **)&h->cnn_Mp, (size_t)NTS * 72 * 256 * sizeof(float)));
+    const float *W[4];
+    static const int foff[4] = {0, 256, 384, 512}, nf[4] = {256, 128, 128, 64};
+    for (int i = 0; i < 4; ++i) {
+      W[i] = h->vars[h->cnn_W[i]].dev;
+      HIPCHECK(h, hipMemcpyAsync(h->cnn_bias + foff[i], h->vars[h->cnn_b[i]].dev, nf[i] * sizeof(float),
+                                 hipMemcpyDeviceToDevice, st));
+    }
+    HIPCHECK(h, launch_pack_conv(W, c.embedding_size, Ep, h->cnn_Wc, st));
+    HIPCHECK(h, launch_pack_kn(h->vars[h->cnn_M].dev, 576, c.encoding_size, 72, h->cnn_Mp, st));
+  }
   h->packed_dirty = false;
   return 0;
 }
@@ -181,7 +200,29 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
   if (side != SSE_SIDE_SOURCE && side != SSE_SIDE_TARGET) return fail(h, "side must be 0 (source) or 1 (target)");
   if (B < 0 || T < 1) return fail(h, "bad batch shape B=%d T=%d", B, T);
   if (B == 0) return 0;
-  if (c.network_mode == SSE_MODE_SOURCE_ONLY_CNN) return fail(h, "source_only_cnn encoder: not built yet");
+  if (side == SSE_SIDE_TARGET && h->tgt_table >= 0) {
+    // source-encoder-only / source_only_cnn: the "target encoder" is the free matrix
+    // tgt_seq_embedding [N,S] (sse_model.py:214,233); norm_tgt_seq_embedding ignores the feed
+    // and yields all N rows.  Honour that contract when the caller asks for exactly N rows.
+    const Variable &tv = h->vars[h->tgt_table];
+    if (B != tv.rows)
+      return fail(h, "network mode has no target sequence encoder: tgt_seq_embedding is a [%d,%d] variable "
+                     "(sse_model.py:214,233); request exactly %d rows", tv.rows, tv.cols, tv.rows);
+    if (normalize) HIPCHECK(h, launch_l2_normalize(tv.dev, out, tv.rows, tv.cols, st));
+    else HIPCHECK(h, hipMemcpyAsync(out, tv.dev, tv.count * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+  }
+  if (c.network_mode == SSE_MODE_SOURCE_ONLY_CNN) {
+    if (ensure_packed(h, st)) return 1;
+    const int Ep = round_up(c.embedding_size, 8);
+    if (T < 5) return fail(h, "source_only_cnn needs max_seq_length >= 5 (widest filter)");
+    if (cnn_lds_bytes(T, Ep) > 160 * 1024)
+      return fail(h, "source_only_cnn: T*E = %d*%d does not fit the LDS tile of the gfx950 kernel", T, c.embedding_size);
+    if (reserve(h, h->s_feat, (size_t)((B + 31) / 32) * 72 * 256 * sizeof(float))) return 1;
+    HIPCHECK(h, launch_cnn_fwd(ids, h->emb_pad, h->cnn_Wc, h->cnn_bias, h->cnn_Mp, (float *)h->s_feat.p, out, h->err_flag, B,
+                               T, c.vocab_size, Ep, c.encoding_size, normalize ? 1 : 0, st));
+    return 0;
+  }
   Encoder &e = h->enc[side];
   if (e.kernel < 0) return fail(h, "network mode has no %s sequence encoder (sse_model.py:231-233)", side ? "target" : "source");
   if (ensure_packed(h, st)) return 1;
@@ -333,19 +374,19 @@ int sse_create(const sse_config *cfg, sse_handle **out) {
       break;
     case SSE_MODE_SOURCE_ENCODER_ONLY:
       setup_encoder(h, h->enc[0], "source_only_encoder", "source_only_encoder/src_M", cfg->src_cell_size, cfg->src_cell_size);
-      add_var(h, "target_embedding/tgt_seq_embedding", cfg->target_space_size, cfg->encoding_size);
+      h->tgt_table = add_var(h, "target_embedding/tgt_seq_embedding", cfg->target_space_size, cfg->encoding_size);
       break;
     case SSE_MODE_SOURCE_ONLY_CNN: {
       static const int fs[4] = {2, 3, 4, 5}, nf[4] = {256, 128, 128, 64};
       for (int i = 0; i < 4; ++i) {
         char nm[96];
         snprintf(nm, sizeof nm, "source_only_cnn/conv-maxpool-%d/W", fs[i]);
-        add_var(h, nm, fs[i] * cfg->embedding_size, nf[i]);
+        h->cnn_W[i] = add_var(h, nm, fs[i] * cfg->embedding_size, nf[i]);
         snprintf(nm, sizeof nm, "source_only_cnn/conv-maxpool-%d/b", fs[i]);
-        add_var(h, nm, 1, nf[i]);
+        h->cnn_b[i] = add_var(h, nm, 1, nf[i]);
       }
-      add_var(h, "source_only_cnn/src_M", 576, cfg->encoding_size);
-      add_var(h, "target_embedding/tgt_seq_embedding", cfg->target_space_size, cfg->encoding_size);
+      h->cnn_M = add_var(h, "source_only_cnn/src_M", 576, cfg->encoding_size);
+      h->tgt_table = add_var(h, "target_embedding/tgt_seq_embedding", cfg->target_space_size, cfg->encoding_size);
       break;
     }
     default:
@@ -393,7 +434,10 @@ void sse_destroy(sse_handle *h) {
   if (h->err_flag) hipFree(h->err_flag);
   if (h->idxp) hipFree(h->idxp);
   if (h->idx64) hipFree(h->idx64);
-  DevBuf *bufs[] = {&h->s_ids, &h->s_out, &h->s_q, &h->s_qp, &h->s_ps, &h->s_pi, &h->s_cert, &h->s_os, &h->s_oi, &h->s_tmp, &h->s_tmp2};
+  DevBuf *bufs[] = {&h->s_ids, &h->s_out, &h->s_q, &h->s_qp, &h->s_ps, &h->s_pi, &h->s_cert, &h->s_os, &h->s_oi, &h->s_tmp, &h->s_tmp2, &h->s_feat};
+  if (h->cnn_Wc) (void)hipFree(h->cnn_Wc);
+  if (h->cnn_bias) (void)hipFree(h->cnn_bias);
+  if (h->cnn_Mp) (void)hipFree(h->cnn_Mp);
   for (DevBuf *b : bufs)
     if (b->p) hipFree(b->p);
   if (h->train) {

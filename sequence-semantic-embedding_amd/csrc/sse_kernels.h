@@ -95,3 +95,11 @@ hipError_t launch_fill(float *p, int64_t n, float v, hipStream_t stream);
 hipError_t launch_exact_topk(const float *q, const float *idxp, const double *idx64, const int32_t *cert,
                              double *out_scores, int64_t *out_ids, int64_t id_base, int64_t N, int Q, int S,
                              int k, hipStream_t stream);
+
+// ------------------------------ CNN encoder --------------------------------
+size_t cnn_lds_bytes(int T, int Ep);
+size_t cnn_packed_weight_floats(int Ep);
+hipError_t launch_pack_conv(const float *const W[4], int E, int Ep, float *out, hipStream_t stream);
+hipError_t launch_cnn_fwd(const int32_t *ids, const float *emb, const float *Wc, const float *bias, const float *Mp,
+                          float *featp, float *out, int32_t *err, int B, int T, int V, int Ep, int S, int normalize,
+                          hipStream_t stream);
