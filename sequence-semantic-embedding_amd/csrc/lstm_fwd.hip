@@ -38,25 +38,36 @@ size_t lstm_fwd_lds_bytes(int KGx, int KGh) {
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504089f * x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008178f * x)); }
 
-// One GEMM pass of a wave: two gate tiles (B operands at wp and wp+256 floats, k-group
-// stride 1024 floats) times MT row tiles, over k-groups [0, kend).  A fragments come from
-// the x tile (kg < KGx) or the h tile.  Hand software-pipelined with two named operand
-// sets (no register copies): the operands of k-group kg+1 are in flight while kg's
-// 8*MT MFMAs issue.
-template <int MT>
-__device__ __forceinline__ void gemm_pass(const float *__restrict__ wp, const float *const (&xa)[MT],
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// B operand: one 1 KiB wave load through a buffer descriptor -- the address is
+// (SGPR descriptor) + (SGPR soffset) + (per-lane voffset = 16*lane, constant): no 64-bit
+// per-lane pointer arithmetic, no address VGPRs.
+__device__ __forceinline__ f32x4 wload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+// One GEMM pass of a wave: two gate tiles (B operands at byte offsets soff and soff+1024 of
+// the packed kernel, k-group stride 4096 B) times MT row tiles, over k-groups [0, kend).
+// A fragments: LIN -> x and h parts are contiguous in LDS (xa[m] + kg*256); otherwise x tile
+// for kg < KGx, h tile after.  Hand software-pipelined with two named operand sets (no
+// register copies): the operands of k-group kg+1 are in flight while kg's 8*MT MFMAs issue.
+template <int MT, bool LIN>
+__device__ __forceinline__ void gemm_pass(__amdgpu_buffer_rsrc_t wr, int voff, int soff, const float *const (&xa)[MT],
                                           const float *const (&ha)[MT], int KGx, int kend, f32x16 (&acc)[MT][2]) {
   auto a_frag = [&](int m, int kg) -> f32x4 {
+    if constexpr (LIN) return *reinterpret_cast<const f32x4 *>(xa[m] + kg * 256);
     return *reinterpret_cast<const f32x4 *>(kg < KGx ? xa[m] + kg * 256 : ha[m] + (kg - KGx) * 256);
   };
-  f32x4 p0 = *reinterpret_cast<const f32x4 *>(wp), p1 = *reinterpret_cast<const f32x4 *>(wp + 256);
+  f32x4 p0 = wload(wr, voff, soff), p1 = wload(wr, voff + 1024, soff);
   f32x4 q0, q1, a0[MT], a1[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) a0[m] = a_frag(m, 0);
+  __builtin_amdgcn_s_setprio(1);  // the MFMA stream outranks the partner wave's epilogue VALU
   int kg = 0;
   for (; kg + 1 < kend; kg += 2) {
-    q0 = *reinterpret_cast<const f32x4 *>(wp + (size_t)(kg + 1) * 1024);
-    q1 = *reinterpret_cast<const f32x4 *>(wp + (size_t)(kg + 1) * 1024 + 256);
+    q0 = wload(wr, voff, soff + (kg + 1) * 4096);
+    q1 = wload(wr, voff + 1024, soff + (kg + 1) * 4096);
 #pragma unroll
     for (int m = 0; m < MT; ++m) a1[m] = a_frag(m, kg + 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -69,8 +80,8 @@ __device__ __forceinline__ void gemm_pass(const float *__restrict__ wp, const fl
       }
     __builtin_amdgcn_sched_barrier(0);
     const int k2 = (kg + 2 < kend) ? kg + 2 : kg;  // clamped: harmless reload on the last pair
-    p0 = *reinterpret_cast<const f32x4 *>(wp + (size_t)k2 * 1024);
-    p1 = *reinterpret_cast<const f32x4 *>(wp + (size_t)k2 * 1024 + 256);
+    p0 = wload(wr, voff, soff + k2 * 4096);
+    p1 = wload(wr, voff + 1024, soff + k2 * 4096);
 #pragma unroll
     for (int m = 0; m < MT; ++m) a0[m] = a_frag(m, k2);
     __builtin_amdgcn_sched_barrier(0);
@@ -92,9 +103,10 @@ __device__ __forceinline__ void gemm_pass(const float *__restrict__ wp, const fl
         acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][e], p1[e], acc[m][1], 0, 0, 0);
       }
   }
+  __builtin_amdgcn_s_setprio(0);
 }
 
-template <int MT, bool TRAIN>
+template <int MT, bool TRAIN, bool LIN>
 __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -102,10 +114,18 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   const int ub = (MT == 2) ? w : (w & 3);
   const int mt0 = (MT == 2) ? 0 : (w >> 2);
   const int KGx = a.KGx, KGh = a.KGh, KG = KGx + KGh, T = a.T;
-  const int XD = a.xdouble;                            // x tile double-buffered?
-  float *xbuf = smem;                                  // [XD ? 2 : 1][2][KGx][256]
-  float *hbuf0 = smem + (XD ? 4 : 2) * KGx * 256;      // [2 bufs][2][KGh][256]
-  float *red = hbuf0 + 4 * KGh * 256;                  // [64][4]
+  // LDS.  LIN (x double-buffered, fits 160 KiB): A tiles [2 bufs][2 mt][KG][256], the x part of
+  // a row tile followed by its h part, so a k-loop walks one linear array.  Otherwise:
+  // x [2 mt][KGx][256] single-buffered, then h [2 bufs][2 mt][KGh][256].
+  constexpr bool XD = LIN;
+  auto xptr = [&](int buf, int mt) -> float * {
+    return LIN ? smem + (size_t)((buf * 2 + mt) * KG) * 256 : smem + (size_t)(mt * KGx) * 256;
+  };
+  auto hptr = [&](int buf, int mt) -> float * {
+    return LIN ? smem + (size_t)((buf * 2 + mt) * KG + KGx) * 256
+               : smem + (size_t)(2 * KGx + (buf * 2 + mt) * KGh) * 256;
+  };
+  float *red = smem + (size_t)(LIN ? 4 * KG : 2 * KGx + 4 * KGh) * 256;  // [64][4]
   const int b0 = blockIdx.x * LSTM_BM;
 
   // --- x gather assignment: 8 threads per sequence row, 8 floats (one k-group) each
@@ -121,7 +141,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
     return id;
   };
   auto x_store = [&](int buf, int kg, f32x4 lo, f32x4 hi) {
-    float *dst = xbuf + ((size_t)(((XD ? buf : 0) * 2 + (xr >> 5)) * KGx + kg)) * 256;
+    float *dst = xptr(buf, xr >> 5) + (size_t)kg * 256;
     *reinterpret_cast<f32x4 *>(dst + (xr & 31) * 4) = lo;         // k%8 in 0..3 -> lane half 0
     *reinterpret_cast<f32x4 *>(dst + (32 + (xr & 31)) * 4) = hi;  // k%8 in 4..7 -> lane half 1
   };
@@ -135,7 +155,8 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       f32x4 hi = *reinterpret_cast<const f32x4 *>(src + kg * 8 + 4);
       x_store(0, kg, lo, hi);
     }
-    for (int i = tid; i < 2 * KGh * 64; i += LSTM_THREADS) reinterpret_cast<f32x4 *>(hbuf0)[i] = f32x4{0, 0, 0, 0};
+    for (int i = tid; i < 2 * KGh * 64; i += LSTM_THREADS)  // h_0 = 0 in buffer 0 (both row tiles)
+      reinterpret_cast<f32x4 *>(hptr(0, i / (KGh * 64)))[i % (KGh * 64)] = f32x4{0, 0, 0, 0};
   }
 
   float bias[4];
@@ -150,8 +171,11 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
 
   __syncthreads();
 
-  // weights of this wave's unit block: Wp[ub][kg][gate][256]
-  const float *wp = a.Wp + (size_t)ub * KG * 1024 + lane * 4;
+  // weights of this wave's unit block: Wp[ub][kg][gate][256], read through a buffer descriptor
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(a.Wp), 0, (KGh / 4) * KG * 4096, 0x00020000);
+  const int wsoff = __builtin_amdgcn_readfirstlane(ub) * KG * 4096;
+  const int wvoff = lane * 16;
   const int unit = ub * 32 + (lane & 31);
   const int hoff = (unit >> 3) * 256 + ((((unit >> 2) & 1) * 32) << 2) + (unit & 3);  // h element (row 0, k = unit) in a row tile
   const int NT32 = gridDim.x * 2;
@@ -171,14 +195,12 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       }
     }
 
-    const float *hbuf = hbuf0 + (size_t)(t & 1) * 2 * KGh * 256;   // h_{t-1}
-    float *hnext = hbuf0 + (size_t)((t + 1) & 1) * 2 * KGh * 256;  // h_t goes here
-    const float *xcur = xbuf + (size_t)((XD ? (t & 1) : 0) * 2 * KGx) * 256;
+    const int cur = t & 1, nxt = (t + 1) & 1;  // h_{t-1} (and x_t when XD) live in buffer `cur`
     const float *xa[MT], *ha[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      xa[m] = xcur + (size_t)((mt0 + m) * KGx) * 256 + lane * 4;
-      ha[m] = hbuf + (size_t)((mt0 + m) * KGh) * 256 + lane * 4;
+      xa[m] = xptr(cur, mt0 + m) + lane * 4;
+      ha[m] = hptr(cur, mt0 + m) + lane * 4;
     }
 
     if constexpr (TRAIN) {
@@ -193,10 +215,10 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
         f32x4 v = {0, 0, 0, 0};
         if (kp >= 64) {
           const int un = kp - 64;
-          const float *src = hbuf + (size_t)(mt * KGh + (un >> 3)) * 256 + ((((un >> 2) & 1) * 32 + bl) << 2) + (un & 3);
+          const float *src = hptr(cur, mt) + (size_t)(un >> 3) * 256 + ((((un >> 2) & 1) * 32 + bl) << 2) + (un & 3);
           v = f32x4{src[0], src[4], src[8], src[12]};
         } else if (kp < KGx * 8) {
-          const float *src = xcur + (size_t)(mt * KGx + (kp >> 3)) * 256 + ((((kp >> 2) & 1) * 32 + bl) << 2) + (kp & 3);
+          const float *src = xptr(cur, mt) + (size_t)(kp >> 3) * 256 + ((((kp >> 2) & 1) * 32 + bl) << 2) + (kp & 3);
           v = f32x4{src[0], src[4], src[8], src[12]};
         }
         const size_t rg = ((size_t)t * NT32 + blockIdx.x * 2 + mt) * 4 + (bl >> 3);
@@ -223,7 +245,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
         g[m][0][r] = bias[0];
         g[m][1][r] = bias[1];
       }
-    gemm_pass<MT>(wp, xa, ha, KGx, kend, g);
+    gemm_pass<MT, LIN>(wr, wvoff, wsoff, xa, ha, KGx, kend, g);
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -244,10 +266,10 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
         g[m][0][r] = bias[2];
         g[m][1][r] = bias[3];
       }
-    gemm_pass<MT>(wp + 512, xa, ha, KGx, kend, g);
+    gemm_pass<MT, LIN>(wr, wvoff, wsoff + 2048, xa, ha, KGx, kend, g);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      float *hdst = hnext + (size_t)((mt0 + m) * KGh) * 256 + hoff;
+      float *hdst = hptr(nxt, mt0 + m) + hoff;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float sf = fast_sigmoid(g[m][0][r]);
@@ -286,7 +308,6 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       __syncthreads();
     }
   }
-  const float *hbuf = hbuf0 + (size_t)(T & 1) * 2 * KGh * 256;  // h_T
 
   if constexpr (TRAIN) {
     // h_T, row-major [Bp][Hp], for dM = h_T^T . d(out)
@@ -294,7 +315,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
     for (int i = tid; i < LSTM_BM * Hp; i += LSTM_THREADS) {
       const int un = i % Hp, b = i / Hp;
       a.h_last[(size_t)(b0 + b) * Hp + un] =
-          hbuf[(size_t)((b >> 5) * KGh + (un >> 3)) * 256 + ((((un >> 2) & 1) * 32 + (b & 31)) << 2) + (un & 3)];
+          hptr(T & 1, b >> 5)[(size_t)(un >> 3) * 256 + ((((un >> 2) & 1) * 32 + (b & 31)) << 2) + (un & 3)];
     }
   }
 
@@ -302,7 +323,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   // N tiles nt = (w&3), (w&3)+4, ...
   const int wn = w & 3, wm = w >> 2;
   constexpr int PT = 4;  // up to Sp = 512
-  const float *hp = hbuf + (size_t)(wm * KGh) * 256 + lane * 4;
+  const float *hp = hptr(T & 1, wm) + lane * 4;  // h_T
   f32x16 pacc[PT];
   float ss[16];
 #pragma unroll
@@ -361,13 +382,20 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   }
 }
 
-template <int MT, bool TRAIN>
+template <int MT, bool TRAIN, bool LIN>
 static hipError_t launch_one(const LstmFwdArgs &a, size_t lds, dim3 grid, dim3 block, hipStream_t stream) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_kernel<MT, TRAIN>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_kernel<MT, TRAIN, LIN>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((lstm_fwd_kernel<MT, TRAIN>), grid, block, lds, stream, a);
+  hipLaunchKernelGGL((lstm_fwd_kernel<MT, TRAIN, LIN>), grid, block, lds, stream, a);
   return hipGetLastError();
+}
+
+template <int MT>
+static hipError_t launch_mt(const LstmFwdArgs &a, size_t lds, dim3 grid, dim3 block, hipStream_t stream) {
+  const bool train = a.tape_g != nullptr;
+  if (a.xdouble) return train ? launch_one<MT, true, true>(a, lds, grid, block, stream) : launch_one<MT, false, true>(a, lds, grid, block, stream);
+  return train ? launch_one<MT, true, false>(a, lds, grid, block, stream) : launch_one<MT, false, false>(a, lds, grid, block, stream);
 }
 
 hipError_t launch_lstm_fwd(const LstmFwdArgs &a_in, int Hp, hipStream_t stream) {
@@ -375,9 +403,8 @@ hipError_t launch_lstm_fwd(const LstmFwdArgs &a_in, int Hp, hipStream_t stream) 
   a.xdouble = lstm_fwd_x_double(a.KGx, a.KGh) ? 1 : 0;
   const size_t lds = lstm_fwd_lds_bytes(a.KGx, a.KGh);
   const dim3 grid((a.B + LSTM_BM - 1) / LSTM_BM), block(LSTM_THREADS);
-  const bool train = a.tape_g != nullptr;
   // Hp = 128: 4 unit blocks x 2 row halves over the 8 waves; Hp = 256: 8 unit blocks, both halves per wave
-  if (Hp == 128) return train ? launch_one<1, true>(a, lds, grid, block, stream) : launch_one<1, false>(a, lds, grid, block, stream);
-  if (Hp == 256) return train ? launch_one<2, true>(a, lds, grid, block, stream) : launch_one<2, false>(a, lds, grid, block, stream);
+  if (Hp == 128) return launch_mt<1>(a, lds, grid, block, stream);
+  if (Hp == 256) return launch_mt<2>(a, lds, grid, block, stream);
   return hipErrorInvalidValue;
 }
