@@ -16,7 +16,7 @@
 //   3. exact_topk_kernel recomputes flagged queries by float64 brute force.
 #include "sse_kernels.h"
 
-#define SC_THREADS 256
+#define SC_THREADS 512
 #define SC_KC 16
 #define NEG_INF (-__builtin_inff())
 
@@ -36,6 +36,11 @@ __device__ __forceinline__ void list_insert(float (&ls)[KC], int (&li)[KC], floa
   }
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 8 waves per workgroup = 2 per SIMD: there is no barrier in the sweep, so the waves drift
+// apart and one wave's top-k epilogue (VALU) overlaps its partner's MFMA stream.
+// Wave tile: 1 index tile (32 rows, M) x 4 query tiles (N): 4 accumulators + 4 private lists.
 template <int KC>
 __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // query block [4][KG][256]
@@ -82,88 +87,79 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   const int tps = (a.NT + a.NSPLIT - 1) / a.NSPLIT;  // n-tiles per split
   const int t0 = split * tps, t1 = min(a.NT, t0 + tps);
   const float *qs = smem + lane * 4;
+  const int voff = lane * 16;
 
-  for (int base = t0 + w * 2; base < t1; base += 8) {
-    const bool validB = (base + 1) < t1;
-    const float *pa = a.idxp + (size_t)base * KG * 256 + lane * 4;
-    const float *pb = validB ? pa + (size_t)KG * 256 : pa;
-    f32x16 acc[2][4];
+  for (int tile = t0 + w; tile < t1; tile += SC_THREADS / 64) {
+    // index tile through a buffer descriptor (base = this tile: stays below the 4 GiB
+    // descriptor range for any index size); per-lane offset is the constant 16*lane
+    const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.idxp) + (size_t)__builtin_amdgcn_readfirstlane(tile) * KG * 256, 0, KG * 1024, 0x00020000);
+    auto iload = [&](int kg) -> f32x4 {
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ir, voff, kg * 1024, 0));
+    };
+    f32x16 acc[4];
 #pragma unroll
-    for (int na = 0; na < 2; ++na)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[na][q][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
 
-    // k-loop, hand software-pipelined with two named operand sets (X / Y): index
-    // fragments of k-group kg+1 (global) and query fragments (LDS) are in flight
-    // while kg's 32 MFMAs issue; no register copies.
-    f32x4 ax0 = *reinterpret_cast<const f32x4 *>(pa), ax1 = *reinterpret_cast<const f32x4 *>(pb);
-    f32x4 bx[4], by[4], ay0, ay1;
+    // k-loop, hand software-pipelined with two named operand sets (X / Y): the index
+    // fragment of k-group kg+1 (global) and the query fragments (LDS) are in flight while
+    // kg's 16 MFMAs issue; no register copies.
+    f32x4 ax = iload(0), ay;
+    f32x4 bx[4], by[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) bx[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG) * 256);
+    __builtin_amdgcn_s_setprio(1);
     int kg = 0;
     for (; kg + 1 < KG; kg += 2) {
-      ay0 = *reinterpret_cast<const f32x4 *>(pa + (kg + 1) * 256);
-      ay1 = *reinterpret_cast<const f32x4 *>(pb + (kg + 1) * 256);
+      ay = iload(kg + 1);
 #pragma unroll
       for (int q = 0; q < 4; ++q) by[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG + kg + 1) * 256);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax0[e], bx[q][e], acc[0][q], 0, 0, 0);
-          acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax1[e], bx[q][e], acc[1][q], 0, 0, 0);
-        }
+        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[q][e], acc[q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       const int k2 = (kg + 2 < KG) ? kg + 2 : kg;
-      ax0 = *reinterpret_cast<const f32x4 *>(pa + k2 * 256);
-      ax1 = *reinterpret_cast<const f32x4 *>(pb + k2 * 256);
+      ax = iload(k2);
 #pragma unroll
       for (int q = 0; q < 4; ++q) bx[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG + k2) * 256);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay0[e], by[q][e], acc[0][q], 0, 0, 0);
-          acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay1[e], by[q][e], acc[1][q], 0, 0, 0);
-        }
+        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[e], by[q][e], acc[q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (kg < KG) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax0[e], bx[q][e], acc[0][q], 0, 0, 0);
-          acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax1[e], bx[q][e], acc[1][q], 0, 0, 0);
-        }
+        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[q][e], acc[q], 0, 0, 0);
     }
+    __builtin_amdgcn_s_setprio(0);
 
     // fused top-k: lane owns query column (lane & 31) of each q-tile and sees
     // 16 index rows per n-tile, in increasing row order (ties keep the lower row)
+    const int nrow0 = tile * 32;
 #pragma unroll
-    for (int na = 0; na < 2; ++na) {
-      if (na == 1 && !validB) break;
-      const int nrow0 = (base + na) * 32;
+    for (int q = 0; q < 4; ++q) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int n = nrow0 + mfma_row(r, lane);
-          const float s = (n < a.N) ? acc[na][q][r] : NEG_INF;
-          const bool take = s > ls[q][KC - 1];
-          if (__any(take)) list_insert<KC>(ls[q], li[q], s, n, take);
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int n = nrow0 + mfma_row(r, lane);
+        const float s = (n < a.N) ? acc[q][r] : NEG_INF;
+        const bool take = s > ls[q][KC - 1];
+        if (__any(take)) list_insert<KC>(ls[q], li[q], s, n, take);
       }
     }
   }
 
   // partial lists -> global: candidate slot (split, wave, lane half)
-  const int slot = (split * 4 + w) * 2 + (lane >> 5);
-  const int nslots = a.NSPLIT * 8;
+  constexpr int WAVES = SC_THREADS / 64;
+  const int slot = (split * WAVES + w) * 2 + (lane >> 5);
+  const int nslots = a.NSPLIT * WAVES * 2;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int query = (qb * 4 + q) * 32 + (lane & 31);
@@ -178,6 +174,8 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
     }
   }
 }
+
+int score_slots_per_split() { return (SC_THREADS / 64) * 2; }
 
 hipError_t launch_score_topk(const ScoreArgs &a, hipStream_t stream) {
   if (a.KC != SC_KC) return hipErrorInvalidValue;
@@ -231,6 +229,7 @@ __device__ __forceinline__ bool before(double sa, int64_t ia, double sb, int64_t
 // One 256-thread workgroup per query.  NC candidates (f32 score, local row id).
 #define RS_THREADS 256
 #define RS_MAXWIN 256
+#define RS_MAXNC 2048  // candidates per query the re-scoring pass accepts
 __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
   __shared__ float s_thr[RS_THREADS / 64];
   __shared__ int s_cnt;
@@ -238,6 +237,7 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
   __shared__ double s_ex[RS_MAXWIN];
   __shared__ float s_m[RS_THREADS / 64];
   __shared__ double s_qn[RS_THREADS / 64];
+  __shared__ unsigned long long s_key[RS_MAXNC];
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const float *ps = a.part_scores + (size_t)q * a.NC;
   const int32_t *pi = a.part_ids + (size_t)q * a.NC;
@@ -256,21 +256,23 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
   __syncthreads();
   const float eps_q = a.eps * (float)sqrt(s_qn[0] + s_qn[1] + s_qn[2] + s_qn[3]);
 
-  // k-th largest fp32 candidate score: each thread ranks its candidates by counting
-  // (NC is a few hundred; O(NC^2/256) compares per thread)
-  float kth = NEG_INF;
+  // k-th largest fp32 candidate: stage one sortable 64-bit key per candidate in LDS
+  // (monotone score bits << 32 | inverted row id, 0 = empty slot), then every thread
+  // ranks its candidates by counting larger keys (LDS broadcast reads).
   for (int c = tid; c < a.NC; c += RS_THREADS) {
     const int id = pi[c];
-    if (id < 0) continue;
-    const float s = ps[c];
+    unsigned u = __float_as_uint(ps[c]);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    s_key[c] = (id < 0) ? 0ull : (((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)id));
+  }
+  __syncthreads();
+  float kth = NEG_INF;
+  for (int c = tid; c < a.NC; c += RS_THREADS) {
+    const unsigned long long key = s_key[c];
+    if (key == 0ull) continue;
     int rank = 0;
-    for (int j = 0; j < a.NC; ++j) {
-      const int idj = pi[j];
-      if (idj < 0) continue;
-      const float sj = ps[j];
-      rank += (sj > s) || (sj == s && idj < id);
-    }
-    if (rank == a.k - 1) kth = s;
+    for (int j = 0; j < a.NC; ++j) rank += (s_key[j] > key) ? 1 : 0;
+    if (rank == a.k - 1) kth = ps[c];
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) kth = fmaxf(kth, __shfl_xor(kth, o));
@@ -338,6 +340,7 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
 }
 
 hipError_t launch_rescore(const RescoreArgs &a, hipStream_t stream) {
+  if (a.NC > RS_MAXNC) return hipErrorInvalidValue;
   hipLaunchKernelGGL(rescore_kernel, dim3(a.Q), dim3(RS_THREADS), 0, stream, a);
   return hipGetLastError();
 }

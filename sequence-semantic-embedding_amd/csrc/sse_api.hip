@@ -294,8 +294,8 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   // splits of the index range: enough workgroups to fill 256 CUs, >= 8 n-tiles per split,
   // <= 16 splits (candidate lists stay small)
   int nsplit = 1;
-  while (nsplit < 16 && QB * nsplit < 256 && NT / (nsplit * 2) >= 8) nsplit *= 2;
-  const int NC = nsplit * 8 * 16;
+  while (nsplit < 8 && QB * nsplit < 256 && NT / (nsplit * 2) >= 8) nsplit *= 2;
+  const int NC = nsplit * score_slots_per_split() * 16;
   if (reserve(h, h->s_qp, (size_t)QB * 4 * KG * 256 * sizeof(float))) return 1;
   if (reserve(h, h->s_ps, (size_t)Q * NC * sizeof(float))) return 1;
   if (reserve(h, h->s_pi, (size_t)Q * NC * sizeof(int32_t))) return 1;

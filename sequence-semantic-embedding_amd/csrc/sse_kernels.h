@@ -61,6 +61,7 @@ struct ScoreArgs {
   int32_t Q, KG, NT, QT, NSPLIT, KC;
 };
 hipError_t launch_score_topk(const ScoreArgs &a, hipStream_t stream);
+int score_slots_per_split();  // candidate lists per query and index split (waves x lane halves)
 
 struct RescoreArgs {
   const float *q;          // [Q][S] f32 row-major queries

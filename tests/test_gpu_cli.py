@@ -71,9 +71,12 @@ def test_train_index_eval_demo_cli(tmp_path):
                                  sse_amd.Session(model))
     got = ev.eval()
     src_rows = np.array([e[0] for e in data.rawEvalCorpus], np.int32)
-    src_enc = O.encode(p, ocfg, "src", src_rows)
+    gpu_src = model.encode_source(src_rows)
+    assert np.abs(gpu_src - O.encode(p, ocfg, "src", src_rows)).max() < 1e-4
     labels = [[ids.index(t) for t in e[1]] for e in data.rawEvalCorpus]
-    want_acc = O.evaluator_accuracy(src_enc, enc, labels)
+    # ranking parity is judged on identical inputs (the GPU's source encodings): a 1e-7 difference
+    # between two encoders may legitimately swap near-tied neighbours of a barely trained model
+    want_acc = O.evaluator_accuracy(gpu_src, enc, labels)
     assert got == pytest.approx(want_acc, abs=1e-12)
 
     # sse_demo: un-normalised source encoding x index, top-N printed (sse_demo.py:121-134)
