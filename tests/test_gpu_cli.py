@@ -87,7 +87,8 @@ def test_train_index_eval_demo_cli(tmp_path):
     text = out.getvalue()
     assert "Top 5 Prediction results are:" in text and text.count("top") >= 5
     q_ids = np.array([sse_amd.sse_text.pad_tokens(data.encoder.encode(query.lower()), 24)], np.int32)
-    raw_enc = O.encode(p, ocfg, "src", q_ids, normalize=False)
+    raw_enc = model.encode_source(q_ids, normalize=False)      # same inputs as the demo: only the ranking is compared
+    assert np.abs(raw_enc - O.encode(p, ocfg, "src", q_ids, normalize=False)).max() < 1e-4 * max(1.0, np.abs(raw_enc).max())
     wsc, wids = O.topk(O.scores_f64(raw_enc, enc), 5)
     assert ("top1:  %s , %f" % (ids[wids[0][0]], wsc[0][0])) in text
 
