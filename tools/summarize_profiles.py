@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 CSV outputs under gpurun_out/ into the small tracked summaries under profiles/.
+usage: tools/summarize_profiles.py <tag> <stats_dir> <pmc_dir> [<pmc_dir> ...]"""
+import collections
+import csv
+import os
+import sys
+
+OURS = ("lstm_fwd", "lstm_bwd", "score_topk", "rescore", "exact_topk", "pack_", "merge_topk", "row_norm2", "pad_rows",
+        "l2_normalize", "conv_pool", "proj_norm", "dk_gemm", "dx_kernel", "loss_", "adagrad", "sumsq", "clip_scale",
+        "proj_bwd", "db_reduce", "dk_reduce")
+
+
+def main():
+    tag, stats_dir, pmc_dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    rows = list(csv.DictReader(open(os.path.join(stats_dir, "p_kernel_stats.csv"))))
+    with open(os.path.join(root, "%s_kernel_stats.csv" % tag), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+                "  (library kernels only; torch setup kernels dropped)\n")
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        for r in rows:
+            if any(k in r["Name"] for k in OURS):
+                w.writerow(r)
+    out = ["# rocprofv3 --pmc <counters> --kernel-trace (separate passes) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --score-iters 1",
+           "# per-dispatch averages by (kernel, grid); FETCH_SIZE/WRITE_SIZE in KB (MI355X_MICROARCH.md: FETCH_SIZE under-reports",
+           "# wide 16 B/lane streaming reads 2x on gfx950); SQ_WAVE_CYCLES/SQ_WAIT_*/SQ_ACTIVE_* are quad-cycles summed over waves;",
+           "# SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs"]
+    for d in pmc_dirs:
+        agg = collections.defaultdict(list)
+        dur = collections.defaultdict(list)
+        for r in csv.DictReader(open(os.path.join(d, "p_counter_collection.csv"))):
+            if any(k in r["Kernel_Name"] for k in ("lstm_fwd", "score_topk", "rescore_kernel")):
+                key = (r["Kernel_Name"].split("(")[0][:40], r["Grid_Size"])
+                agg[key + (r["Counter_Name"],)].append(float(r["Counter_Value"]))
+                dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        for (k, g, c), v in sorted(agg.items()):
+            out.append("%-42s grid=%-8s %-26s n=%-3d avg=%.5g  (avg dispatch %.3f ms)"
+                       % (k, g, c, len(v), sum(v) / len(v), sum(dur[(k, g)]) / len(dur[(k, g)]) / 1e6))
+    open(os.path.join(root, "%s_pmc.txt" % tag), "w").write("\n".join(out) + "\n")
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main()
