@@ -237,14 +237,19 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
     }
 
     // pass A: gates i, j  ->  pij = sigmoid(i) * tanh(j)      (BasicLSTMCell, TF 1.x)
-    f32x16 g[MT][2], pij[MT];
+    // pij is parked in the (still unused) h_t slots of the other h buffer -- same (row, unit)
+    // coordinates -- instead of 16*MT registers held across pass B.
+    f32x16 g[MT][2];
+    float *hdst[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m) {
+      hdst[m] = hptr(nxt, mt0 + m) + hoff;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         g[m][0][r] = bias[0];
         g[m][1][r] = bias[1];
       }
+    }
     gemm_pass<MT, LIN>(wr, wvoff, wsoff, xa, ha, KGx, kend, g);
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -252,12 +257,21 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       for (int r = 0; r < 16; ++r) {
         const float si = fast_sigmoid(g[m][0][r]);
         const float tj = fast_tanh(g[m][1][r]);
-        pij[m][r] = si * tj;
+        hdst[m][mfma_row(r, lane) << 2] = si * tj;
         if constexpr (TRAIN) {
           tp[m][r * 64] = si;
           tp[m][1024 + r * 64] = tj;
         }
       }
+    if (XD && have_next) {
+      // x_{t+1}: its buffer was last read in step t-1, so it can be written as soon as the
+      // prefetch has landed (frees the staging registers before pass B)
+      if (xq < KGx) x_store(nxt, xq, nlo, nhi);
+      for (int kg = xq + 8; kg < KGx; kg += 8) {
+        const float *src = a.emb + (size_t)nid * a.Ep + kg * 8;
+        x_store(nxt, kg, *reinterpret_cast<const f32x4 *>(src), *reinterpret_cast<const f32x4 *>(src + 4));
+      }
+    }
     // pass B: gates f (+1 folded into the bias), o -> c' = c*sigmoid(f) + pij ; h' = tanh(c')*sigmoid(o)
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -269,14 +283,13 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
     gemm_pass<MT, LIN>(wr, wvoff, wsoff + 2048, xa, ha, KGx, kend, g);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      float *hdst = hptr(nxt, mt0 + m) + hoff;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float sf = fast_sigmoid(g[m][0][r]);
         const float so = fast_sigmoid(g[m][1][r]);
-        const float cn = c[m][r] * sf + pij[m][r];
+        const float cn = c[m][r] * sf + hdst[m][mfma_row(r, lane) << 2];
         c[m][r] = cn;
-        hdst[mfma_row(r, lane) << 2] = fast_tanh(cn) * so;  // h_t -> the other h buffer, A-fragment order
+        hdst[m][mfma_row(r, lane) << 2] = fast_tanh(cn) * so;  // h_t, A-fragment order
         if constexpr (TRAIN) {
           tp[m][2048 + r * 64] = sf;
           tp[m][3072 + r * 64] = so;
@@ -288,13 +301,6 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
     // stage x_{t+1}: with a double-buffered x tile its buffer was last read in step
     // t-1; with a single buffer it must wait until every wave finished step t
     if (XD) {
-      if (have_next) {
-        if (xq < KGx) x_store((t + 1) & 1, xq, nlo, nhi);
-        for (int kg = xq + 8; kg < KGx; kg += 8) {
-          const float *src = a.emb + (size_t)nid * a.Ep + kg * 8;
-          x_store((t + 1) & 1, kg, *reinterpret_cast<const f32x4 *>(src), *reinterpret_cast<const f32x4 *>(src + 4));
-        }
-      }
       __syncthreads();  // h_t complete and visible; h_{t-1} / x_t no longer needed
     } else {
       __syncthreads();
