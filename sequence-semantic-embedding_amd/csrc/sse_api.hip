@@ -39,8 +39,10 @@ struct DevBuf {
 
 // device buffers of the training path, grown on demand
 struct TrainState {
-  DevBuf ids[2], labels, raw[2], draw[2], tape_g[2], tape_a[2], h_last[2], dh_last, dg_a, dg_b, db_part, dk_part,
-      sq_part, norm_part, row_loss, row_acc, scal;
+  DevBuf ids[2], labels, raw[2], draw[2], tape_g[2], tape_a[2], h_last[2], dh_last[2], dg_a[2], dg_b[2], db_part[2],
+      dk_part[2], dm_part[2], sq_part, norm_part, row_loss, row_acc, scal;
+  hipStream_t side[2] = {nullptr, nullptr};  // the two encoders run concurrently (forward and backward)
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   float *KhT[2] = {nullptr, nullptr}, *KxT[2] = {nullptr, nullptr};
   bool packed_dirty = true;
 };
@@ -443,14 +445,17 @@ void sse_destroy(sse_handle *h) {
   if (h->train) {
     TrainState *t = h->train;
     DevBuf *tb[] = {&t->ids[0], &t->ids[1], &t->labels, &t->raw[0], &t->raw[1], &t->draw[0], &t->draw[1], &t->tape_g[0],
-                    &t->tape_g[1], &t->tape_a[0], &t->tape_a[1], &t->h_last[0], &t->h_last[1], &t->dh_last, &t->dg_a,
-                    &t->dg_b, &t->db_part, &t->dk_part, &t->sq_part, &t->norm_part, &t->row_loss, &t->row_acc, &t->scal};
+                    &t->tape_g[1], &t->tape_a[0], &t->tape_a[1], &t->h_last[0], &t->h_last[1], &t->dh_last[0], &t->dh_last[1], &t->dg_a[0], &t->dg_a[1],
+                    &t->dg_b[0], &t->dg_b[1], &t->db_part[0], &t->db_part[1], &t->dk_part[0], &t->dk_part[1], &t->dm_part[0], &t->dm_part[1], &t->sq_part, &t->norm_part, &t->row_loss, &t->row_acc, &t->scal};
     for (DevBuf *b : tb)
       if (b->p) (void)hipFree(b->p);
     for (int s = 0; s < 2; ++s) {
+      if (t->side[s]) (void)hipStreamDestroy(t->side[s]);
+      if (t->ev_join[s]) (void)hipEventDestroy(t->ev_join[s]);
       if (t->KhT[s] && (s == 0 || t->KhT[s] != t->KhT[0])) (void)hipFree(t->KhT[s]);
       if (t->KxT[s] && (s == 0 || t->KxT[s] != t->KxT[0])) (void)hipFree(t->KxT[s]);
     }
+    if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
     delete t;
   }
   for (hipEvent_t e : h->events)
@@ -625,6 +630,13 @@ int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tg
   hipStream_t st = nullptr;
   if (!h->train) h->train = new TrainState();
   TrainState &ts = *h->train;
+  if (!ts.side[0]) {
+    for (int s = 0; s < 2; ++s) {
+      HIPCHECK(h, hipStreamCreateWithFlags(&ts.side[s], hipStreamNonBlocking));
+      HIPCHECK(h, hipEventCreateWithFlags(&ts.ev_join[s], hipEventDisableTiming));
+    }
+    HIPCHECK(h, hipEventCreateWithFlags(&ts.ev_fork, hipEventDisableTiming));
+  }
   const int E = c.embedding_size, S = c.encoding_size, V = c.vocab_size;
   const int Bp = round_up(B, 64), NT32 = Bp / 32;
   const bool shared = c.network_mode == SSE_MODE_SHARED_ENCODER;
@@ -659,8 +671,11 @@ int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tg
   if (reserve(h, ts.labels, (size_t)B * sizeof(float))) return 1;
   HIPCHECK(h, hipMemcpyAsync(ts.labels.p, labels_host, (size_t)B * sizeof(float), hipMemcpyHostToDevice, st));
 
-  // ---- forward with tapes (un-normalised encodings; the loss kernel normalises)
+  // ---- forward with tapes (un-normalised encodings; the loss kernel normalises); the two
+  // encoders are independent: fork onto two side streams, join before the loss
+  HIPCHECK(h, hipEventRecord(ts.ev_fork, st));
   for (int s = 0; s < 2; ++s) {
+    HIPCHECK(h, hipStreamWaitEvent(ts.side[s], ts.ev_fork, 0));
     Encoder &e = h->enc[s];
     const int KT = 2 + e.Hp / 32;
     if (reserve(h, ts.raw[s], (size_t)Bp * S * sizeof(float))) return 1;
@@ -688,7 +703,9 @@ int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tg
     a.tape_g = (float *)ts.tape_g[s].p;
     a.tape_a = (float *)ts.tape_a[s].p;
     a.h_last = (float *)ts.h_last[s].p;
-    HIPCHECK(h, launch_lstm_fwd(a, e.Hp, st));
+    HIPCHECK(h, launch_lstm_fwd(a, e.Hp, ts.side[s]));
+    HIPCHECK(h, hipEventRecord(ts.ev_join[s], ts.side[s]));
+    HIPCHECK(h, hipStreamWaitEvent(st, ts.ev_join[s], 0));
   }
   if (check_err_flag(h, st)) return 1;
 
@@ -707,25 +724,35 @@ int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tg
   const int NORM_BLOCKS = 64;
   int nparts = 0;
   if (reserve(h, ts.sq_part, (size_t)2 * T * NT32 * sizeof(float))) return 1;
+  HIPCHECK(h, hipEventRecord(ts.ev_fork, st));  // loss + zeroed embedding gradient are ready
   for (int s = 0; s < 2; ++s) {
     Encoder &e = h->enc[s];
     const int Hp = e.Hp, KGn = Hp / 2, NTn = Hp / 8, KT = 2 + Hp / 32, RG = T * NT32 * 4;
     const int SL = dk_slices(RG);
-    if (reserve(h, ts.dh_last, (size_t)Bp * Hp * sizeof(float))) return 1;
-    if (reserve(h, ts.dg_a, (size_t)T * NT32 * KGn * 256 * sizeof(float))) return 1;
-    if (reserve(h, ts.dg_b, (size_t)RG * NTn * 256 * sizeof(float))) return 1;
-    if (reserve(h, ts.db_part, (size_t)NT32 * 4 * Hp * sizeof(float))) return 1;
-    if (reserve(h, ts.dk_part, (size_t)SL * KT * 32 * NTn * 32 * sizeof(float))) return 1;
+    // dual-encoder: the two backward chains are independent -> side streams; shared-encoder: the
+    // target side accumulates onto the source side's kernel/bias gradient -> one stream, in order
+    hipStream_t bs = shared ? ts.side[0] : ts.side[s];
+    if (!shared || s == 0) HIPCHECK(h, hipStreamWaitEvent(bs, ts.ev_fork, 0));
+    if (reserve(h, ts.dh_last[s], (size_t)Bp * Hp * sizeof(float))) return 1;
+    if (reserve(h, ts.dg_a[s], (size_t)T * NT32 * KGn * 256 * sizeof(float))) return 1;
+    if (reserve(h, ts.dg_b[s], (size_t)RG * NTn * 256 * sizeof(float))) return 1;
+    if (reserve(h, ts.db_part[s], (size_t)NT32 * 4 * Hp * sizeof(float))) return 1;
+    if (reserve(h, ts.dk_part[s], (size_t)SL * KT * 32 * NTn * 32 * sizeof(float))) return 1;
+    if (reserve(h, ts.dm_part[s], (size_t)proj_bwd_chunks(Bp) * e.H * S * sizeof(float))) return 1;
     HIPCHECK(h, launch_proj_bwd((const float *)ts.h_last[s].p, (const float *)ts.draw[s].p, h->vars[e.proj].dev, Bp, e.H, Hp,
-                                S, h->vars[e.proj].grad, (float *)ts.dh_last.p, st));
-    HIPCHECK(h, launch_lstm_bwd((const float *)ts.tape_g[s].p, (const float *)ts.dh_last.p, ts.KhT[s], (float *)ts.dg_a.p,
-                                (float *)ts.dg_b.p, (float *)ts.db_part.p, T, NT32, Hp, st));
+                                S, h->vars[e.proj].grad, (float *)ts.dh_last[s].p, (float *)ts.dm_part[s].p, bs));
+    HIPCHECK(h, launch_lstm_bwd((const float *)ts.tape_g[s].p, (const float *)ts.dh_last[s].p, ts.KhT[s],
+                                (float *)ts.dg_a[s].p, (float *)ts.dg_b[s].p, (float *)ts.db_part[s].p, T, NT32, Hp, bs));
     const int accumulate = (shared && s == 1) ? 1 : 0;
-    HIPCHECK(h, launch_dk((const float *)ts.tape_a[s].p, (const float *)ts.dg_b.p, (float *)ts.dk_part.p, RG, KT, NTn, SL, E,
-                          e.H, Hp, accumulate, h->vars[e.kernel].grad, st));
-    HIPCHECK(h, launch_db_reduce((const float *)ts.db_part.p, NT32, e.H, Hp, accumulate, h->vars[e.bias].grad, st));
-    HIPCHECK(h, launch_dx((const float *)ts.dg_a.p, ts.KxT[s], (const int32_t *)ts.ids[s].p, emb.grad,
-                          (float *)ts.sq_part.p + (size_t)s * T * NT32, T, NT32, KGn, B, E, V, st));
+    HIPCHECK(h, launch_dk((const float *)ts.tape_a[s].p, (const float *)ts.dg_b[s].p, (float *)ts.dk_part[s].p, RG, KT, NTn, SL,
+                          E, e.H, Hp, accumulate, h->vars[e.kernel].grad, bs));
+    HIPCHECK(h, launch_db_reduce((const float *)ts.db_part[s].p, NT32, e.H, Hp, accumulate, h->vars[e.bias].grad, bs));
+    HIPCHECK(h, launch_dx((const float *)ts.dg_a[s].p, ts.KxT[s], (const int32_t *)ts.ids[s].p, emb.grad,
+                          (float *)ts.sq_part.p + (size_t)s * T * NT32, T, NT32, KGn, B, E, V, bs));
+    if (!shared || s == 1) {
+      HIPCHECK(h, hipEventRecord(ts.ev_join[s], bs));
+      HIPCHECK(h, hipStreamWaitEvent(st, ts.ev_join[s], 0));
+    }
   }
 
   // ---- global norm over the dense gradients + the raw (un-deduplicated) embedding slices

@@ -5,8 +5,9 @@
 
 hipError_t launch_loss(const float *src_raw, const float *tgt_raw, const float *labels, float *d_src, float *d_tgt,
                        float *row_loss, float *row_acc, float *out2, int B, int Bp, int S, hipStream_t st);
+int proj_bwd_chunks(int Bp);
 hipError_t launch_proj_bwd(const float *hT, const float *d, const float *M, int Bp, int H, int Hp, int S, float *dM,
-                           float *dh, hipStream_t st);
+                           float *dh, float *dm_part /* [proj_bwd_chunks(Bp)][H*S] */, hipStream_t st);
 hipError_t launch_lstm_bwd(const float *tape_g, const float *dh_last, const float *KhT, float *dg_a, float *dg_b,
                            float *db_part, int T, int NT32, int Hp, hipStream_t st);
 int dk_slices(int RG);

@@ -104,24 +104,95 @@ __global__ void loss_reduce_kernel(const float *row_loss, const float *row_acc, 
 }
 
 // ---------------------------------------------------------------------------
-// Projection backward: dM[j][s] = sum_b hT[b][j] * d[b][s];  dh[b][j] = sum_s d[b][s] * M[j][s]
-__global__ void proj_bwd_dm_kernel(const float *hT, const float *d, int Bp, int H, int Hp, int S, float *dM) {
+// Projection backward (two small GEMMs, LDS-tiled 64x64 output tiles, 4x4 per thread):
+//   dM[j][s] = sum_b hT[b][j] * d[b][s]     (reduction over the batch, split into chunks ->
+//                                            per-chunk partials, summed in fixed order)
+//   dh[b][j] = sum_s d[b][s] * M[j][s]
+#define PB_TILE 64
+#define PB_K 16
+
+__global__ __launch_bounds__(256) void proj_bwd_dm_kernel(const float *__restrict__ hT, const float *__restrict__ d,
+                                                          int Bp, int H, int Hp, int S, int chunk, float *__restrict__ part) {
+  __shared__ float As[PB_K][PB_TILE + 4], Bs[PB_K][PB_TILE + 4];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int j0 = blockIdx.y * PB_TILE, s0 = blockIdx.x * PB_TILE;
+  const int b_begin = blockIdx.z * chunk, b_end = min(Bp, b_begin + chunk);
+  float acc[4][4] = {};
+  for (int b0 = b_begin; b0 < b_end; b0 += PB_K) {
+    for (int i = threadIdx.x; i < PB_K * PB_TILE; i += 256) {
+      const int kk = i / PB_TILE, c = i % PB_TILE, b = b0 + kk;
+      As[kk][c] = (b < b_end && j0 + c < H) ? hT[(size_t)b * Hp + j0 + c] : 0.0f;
+      Bs[kk][c] = (b < b_end && s0 + c < S) ? d[(size_t)b * S + s0 + c] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < PB_K; ++kk) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[u] = As[kk][ty * 4 + u];
+        bv[u] = Bs[kk][tx * 4 + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] += av[u] * bv[v];
+    }
+    __syncthreads();
+  }
+  float *out = part + (size_t)blockIdx.z * H * S;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int j = j0 + ty * 4 + u, sidx = s0 + tx * 4 + v;
+      if (j < H && sidx < S) out[(size_t)j * S + sidx] = acc[u][v];
+    }
+}
+
+__global__ void proj_bwd_dm_reduce_kernel(const float *part, int nchunks, int n, float *dM) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= H * S) return;
-  const int s = i % S, j = i / S;
+  if (i >= n) return;
   float acc = 0.0f;
-  for (int b = 0; b < Bp; ++b) acc += hT[(size_t)b * Hp + j] * d[(size_t)b * S + s];
+  for (int c = 0; c < nchunks; ++c) acc += part[(size_t)c * n + i];
   dM[i] = acc;
 }
 
-__global__ void proj_bwd_dh_kernel(const float *d, const float *M, int Bp, int H, int Hp, int S, float *dh) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Bp * Hp) return;
-  const int j = i % Hp, b = i / Hp;
-  float acc = 0.0f;
-  if (j < H)
-    for (int s = 0; s < S; ++s) acc += d[(size_t)b * S + s] * M[(size_t)j * S + s];
-  dh[i] = acc;
+__global__ __launch_bounds__(256) void proj_bwd_dh_kernel(const float *__restrict__ d, const float *__restrict__ M, int Bp,
+                                                          int H, int Hp, int S, float *__restrict__ dh) {
+  __shared__ float As[PB_K][PB_TILE + 4], Bs[PB_K][PB_TILE + 4];  // [s][b] and [s][j]
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int b0 = blockIdx.y * PB_TILE, j0 = blockIdx.x * PB_TILE;
+  float acc[4][4] = {};
+  for (int s0 = 0; s0 < S; s0 += PB_K) {
+    for (int i = threadIdx.x; i < PB_K * PB_TILE; i += 256) {
+      const int r = i / PB_K, kk = i % PB_K;  // 16 consecutive s of one row: 64-byte segments
+      As[kk][r] = (b0 + r < Bp && s0 + kk < S) ? d[(size_t)(b0 + r) * S + s0 + kk] : 0.0f;
+      Bs[kk][r] = (j0 + r < H && s0 + kk < S) ? M[(size_t)(j0 + r) * S + s0 + kk] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < PB_K; ++kk) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[u] = As[kk][ty * 4 + u];
+        bv[u] = Bs[kk][tx * 4 + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] += av[u] * bv[v];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int b = b0 + ty * 4 + u, j = j0 + tx * 4 + v;
+      if (b < Bp && j < Hp) dh[(size_t)b * Hp + j] = acc[u][v];  // j >= H: weights read as 0 -> dh = 0
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -459,10 +530,18 @@ hipError_t launch_loss(const float *src_raw, const float *tgt_raw, const float *
   return hipGetLastError();
 }
 
+int proj_bwd_chunks(int Bp) { return Bp <= 512 ? 1 : (Bp + 511) / 512 > 32 ? 32 : (Bp + 511) / 512; }
+
 hipError_t launch_proj_bwd(const float *hT, const float *d, const float *M, int Bp, int H, int Hp, int S, float *dM,
-                           float *dh, hipStream_t st) {
-  hipLaunchKernelGGL(proj_bwd_dm_kernel, dim3((H * S + 255) / 256), dim3(256), 0, st, hT, d, Bp, H, Hp, S, dM);
-  hipLaunchKernelGGL(proj_bwd_dh_kernel, dim3((Bp * Hp + 255) / 256), dim3(256), 0, st, d, M, Bp, H, Hp, S, dh);
+                           float *dh, float *dm_part, hipStream_t st) {
+  const int nch = proj_bwd_chunks(Bp);
+  const int chunk = ((Bp + nch - 1) / nch + PB_K - 1) / PB_K * PB_K;
+  hipLaunchKernelGGL(proj_bwd_dm_kernel, dim3((S + PB_TILE - 1) / PB_TILE, (H + PB_TILE - 1) / PB_TILE, nch), dim3(256), 0, st,
+                     hT, d, Bp, H, Hp, S, chunk, nch == 1 ? dM : dm_part);
+  if (nch > 1)
+    hipLaunchKernelGGL(proj_bwd_dm_reduce_kernel, dim3((H * S + 255) / 256), dim3(256), 0, st, dm_part, nch, H * S, dM);
+  hipLaunchKernelGGL(proj_bwd_dh_kernel, dim3((Hp + PB_TILE - 1) / PB_TILE, (Bp + PB_TILE - 1) / PB_TILE), dim3(256), 0, st, d,
+                     M, Bp, H, Hp, S, dh);
   return hipGetLastError();
 }
 

@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""Training-step timing (sse_train_step through the C ABI, host buffers in -> loss/acc out),
+configs[1] model (dual-encoder E=50 H=S=256 T=32 V=32000)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sse_amd  # noqa: E402
+
+V, E, H, S, T = 32000, 50, 256, 256, 32
+params = dict(forward_only=False, network_mode="dual-encoder", predict_nbest=10, max_seq_length=T, vocab_size=V,
+              embedding_size=E, encoding_size=S, src_cell_size=H, tgt_cell_size=H, learning_rate=0.9,
+              learning_rate_decay_factor=0.99, targetSpaceSize=571)
+m = sse_amd.SSEModel(params)
+m.init_variables(seed=0)
+rng = np.random.RandomState(0)
+for B in [int(x) for x in (sys.argv[1:] or ["128", "1024", "8192"])]:
+    src = rng.randint(2, V, size=(B, T)).astype(np.int32)
+    tgt = rng.randint(2, V, size=(B, T)).astype(np.int32)
+    z = np.tile(np.array([1.0, 0.0], np.float32), B // 2)
+    for _ in range(3):
+        m.train_step(src, tgt, z)
+    n = 20 if B <= 1024 else 5
+    t0 = time.perf_counter()
+    for _ in range(n):
+        loss, acc = m.train_step(src, tgt, z)
+    dt = (time.perf_counter() - t0) / n
+    flops = 3 * 2 * B * (T * 8 * H * (E + H) + 2 * H * S)       # ~3x forward, two encoders
+    print("B_rows=%d: %.3f ms/step, %.0f pair-rows/s, %.1f TFLOP/s algorithmic, loss %.4f" % (B, dt * 1e3, B / dt, flops / dt / 1e12, loss))
