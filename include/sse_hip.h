@@ -80,6 +80,12 @@ int sse_encode(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int3
 int sse_encode_dev(sse_handle *h, int side, const int32_t *ids_dev, int32_t B, int32_t T,
                    int32_t normalize, float *out_dev, void *stream);
 
+/* Library options.  "pad_skip" (default 1): inference encodes skip the left-PAD prefix of
+ * every 64-row tile exactly -- the LSTM state after p leading PAD (id 0) steps is
+ * sequence-independent (sse_index.py:79-85 left-pads; sse_model.py:240-242 runs all T steps),
+ * so it is precomputed per p with the same kernel; results are bit-identical to pad_skip = 0. */
+int sse_set_option(sse_handle *h, const char *name, int32_t value);
+
 /* tf.nn.l2_normalize(x, dim=-1) on device rows (sse_model.py:282-283). */
 int sse_l2_normalize_dev(sse_handle *h, const float *x_dev, float *out_dev, int64_t rows, int32_t cols,
                          void *stream);

@@ -36,6 +36,7 @@ SYMBOLS = {
     "sse_get_variable": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
     "sse_encode": (C.c_int, [_P, C.c_int, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "sse_encode_dev": (C.c_int, [_P, C.c_int, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "sse_set_option": (C.c_int, [_P, C.c_char_p, C.c_int32]),
     "sse_l2_normalize_dev": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P]),
     "sse_index_upload": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int64]),
     "sse_index_upload_f64": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int64]),
@@ -145,6 +146,9 @@ class Handle(object):
 
     def encode_dev(self, side, ids_ptr, B, T, normalize, out_ptr, stream=0):
         self.check(self.lib.sse_encode_dev(self._h, side, ids_ptr, B, T, 1 if normalize else 0, out_ptr, stream))
+
+    def set_option(self, name, value):
+        self.check(self.lib.sse_set_option(self._h, name.encode(), int(value)))
 
     def l2_normalize_dev(self, x_ptr, out_ptr, rows, cols, stream=0):
         self.check(self.lib.sse_l2_normalize_dev(self._h, x_ptr, out_ptr, rows, cols, stream))

@@ -146,17 +146,44 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
     *reinterpret_cast<f32x4 *>(dst + (32 + (xr & 31)) * 4) = hi;  // k%8 in 4..7 -> lane half 1
   };
 
-  // --- prologue: x_0 -> x buffer 0, h_0 = 0
+  // --- left-pad prefix skip: first step this tile has to compute (0 when disabled / training)
+  int t0 = 0;
+  if (!TRAIN && a.pad_h != nullptr) {
+    // leading-PAD count of row xr (8 threads per row scan interleaved positions), min over the tile;
+    // rows beyond B count as all-PAD
+    int lead = T;
+    if (row_ok) {
+      for (int t = xq; t < T; t += 8)
+        if (id_row[t] != 0) {
+          lead = t;
+          break;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lead = min(lead, __shfl_xor(lead, o));
+    if (lane == 0) red[w] = __int_as_float(lead);
+    __syncthreads();
+    lead = T;
+    for (int i = 0; i < LSTM_THREADS / 64; ++i) lead = min(lead, __float_as_int(red[i]));
+    t0 = min(lead, T - 1);  // every real sequence ends in EOS, but stay safe: at least one step
+    __syncthreads();
+  }
+
+  // --- prologue: x_{t0} -> x buffer (t0 & 1), h_{t0-1} = state after t0 PAD steps (0 when t0 = 0)
   {
-    const int id = fetch_id(0);
+    const int id = fetch_id(t0);
     const float *src = a.emb + (size_t)id * a.Ep;
     for (int kg = xq; kg < KGx; kg += 8) {
       f32x4 lo = *reinterpret_cast<const f32x4 *>(src + kg * 8);
       f32x4 hi = *reinterpret_cast<const f32x4 *>(src + kg * 8 + 4);
-      x_store(0, kg, lo, hi);
+      x_store(t0 & 1, kg, lo, hi);
     }
-    for (int i = tid; i < 2 * KGh * 64; i += LSTM_THREADS)  // h_0 = 0 in buffer 0 (both row tiles)
-      reinterpret_cast<f32x4 *>(hptr(0, i / (KGh * 64)))[i % (KGh * 64)] = f32x4{0, 0, 0, 0};
+    const int Hp = KGh * 8;
+    for (int i = tid; i < 2 * KGh * 256; i += LSTM_THREADS) {  // both row tiles of buffer t0 & 1
+      const int mt = i / (KGh * 256), e = i % (KGh * 256);
+      const int un = (e >> 8) * 8 + ((e >> 7) & 1) * 4 + (e & 3);  // k index of element e of a frag32 row tile
+      hptr(t0 & 1, mt)[e] = (t0 > 0) ? a.pad_h[(size_t)t0 * Hp + un] : 0.0f;
+    }
   }
 
   float bias[4];
@@ -164,10 +191,13 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   for (int g = 0; g < 4; ++g) bias[g] = a.bias[(ub * 4 + g) * 32 + (lane & 31)];
 
   f32x16 c[MT];
+  {
+    const float c0 = (t0 > 0) ? a.pad_c[(size_t)t0 * (KGh * 8) + ub * 32 + (lane & 31)] : 0.0f;
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) c[m][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) c[m][r] = c0;
+  }
 
   __syncthreads();
 
@@ -180,7 +210,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   const int hoff = (unit >> 3) * 256 + ((((unit >> 2) & 1) * 32) << 2) + (unit & 3);  // h element (row 0, k = unit) in a row tile
   const int NT32 = gridDim.x * 2;
 
-  for (int t = 0; t < T; ++t) {
+  for (int t = t0; t < T; ++t) {
     // prefetch the embedding rows of step t+1 into registers (one k-group per
     // thread covers E <= 64; wider embeddings are completed after the GEMM)
     const bool have_next = (t + 1) < T;
@@ -226,7 +256,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
         *reinterpret_cast<f32x4 *>(dst) = v;
       }
     }
-    const int kend = (t == 0) ? KGx : KG;  // h_0 = 0: skip the recurrent part of step 0
+    const int kend = (t == 0) ? KGx : KG;  // h_{-1} = 0: skip the recurrent part of step 0
 
     // gate tape, accumulator layout: [t][tile32][unit block][q][reg][lane], q = si,tj,sf,so,c
     float *tp[MT];
@@ -289,7 +319,13 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
         const float so = fast_sigmoid(g[m][1][r]);
         const float cn = c[m][r] * sf + hdst[m][mfma_row(r, lane) << 2];
         c[m][r] = cn;
-        hdst[m][mfma_row(r, lane) << 2] = fast_tanh(cn) * so;  // h_t, A-fragment order
+        const float hv = fast_tanh(cn) * so;
+        hdst[m][mfma_row(r, lane) << 2] = hv;  // h_t, A-fragment order
+        if (!TRAIN && a.rec_h != nullptr && blockIdx.x == 0 && mt0 + m == 0 && r == 0 && lane < 32) {
+          // row 0 of the launch: state after t+1 steps (used to build the pad-prefix table)
+          a.rec_h[(size_t)(t + 1) * (KGh * 8) + unit] = hv;
+          a.rec_c[(size_t)(t + 1) * (KGh * 8) + unit] = cn;
+        }
         if constexpr (TRAIN) {
           tp[m][2048 + r * 64] = sf;
           tp[m][3072 + r * 64] = so;

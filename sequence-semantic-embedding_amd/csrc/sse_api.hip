@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -30,6 +31,10 @@ struct Encoder {
   int H = 0, Hp = 0, UB = 0, KGx = 0, KGh = 0, Ep = 0;
   float *Wp = nullptr, *biasp = nullptr, *Mp = nullptr;
   int shares_lstm_with = -1;  // shared-encoder: target reuses the source LSTM packing
+  // pad-prefix table: state after p leading PAD steps, p = 0..pad_T ([pad_T+1][Hp] each)
+  float *pad_h = nullptr, *pad_c = nullptr;
+  int pad_T = 0;
+  bool pad_valid = false;
 };
 
 struct DevBuf {
@@ -56,6 +61,7 @@ struct sse_handle {
   std::vector<Variable> vars;
   Encoder enc[2];
   bool packed_dirty = true;
+  bool pad_skip = true;      // option "pad_skip": exact left-pad prefix skip in inference encodes
   float *emb_pad = nullptr;  // [V][Ep]
   // source_only_cnn
   int cnn_W[4] = {-1, -1, -1, -1}, cnn_b[4] = {-1, -1, -1, -1}, cnn_M = -1, tgt_table = -1;
@@ -68,7 +74,7 @@ struct sse_handle {
   int idx_S = 0;
   float idx_norm_max = 1.0f;
   // scratch
-  DevBuf s_ids, s_out, s_q, s_qp, s_ps, s_pi, s_cert, s_os, s_oi, s_tmp, s_tmp2, s_feat;
+  DevBuf s_ids, s_out, s_q, s_qp, s_ps, s_pi, s_cert, s_os, s_oi, s_tmp, s_tmp2, s_feat, s_zero;
   // training
   float lr = 0.9f;
   int64_t global_step = 0;
@@ -162,6 +168,7 @@ int ensure_packed(sse_handle *h, hipStream_t st) {
   for (int s = 0; s < 2; ++s) {
     Encoder &e = h->enc[s];
     if (e.H <= 0 || e.kernel < 0) continue;
+    e.pad_valid = false;
     const int KG = e.KGx + e.KGh;
     if (e.shares_lstm_with < 0) {
       if (!e.Wp) HIPCHECK(h, hipMalloc((void **)&e.Wp, (size_t)(e.Hp / 32) * KG * 4 * 256 * sizeof(float)));
@@ -193,6 +200,57 @@ int ensure_packed(sse_handle *h, hipStream_t st) {
     HIPCHECK(h, launch_pack_kn(h->vars[h->cnn_M].dev, 576, c.encoding_size, 72, h->cnn_Mp, st));
   }
   h->packed_dirty = false;
+  return 0;
+}
+
+void fill_fwd_args(sse_handle *h, Encoder &e, LstmFwdArgs &a) {
+  const sse_config &c = h->cfg;
+  a.emb = h->emb_pad;
+  a.Wp = e.Wp;
+  a.bias = e.biasp;
+  a.Mp = e.Mp;
+  a.err = h->err_flag;
+  a.V = c.vocab_size;
+  a.Ep = e.Ep;
+  a.KGx = e.KGx;
+  a.KGh = e.KGh;
+  a.S = c.encoding_size;
+  a.NTS = (c.encoding_size + 31) / 32;
+}
+
+// state after p leading PAD steps for p = 0..T: one all-PAD row through the SAME kernel
+// (bit-identical arithmetic), recorded step by step
+int ensure_pad_table(sse_handle *h, int side, int T, hipStream_t st) {
+  Encoder &e = h->enc[side];
+  Encoder &own = e.shares_lstm_with >= 0 ? h->enc[e.shares_lstm_with] : e;
+  if (!(own.pad_valid && own.pad_T >= T)) {
+    const int Tt = T > h->cfg.max_seq_length ? T : h->cfg.max_seq_length;
+    if (own.pad_T < Tt || !own.pad_h) {
+      if (own.pad_h) HIPCHECK(h, hipFree(own.pad_h));
+      if (own.pad_c) HIPCHECK(h, hipFree(own.pad_c));
+      own.pad_h = own.pad_c = nullptr;
+      HIPCHECK(h, hipMalloc((void **)&own.pad_h, (size_t)(Tt + 1) * own.Hp * sizeof(float)));
+      HIPCHECK(h, hipMalloc((void **)&own.pad_c, (size_t)(Tt + 1) * own.Hp * sizeof(float)));
+      own.pad_T = Tt;
+    }
+    HIPCHECK(h, hipMemsetAsync(own.pad_h, 0, (size_t)(Tt + 1) * own.Hp * sizeof(float), st));
+    HIPCHECK(h, hipMemsetAsync(own.pad_c, 0, (size_t)(Tt + 1) * own.Hp * sizeof(float), st));
+    if (reserve(h, h->s_zero, (size_t)Tt * sizeof(int32_t) + (size_t)h->cfg.encoding_size * sizeof(float))) return 1;
+    HIPCHECK(h, hipMemsetAsync(h->s_zero.p, 0, (size_t)Tt * sizeof(int32_t), st));
+    LstmFwdArgs a;
+    fill_fwd_args(h, own, a);
+    a.ids = (const int32_t *)h->s_zero.p;
+    a.out = (float *)((char *)h->s_zero.p + (size_t)Tt * sizeof(int32_t));
+    a.B = 1;
+    a.T = Tt;
+    a.normalize = 0;
+    a.rec_h = own.pad_h;
+    a.rec_c = own.pad_c;
+    HIPCHECK(h, launch_lstm_fwd(a, own.Hp, st));
+    own.pad_valid = true;
+  }
+  e.pad_h = own.pad_h;
+  e.pad_c = own.pad_c;
   return 0;
 }
 
@@ -229,22 +287,17 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
   if (e.kernel < 0) return fail(h, "network mode has no %s sequence encoder (sse_model.py:231-233)", side ? "target" : "source");
   if (ensure_packed(h, st)) return 1;
   LstmFwdArgs a;
+  fill_fwd_args(h, e, a);
   a.ids = ids;
-  a.emb = h->emb_pad;
-  a.Wp = e.Wp;
-  a.bias = e.biasp;
-  a.Mp = e.Mp;
   a.out = out;
-  a.err = h->err_flag;
   a.B = B;
   a.T = T;
-  a.V = c.vocab_size;
-  a.Ep = e.Ep;
-  a.KGx = e.KGx;
-  a.KGh = e.KGh;
-  a.S = c.encoding_size;
-  a.NTS = (c.encoding_size + 31) / 32;
   a.normalize = normalize ? 1 : 0;
+  if (h->pad_skip && T > 1) {
+    if (ensure_pad_table(h, side, T, st)) return 1;
+    a.pad_h = e.pad_h;
+    a.pad_c = e.pad_c;
+  }
   HIPCHECK(h, launch_lstm_fwd(a, e.Hp, st));
   return 0;
 }
@@ -429,6 +482,8 @@ void sse_destroy(sse_handle *h) {
     if (e.shares_lstm_with < 0) {
       if (e.Wp) hipFree(e.Wp);
       if (e.biasp) hipFree(e.biasp);
+      if (e.pad_h) (void)hipFree(e.pad_h);
+      if (e.pad_c) (void)hipFree(e.pad_c);
     }
     if (e.Mp) hipFree(e.Mp);
   }
@@ -436,7 +491,7 @@ void sse_destroy(sse_handle *h) {
   if (h->err_flag) hipFree(h->err_flag);
   if (h->idxp) hipFree(h->idxp);
   if (h->idx64) hipFree(h->idx64);
-  DevBuf *bufs[] = {&h->s_ids, &h->s_out, &h->s_q, &h->s_qp, &h->s_ps, &h->s_pi, &h->s_cert, &h->s_os, &h->s_oi, &h->s_tmp, &h->s_tmp2, &h->s_feat};
+  DevBuf *bufs[] = {&h->s_ids, &h->s_out, &h->s_q, &h->s_qp, &h->s_ps, &h->s_pi, &h->s_cert, &h->s_os, &h->s_oi, &h->s_tmp, &h->s_tmp2, &h->s_feat, &h->s_zero};
   if (h->cnn_Wc) (void)hipFree(h->cnn_Wc);
   if (h->cnn_bias) (void)hipFree(h->cnn_bias);
   if (h->cnn_Mp) (void)hipFree(h->cnn_Mp);
@@ -524,11 +579,48 @@ int sse_encode(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int3
   if (reserve(h, h->s_ids, (size_t)B * T * sizeof(int32_t))) return 1;
   if (reserve(h, h->s_out, (size_t)B * S * sizeof(float))) return 1;
   hipStream_t st = nullptr;
-  HIPCHECK(h, hipMemcpyAsync(h->s_ids.p, ids_host, (size_t)B * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  // Group rows by their leading-PAD count (left-padded inputs, sse_index.py:79-85) so that every
+  // 64-row tile can skip its whole common PAD prefix; results are scattered back in caller order.
+  const bool lstm_side = h->cfg.network_mode != SSE_MODE_SOURCE_ONLY_CNN && !(side == SSE_SIDE_TARGET && h->tgt_table >= 0);
+  std::vector<int32_t> order;
+  const int32_t *src_ids = ids_host;
+  std::vector<int32_t> sorted_ids;
+  if (h->pad_skip && lstm_side && B > 64) {
+    std::vector<int32_t> lead(B);
+    for (int b = 0; b < B; ++b) {
+      const int32_t *row = ids_host + (size_t)b * T;
+      int t = 0;
+      while (t < T && row[t] == 0) ++t;
+      lead[b] = t;
+    }
+    order.resize(B);
+    for (int b = 0; b < B; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return lead[x] > lead[y]; });
+    sorted_ids.resize((size_t)B * T);
+    for (int b = 0; b < B; ++b) memcpy(&sorted_ids[(size_t)b * T], ids_host + (size_t)order[b] * T, (size_t)T * sizeof(int32_t));
+    src_ids = sorted_ids.data();
+  }
+  HIPCHECK(h, hipMemcpyAsync(h->s_ids.p, src_ids, (size_t)B * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
   if (encode_dev_locked(h, side, (const int32_t *)h->s_ids.p, B, T, normalize, (float *)h->s_out.p, st)) return 1;
   if (check_err_flag(h, st)) return 1;
-  HIPCHECK(h, hipMemcpy(out_host, h->s_out.p, (size_t)B * S * sizeof(float), hipMemcpyDeviceToHost));
+  if (order.empty()) {
+    HIPCHECK(h, hipMemcpy(out_host, h->s_out.p, (size_t)B * S * sizeof(float), hipMemcpyDeviceToHost));
+  } else {
+    std::vector<float> tmp((size_t)B * S);
+    HIPCHECK(h, hipMemcpy(tmp.data(), h->s_out.p, (size_t)B * S * sizeof(float), hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b) memcpy(out_host + (size_t)order[b] * S, &tmp[(size_t)b * S], S * sizeof(float));
+  }
   return 0;
+}
+
+int sse_set_option(sse_handle *h, const char *name, int32_t value) {
+  if (!h || !name) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (strcmp(name, "pad_skip") == 0) {
+    h->pad_skip = value != 0;
+    return 0;
+  }
+  return fail(h, "unknown option '%s'", name);
 }
 
 int sse_l2_normalize_dev(sse_handle *h, const float *x_dev, float *out_dev, int64_t rows, int32_t cols, void *stream) {

@@ -41,6 +41,12 @@ struct LstmFwdArgs {
   int32_t *err;         // bit 0: token id out of range
   int32_t B, T, V, Ep, KGx, KGh, S, NTS, normalize;
   int32_t xdouble = 1;  // set by launch_lstm_fwd from lstm_fwd_x_double()
+  // Left-pad prefix skip (exact): the state after p leading PAD (id 0) steps does not depend on
+  // the sequence, so a tile starts at t0 = min over its rows of the leading-PAD count with
+  // (h, c) = pad_h/pad_c[t0].  pad_* [T+1][Hp] come from rec_* of an all-PAD launch by the same
+  // kernel (bit-identical arithmetic).  nullptr disables either side.
+  const float *pad_h = nullptr, *pad_c = nullptr;
+  float *rec_h = nullptr, *rec_c = nullptr;
   // training only (nullptr for inference): tapes consumed by the backward kernels
   float *tape_g = nullptr;  // [T][NT32][4][UB][5][16][64] gate activations + c, accumulator layout
   float *tape_a = nullptr;  // [(T*NT32*4)][KT][256]  [x_t | h_{t-1}] as frag32(rows = k', red = r)

@@ -104,3 +104,32 @@ def test_large_batch_property_rows_independent():
     assert np.array_equal(small, big[pick])          # bit-identical: no cross-row coupling
     want = O.encode(p, params, "src", ids[pick[:16]])
     assert np.abs(small[:16] - want).max() <= TOL
+
+
+def test_pad_prefix_skip_is_bit_identical_and_survives_weight_updates():
+    """Option pad_skip: tiles start after their common left-PAD prefix from a precomputed state
+    (same kernel arithmetic) -- results must equal the full T-step run bit for bit."""
+    params = model_params("dual-encoder", 300, 50, 256, 96, 64, 40)
+    m, p = make_pair(params, seed=6)
+    rng = np.random.RandomState(12)
+    ids = random_ids(rng, 300, 40, 300, pad_frac=0.95)
+    ids[7, :] = 0
+    ids[7, -1] = 1                                        # only EOS
+    ids[8, :] = rng.randint(2, 300, size=40)              # no padding at all
+    ids[8, -1] = 1
+    for side, enc in (("src", m.encode_source), ("tgt", m.encode_target)):
+        m.handle.set_option("pad_skip", 1)
+        fast = enc(ids)
+        m.handle.set_option("pad_skip", 0)
+        full = enc(ids)
+        assert np.array_equal(fast, full), side
+        assert np.abs(full - O.encode(p, params, side, ids)).max() <= TOL
+    # a weight change invalidates the prefix table
+    m.handle.set_option("pad_skip", 1)
+    p2 = {k: (v * 1.1).astype(np.float32) for k, v in p.items()}
+    m.set_variables(p2)
+    assert np.abs(m.encode_source(ids) - O.encode(p2, params, "src", ids)).max() <= TOL
+    # a small (unsorted, single-tile) batch with a PAD in the middle of a sequence
+    ids2 = ids[:5].copy()
+    ids2[2, 20] = 0
+    assert np.abs(m.encode_source(ids2) - O.encode(p2, params, "src", ids2)).max() <= TOL
