@@ -131,7 +131,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   // --- x gather assignment: 8 threads per sequence row, 8 floats (one k-group) each
   const int xr = tid >> 3, xq = tid & 7;
   const bool row_ok = (b0 + xr) < a.B;
-  const int32_t *id_row = a.ids + (size_t)(row_ok ? (b0 + xr) : 0) * T;
+  const int32_t *id_row = a.ids + (size_t)(row_ok ? (a.row_map ? a.row_map[b0 + xr] : b0 + xr) : 0) * T;
   auto fetch_id = [&](int t) -> int {
     int id = row_ok ? id_row[t] : 0;
     if (id < 0 || id >= a.V) {
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = b0 + wm * 32 + mfma_row(r, lane);
-        if (row < a.B) a.out[(size_t)row * a.S + col] = pacc[i][r] * scale[r];
+        if (row < a.B) a.out[(size_t)(a.row_map ? a.row_map[row] : row) * a.S + col] = pacc[i][r] * scale[r];
       }
     }
   }

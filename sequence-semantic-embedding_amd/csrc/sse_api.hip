@@ -74,7 +74,8 @@ struct sse_handle {
   int idx_S = 0;
   float idx_norm_max = 1.0f;
   // scratch
-  DevBuf s_ids, s_out, s_q, s_qp, s_ps, s_pi, s_cert, s_os, s_oi, s_tmp, s_tmp2, s_feat, s_zero;
+  DevBuf s_ids, s_out, s_q, s_qp, s_ps, s_pi, s_cert, s_os, s_oi, s_tmp, s_tmp2, s_feat, s_zero, s_map;
+  const int32_t *cur_row_map = nullptr;  // set by sse_encode around its launch
   // training
   float lr = 0.9f;
   int64_t global_step = 0;
@@ -293,6 +294,7 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
   a.B = B;
   a.T = T;
   a.normalize = normalize ? 1 : 0;
+  a.row_map = h->cur_row_map;
   if (h->pad_skip && T > 1) {
     if (ensure_pad_table(h, side, T, st)) return 1;
     a.pad_h = e.pad_h;
@@ -491,7 +493,7 @@ void sse_destroy(sse_handle *h) {
   if (h->err_flag) hipFree(h->err_flag);
   if (h->idxp) hipFree(h->idxp);
   if (h->idx64) hipFree(h->idx64);
-  DevBuf *bufs[] = {&h->s_ids, &h->s_out, &h->s_q, &h->s_qp, &h->s_ps, &h->s_pi, &h->s_cert, &h->s_os, &h->s_oi, &h->s_tmp, &h->s_tmp2, &h->s_feat, &h->s_zero};
+  DevBuf *bufs[] = {&h->s_ids, &h->s_out, &h->s_q, &h->s_qp, &h->s_ps, &h->s_pi, &h->s_cert, &h->s_os, &h->s_oi, &h->s_tmp, &h->s_tmp2, &h->s_feat, &h->s_zero, &h->s_map};
   if (h->cnn_Wc) (void)hipFree(h->cnn_Wc);
   if (h->cnn_bias) (void)hipFree(h->cnn_bias);
   if (h->cnn_Mp) (void)hipFree(h->cnn_Mp);
@@ -582,34 +584,31 @@ int sse_encode(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int3
   // Group rows by their leading-PAD count (left-padded inputs, sse_index.py:79-85) so that every
   // 64-row tile can skip its whole common PAD prefix; results are scattered back in caller order.
   const bool lstm_side = h->cfg.network_mode != SSE_MODE_SOURCE_ONLY_CNN && !(side == SSE_SIDE_TARGET && h->tgt_table >= 0);
-  std::vector<int32_t> order;
-  const int32_t *src_ids = ids_host;
-  std::vector<int32_t> sorted_ids;
+  const int32_t *row_map_dev = nullptr;
   if (h->pad_skip && lstm_side && B > 64) {
-    std::vector<int32_t> lead(B);
+    // counting sort of the row numbers by leading-PAD count, longest prefix first
+    std::vector<int32_t> lead(B), start(T + 2, 0), order(B);
     for (int b = 0; b < B; ++b) {
       const int32_t *row = ids_host + (size_t)b * T;
       int t = 0;
       while (t < T && row[t] == 0) ++t;
       lead[b] = t;
+      ++start[T - t + 1];
     }
-    order.resize(B);
-    for (int b = 0; b < B; ++b) order[b] = b;
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return lead[x] > lead[y]; });
-    sorted_ids.resize((size_t)B * T);
-    for (int b = 0; b < B; ++b) memcpy(&sorted_ids[(size_t)b * T], ids_host + (size_t)order[b] * T, (size_t)T * sizeof(int32_t));
-    src_ids = sorted_ids.data();
+    for (int i = 1; i <= T + 1; ++i) start[i] += start[i - 1];
+    for (int b = 0; b < B; ++b) order[start[T - lead[b]]++] = b;
+    if (reserve(h, h->s_map, (size_t)B * sizeof(int32_t))) return 1;
+    HIPCHECK(h, hipMemcpyAsync(h->s_map.p, order.data(), (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHECK(h, hipStreamSynchronize(st));  // `order` is a local
+    row_map_dev = (const int32_t *)h->s_map.p;
   }
-  HIPCHECK(h, hipMemcpyAsync(h->s_ids.p, src_ids, (size_t)B * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
-  if (encode_dev_locked(h, side, (const int32_t *)h->s_ids.p, B, T, normalize, (float *)h->s_out.p, st)) return 1;
+  HIPCHECK(h, hipMemcpyAsync(h->s_ids.p, ids_host, (size_t)B * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  h->cur_row_map = row_map_dev;
+  const int rc = encode_dev_locked(h, side, (const int32_t *)h->s_ids.p, B, T, normalize, (float *)h->s_out.p, st);
+  h->cur_row_map = nullptr;
+  if (rc) return 1;
   if (check_err_flag(h, st)) return 1;
-  if (order.empty()) {
-    HIPCHECK(h, hipMemcpy(out_host, h->s_out.p, (size_t)B * S * sizeof(float), hipMemcpyDeviceToHost));
-  } else {
-    std::vector<float> tmp((size_t)B * S);
-    HIPCHECK(h, hipMemcpy(tmp.data(), h->s_out.p, (size_t)B * S * sizeof(float), hipMemcpyDeviceToHost));
-    for (int b = 0; b < B; ++b) memcpy(out_host + (size_t)order[b] * S, &tmp[(size_t)b * S], S * sizeof(float));
-  }
+  HIPCHECK(h, hipMemcpy(out_host, h->s_out.p, (size_t)B * S * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }
 

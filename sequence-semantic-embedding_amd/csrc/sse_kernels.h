@@ -46,6 +46,7 @@ struct LstmFwdArgs {
   // (h, c) = pad_h/pad_c[t0].  pad_* [T+1][Hp] come from rec_* of an all-PAD launch by the same
   // kernel (bit-identical arithmetic).  nullptr disables either side.
   const float *pad_h = nullptr, *pad_c = nullptr;
+  const int32_t *row_map = nullptr;  // optional: logical row b reads ids / writes out at row row_map[b]
   float *rec_h = nullptr, *rec_c = nullptr;
   // training only (nullptr for inference): tapes consumed by the backward kernels
   float *tape_g = nullptr;  // [T][NT32][4][UB][5][16][64] gate activations + c, accumulator layout
