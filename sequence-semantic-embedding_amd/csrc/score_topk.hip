@@ -38,12 +38,45 @@ __device__ __forceinline__ void list_insert(float (&ls)[KC], int (&li)[KC], floa
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ bool entry_before(float sa, int ia, float sb, int ib) {
+  return (sa > sb) || (sa == sb && (unsigned)ia < (unsigned)ib);  // score desc, then lower row (empty = -1 last)
+}
+
+// top-KC of two descending lists (A in registers, B given) -> A.  Bitonic: max(A[i], B[KC-1-i])
+// is a bitonic sequence holding the KC best; log2(KC) compare-exchange stages sort it.
+template <int KC>
+__device__ __forceinline__ void merge_lists(float (&ls)[KC], int (&li)[KC], const float (&bs)[KC], const int (&bi)[KC]) {
+#pragma unroll
+  for (int i = 0; i < KC; ++i) {
+    const bool tb = entry_before(bs[KC - 1 - i], bi[KC - 1 - i], ls[i], li[i]);
+    ls[i] = tb ? bs[KC - 1 - i] : ls[i];
+    li[i] = tb ? bi[KC - 1 - i] : li[i];
+  }
+#pragma unroll
+  for (int stride = KC / 2; stride > 0; stride >>= 1)
+#pragma unroll
+    for (int i = 0; i < KC; ++i)
+      if ((i & stride) == 0) {
+        const bool sw = entry_before(ls[i + stride], li[i + stride], ls[i], li[i]);
+        const float ts = ls[i];
+        const int ti = li[i];
+        ls[i] = sw ? ls[i + stride] : ts;
+        li[i] = sw ? li[i + stride] : ti;
+        ls[i + stride] = sw ? ts : ls[i + stride];
+        li[i + stride] = sw ? ti : li[i + stride];
+      }
+}
+
 // 8 waves per workgroup = 2 per SIMD: there is no barrier in the sweep, so the waves drift
 // apart and one wave's top-k epilogue (VALU) overlaps its partner's MFMA stream.
-// Wave tile: 1 index tile (32 rows, M) x 4 query tiles (N): 4 accumulators + 4 private lists.
-template <int KC>
+// Wave tile: 1 index tile (32 rows, M) x NQ query tiles (N): NQ accumulators + NQ private lists.
+//   NQ = 4: 128-query block (MFMA-bound regime).  NQ = 1: <= 32 queries (demo / web, Q = 1):
+//   a quarter of the MFMA work per index byte, so the sweep runs at HBM speed.
+//   MERGE: the 16 lists per query of a workgroup are merged to one (in-wave via shuffles,
+//   across waves through LDS) so that many index splits stay cheap to re-score.
+template <int KC, int NQ, bool MERGE>
 __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // query block [4][KG][256]
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // query block [NQ][KG][256]; later merge scratch
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int KG = a.KG;
 
@@ -62,22 +95,22 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
       qb = j / m;
     }
   }
-  const int QB = (a.QT + 3) >> 2;
+  const int QB = (a.QT + NQ - 1) / NQ;
   if (qb >= QB) return;
 
-  // stage the 128-query block (already frag32-packed) into LDS
+  // stage the query block (already frag32-packed) into LDS
   {
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(a.qp) + (size_t)qb * 4 * KG * 64;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(a.qp) + (size_t)qb * NQ * KG * 64;
     f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
-    const int valid = min(4, a.QT - qb * 4) * KG * 64;
-    for (int i = tid; i < 4 * KG * 64; i += SC_THREADS) dst[i] = (i < valid) ? src[i] : f32x4{0, 0, 0, 0};
+    const int valid = min(NQ, a.QT - qb * NQ) * KG * 64;
+    for (int i = tid; i < NQ * KG * 64; i += SC_THREADS) dst[i] = (i < valid) ? src[i] : f32x4{0, 0, 0, 0};
   }
   __syncthreads();
 
-  float ls[4][KC];
-  int li[4][KC];
+  float ls[NQ][KC];
+  int li[NQ][KC];
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < NQ; ++q)
 #pragma unroll
     for (int i = 0; i < KC; ++i) {
       ls[q][i] = NEG_INF;
@@ -97,47 +130,47 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
     auto iload = [&](int kg) -> f32x4 {
       return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ir, voff, kg * 1024, 0));
     };
-    f32x16 acc[4];
+    f32x16 acc[NQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
 
     // k-loop, hand software-pipelined with two named operand sets (X / Y): the index
     // fragment of k-group kg+1 (global) and the query fragments (LDS) are in flight while
-    // kg's 16 MFMAs issue; no register copies.
+    // kg's 4*NQ MFMAs issue; no register copies.
     f32x4 ax = iload(0), ay;
-    f32x4 bx[4], by[4];
+    f32x4 bx[NQ], by[NQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bx[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG) * 256);
+    for (int q = 0; q < NQ; ++q) bx[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG) * 256);
     __builtin_amdgcn_s_setprio(1);
     int kg = 0;
     for (; kg + 1 < KG; kg += 2) {
       ay = iload(kg + 1);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) by[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG + kg + 1) * 256);
+      for (int q = 0; q < NQ; ++q) by[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG + kg + 1) * 256);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[q][e], acc[q], 0, 0, 0);
+        for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[q][e], acc[q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       const int k2 = (kg + 2 < KG) ? kg + 2 : kg;
       ax = iload(k2);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bx[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG + k2) * 256);
+      for (int q = 0; q < NQ; ++q) bx[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG + k2) * 256);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[e], by[q][e], acc[q], 0, 0, 0);
+        for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[e], by[q][e], acc[q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (kg < KG) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[q][e], acc[q], 0, 0, 0);
+        for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[q][e], acc[q], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
 
@@ -145,7 +178,7 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
     // 16 index rows per n-tile, in increasing row order (ties keep the lower row)
     const int nrow0 = tile * 32;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = nrow0 + mfma_row(r, lane);
@@ -156,32 +189,96 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
     }
   }
 
-  // partial lists -> global: candidate slot (split, wave, lane half)
   constexpr int WAVES = SC_THREADS / 64;
-  const int slot = (split * WAVES + w) * 2 + (lane >> 5);
-  const int nslots = a.NSPLIT * WAVES * 2;
+  if constexpr (MERGE) {
+    // (1) the two lane halves hold lists of the same query over different rows: merge into lanes 0-31
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int query = (qb * 4 + q) * 32 + (lane & 31);
-    if (query < a.Q) {
-      float *ps = a.part_scores + ((size_t)query * nslots + slot) * KC;
-      int32_t *pi = a.part_ids + ((size_t)query * nslots + slot) * KC;
+    for (int q = 0; q < NQ; ++q) {
+      float os[KC];
+      int oi[KC];
 #pragma unroll
-      for (int i = 0; i < KC; i += 4) {
-        *reinterpret_cast<f32x4 *>(ps + i) = f32x4{ls[q][i], ls[q][i + 1], ls[q][i + 2], ls[q][i + 3]};
-        *reinterpret_cast<int4 *>(pi + i) = int4{li[q][i], li[q][i + 1], li[q][i + 2], li[q][i + 3]};
+      for (int i = 0; i < KC; ++i) {
+        os[i] = __shfl_xor(ls[q][i], 32);
+        oi[i] = __shfl_xor(li[q][i], 32);
+      }
+      merge_lists<KC>(ls[q], li[q], os, oi);
+    }
+    // (2) tree over the 8 waves through LDS (the query block is no longer needed):
+    // scratch [wave][q][entry][32 queries], one (score, id) plane pair per sender wave
+    __syncthreads();
+    float *ms = smem;
+    int *mi = reinterpret_cast<int *>(smem) + (WAVES / 2) * NQ * KC * 32;
+    for (int half = WAVES / 2; half >= 1; half >>= 1) {
+      if (w >= half && w < 2 * half && lane < 32) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int i = 0; i < KC; ++i) {
+            ms[(((w - half) * NQ + q) * KC + i) * 32 + lane] = ls[q][i];
+            mi[(((w - half) * NQ + q) * KC + i) * 32 + lane] = li[q][i];
+          }
+      }
+      __syncthreads();
+      if (w < half && lane < 32) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          float os[KC];
+          int oi[KC];
+#pragma unroll
+          for (int i = 0; i < KC; ++i) {
+            os[i] = ms[((w * NQ + q) * KC + i) * 32 + lane];
+            oi[i] = mi[((w * NQ + q) * KC + i) * 32 + lane];
+          }
+          merge_lists<KC>(ls[q], li[q], os, oi);
+        }
+      }
+      __syncthreads();
+    }
+    if (w == 0 && lane < 32) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int query = (qb * NQ + q) * 32 + lane;
+        if (query < a.Q) {
+          float *ps = a.part_scores + ((size_t)query * a.NSPLIT + split) * KC;
+          int32_t *pi = a.part_ids + ((size_t)query * a.NSPLIT + split) * KC;
+#pragma unroll
+          for (int i = 0; i < KC; i += 4) {
+            *reinterpret_cast<f32x4 *>(ps + i) = f32x4{ls[q][i], ls[q][i + 1], ls[q][i + 2], ls[q][i + 3]};
+            *reinterpret_cast<int4 *>(pi + i) = int4{li[q][i], li[q][i + 1], li[q][i + 2], li[q][i + 3]};
+          }
+        }
+      }
+    }
+  } else {
+    // partial lists -> global: candidate slot (split, wave, lane half)
+    const int slot = (split * WAVES + w) * 2 + (lane >> 5);
+    const int nslots = a.NSPLIT * WAVES * 2;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int query = (qb * NQ + q) * 32 + (lane & 31);
+      if (query < a.Q) {
+        float *ps = a.part_scores + ((size_t)query * nslots + slot) * KC;
+        int32_t *pi = a.part_ids + ((size_t)query * nslots + slot) * KC;
+#pragma unroll
+        for (int i = 0; i < KC; i += 4) {
+          *reinterpret_cast<f32x4 *>(ps + i) = f32x4{ls[q][i], ls[q][i + 1], ls[q][i + 2], ls[q][i + 3]};
+          *reinterpret_cast<int4 *>(pi + i) = int4{li[q][i], li[q][i + 1], li[q][i + 2], li[q][i + 3]};
+        }
       }
     }
   }
 }
 
-int score_slots_per_split() { return (SC_THREADS / 64) * 2; }
+// candidate lists per query and index split
+int score_slots_per_split(int merge) { return merge ? 1 : (SC_THREADS / 64) * 2; }
 
-hipError_t launch_score_topk(const ScoreArgs &a, hipStream_t stream) {
-  if (a.KC != SC_KC) return hipErrorInvalidValue;
-  const size_t lds = (size_t)4 * a.KG * 256 * sizeof(float);
+template <int NQ, bool MERGE>
+static hipError_t launch_score_variant(const ScoreArgs &a, hipStream_t stream) {
+  size_t lds = (size_t)NQ * a.KG * 256 * sizeof(float);
+  const size_t merge_lds = (size_t)(SC_THREADS / 128) * NQ * SC_KC * 32 * 8;
+  if (MERGE && merge_lds > lds) lds = merge_lds;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  const int QB = (a.QT + 3) / 4;
+  const int QB = (a.QT + NQ - 1) / NQ;
   int grid;
   if (a.NSPLIT <= 8) {
     const int per = 8 / a.NSPLIT;
@@ -189,11 +286,19 @@ hipError_t launch_score_topk(const ScoreArgs &a, hipStream_t stream) {
   } else {
     grid = QB * a.NSPLIT;
   }
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(score_topk_kernel<SC_KC>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(score_topk_kernel<SC_KC, NQ, MERGE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(score_topk_kernel<SC_KC>, dim3(grid), dim3(SC_THREADS), lds, stream, a);
+  hipLaunchKernelGGL((score_topk_kernel<SC_KC, NQ, MERGE>), dim3(grid), dim3(SC_THREADS), lds, stream, a);
   return hipGetLastError();
+}
+
+hipError_t launch_score_topk(const ScoreArgs &a, hipStream_t stream) {
+  if (a.KC != SC_KC) return hipErrorInvalidValue;
+  if (a.NSPLIT > 8 && (a.NSPLIT & 7)) return hipErrorInvalidValue;
+  if (a.NQ == 1) return a.MERGE ? launch_score_variant<1, true>(a, stream) : launch_score_variant<1, false>(a, stream);
+  if (a.NQ == 4) return a.MERGE ? launch_score_variant<4, true>(a, stream) : launch_score_variant<4, false>(a, stream);
+  return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------------------
@@ -229,7 +334,7 @@ __device__ __forceinline__ bool before(double sa, int64_t ia, double sb, int64_t
 // One 256-thread workgroup per query.  NC candidates (f32 score, local row id).
 #define RS_THREADS 256
 #define RS_MAXWIN 256
-#define RS_MAXNC 2048  // candidates per query the re-scoring pass accepts
+#define RS_MAXNC 4096  // candidates per query the re-scoring pass accepts
 __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
   __shared__ float s_thr[RS_THREADS / 64];
   __shared__ int s_cnt;
@@ -237,7 +342,7 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
   __shared__ double s_ex[RS_MAXWIN];
   __shared__ float s_m[RS_THREADS / 64];
   __shared__ double s_qn[RS_THREADS / 64];
-  __shared__ unsigned long long s_key[RS_MAXNC];
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_key[];  // [NC] (dynamic: keeps occupancy for small NC)
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const float *ps = a.part_scores + (size_t)q * a.NC;
   const int32_t *pi = a.part_ids + (size_t)q * a.NC;
@@ -341,7 +446,7 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
 
 hipError_t launch_rescore(const RescoreArgs &a, hipStream_t stream) {
   if (a.NC > RS_MAXNC) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(rescore_kernel, dim3(a.Q), dim3(RS_THREADS), 0, stream, a);
+  hipLaunchKernelGGL(rescore_kernel, dim3(a.Q), dim3(RS_THREADS), (size_t)a.NC * sizeof(unsigned long long), stream, a);
   return hipGetLastError();
 }
 

@@ -346,14 +346,23 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   if (k < 1 || k > h->idx_N) return fail(h, "k=%d must be in [1, N=%lld]", k, (long long)h->idx_N);
   if (k > 16) return fail(h, "k=%d > 16 not supported by the fused top-k kernel yet", k);
   const int S = h->idx_S, KG = (S + 7) / 8;
-  const int QT = (Q + 31) / 32, QB = (QT + 3) / 4;
+  const int QT = (Q + 31) / 32;
+  const int NQ = (Q <= 32) ? 1 : 4;  // <= 32 queries (demo / web): single query tile, HBM-bound sweep
+  const int QB = (QT + NQ - 1) / NQ;
   const int64_t NT = (h->idx_N + 31) / 32;
-  // splits of the index range: enough workgroups to fill 256 CUs, >= 8 n-tiles per split,
-  // <= 16 splits (candidate lists stay small)
+  // splits of the index range: enough workgroups to fill the 256 CUs (2 waves of them when the
+  // sweep is long), at least 16 n-tiles (2 per wave) per split.  Up to 8 splits keep the 16
+  // per-wave lists; more splits merge them inside the workgroup so the candidate set stays small.
   int nsplit = 1;
-  while (nsplit < 8 && QB * nsplit < 256 && NT / (nsplit * 2) >= 8) nsplit *= 2;
-  const int NC = nsplit * score_slots_per_split() * 16;
-  if (reserve(h, h->s_qp, (size_t)QB * 4 * KG * 256 * sizeof(float))) return 1;
+  const int max_split = (NQ == 1) ? 256 : 128;
+  while (nsplit < max_split && QB * nsplit < 512 && NT / (nsplit * 2) >= 16) nsplit *= 2;
+  if (nsplit <= 8) {
+    nsplit = 1;
+    while (nsplit < 8 && QB * nsplit < 256 && NT / (nsplit * 2) >= 8) nsplit *= 2;
+  }
+  const int merge = nsplit > 8 ? 1 : 0;
+  const int NC = nsplit * score_slots_per_split(merge) * 16;
+  if (reserve(h, h->s_qp, (size_t)QB * NQ * KG * 256 * sizeof(float))) return 1;
   if (reserve(h, h->s_ps, (size_t)Q * NC * sizeof(float))) return 1;
   if (reserve(h, h->s_pi, (size_t)Q * NC * sizeof(int32_t))) return 1;
   if (reserve(h, h->s_cert, (size_t)Q * sizeof(int32_t))) return 1;
@@ -370,6 +379,8 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   a.QT = QT;
   a.NSPLIT = nsplit;
   a.KC = 16;
+  a.NQ = NQ;
+  a.MERGE = merge;
   HIPCHECK(h, launch_score_topk(a, st));
   RescoreArgs r;
   r.q = q;

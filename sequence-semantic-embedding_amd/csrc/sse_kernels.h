@@ -66,9 +66,11 @@ struct ScoreArgs {
   int32_t *part_ids;     // [Q][NSPLIT][KC] row numbers local to this index (or -1)
   int64_t N;             // index rows
   int32_t Q, KG, NT, QT, NSPLIT, KC;
+  int32_t NQ = 4;     // query tiles (of 32) per workgroup: 4 (128-query blocks) or 1 (Q <= 32)
+  int32_t MERGE = 0;  // 1: one merged list per (query, split); 0: 16 lists (waves x lane halves)
 };
 hipError_t launch_score_topk(const ScoreArgs &a, hipStream_t stream);
-int score_slots_per_split();  // candidate lists per query and index split (waves x lane halves)
+int score_slots_per_split(int merge);  // candidate lists per query and index split
 
 struct RescoreArgs {
   const float *q;          // [Q][S] f32 row-major queries

@@ -170,3 +170,26 @@ def test_large_index_properties():
     wsc, wids = O.topk(O.scores_f64(tq, t.cpu().numpy().astype(np.float64)), k)
     assert np.array_equal(i[:8], wids)
     assert np.abs(s[:8] - wsc).max() < 1e-12
+
+
+@pytest.mark.parametrize("Q,N,S", [(1, 200_000, 64), (7, 150_000, 256), (40, 300_000, 64), (32, 5000, 50)])
+def test_few_queries_many_splits_merged_lists(Q, N, S):
+    """Demo / web regime (sse_demo.py:121-134): a handful of queries against a large index uses the
+    single-query-tile kernel with up to 256 index splits and in-workgroup list merging."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(Q + N)
+    t = torch.nn.functional.normalize(torch.randn((N, S), generator=g, device=dev), dim=1)
+    q = torch.nn.functional.normalize(torch.randn((Q, S), generator=g, device=dev), dim=1)
+    t[N - 1] = q[0]                      # best match in the very last (partial) tile
+    t[12345 % N] = q[0]                  # and an exact duplicate earlier: tie -> lower row first
+    h = _scorer()
+    h.index_set_dev(t.data_ptr(), N, S)
+    out_s = torch.empty((Q, 10), dtype=torch.float64, device=dev)
+    out_i = torch.empty((Q, 10), dtype=torch.int64, device=dev)
+    h.score_topk_dev(q.data_ptr(), Q, 10, out_s.data_ptr(), out_i.data_ptr())
+    torch.cuda.synchronize()
+    wsc, wids = O.topk(O.scores_f64(q.cpu().numpy(), t.cpu().numpy().astype(np.float64)), 10)
+    assert np.array_equal(out_i.cpu().numpy(), wids)
+    assert np.abs(out_s.cpu().numpy() - wsc).max() < 1e-12
+    assert out_i[0, 0].item() == 12345 % N and out_i[0, 1].item() == N - 1

@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""Single-query (demo / web, sse_demo.py:121-134) scoring against a large resident index: HBM-bound
+regime, algorithmic bytes = N*S*4 per pass."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import sse_amd  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+S = 256
+dev = torch.device("cuda:0")
+params = dict(forward_only=True, network_mode="dual-encoder", predict_nbest=10, max_seq_length=8, vocab_size=50,
+              embedding_size=8, encoding_size=S, src_cell_size=16, tgt_cell_size=16, learning_rate=0.9,
+              learning_rate_decay_factor=0.99, targetSpaceSize=5)
+h = sse_amd.SSEModel(params).handle
+t = torch.empty((N, S), device=dev)
+for i in range(0, N, 1_000_000):
+    t[i:i + 1_000_000] = torch.nn.functional.normalize(torch.randn((min(1_000_000, N - i), S), device=dev), dim=1)
+h.index_set_dev(t.data_ptr(), N, S)
+del t
+for Q in (1, 8, 32):
+    q = torch.nn.functional.normalize(torch.randn((Q, S), device=dev), dim=1)
+    os_ = torch.empty((Q, 10), dtype=torch.float64, device=dev)
+    oi = torch.empty((Q, 10), dtype=torch.int64, device=dev)
+    h.score_topk_dev(q.data_ptr(), Q, 10, os_.data_ptr(), oi.data_ptr())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        h.score_topk_dev(q.data_ptr(), Q, 10, os_.data_ptr(), oi.data_ptr())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    print("Q=%d N=%d S=%d: %.3f ms/pass, %.2f TB/s of index streamed, %.3g scores/s"
+          % (Q, N, S, dt * 1e3, N * S * 4 / dt / 1e12, Q * N / dt))
