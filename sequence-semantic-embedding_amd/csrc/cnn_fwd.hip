@@ -24,7 +24,7 @@ struct CnnArgs {
   const float *bias;   // [576]
   float *featp;        // frag32(rows = b, red = feature): [ceil(B/32)][72][256]
   int32_t *err;
-  int32_t B, T, V, Ep;
+  int32_t B, T, V, Ep, wbytes;
 };
 
 __constant__ int c_fs[4] = {2, 3, 4, 5};
@@ -36,7 +36,9 @@ __global__ __launch_bounds__(CNN_THREADS) void conv_pool_kernel(CnnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int T = a.T, Ep = a.Ep, E4 = Ep / 4;
   const int b0 = blockIdx.x * CNN_NB;
-  int *s_next = reinterpret_cast<int *>(xs + CNN_NB * T * Ep + 5 * Ep);  // all LDS in the dynamic region (16-B aligned base)
+  // all LDS in the dynamic region (16-B aligned base): xs | 5*Ep pad | feat[NB][576] | work counter
+  int *feat = reinterpret_cast<int *>(xs + CNN_NB * T * Ep + 5 * Ep);  // running max as int bits (values >= 0)
+  int *s_next = feat + CNN_NB * 576;
 
   // stage the embedded sequences (row-major, Ep-padded rows: 16-byte aligned windows)
   for (int i = tid; i < CNN_NB * T * E4; i += CNN_THREADS) {
@@ -50,51 +52,79 @@ __global__ __launch_bounds__(CNN_THREADS) void conv_pool_kernel(CnnArgs a) {
     reinterpret_cast<f32x4 *>(xs)[i] = *reinterpret_cast<const f32x4 *>(a.emb + (size_t)id * Ep + q * 4);
   }
   for (int i = tid; i < 5 * Ep; i += CNN_THREADS) xs[CNN_NB * T * Ep + i] = 0.0f;  // windows of the last rows read past the tile
+  for (int i = tid; i < CNN_NB * 576; i += CNN_THREADS) feat[i] = 0;
   if (tid == 0) *s_next = 0;
   __syncthreads();
 
-  // work items, most expensive first: (width 5..2) x (filter tile) x (sequence group); waves pull from an LDS counter
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.Wc), 0, a.wbytes, 0x00020000);
+  const int voff = lane * 16;
+  // work items, most expensive first: (width 5..2) x (filter tile) x (position tile) x (sequence
+  // group); waves pull them from an LDS counter; partial maxima meet in feat[] via atomicMax
   const int NSG = CNN_NB / CNN_SG;
-  const int n_items = 18 * NSG;
   const int PT = (T + 31) / 32;  // position tiles (positions >= P are masked)
+  const int n_items = 18 * NSG * PT;
   for (;;) {
     int item = 0;
     if (lane == 0) item = atomicAdd(s_next, 1);
     item = __builtin_amdgcn_readfirstlane(item);
     if (item >= n_items) break;
-    const int sg = item % NSG;
-    int tile = item / NSG, wi = 3, woff_tiles = 0;  // tile counted from the widest filter down
+    const int sg = item % NSG, pt = (item / NSG) % PT;
+    int tile = item / (NSG * PT), wi = 3, woff_tiles = 0;  // tile counted from the widest filter down
     while (tile >= c_nt[wi]) {
       tile -= c_nt[wi];
       --wi;
     }
     for (int j = 0; j < wi; ++j) woff_tiles += c_nt[j] * (c_fs[j] * Ep / 8);
     const int fs = c_fs[wi], KG = fs * Ep / 8, P = T - fs + 1;
-    const float *wp = a.Wc + ((size_t)woff_tiles + (size_t)tile * KG) * 256 + lane * 4;
+    const int wsoff = (woff_tiles + tile * KG) * 1024;  // byte offset of this filter tile in the packed weights
     const float bias = a.bias[c_foff[wi] + tile * 32 + (lane & 31)];
     const float *xb = xs + (size_t)(sg * CNN_SG) * T * Ep + (lane & 31) * Ep + (lane >> 5) * 4;
-    float runmax[CNN_SG];
-#pragma unroll
-    for (int s = 0; s < CNN_SG; ++s) runmax[s] = 0.0f;  // ReLU output >= 0 and P >= 1
-    for (int pt = 0; pt < PT; ++pt) {
+    {
       f32x16 acc[CNN_SG];
 #pragma unroll
       for (int s = 0; s < CNN_SG; ++s)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[s][r] = 0.0f;
       const float *xa = xb + (size_t)pt * 32 * Ep;
-      f32x4 bcur = *reinterpret_cast<const f32x4 *>(wp);
-      for (int kg = 0; kg < KG; ++kg) {
-        const f32x4 bnxt = *reinterpret_cast<const f32x4 *>(wp + (size_t)((kg + 1 < KG) ? kg + 1 : kg) * 256);
-        f32x4 a4[CNN_SG];
+      // k-loop, hand software-pipelined (two named operand sets, no copies): filter fragment
+      // of k-group kg+1 (global, via buffer descriptor) and the 4 window fragments (LDS) are in
+      // flight while kg's 16 MFMAs issue
+      auto wl = [&](int kg) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, voff, wsoff + kg * 1024, 0));
+      };
+      f32x4 bx = wl(0), by, ax[CNN_SG], ay[CNN_SG];
 #pragma unroll
-        for (int s = 0; s < CNN_SG; ++s) a4[s] = *reinterpret_cast<const f32x4 *>(xa + (size_t)s * T * Ep + kg * 8);
+      for (int s = 0; s < CNN_SG; ++s) ax[s] = *reinterpret_cast<const f32x4 *>(xa + (size_t)s * T * Ep);
+      __builtin_amdgcn_s_setprio(1);
+      int kg = 0;
+      for (; kg + 1 < KG; kg += 2) {
+        by = wl(kg + 1);
+#pragma unroll
+        for (int s = 0; s < CNN_SG; ++s) ay[s] = *reinterpret_cast<const f32x4 *>(xa + (size_t)s * T * Ep + (kg + 1) * 8);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int s = 0; s < CNN_SG; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s][e], bcur[e], acc[s], 0, 0, 0);
-        bcur = bnxt;
+          for (int s = 0; s < CNN_SG; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[s][e], bx[e], acc[s], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int k2 = (kg + 2 < KG) ? kg + 2 : kg;
+        bx = wl(k2);
+#pragma unroll
+        for (int s = 0; s < CNN_SG; ++s) ax[s] = *reinterpret_cast<const f32x4 *>(xa + (size_t)s * T * Ep + k2 * 8);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int s = 0; s < CNN_SG; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[s][e], by[e], acc[s], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      if (kg < KG) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int s = 0; s < CNN_SG; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[s][e], bx[e], acc[s], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
       // bias + ReLU + max over this tile's valid positions (row = position, column = filter)
 #pragma unroll
       for (int s = 0; s < CNN_SG; ++s) {
@@ -106,18 +136,16 @@ __global__ __launch_bounds__(CNN_THREADS) void conv_pool_kernel(CnnArgs a) {
           m = fmaxf(m, (p < P) ? v : 0.0f);
         }
         m = fmaxf(m, __shfl_xor(m, 32));
-        runmax[s] = fmaxf(runmax[s], m);
+        if (lane < 32) atomicMax(&feat[(sg * CNN_SG + s) * 576 + c_foff[wi] + tile * 32 + lane], __float_as_int(m));
       }
     }
-    if (lane < 32) {
-      const int j = c_foff[wi] + tile * 32 + lane;  // feature index
-#pragma unroll
-      for (int s = 0; s < CNN_SG; ++s) {
-        const int b = b0 + sg * CNN_SG + s;
-        if (b < a.B)
-          a.featp[((size_t)(b >> 5) * 72 + (j >> 3)) * 256 + ((((j >> 2) & 1) * 32 + (b & 31)) << 2) + (j & 3)] = runmax[s];
-      }
-    }
+  }
+  __syncthreads();
+  // features -> global, frag32(rows = b, red = feature)
+  for (int i = tid; i < CNN_NB * 576; i += CNN_THREADS) {
+    const int j = i % 576, b = b0 + i / 576;
+    if (b < a.B)
+      a.featp[((size_t)(b >> 5) * 72 + (j >> 3)) * 256 + ((((j >> 2) & 1) * 32 + (b & 31)) << 2) + (j & 3)] = __int_as_float(feat[i]);
   }
 }
 
@@ -211,7 +239,7 @@ __global__ void pack_conv_kernel_k(const float *__restrict__ W, int fs, int E, i
   }
 }
 
-size_t cnn_lds_bytes(int T, int Ep) { return (size_t)(CNN_NB * T * Ep + 5 * Ep) * sizeof(float) + 16; }
+size_t cnn_lds_bytes(int T, int Ep) { return (size_t)(CNN_NB * T * Ep + 5 * Ep + CNN_NB * 576) * sizeof(float) + 16; }
 
 size_t cnn_packed_weight_floats(int Ep) {
   static const int fs[4] = {2, 3, 4, 5}, nt[4] = {8, 4, 4, 2};
@@ -240,7 +268,7 @@ hipError_t launch_cnn_fwd(const int32_t *ids, const float *emb, const float *Wc,
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pool_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  CnnArgs a{ids, emb, Wc, bias, featp, err, B, T, V, Ep};
+  CnnArgs a{ids, emb, Wc, bias, featp, err, B, T, V, Ep, (int32_t)(cnn_packed_weight_floats(Ep) * sizeof(float))};
   hipLaunchKernelGGL(conv_pool_kernel, dim3((B + CNN_NB - 1) / CNN_NB), dim3(CNN_THREADS), lds, stream, a);
   ProjArgs p{featp, Mp, out, B, S, 72, (S + 31) / 32, normalize};
   hipLaunchKernelGGL(proj_norm_kernel, dim3((B + 31) / 32), dim3(256), 0, stream, p);

@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""Text-CNN encoder forward throughput (BASELINE configs[4] shapes: source_only_cnn, T=64, S=512, E=50),
+inputs resident in HBM.  Algorithmic work 2E*sum((T-fs+1)*fs*nf) + 2*576*S = 11.24 MFLOP/sequence."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import sse_amd  # noqa: E402
+
+V, E, S, T = 32000, 50, 512, 64
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+dev = torch.device("cuda:0")
+params = dict(forward_only=True, network_mode="source_only_cnn", predict_nbest=10, max_seq_length=T, vocab_size=V,
+              embedding_size=E, encoding_size=S, src_cell_size=96, tgt_cell_size=96, learning_rate=0.9,
+              learning_rate_decay_factor=0.99, targetSpaceSize=571)
+m = sse_amd.SSEModel(params)
+m.init_variables(seed=0)
+h = m.handle
+ids = torch.randint(2, V, (B, T), device=dev, dtype=torch.int32)
+out = torch.empty((B, S), device=dev)
+flop = 2 * E * sum((T - fs + 1) * fs * nf for fs, nf in zip((2, 3, 4, 5), (256, 128, 128, 64))) + 2 * 576 * S
+for _ in range(3):
+    h.encode_dev(0, ids.data_ptr(), B, T, True, out.data_ptr())
+n = 10
+h.timer_record(0)
+for _ in range(n):
+    h.encode_dev(0, ids.data_ptr(), B, T, True, out.data_ptr())
+h.timer_record(1)
+ms = h.timer_elapsed_ms(0, 1) / n
+print("CNN encode B=%d T=%d S=%d: %.3f ms  %.0f seq/s  %.1f TFLOP/s algorithmic (%.1f%% of fp32 MFMA peak)"
+      % (B, T, S, ms, B / ms * 1e3, B * flop / ms / 1e9, B * flop / ms / 1e9 / 157.3 * 100))
