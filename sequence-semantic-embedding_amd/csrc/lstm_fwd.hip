@@ -25,13 +25,14 @@
 #define LSTM_THREADS 512
 #define LSTM_BM 64
 
-// LDS: xbuf[XD ? 2 : 1][2 mt][KGx][256] + hbuf[2 bufs][2 mt][KGh][256] + red[64][4].
+// LDS: xbuf[XD ? 2 : 1][RT][KGx][256] + hbuf[2 bufs][RT][KGh][256] + red[256 floats].
 // h is double-buffered (step t reads buffer t&1, writes (t+1)&1: one barrier per
 // step); x is double-buffered too when it fits in the 160 KiB (XD).
-bool lstm_fwd_x_double(int KGx, int KGh) { return (size_t)(4 * KGx + 4 * KGh + 1) * 1024 <= 160 * 1024; }
-size_t lstm_fwd_lds_bytes(int KGx, int KGh) {
-  const int xb = lstm_fwd_x_double(KGx, KGh) ? 2 : 1;
-  return (size_t)(xb * 2 * KGx + 4 * KGh) * 256 * sizeof(float) + 64 * 4 * sizeof(float);
+// (RT = 32-row tiles per workgroup: 2, or 1 for the low-latency / Hp = 512 configurations)
+bool lstm_fwd_x_double(int KGx, int KGh, int RT) { return (size_t)(2 * RT * (KGx + KGh) + 1) * 1024 <= 160 * 1024; }
+size_t lstm_fwd_lds_bytes(int KGx, int KGh, int RT) {
+  const int xb = lstm_fwd_x_double(KGx, KGh, RT) ? 2 : 1;
+  return (size_t)(xb * RT * KGx + 2 * RT * KGh) * 256 * sizeof(float) + 64 * 4 * sizeof(float);
 }
 
 // v_exp_f32 (2^x) + v_rcp_f32 (1 ulp); plain `/` or __fdividef would expand to the ~10-instruction IEEE division
@@ -106,30 +107,40 @@ __device__ __forceinline__ void gemm_pass(__amdgpu_buffer_rsrc_t wr, int voff, i
   __builtin_amdgcn_s_setprio(0);
 }
 
-template <int MT, bool TRAIN, bool LIN>
+// Kernel configurations (RT = 32-row tiles per workgroup, MT = row tiles per wave, UBW = unit
+// blocks of 32 hidden units a wave processes one after the other); always 8 waves:
+//   <2,2,1>  Hp = 256, 64 rows: wave w owns unit block w for both row tiles      (throughput)
+//   <2,1,1>  Hp = 128, 64 rows: wave w: unit block w&3, row tile w>>2
+//   <1,1,1>  Hp = 256, 32 rows: wave w owns unit block w      (half the per-step latency: used
+//            when the batch cannot fill the chip with 64-row tiles)
+//   <1,1,2>  Hp = 512, 32 rows: wave w owns unit blocks w and w+8
+template <int RT, int MT, int UBW, bool TRAIN, bool LIN>
 __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int ROWS = RT * 32;                 // sequences per workgroup
+  constexpr int TPR = LSTM_THREADS / ROWS;      // threads per sequence row in the x gather
+  constexpr int NWR = 8 / RT;                   // waves sharing one row tile (projection tail)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  // unit block owned by this wave, and its first row tile
-  const int ub = (MT == 2) ? w : (w & 3);
-  const int mt0 = (MT == 2) ? 0 : (w >> 2);
+  // first unit block owned by this wave (further ones at +8), and its first row tile
+  const int ub0 = (RT == 2 && MT == 1) ? (w & 3) : w;
+  const int mt0 = (RT == 2 && MT == 1) ? (w >> 2) : 0;
   const int KGx = a.KGx, KGh = a.KGh, KG = KGx + KGh, T = a.T;
-  // LDS.  LIN (x double-buffered, fits 160 KiB): A tiles [2 bufs][2 mt][KG][256], the x part of
+  // LDS.  LIN (x double-buffered, fits 160 KiB): A tiles [2 bufs][RT][KG][256], the x part of
   // a row tile followed by its h part, so a k-loop walks one linear array.  Otherwise:
-  // x [2 mt][KGx][256] single-buffered, then h [2 bufs][2 mt][KGh][256].
+  // x [RT][KGx][256] single-buffered, then h [2 bufs][RT][KGh][256].
   constexpr bool XD = LIN;
   auto xptr = [&](int buf, int mt) -> float * {
-    return LIN ? smem + (size_t)((buf * 2 + mt) * KG) * 256 : smem + (size_t)(mt * KGx) * 256;
+    return LIN ? smem + (size_t)((buf * RT + mt) * KG) * 256 : smem + (size_t)(mt * KGx) * 256;
   };
   auto hptr = [&](int buf, int mt) -> float * {
-    return LIN ? smem + (size_t)((buf * 2 + mt) * KG + KGx) * 256
-               : smem + (size_t)(2 * KGx + (buf * 2 + mt) * KGh) * 256;
+    return LIN ? smem + (size_t)((buf * RT + mt) * KG + KGx) * 256
+               : smem + (size_t)(RT * KGx + (buf * RT + mt) * KGh) * 256;
   };
-  float *red = smem + (size_t)(LIN ? 4 * KG : 2 * KGx + 4 * KGh) * 256;  // [64][4]
-  const int b0 = blockIdx.x * LSTM_BM;
+  float *red = smem + (size_t)(LIN ? 2 * RT * KG : RT * KGx + 2 * RT * KGh) * 256;  // [ROWS][NWR] (>= 8 floats)
+  const int b0 = blockIdx.x * ROWS;
 
-  // --- x gather assignment: 8 threads per sequence row, 8 floats (one k-group) each
-  const int xr = tid >> 3, xq = tid & 7;
+  // --- x gather assignment: TPR threads per sequence row, 8 floats (one k-group) each
+  const int xr = tid / TPR, xq = tid % TPR;
   const bool row_ok = (b0 + xr) < a.B;
   const int32_t *id_row = a.ids + (size_t)(row_ok ? (a.row_map ? a.row_map[b0 + xr] : b0 + xr) : 0) * T;
   auto fetch_id = [&](int t) -> int {
@@ -149,11 +160,11 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   // --- left-pad prefix skip: first step this tile has to compute (0 when disabled / training)
   int t0 = 0;
   if (!TRAIN && a.pad_h != nullptr) {
-    // leading-PAD count of row xr (8 threads per row scan interleaved positions), min over the tile;
-    // rows beyond B count as all-PAD
+    // leading-PAD count of row xr (TPR threads per row scan interleaved positions), min over the
+    // tile; rows beyond B count as all-PAD
     int lead = T;
     if (row_ok) {
-      for (int t = xq; t < T; t += 8)
+      for (int t = xq; t < T; t += TPR)
         if (id_row[t] != 0) {
           lead = t;
           break;
@@ -173,46 +184,46 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   {
     const int id = fetch_id(t0);
     const float *src = a.emb + (size_t)id * a.Ep;
-    for (int kg = xq; kg < KGx; kg += 8) {
+    for (int kg = xq; kg < KGx; kg += TPR) {
       f32x4 lo = *reinterpret_cast<const f32x4 *>(src + kg * 8);
       f32x4 hi = *reinterpret_cast<const f32x4 *>(src + kg * 8 + 4);
       x_store(t0 & 1, kg, lo, hi);
     }
     const int Hp = KGh * 8;
-    for (int i = tid; i < 2 * KGh * 256; i += LSTM_THREADS) {  // both row tiles of buffer t0 & 1
+    for (int i = tid; i < RT * KGh * 256; i += LSTM_THREADS) {  // all row tiles of buffer t0 & 1
       const int mt = i / (KGh * 256), e = i % (KGh * 256);
       const int un = (e >> 8) * 8 + ((e >> 7) & 1) * 4 + (e & 3);  // k index of element e of a frag32 row tile
       hptr(t0 & 1, mt)[e] = (t0 > 0) ? a.pad_h[(size_t)t0 * Hp + un] : 0.0f;
     }
   }
 
-  float bias[4];
+  float bias[UBW][4];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) bias[g] = a.bias[(ub * 4 + g) * 32 + (lane & 31)];
+  for (int u = 0; u < UBW; ++u)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[u][g] = a.bias[((ub0 + 8 * u) * 4 + g) * 32 + (lane & 31)];
 
-  f32x16 c[MT];
-  {
-    const float c0 = (t0 > 0) ? a.pad_c[(size_t)t0 * (KGh * 8) + ub * 32 + (lane & 31)] : 0.0f;
+  f32x16 c[UBW][MT];
+#pragma unroll
+  for (int u = 0; u < UBW; ++u) {
+    const float c0 = (t0 > 0) ? a.pad_c[(size_t)t0 * (KGh * 8) + (ub0 + 8 * u) * 32 + (lane & 31)] : 0.0f;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) c[m][r] = c0;
+      for (int r = 0; r < 16; ++r) c[u][m][r] = c0;
   }
 
   __syncthreads();
 
-  // weights of this wave's unit block: Wp[ub][kg][gate][256], read through a buffer descriptor
+  // weights: Wp[unit block][kg][gate][256], read through a buffer descriptor
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(a.Wp), 0, (KGh / 4) * KG * 4096, 0x00020000);
-  const int wsoff = __builtin_amdgcn_readfirstlane(ub) * KG * 4096;
   const int wvoff = lane * 16;
-  const int unit = ub * 32 + (lane & 31);
-  const int hoff = (unit >> 3) * 256 + ((((unit >> 2) & 1) * 32) << 2) + (unit & 3);  // h element (row 0, k = unit) in a row tile
-  const int NT32 = gridDim.x * 2;
+  const int NT32 = a.NT32 > 0 ? a.NT32 : gridDim.x * RT;  // 32-row tiles in the launch (tape indexing)
 
   for (int t = t0; t < T; ++t) {
     // prefetch the embedding rows of step t+1 into registers (one k-group per
-    // thread covers E <= 64; wider embeddings are completed after the GEMM)
+    // thread covers E <= 8*TPR; wider embeddings are completed at the store)
     const bool have_next = (t + 1) < T;
     int nid = 0;
     f32x4 nlo = {0, 0, 0, 0}, nhi = {0, 0, 0, 0};
@@ -239,8 +250,8 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       // r = (t*NT32 + tile32)*32 + b, i.e. AT[(r/8)*KT + k'/32][256].
       const int KT = 2 + KGh / 4;
       const int nk = 64 + KGh * 8;
-      for (int i = tid; i < nk * 16; i += LSTM_THREADS) {
-        const int kp = i % nk, b4 = i / nk;  // b4: rows 4*b4 .. 4*b4+3 of the 64
+      for (int i = tid; i < nk * (ROWS / 4); i += LSTM_THREADS) {
+        const int kp = i % nk, b4 = i / nk;  // b4: rows 4*b4 .. 4*b4+3 of the tile
         const int mt = b4 >> 3, bl = (b4 & 7) * 4;
         f32x4 v = {0, 0, 0, 0};
         if (kp >= 64) {
@@ -251,98 +262,105 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
           const float *src = xptr(cur, mt) + (size_t)(kp >> 3) * 256 + ((((kp >> 2) & 1) * 32 + bl) << 2) + (kp & 3);
           v = f32x4{src[0], src[4], src[8], src[12]};
         }
-        const size_t rg = ((size_t)t * NT32 + blockIdx.x * 2 + mt) * 4 + (bl >> 3);
+        const size_t rg = ((size_t)t * NT32 + blockIdx.x * RT + mt) * 4 + (bl >> 3);
         float *dst = a.tape_a + (rg * KT + (kp >> 5)) * 256 + ((((bl >> 2) & 1) * 32 + (kp & 31)) << 2);
         *reinterpret_cast<f32x4 *>(dst) = v;
       }
     }
     const int kend = (t == 0) ? KGx : KG;  // h_{-1} = 0: skip the recurrent part of step 0
 
-    // gate tape, accumulator layout: [t][tile32][unit block][q][reg][lane], q = si,tj,sf,so,c
-    float *tp[MT];
-    if constexpr (TRAIN) {
+#pragma unroll
+    for (int u = 0; u < UBW; ++u) {
+      const int ub = ub0 + 8 * u;
+      const int unit = ub * 32 + (lane & 31);
+      const int hoff = (unit >> 3) * 256 + ((((unit >> 2) & 1) * 32) << 2) + (unit & 3);  // h element (row 0, k = unit) in a row tile
+      const int wsoff = __builtin_amdgcn_readfirstlane(ub) * KG * 4096;
+      // gate tape, accumulator layout: [t][tile32][unit block][q][reg][lane], q = si,tj,sf,so,c
+      float *tp[MT];
+      if constexpr (TRAIN) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          tp[m] = a.tape_g + (((size_t)t * NT32 + blockIdx.x * RT + mt0 + m) * (KGh / 4) + ub) * 5 * 1024 + lane;
+      }
+
+      // pass A: gates i, j  ->  pij = sigmoid(i) * tanh(j)      (BasicLSTMCell, TF 1.x)
+      // pij is parked in the (still unused) h_t slots of the other h buffer -- same (row, unit)
+      // coordinates -- instead of 16*MT registers held across pass B.
+      f32x16 g[MT][2];
+      float *hdst[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        hdst[m] = hptr(nxt, mt0 + m) + hoff;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          g[m][0][r] = bias[u][0];
+          g[m][1][r] = bias[u][1];
+        }
+      }
+      gemm_pass<MT, LIN>(wr, wvoff, wsoff, xa, ha, KGx, kend, g);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
-        tp[m] = a.tape_g + (((size_t)t * NT32 + blockIdx.x * 2 + mt0 + m) * (KGh / 4) + ub) * 5 * 1024 + lane;
-    }
-
-    // pass A: gates i, j  ->  pij = sigmoid(i) * tanh(j)      (BasicLSTMCell, TF 1.x)
-    // pij is parked in the (still unused) h_t slots of the other h buffer -- same (row, unit)
-    // coordinates -- instead of 16*MT registers held across pass B.
-    f32x16 g[MT][2];
-    float *hdst[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      hdst[m] = hptr(nxt, mt0 + m) + hoff;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        g[m][0][r] = bias[0];
-        g[m][1][r] = bias[1];
-      }
-    }
-    gemm_pass<MT, LIN>(wr, wvoff, wsoff, xa, ha, KGx, kend, g);
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float si = fast_sigmoid(g[m][0][r]);
-        const float tj = fast_tanh(g[m][1][r]);
-        hdst[m][mfma_row(r, lane) << 2] = si * tj;
-        if constexpr (TRAIN) {
-          tp[m][r * 64] = si;
-          tp[m][1024 + r * 64] = tj;
+        for (int r = 0; r < 16; ++r) {
+          const float si = fast_sigmoid(g[m][0][r]);
+          const float tj = fast_tanh(g[m][1][r]);
+          hdst[m][mfma_row(r, lane) << 2] = si * tj;
+          if constexpr (TRAIN) {
+            tp[m][r * 64] = si;
+            tp[m][1024 + r * 64] = tj;
+          }
+        }
+      if (u == 0 && XD && have_next) {
+        // x_{t+1}: its buffer was last read in step t-1, so it can be written as soon as the
+        // prefetch has landed (frees the staging registers before pass B)
+        if (xq < KGx) x_store(nxt, xq, nlo, nhi);
+        for (int kg = xq + TPR; kg < KGx; kg += TPR) {
+          const float *src = a.emb + (size_t)nid * a.Ep + kg * 8;
+          x_store(nxt, kg, *reinterpret_cast<const f32x4 *>(src), *reinterpret_cast<const f32x4 *>(src + 4));
         }
       }
-    if (XD && have_next) {
-      // x_{t+1}: its buffer was last read in step t-1, so it can be written as soon as the
-      // prefetch has landed (frees the staging registers before pass B)
-      if (xq < KGx) x_store(nxt, xq, nlo, nhi);
-      for (int kg = xq + 8; kg < KGx; kg += 8) {
-        const float *src = a.emb + (size_t)nid * a.Ep + kg * 8;
-        x_store(nxt, kg, *reinterpret_cast<const f32x4 *>(src), *reinterpret_cast<const f32x4 *>(src + 4));
-      }
-    }
-    // pass B: gates f (+1 folded into the bias), o -> c' = c*sigmoid(f) + pij ; h' = tanh(c')*sigmoid(o)
+      // pass B: gates f (+1 folded into the bias), o -> c' = c*sigmoid(f) + pij ; h' = tanh(c')*sigmoid(o)
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        g[m][0][r] = bias[2];
-        g[m][1][r] = bias[3];
-      }
-    gemm_pass<MT, LIN>(wr, wvoff, wsoff + 2048, xa, ha, KGx, kend, g);
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float sf = fast_sigmoid(g[m][0][r]);
-        const float so = fast_sigmoid(g[m][1][r]);
-        const float cn = c[m][r] * sf + hdst[m][mfma_row(r, lane) << 2];
-        c[m][r] = cn;
-        const float hv = fast_tanh(cn) * so;
-        hdst[m][mfma_row(r, lane) << 2] = hv;  // h_t, A-fragment order
-        if (!TRAIN && a.rec_h != nullptr && blockIdx.x == 0 && mt0 + m == 0 && r == 0 && lane < 32) {
-          // row 0 of the launch: state after t+1 steps (used to build the pad-prefix table)
-          a.rec_h[(size_t)(t + 1) * (KGh * 8) + unit] = hv;
-          a.rec_c[(size_t)(t + 1) * (KGh * 8) + unit] = cn;
+        for (int r = 0; r < 16; ++r) {
+          g[m][0][r] = bias[u][2];
+          g[m][1][r] = bias[u][3];
         }
-        if constexpr (TRAIN) {
-          tp[m][2048 + r * 64] = sf;
-          tp[m][3072 + r * 64] = so;
-          tp[m][4096 + r * 64] = cn;
+      gemm_pass<MT, LIN>(wr, wvoff, wsoff + 2048, xa, ha, KGx, kend, g);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float sf = fast_sigmoid(g[m][0][r]);
+          const float so = fast_sigmoid(g[m][1][r]);
+          const float cn = c[u][m][r] * sf + hdst[m][mfma_row(r, lane) << 2];
+          c[u][m][r] = cn;
+          const float hv = fast_tanh(cn) * so;
+          hdst[m][mfma_row(r, lane) << 2] = hv;  // h_t, A-fragment order
+          if (!TRAIN && a.rec_h != nullptr && blockIdx.x == 0 && mt0 + m == 0 && r == 0 && lane < 32) {
+            // row 0 of the launch: state after t+1 steps (used to build the pad-prefix table)
+            a.rec_h[(size_t)(t + 1) * (KGh * 8) + unit] = hv;
+            a.rec_c[(size_t)(t + 1) * (KGh * 8) + unit] = cn;
+          }
+          if constexpr (TRAIN) {
+            tp[m][2048 + r * 64] = sf;
+            tp[m][3072 + r * 64] = so;
+            tp[m][4096 + r * 64] = cn;
+          }
         }
       }
     }
 
-    // stage x_{t+1}: with a double-buffered x tile its buffer was last read in step
-    // t-1; with a single buffer it must wait until every wave finished step t
+    // end of step: with a double-buffered x tile x_{t+1} is already in place; with a single
+    // buffer it must wait until every wave finished step t
     if (XD) {
       __syncthreads();  // h_t complete and visible; h_{t-1} / x_t no longer needed
     } else {
       __syncthreads();
       if (have_next) {
         if (xq < KGx) x_store(0, xq, nlo, nhi);
-        for (int kg = xq + 8; kg < KGx; kg += 8) {
+        for (int kg = xq + TPR; kg < KGx; kg += TPR) {
           const float *src = a.emb + (size_t)nid * a.Ep + kg * 8;
           x_store(0, kg, *reinterpret_cast<const f32x4 *>(src), *reinterpret_cast<const f32x4 *>(src + 4));
         }
@@ -354,25 +372,25 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   if constexpr (TRAIN) {
     // h_T, row-major [Bp][Hp], for dM = h_T^T . d(out)
     const int Hp = KGh * 8;
-    for (int i = tid; i < LSTM_BM * Hp; i += LSTM_THREADS) {
+    for (int i = tid; i < ROWS * Hp; i += LSTM_THREADS) {
       const int un = i % Hp, b = i / Hp;
       a.h_last[(size_t)(b0 + b) * Hp + un] =
           hptr(T & 1, b >> 5)[(size_t)(un >> 3) * 256 + ((((un >> 2) & 1) * 32 + (b & 31)) << 2) + (un & 3)];
     }
   }
 
-  // --- projection  out = h_T . M   (+ optional l2_normalize): wave w -> row tile w>>2,
-  // N tiles nt = (w&3), (w&3)+4, ...
-  const int wn = w & 3, wm = w >> 2;
-  constexpr int PT = 4;  // up to Sp = 512
+  // --- projection  out = h_T . M   (+ optional l2_normalize): NWR waves per row tile,
+  // wave -> row tile wm, N tiles nt = wn, wn + NWR, ...
+  const int wn = w % NWR, wm = w / NWR;
+  constexpr int PT = 16 / NWR;  // up to Sp = 512
   const float *hp = hptr(T & 1, wm) + lane * 4;  // h_T
   f32x16 pacc[PT];
-  float ss[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) ss[r] = 0.0f;
+  // per-(row, N-tile) sums of squares go to LDS (the h buffer that is NOT h_T is free now) and
+  // are added in fixed tile order, so a row's result does not depend on the wave decomposition
+  float *ssq = hptr((T + 1) & 1, 0);  // [ROWS][16]
 #pragma unroll
   for (int i = 0; i < PT; ++i) {
-    const int nt = wn + 4 * i;
+    const int nt = wn + NWR * i;
 #pragma unroll
     for (int r = 0; r < 16; ++r) pacc[i][r] = 0.0f;
     if (nt < a.NTS) {
@@ -383,27 +401,28 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) pacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], pacc[i], 0, 0, 0);
       }
+      if (a.normalize) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ss[r] += pacc[i][r] * pacc[i][r];
+        for (int r = 0; r < 16; ++r) {
+          float v = pacc[i][r] * pacc[i][r];
+          v += __shfl_xor(v, 1);
+          v += __shfl_xor(v, 2);
+          v += __shfl_xor(v, 4);
+          v += __shfl_xor(v, 8);
+          v += __shfl_xor(v, 16);
+          if ((lane & 31) == 0) ssq[(wm * 32 + mfma_row(r, lane)) * 16 + nt] = v;
+        }
+      }
     }
   }
   float scale[16];
   if (a.normalize) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = ss[r];
-      v += __shfl_xor(v, 1);
-      v += __shfl_xor(v, 2);
-      v += __shfl_xor(v, 4);
-      v += __shfl_xor(v, 8);
-      v += __shfl_xor(v, 16);
-      if ((lane & 31) == 0) red[(wm * 32 + mfma_row(r, lane)) * 4 + wn] = v;
-    }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const f32x4 p = *reinterpret_cast<const f32x4 *>(red + (wm * 32 + mfma_row(r, lane)) * 4);
-      const float tot = (p[0] + p[1]) + (p[2] + p[3]);
+      const float *pr = ssq + (wm * 32 + mfma_row(r, lane)) * 16;
+      float tot = 0.0f;
+      for (int j = 0; j < a.NTS; ++j) tot += pr[j];
       scale[r] = 1.0f / sqrtf(fmaxf(tot, 1e-12f));  // tf.nn.l2_normalize epsilon
     }
   } else {
@@ -412,7 +431,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   }
 #pragma unroll
   for (int i = 0; i < PT; ++i) {
-    const int nt = wn + 4 * i;
+    const int nt = wn + NWR * i;
     const int col = nt * 32 + (lane & 31);
     if (nt < a.NTS && col < a.S) {
 #pragma unroll
@@ -424,29 +443,38 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   }
 }
 
-template <int MT, bool TRAIN, bool LIN>
-static hipError_t launch_one(const LstmFwdArgs &a, size_t lds, dim3 grid, dim3 block, hipStream_t stream) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_kernel<MT, TRAIN, LIN>),
+template <int RT, int MT, int UBW, bool TRAIN, bool LIN>
+static hipError_t launch_one(const LstmFwdArgs &a, size_t lds, hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_kernel<RT, MT, UBW, TRAIN, LIN>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((lstm_fwd_kernel<MT, TRAIN, LIN>), grid, block, lds, stream, a);
+  const dim3 grid(a.NT32 > 0 ? a.NT32 / RT : (a.B + RT * 32 - 1) / (RT * 32)), block(LSTM_THREADS);
+  hipLaunchKernelGGL((lstm_fwd_kernel<RT, MT, UBW, TRAIN, LIN>), grid, block, lds, stream, a);
   return hipGetLastError();
 }
 
-template <int MT>
-static hipError_t launch_mt(const LstmFwdArgs &a, size_t lds, dim3 grid, dim3 block, hipStream_t stream) {
+template <int RT, int MT, int UBW>
+static hipError_t launch_cfg(const LstmFwdArgs &a_in, hipStream_t stream) {
+  LstmFwdArgs a = a_in;
+  a.xdouble = lstm_fwd_x_double(a.KGx, a.KGh, RT) ? 1 : 0;
+  const size_t lds = lstm_fwd_lds_bytes(a.KGx, a.KGh, RT);
   const bool train = a.tape_g != nullptr;
-  if (a.xdouble) return train ? launch_one<MT, true, true>(a, lds, grid, block, stream) : launch_one<MT, false, true>(a, lds, grid, block, stream);
-  return train ? launch_one<MT, true, false>(a, lds, grid, block, stream) : launch_one<MT, false, false>(a, lds, grid, block, stream);
+  if (a.xdouble) return train ? launch_one<RT, MT, UBW, true, true>(a, lds, stream) : launch_one<RT, MT, UBW, false, true>(a, lds, stream);
+  return train ? launch_one<RT, MT, UBW, true, false>(a, lds, stream) : launch_one<RT, MT, UBW, false, false>(a, lds, stream);
 }
 
-hipError_t launch_lstm_fwd(const LstmFwdArgs &a_in, int Hp, hipStream_t stream) {
-  LstmFwdArgs a = a_in;
-  a.xdouble = lstm_fwd_x_double(a.KGx, a.KGh) ? 1 : 0;
-  const size_t lds = lstm_fwd_lds_bytes(a.KGx, a.KGh);
-  const dim3 grid((a.B + LSTM_BM - 1) / LSTM_BM), block(LSTM_THREADS);
-  // Hp = 128: 4 unit blocks x 2 row halves over the 8 waves; Hp = 256: 8 unit blocks, both halves per wave
-  if (Hp == 128) return launch_mt<1>(a, lds, grid, block, stream);
-  if (Hp == 256) return launch_mt<2>(a, lds, grid, block, stream);
+// rows per workgroup the launcher will use for (Hp, B): 64, or 32 when 64-row tiles cannot fill
+// the 256 CUs (half the per-step latency, all tiles still resident) and for Hp = 512
+int lstm_fwd_rows_per_wg(int Hp, int B) {
+  if (Hp == 512) return 32;
+  if (Hp == 256 && (B + 31) / 32 <= 256) return 32;
+  return 64;
+}
+
+hipError_t launch_lstm_fwd(const LstmFwdArgs &a, int Hp, hipStream_t stream) {
+  const int rows = lstm_fwd_rows_per_wg(Hp, a.B);
+  if (Hp == 128) return launch_cfg<2, 1, 1>(a, stream);
+  if (Hp == 256) return rows == 32 ? launch_cfg<1, 1, 1>(a, stream) : launch_cfg<2, 2, 1>(a, stream);
+  if (Hp == 512) return launch_cfg<1, 1, 2>(a, stream);
   return hipErrorInvalidValue;
 }

@@ -147,13 +147,13 @@ int setup_encoder(sse_handle *h, Encoder &e, const std::string &scope, const std
 int geometry(sse_handle *h, Encoder &e) {
   const sse_config &c = h->cfg;
   if (e.H <= 0) return 0;
-  if (e.H > 256) return fail(h, "LSTM cell size %d > 256 is not supported by the gfx950 kernel yet", e.H);
-  e.Hp = e.H <= 128 ? 128 : 256;
+  if (e.H > 512) return fail(h, "LSTM cell size %d > 512 is not supported by the gfx950 kernel yet", e.H);
+  e.Hp = e.H <= 128 ? 128 : e.H <= 256 ? 256 : 512;
   e.UB = e.Hp / 128;
   e.Ep = round_up(c.embedding_size, 8);
   e.KGx = e.Ep / 8;
   e.KGh = e.Hp / 8;
-  if (lstm_fwd_lds_bytes(e.KGx, e.KGh) > 160 * 1024)
+  if (lstm_fwd_lds_bytes(e.KGx, e.KGh, e.Hp == 512 ? 1 : 2) > 160 * 1024)
     return fail(h, "embedding_size %d too large for the LSTM kernel's LDS tile", c.embedding_size);
   if (c.encoding_size > 512) return fail(h, "encoding_size %d > 512 not supported", c.encoding_size);
   return 0;
@@ -763,6 +763,8 @@ int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tg
     ts.packed_dirty = false;
   }
   if (E > 64) return fail(h, "train step: embedding_size %d > 64 not supported yet", E);
+  for (int s = 0; s < 2; ++s)
+    if (h->enc[s].Hp > 256) return fail(h, "train step: LSTM cell size %d > 256 not supported yet (inference only)", h->enc[s].H);
 
   // ---- inputs
   const int32_t *ids_host[2] = {src_ids_host, tgt_ids_host};
@@ -802,6 +804,7 @@ int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tg
     a.S = S;
     a.NTS = (S + 31) / 32;
     a.normalize = 0;
+    a.NT32 = NT32;
     a.tape_g = (float *)ts.tape_g[s].p;
     a.tape_a = (float *)ts.tape_a[s].p;
     a.h_last = (float *)ts.h_last[s].p;

@@ -40,6 +40,7 @@ struct LstmFwdArgs {
   float *out;           // [B][S]
   int32_t *err;         // bit 0: token id out of range
   int32_t B, T, V, Ep, KGx, KGh, S, NTS, normalize;
+  int32_t NT32 = 0;     // training: number of 32-row tiles the tapes are laid out for (0: from the grid)
   int32_t xdouble = 1;  // set by launch_lstm_fwd from lstm_fwd_x_double()
   // Left-pad prefix skip (exact): the state after p leading PAD (id 0) steps does not depend on
   // the sequence, so a tile starts at t0 = min over its rows of the leading-PAD count with
@@ -54,8 +55,9 @@ struct LstmFwdArgs {
   float *h_last = nullptr;  // [Bp][Hp] h_T
 };
 // Hp = 128 * UB hidden units; 512 threads; dynamic LDS = lstm_fwd_lds_bytes()
-size_t lstm_fwd_lds_bytes(int KGx, int KGh);
-bool lstm_fwd_x_double(int KGx, int KGh);
+size_t lstm_fwd_lds_bytes(int KGx, int KGh, int RT);
+bool lstm_fwd_x_double(int KGx, int KGh, int RT);
+int lstm_fwd_rows_per_wg(int Hp, int B);
 hipError_t launch_lstm_fwd(const LstmFwdArgs &a, int Hp, hipStream_t stream);
 
 // ------------------------------ scoring ------------------------------------

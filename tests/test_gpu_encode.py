@@ -19,6 +19,8 @@ CASES = [
     ("dual-encoder", 120, 30, 128, 64, 64, 7, 1),          # ranking recipe sizes, B = 1 (demo)
     ("dual-encoder", 64, 50, 96, 200, 64, 2, 129),         # T = 2 minimum, odd cell sizes
     ("source-encoder-only", 64, 8, 32, 32, 16, 5, 3),
+    ("dual-encoder", 200, 50, 512, 300, 128, 12, 45),      # cell sizes up to 512 (32-row tiles, 2 unit blocks per wave)
+    ("dual-encoder", 500, 50, 256, 256, 256, 32, 9000),    # > 8192 rows: 64-row tiles; below: 32-row tiles
 ]
 
 
