@@ -344,7 +344,11 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   if (Q < 0) return fail(h, "bad Q");
   if (Q == 0) return 0;
   if (k < 1 || k > h->idx_N) return fail(h, "k=%d must be in [1, N=%lld]", k, (long long)h->idx_N);
-  if (k > 16) return fail(h, "k=%d > 16 not supported by the fused top-k kernel yet", k);
+  if (k > 16) {
+    // beyond the fused kernel's list size: exact float64 paging (correct for any k <= N)
+    HIPCHECK(h, launch_exact_topk(q, h->idxp, h->idx64, nullptr, out_s, out_i, h->idx_base, h->idx_N, Q, h->idx_S, k, st));
+    return 0;
+  }
   const int S = h->idx_S, KG = (S + 7) / 8;
   const int QT = (Q + 31) / 32;
   const int NQ = (Q <= 32) ? 1 : 4;  // <= 32 queries (demo / web): single query tile, HBM-bound sweep

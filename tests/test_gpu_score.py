@@ -106,8 +106,8 @@ def test_adversarial_ascending_scores_and_argument_checks():
     h.index_upload(t)
     sc, ids = h.score_topk(base[None], 10)
     assert ids[0].tolist() == list(range(N - 1, N - 11, -1))
-    with pytest.raises(sse_amd.SSEError):
-        h.score_topk(base[None], 17)              # documented limit of the fused path
+    sc17, ids17 = h.score_topk(base[None], 17)      # beyond the fused kernel's list: exact paging path
+    assert ids17[0].tolist() == list(range(N - 1, N - 18, -1))
     with pytest.raises(sse_amd.SSEError):
         h.score_topk(base[None], 0)
 
@@ -193,3 +193,18 @@ def test_few_queries_many_splits_merged_lists(Q, N, S):
     assert np.array_equal(out_i.cpu().numpy(), wids)
     assert np.abs(out_s.cpu().numpy() - wsc).max() < 1e-12
     assert out_i[0, 0].item() == 12345 % N and out_i[0, 1].item() == N - 1
+
+
+@pytest.mark.parametrize("Q,N,S,k", [(3, 571, 64, 571), (5, 3000, 32, 100), (2, 40, 16, 33)])
+def test_large_k_exact_paging(Q, N, S, k):
+    """nbest is user-chosen in sse_demo.py:146; any k <= N must work (ties: lower row first)."""
+    rng = np.random.RandomState(k)
+    q, t = _unit(rng, Q, S), _unit(rng, N, S)
+    t[N // 2] = t[1]
+    t[N - 1] = t[1]
+    h = _scorer()
+    h.index_upload(t)
+    sc, ids = h.score_topk(q, k)
+    wsc, wids = O.topk(O.scores_f64(q, t.astype(np.float64)), k)
+    assert np.array_equal(ids, wids)
+    assert np.abs(sc - wsc).max() < 1e-12
