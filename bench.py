@@ -255,6 +255,10 @@ def main():
                    "frac_of_f32_mfma_peak": 2.0 * S * Q * Ns / sdt / 1e12 / PEAK_F32_MFMA_TFLOPS,
                    "top1_planted_acc": planted_ok}
 
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and B == 16384:          # PMC pass of this same command (tools/summarize_profiles.py)
+        traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
     if rank == 0:
         line = {
             "metric": "encoded seqs/sec (+ query x target cosine-scores/sec, top-1 vs ref)",
@@ -269,7 +273,8 @@ def main():
             "top1_match_vs_oracle": top1_match, "encode_max_abs_err_vs_oracle": enc_err,
             "roofline": {"kernel": "lstm_fwd_kernel<2>", "bound": "mfma", "achieved": achieved_tflops,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None, "avg_kernel_ms": enc_ms_avg,
+                         "traffic": traffic, "traffic_unit": "bytes/launch (PMC, separate rocprofv3 pass; null if no pass on record)",
+                         "avg_kernel_ms": enc_ms_avg,
                          "algorithmic_flop_per_launch": B * FLOP_PER_SEQ},
         }
         if scoring is not None:

@@ -39,6 +39,21 @@ def main():
             out.append("%-42s grid=%-8s %-26s n=%-3d avg=%.5g  (avg dispatch %.3f ms)"
                        % (k, g, c, len(v), sum(v) / len(v), sum(dur[(k, g)]) / len(dur[(k, g)]) / 1e6))
     open(os.path.join(root, "%s_pmc.txt" % tag), "w").write("\n".join(out) + "\n")
+    # HBM traffic of the dominant kernel's full-size launches for bench.py's roofline.traffic:
+    # bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md)
+    import json
+    traffic = {}
+    for d in pmc_dirs:
+        for r in csv.DictReader(open(os.path.join(d, "p_counter_collection.csv"))):
+            if "lstm_fwd" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE") and int(r["Grid_Size"]) >= 65536:
+                traffic.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
+        f = sum(traffic["FETCH_SIZE"]) / len(traffic["FETCH_SIZE"])
+        w_ = sum(traffic["WRITE_SIZE"]) / len(traffic["WRITE_SIZE"])
+        json.dump({"kernel": "lstm_fwd_kernel (16384-sequence launches)", "fetch_size_kb": f, "write_size_kb": w_,
+                   "hbm_bytes_per_launch": (2 * f + w_) * 1024, "source": "profiles/%s_pmc.txt" % tag,
+                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH doubled per the gfx950 correction"},
+                  open(os.path.join(root, "traffic.json"), "w"), indent=1)
     print("\n".join(out))
 
 
