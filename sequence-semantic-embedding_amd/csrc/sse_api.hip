@@ -364,7 +364,9 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
     nsplit = 1;
     while (nsplit < 8 && QB * nsplit < 256 && NT / (nsplit * 2) >= 8) nsplit *= 2;
   }
-  const int merge = nsplit > 8 ? 1 : 0;
+  // the 16 per-wave lists of a workgroup are always merged in-kernel (a few tens of microseconds per
+  // workgroup): the re-scoring pass then ranks 16 candidates per split instead of 256
+  const int merge = 1;
   const int NC = nsplit * score_slots_per_split(merge) * 16;
   if (reserve(h, h->s_qp, (size_t)QB * NQ * KG * 256 * sizeof(float))) return 1;
   if (reserve(h, h->s_ps, (size_t)Q * NC * sizeof(float))) return 1;
