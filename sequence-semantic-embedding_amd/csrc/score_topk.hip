@@ -121,6 +121,18 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
       li[q][i] = -1;
     }
 
+  // Shared per-query insertion thresholds (LDS, order-preserving int encoding of the float):
+  // max over the workgroup's 16 lists of a query of their current minima.  A list minimum is
+  // the KC-th best of a subset of the rows, hence a lower bound of the workgroup's KC-th best:
+  // rows below it can never reach the merged top-KC, so every lane may use it as its
+  // threshold -- the 16 lists of a query share their progress and insertions (a
+  // wave-divergent ~100-instruction path) become ~16x rarer.
+  int *thr_s = reinterpret_cast<int *>(smem + (size_t)a.thr_off);
+  auto enc = [](float f) -> int { const int i = __float_as_int(f); return i >= 0 ? i : (i ^ 0x7FFFFFFF); };
+  auto dec = [](int i) -> float { return __int_as_float(i >= 0 ? i : (i ^ 0x7FFFFFFF)); };
+  for (int i = tid; i < NQ * 32; i += SC_THREADS) thr_s[i] = enc(NEG_INF);
+  __syncthreads();
+
   const int tps = (a.NT + a.NSPLIT - 1) / a.NSPLIT;  // n-tiles per split
   const int t0 = split * tps, t1 = min(a.NT, t0 + tps);
   const float *qs = smem + lane * 4;
@@ -178,17 +190,43 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
     }
     __builtin_amdgcn_s_setprio(0);
 
-    // fused top-k: lane owns query column (lane & 31) of each q-tile and sees
-    // 16 index rows per n-tile, in increasing row order (ties keep the lower row)
+    // fused top-k: lane owns query column (lane & 31) of each q-tile and sees 16 index rows
+    // per n-tile.  Branch-lean: one max tree per q-tile against the (shared) threshold; only
+    // when some lane beats it, lanes repeatedly extract their best remaining score and
+    // insert it (1-2 rounds in practice) -- no per-score branches.
     const int nrow0 = tile * 32;
+    const bool tail = (nrow0 + 32) > a.N;  // only the last tile has rows >= N (zero padding)
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
+      float m = NEG_INF;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = nrow0 + mfma_row(r, lane);
-        const float s = (n < a.N) ? acc[q][r] : NEG_INF;
-        const bool take = s > ls[q][KC - 1];
-        if (__any(take)) list_insert<KC>(ls[q], li[q], s, n, take);
+        if (tail) acc[q][r] = (nrow0 + mfma_row(r, lane) >= a.N) ? NEG_INF : acc[q][r];
+        m = fmaxf(m, acc[q][r]);
+      }
+      float thr = fmaxf(ls[q][KC - 1], dec(thr_s[q * 32 + (lane & 31)]));
+      if (__any(m > thr)) {
+        for (;;) {
+          // this lane's best remaining score and its register index (first one on ties: rows
+          // ascend with r, so equal scores are taken in row order)
+          const bool take = m > thr;
+          int ridx = 0;
+          bool found = false;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool hit = !found && (acc[q][r] == m);
+            ridx = hit ? r : ridx;
+            acc[q][r] = (hit && take) ? NEG_INF : acc[q][r];
+            found = found || hit;
+          }
+          list_insert<KC>(ls[q], li[q], m, nrow0 + (ridx & 3) + 8 * (ridx >> 2) + 4 * (lane >> 5), take);
+          thr = fmaxf(thr, ls[q][KC - 1]);
+          m = NEG_INF;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[q][r]);
+          if (!__any(m > thr)) break;
+        }
+        atomicMax(&thr_s[q * 32 + (lane & 31)], enc(ls[q][KC - 1]));  // publish this list's minimum
       }
     }
   }
@@ -277,10 +315,13 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
 int score_slots_per_split(int merge) { return merge ? 1 : (SC_THREADS / 64) * 2; }
 
 template <int NQ, bool MERGE>
-static hipError_t launch_score_variant(const ScoreArgs &a, hipStream_t stream) {
-  size_t lds = (size_t)NQ * a.KG * 256 * sizeof(float);
+static hipError_t launch_score_variant(const ScoreArgs &a_in, hipStream_t stream) {
+  size_t lds = (size_t)NQ * a_in.KG * 256 * sizeof(float);
   const size_t merge_lds = (size_t)(SC_THREADS / 128) * NQ * SC_KC * 32 * 8;
   if (MERGE && merge_lds > lds) lds = merge_lds;
+  ScoreArgs a = a_in;
+  a.thr_off = (int32_t)(lds / sizeof(float));  // shared thresholds live behind the query block / merge scratch
+  lds += (size_t)NQ * 32 * sizeof(int);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const int QB = (a.QT + NQ - 1) / NQ;
   int grid;

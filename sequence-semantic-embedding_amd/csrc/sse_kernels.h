@@ -70,6 +70,7 @@ struct ScoreArgs {
   int32_t Q, KG, NT, QT, NSPLIT, KC;
   int32_t NQ = 4;     // query tiles (of 32) per workgroup: 4 (128-query blocks) or 1 (Q <= 32)
   int32_t MERGE = 0;  // 1: one merged list per (query, split); 0: 16 lists (waves x lane halves)
+  int32_t thr_off = 0;  // set by the launcher: LDS offset (floats) of the shared per-query thresholds
 };
 hipError_t launch_score_topk(const ScoreArgs &a, hipStream_t stream);
 int score_slots_per_split(int merge);  // candidate lists per query and index split
