@@ -127,6 +127,10 @@ class SSEModel(object):
         self.tgt_seq_embedding = _Sym("tgt_seq_embedding")
         self.norm_src_seq_embedding = _Sym("norm_src_seq_embedding")
         self.norm_tgt_seq_embedding = _Sym("norm_tgt_seq_embedding")
+        # in-graph prediction (sse_model.py:344-352): top-N of the all-pairs cosine matrix, scores l2-normalised
+        self.predicted_tgts_score = _Sym("predicted_tgts_score")
+        self.predicted_labels = _Sym("predicted_labels")
+        self.similarity = _Sym("similarity")
         self.loss = _Sym("loss")
         self.train_acc = _Sym("train_acc")
         self.train = _Sym("train")
@@ -208,6 +212,28 @@ class SSEModel(object):
     def train_step(self, src_ids, tgt_ids, labels):
         return self.handle.train_step(src_ids, tgt_ids, labels)
 
+    def predict(self, src_ids, tgt_ids, top_n=None):
+        """`_def_predict` (sse_model.py:344-352): tf.nn.top_k(similarity, TOP_N) over the batch's
+        own targets, then the k scores l2-normalised per row.  Returns (scores float32 [Bs,k],
+        labels int32 [Bs,k]); the [Bs,Bt] matrix itself is never materialised (fused top-k)."""
+        k = min(int(top_n or self.TOP_N), len(tgt_ids))
+        ns, nt = self.encode_source(src_ids, True), self.encode_target(tgt_ids, True)
+        self.handle.index_upload(nt)
+        sc, idx = self.handle.score_topk(ns, k)
+        sc = sc.astype(np.float32)
+        sc = sc / np.sqrt(np.maximum(np.sum(sc * sc, axis=1, keepdims=True), np.float32(1e-12)))
+        return sc.astype(np.float32), idx.astype(np.int32)
+
+    def similarity_matrix(self, src_ids, tgt_ids):
+        """`self.similarity` (sse_model.py:286) for callers that really want all pairs: every column
+        via the same fused kernel (k = Bt); intended for small Bt."""
+        ns, nt = self.encode_source(src_ids, True), self.encode_target(tgt_ids, True)
+        self.handle.index_upload(nt)
+        sc, idx = self.handle.score_topk(ns, len(nt))
+        out = np.empty((len(ns), len(nt)), np.float32)
+        np.put_along_axis(out, idx, sc.astype(np.float32), axis=1)
+        return out
+
     # -- reference surface ---------------------------------------------------
     def set_top_n(self, top_n):
         self.TOP_N = top_n
@@ -282,6 +308,12 @@ class Session(object):
                 out.append(model.encode_target(feed[model._tgt_input_data], True))
             elif n == "tgt_seq_embedding":
                 out.append(model.encode_target(feed[model._tgt_input_data], False))
+            elif n in ("predicted_tgts_score", "predicted_labels"):
+                if "predict" not in cache:
+                    cache["predict"] = model.predict(feed[model._src_input_data], feed[model._tgt_input_data])
+                out.append(cache["predict"][0 if n == "predicted_tgts_score" else 1])
+            elif n == "similarity":
+                out.append(model.similarity_matrix(feed[model._src_input_data], feed[model._tgt_input_data]))
             elif n == "learning_rate_decay_op":
                 model.handle.decay_learning_rate()
                 out.append(model.handle.learning_rate)

@@ -135,3 +135,24 @@ def test_pad_prefix_skip_is_bit_identical_and_survives_weight_updates():
     ids2 = ids[:5].copy()
     ids2[2, 20] = 0
     assert np.abs(m.encode_source(ids2) - O.encode(p2, params, "src", ids2)).max() <= TOL
+
+
+def test_in_graph_predict_and_similarity():
+    """`_def_predict` / `self.similarity` (sse_model.py:286,344-352): never fetched by the reference's
+    CLIs but part of the model surface."""
+    import sse_amd
+    params = model_params("dual-encoder", 90, 16, 32, 32, 24, 7)
+    m, p = make_pair(params, seed=9)
+    rng = np.random.RandomState(2)
+    src, tgt = random_ids(rng, 6, 7, 90), random_ids(rng, 21, 7, 90)
+    ns, nt = O.encode(p, params, "src", src), O.encode(p, params, "tgt", tgt)
+    sim = O.similarity(ns, nt)
+    sess = sse_amd.Session(m)
+    scores, labels = sess.run([m.predicted_tgts_score, m.predicted_labels], feed_dict=m.get_predict_feed_dict(src, tgt))
+    want_idx = np.argsort(-sim, axis=1, kind="stable")[:, :10]
+    want_sc = np.take_along_axis(sim, want_idx, axis=1)
+    want_sc = want_sc / np.linalg.norm(want_sc, axis=1, keepdims=True)
+    assert np.array_equal(labels, want_idx)
+    assert np.abs(scores - want_sc).max() < 1e-5
+    got_sim = sess.run(m.similarity, feed_dict=m.get_predict_feed_dict(src, tgt))
+    assert np.abs(got_sim - sim).max() < 1e-5
