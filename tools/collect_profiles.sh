@@ -1,0 +1,22 @@
+#!/bin/bash
+# Run on the GPU box from the repo root: bench line + rocprofv3 kernel stats + PMC passes (each counter group in its
+# own run, kernel-trace only, as MI355X_MICROARCH.md prescribes), all under gpurun_out/<tag>/.
+# usage: tools/collect_profiles.sh <tag>;  then: python tools/summarize_profiles.py <tag> gpurun_out/<tag>/stats gpurun_out/<tag>/pmc_*
+set -u
+tag=${1:-prof}
+root=$(pwd)
+out=$root/gpurun_out/$tag
+mkdir -p "$out"
+export TMPDIR=/tmp
+python bench.py > "$out/bench.json" 2> "$out/bench.err"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o p -- \
+    python "$root/bench.py" > "$out/stats.log" 2>&1
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32"; do
+    d="$out/pmc_$(echo $c | tr ' ' '_' | cut -c1-40)"
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$d" -o p -- \
+        python "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --score-iters 1 > "$out/log_$(basename $d).txt" 2>&1
+done
+cd "$root"
+find "$out" -name "*.csv" -size +20M -delete
+ls -la "$out"

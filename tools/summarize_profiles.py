@@ -16,7 +16,7 @@ def main():
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     rows = list(csv.DictReader(open(os.path.join(stats_dir, "p_kernel_stats.csv"))))
     with open(os.path.join(root, "%s_kernel_stats.csv" % tag), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+        f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py"
                 "  (library kernels only; torch setup kernels dropped)\n")
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
         w.writeheader()
