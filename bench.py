@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--score-iters", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scoring-leg", action="store_true")
+    ap.add_argument("--train-rows", type=int, default=8192, help="train leg: pair rows per GPU per step")
+    ap.add_argument("--train-iters", type=int, default=5)
+    ap.add_argument("--no-train-leg", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -255,6 +258,35 @@ def main():
                    "frac_of_f32_mfma_peak": 2.0 * S * Q * Ns / sdt / 1e12 / PEAK_F32_MFMA_TFLOPS,
                    "top1_planted_acc": planted_ok}
 
+    # ---- secondary leg: data-parallel train step (fwd + loss + BPTT, ONE flat RCCL all-reduce, clip + Adagrad);
+    # runs last because it updates the weights
+    training = None
+    if not args.no_train_leg:
+        rng = np.random.RandomState(1234 + rank)
+        Bt = args.train_rows
+        tsrc = np.repeat(rng.randint(2, V, size=(Bt // 2, T)).astype(np.int32), 2, axis=0)   # data.py:95-115: pos,neg share a source
+        ttgt = rng.randint(2, V, size=(Bt, T)).astype(np.int32)
+        tsrc[:, -1] = 1
+        ttgt[:, -1] = 1
+        tz = np.tile(np.array([1.0, 0.0], np.float32), Bt // 2)
+        trainer = sse_amd.DataParallelTrainer(h, device=dev)
+        tl = trainer.train_step(tsrc, ttgt, tz, rows_global=Bt * world)
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(args.train_iters):
+            tl = trainer.train_step(tsrc, ttgt, tz, rows_global=Bt * world)
+        barrier()
+        tdt = (time.perf_counter() - ts) / args.train_iters
+        if world > 1:
+            t = torch.tensor([tdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tdt = float(t.item())
+        training = {"pair_rows_per_s": Bt * world / tdt, "ms_per_step": tdt * 1e3, "pair_rows_per_gpu": Bt,
+                    "collective": ("rccl all_reduce of one flat %.1f MB gradient buffer" % (trainer.arena.numel() * 4 / 1e6))
+                    if world > 1 else "none (1 rank)",
+                    "algorithmic_tflops_per_gpu": 3.0 * 2 * Bt * FLOP_PER_SEQ / tdt / 1e12,
+                    "loss_last": tl[0], "input": "host int32 ids each step (H2D inside the timed region)"}
+
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and B == 16384:          # PMC pass of this same command (tools/summarize_profiles.py)
@@ -279,6 +311,8 @@ def main():
         }
         if scoring is not None:
             line["scoring_leg"] = scoring
+        if training is not None:
+            line["train_leg"] = training
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]

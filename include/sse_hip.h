@@ -120,6 +120,27 @@ int sse_merge_topk_dev(sse_handle *h, const double *in_scores_dev, const int64_t
  * float32 [B] (sse_model.py:420). */
 int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tgt_ids_host,
                    const float *labels_host, int32_t B, int32_t T, float *loss, float *train_acc);
+
+/* Data-parallel training (SURVEY 8e "Training"): sse_train_step split at the
+ * gradient exchange.  sse_train_grads runs forward + loss + backward on this
+ * rank's B pair rows with the loss defined as the mean over rows_global rows
+ * (the sum of B over all ranks) and leaves everything that has to be summed
+ * across ranks in ONE flat float32 device buffer, the gradient arena:
+ *   [ d word_embedding (dense [V,E]) | d <variable 1> | ... | tail[4] ]
+ * in sse_variable_info order, tail = { sum of squares of the un-deduplicated
+ * embedding-gradient slices (what tf.clip_by_global_norm sees for the
+ * IndexedSlices of sse_model.py:355-359), loss, train_acc, rows }.
+ * The caller all-reduces (sum) the arena over RCCL, then sse_train_apply
+ * clips by the global norm of the reduced gradients and applies Adagrad --
+ * bit-identical on every rank.  sse_train_set_grad_arena lets the caller own
+ * the buffer (e.g. a torch tensor handed to torch.distributed.all_reduce);
+ * NULL returns to a library-owned one.  sse_train_step == grads(rows_global =
+ * B) + apply. */
+int sse_train_grad_count(sse_handle *h, int64_t *count);
+int sse_train_set_grad_arena(sse_handle *h, float *arena_dev, int64_t count);
+int sse_train_grads(sse_handle *h, const int32_t *src_ids_host, const int32_t *tgt_ids_host,
+                    const float *labels_host, int32_t B, int32_t T, int64_t rows_global);
+int sse_train_apply(sse_handle *h, float *loss, float *train_acc);
 /* model.learning_rate.eval(), model.global_step.eval(), learning_rate_decay_op
  * (sse_train.py:181,200; sse_model.py:122-125) */
 int sse_get_learning_rate(sse_handle *h, float *lr);

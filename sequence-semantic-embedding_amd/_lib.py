@@ -45,6 +45,10 @@ SYMBOLS = {
     "sse_score_topk_dev": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "sse_merge_topk_dev": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "sse_train_step": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "sse_train_grad_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "sse_train_set_grad_arena": (C.c_int, [_P, _P, C.c_int64]),
+    "sse_train_grads": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int64]),
+    "sse_train_apply": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sse_get_learning_rate": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "sse_set_learning_rate": (C.c_int, [_P, C.c_float]),
     "sse_decay_learning_rate": (C.c_int, [_P]),
@@ -194,6 +198,38 @@ class Handle(object):
         loss, acc = C.c_float(), C.c_float()
         self.check(self.lib.sse_train_step(self._h, _ptr(s), _ptr(t), _ptr(z), s.shape[0], s.shape[1],
                                            C.byref(loss), C.byref(acc)))
+        return float(loss.value), float(acc.value)
+
+    # ---- data-parallel split of the train step: grads -> all-reduce(arena) -> apply
+    def train_grad_count(self):
+        n = C.c_int64()
+        self.check(self.lib.sse_train_grad_count(self._h, C.byref(n)))
+        return int(n.value)
+
+    def train_set_grad_arena(self, dev_ptr, count):
+        """Hand the library a caller-owned float32 device buffer (e.g. tensor.data_ptr()) of train_grad_count()
+        floats for the gradients; dev_ptr=None returns to a library-owned one.  The caller keeps it alive."""
+        self.check(self.lib.sse_train_set_grad_arena(self._h, C.c_void_p(dev_ptr) if dev_ptr else None, int(count)))
+
+    def train_bind_arena(self, tensor):
+        """tensor: contiguous float32 CUDA tensor of train_grad_count() elements on the handle's device."""
+        if not tensor.is_cuda or not tensor.is_contiguous() or str(tensor.dtype) != "torch.float32":
+            raise ValueError("gradient arena must be a contiguous float32 CUDA tensor")
+        self._arena = tensor                                       # keep it alive
+        self.train_set_grad_arena(tensor.data_ptr(), tensor.numel())
+
+    def train_grads(self, src_ids, tgt_ids, labels, rows_global=None):
+        s = np.ascontiguousarray(src_ids, np.int32)
+        t = np.ascontiguousarray(tgt_ids, np.int32)
+        z = np.ascontiguousarray(labels, np.float32)
+        if s.shape != t.shape or s.ndim != 2 or z.shape != (s.shape[0],):
+            raise ValueError("train batch shapes: src/tgt [B,T], labels [B]")
+        self.check(self.lib.sse_train_grads(self._h, _ptr(s), _ptr(t), _ptr(z), s.shape[0], s.shape[1],
+                                            int(rows_global if rows_global is not None else s.shape[0])))
+
+    def train_apply(self):
+        loss, acc = C.c_float(), C.c_float()
+        self.check(self.lib.sse_train_apply(self._h, C.byref(loss), C.byref(acc)))
         return float(loss.value), float(acc.value)
 
     @property

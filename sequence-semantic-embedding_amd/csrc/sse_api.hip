@@ -50,6 +50,11 @@ struct TrainState {
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   float *KhT[2] = {nullptr, nullptr}, *KxT[2] = {nullptr, nullptr};
   bool packed_dirty = true;
+  // gradient arena: [grad of variable 0 | ... | grad of variable n-1 | tail[4]]; tail = {sum of squares of the
+  // un-deduplicated embedding-gradient slices, loss, train_acc, rows}, every entry a plain sum over the
+  // ranks of a data-parallel job (one flat all-reduce)
+  float *arena = nullptr;
+  bool arena_external = false, grads_ready = false;
 };
 
 }  // namespace
@@ -494,8 +499,8 @@ void sse_destroy(sse_handle *h) {
   for (auto &v : h->vars) {
     if (v.dev) hipFree(v.dev);
     if (v.slot) hipFree(v.slot);
-    if (v.grad) hipFree(v.grad);
   }
+  if (h->train && h->train->arena && !h->train->arena_external) hipFree(h->train->arena);
   for (int s = 0; s < 2; ++s) {
     Encoder &e = h->enc[s];
     if (e.shares_lstm_with < 0) {
@@ -725,16 +730,60 @@ int sse_merge_topk_dev(sse_handle *h, const double *in_scores_dev, const int64_t
   return 0;
 }
 
-int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tgt_ids_host, const float *labels_host,
-                   int32_t B, int32_t T, float *loss, float *train_acc) {
+static int64_t grad_arena_count(sse_handle *h) {
+  int64_t n = 4;
+  for (auto &v : h->vars) n += v.count;
+  return n;
+}
+
+static void bind_arena(sse_handle *h, float *p, bool external) {
+  TrainState &ts = *h->train;
+  ts.arena = p;
+  ts.arena_external = external;
+  ts.grads_ready = false;
+  int64_t off = 0;
+  for (auto &v : h->vars) {
+    v.grad = p + off;
+    off += v.count;
+  }
+}
+
+int sse_train_grad_count(sse_handle *h, int64_t *count) {
+  if (!h || !count) return 1;
+  *count = grad_arena_count(h);
+  return 0;
+}
+
+int sse_train_set_grad_arena(sse_handle *h, float *arena_dev, int64_t count) {
   if (!h) return 1;
   std::lock_guard<std::mutex> lk(h->mu);
   HIPCHECK(h, hipSetDevice(h->cfg.device));
+  if (!h->train) h->train = new TrainState();
+  TrainState &ts = *h->train;
+  if (arena_dev && count != grad_arena_count(h))
+    return fail(h, "gradient arena holds %lld floats, the model needs %lld", (long long)count, (long long)grad_arena_count(h));
+  HIPCHECK(h, hipDeviceSynchronize());
+  if (ts.arena && !ts.arena_external) HIPCHECK(h, hipFree(ts.arena));
+  ts.arena = nullptr;
+  if (arena_dev) {
+    bind_arena(h, arena_dev, true);
+  } else {
+    for (auto &v : h->vars) v.grad = nullptr;
+    ts.arena_external = false;
+    ts.grads_ready = false;
+  }
+  return 0;
+}
+
+// Forward, loss and backward of one batch of pair rows; gradients are scaled by 1/rows_global and left in
+// the arena (with the tail sums), nothing is updated.
+static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const int32_t *tgt_ids_host,
+                              const float *labels_host, int32_t B, int32_t T, int64_t rows_global) {
   const sse_config &c = h->cfg;
   if (c.network_mode != SSE_MODE_DUAL_ENCODER && c.network_mode != SSE_MODE_SHARED_ENCODER)
     return fail(h, "train step: the reference loss is ill-shaped for this network mode (sse_model.py:233,290)");
-  if (B < 1 || T < 1 || !src_ids_host || !tgt_ids_host || !labels_host || !loss || !train_acc)
-    return fail(h, "bad arguments to sse_train_step");
+  if (B < 1 || T < 1 || !src_ids_host || !tgt_ids_host || !labels_host || rows_global < B)
+    return fail(h, "bad arguments to the train step");
   hipStream_t st = nullptr;
   if (!h->train) h->train = new TrainState();
   TrainState &ts = *h->train;
@@ -748,8 +797,14 @@ int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tg
   const int E = c.embedding_size, S = c.encoding_size, V = c.vocab_size;
   const int Bp = round_up(B, 64), NT32 = Bp / 32;
   const bool shared = c.network_mode == SSE_MODE_SHARED_ENCODER;
-  for (auto &v : h->vars)
-    if (!v.grad) HIPCHECK(h, hipMalloc((void **)&v.grad, v.count * sizeof(float)));
+  if (!ts.arena) {
+    float *p = nullptr;
+    HIPCHECK(h, hipMalloc((void **)&p, grad_arena_count(h) * sizeof(float)));
+    bind_arena(h, p, false);
+  }
+  ts.grads_ready = false;
+  float *tail = ts.arena + grad_arena_count(h) - 4;
+  const float inv_rows = 1.0f / (float)rows_global;
 
   if (ensure_packed(h, st)) return 1;
   // transposed kernel slices for the backward GEMMs
@@ -823,17 +878,13 @@ int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tg
   // ---- loss, train accuracy, d(raw encodings)
   if (reserve(h, ts.row_loss, (size_t)B * sizeof(float))) return 1;
   if (reserve(h, ts.row_acc, (size_t)B * sizeof(float))) return 1;
-  if (reserve(h, ts.scal, 4 * sizeof(float))) return 1;
-  float *scal = (float *)ts.scal.p;  // [0] gnorm [1] clip scale [2] loss [3] acc
   HIPCHECK(h, launch_loss((const float *)ts.raw[0].p, (const float *)ts.raw[1].p, (const float *)ts.labels.p,
                           (float *)ts.draw[0].p, (float *)ts.draw[1].p, (float *)ts.row_loss.p, (float *)ts.row_acc.p,
-                          scal + 2, B, Bp, S, st));
+                          tail + 1, B, Bp, S, inv_rows, st));
 
   // ---- backward
   Variable &emb = h->vars[0];
   HIPCHECK(h, hipMemsetAsync(emb.grad, 0, emb.count * sizeof(float), st));
-  const int NORM_BLOCKS = 64;
-  int nparts = 0;
   if (reserve(h, ts.sq_part, (size_t)2 * T * NT32 * sizeof(float))) return 1;
   HIPCHECK(h, hipEventRecord(ts.ev_fork, st));  // loss + zeroed embedding gradient are ready
   for (int s = 0; s < 2; ++s) {
@@ -866,16 +917,31 @@ int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tg
     }
   }
 
-  // ---- global norm over the dense gradients + the raw (un-deduplicated) embedding slices
-  if (reserve(h, ts.norm_part, (size_t)(h->vars.size() * NORM_BLOCKS + 2 * T * NT32) * sizeof(float))) return 1;
+  // tail[0] = sum of squares of the raw (un-deduplicated) embedding-gradient slices, tail[3] = rows
+  HIPCHECK(h, launch_sum((const float *)ts.sq_part.p, 2 * T * NT32, (float)B, tail, st));
+  ts.grads_ready = true;
+  return 0;
+}
+
+// clip_by_global_norm over the (possibly all-reduced) arena + Adagrad + global_step (sse_model.py:355-364)
+static int train_apply_locked(sse_handle *h, float *loss, float *train_acc) {
+  if (!h->train || !h->train->grads_ready) return fail(h, "train apply: no gradients pending (call sse_train_grads first)");
+  TrainState &ts = *h->train;
+  hipStream_t st = nullptr;
+  const int NORM_BLOCKS = 64;
+  int nparts = 0;
+  float *tail = ts.arena + grad_arena_count(h) - 4;
+  if (reserve(h, ts.scal, 4 * sizeof(float))) return 1;
+  float *scal = (float *)ts.scal.p;  // [0] global norm [1] clip scale
+  if (reserve(h, ts.norm_part, (size_t)(h->vars.size() * NORM_BLOCKS + 1) * sizeof(float))) return 1;
   float *np_ = (float *)ts.norm_part.p;
   for (size_t i = 1; i < h->vars.size(); ++i) {
     Variable &v = h->vars[i];
     HIPCHECK(h, launch_sumsq(v.grad, v.count, np_ + nparts, NORM_BLOCKS, st));
     nparts += NORM_BLOCKS;
   }
-  HIPCHECK(h, hipMemcpyAsync(np_ + nparts, ts.sq_part.p, (size_t)2 * T * NT32 * sizeof(float), hipMemcpyDeviceToDevice, st));
-  nparts += 2 * T * NT32;
+  HIPCHECK(h, hipMemcpyAsync(np_ + nparts, tail, sizeof(float), hipMemcpyDeviceToDevice, st));
+  nparts += 1;
   HIPCHECK(h, launch_clip_scale(np_, nparts, 5.0f /* max_gradient_norm, sse_model.py:117 */, scal, st));
 
   // ---- Adagrad (dense for every tensor; rows of word_embedding with zero gradient are unchanged)
@@ -883,13 +949,38 @@ int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tg
   h->global_step += 1;
   h->packed_dirty = true;
   ts.packed_dirty = true;
+  ts.grads_ready = false;
 
   float out[4];
-  HIPCHECK(h, hipMemcpyAsync(out, scal, sizeof out, hipMemcpyDeviceToHost, st));
+  HIPCHECK(h, hipMemcpyAsync(out, tail, sizeof out, hipMemcpyDeviceToHost, st));
   HIPCHECK(h, hipStreamSynchronize(st));
-  *loss = out[2];
-  *train_acc = out[3];
+  if (loss) *loss = out[1];
+  if (train_acc) *train_acc = out[2];
   return 0;
+}
+
+int sse_train_grads(sse_handle *h, const int32_t *src_ids_host, const int32_t *tgt_ids_host, const float *labels_host,
+                    int32_t B, int32_t T, int64_t rows_global) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  return train_grads_locked(h, src_ids_host, tgt_ids_host, labels_host, B, T, rows_global);
+}
+
+int sse_train_apply(sse_handle *h, float *loss, float *train_acc) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  return train_apply_locked(h, loss, train_acc);
+}
+
+int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tgt_ids_host, const float *labels_host,
+                   int32_t B, int32_t T, float *loss, float *train_acc) {
+  if (!h || !loss || !train_acc) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  if (train_grads_locked(h, src_ids_host, tgt_ids_host, labels_host, B, T, B)) return 1;
+  return train_apply_locked(h, loss, train_acc);
 }
 
 int sse_get_learning_rate(sse_handle *h, float *lr) {

@@ -4,7 +4,8 @@
 #include <stdint.h>
 
 hipError_t launch_loss(const float *src_raw, const float *tgt_raw, const float *labels, float *d_src, float *d_tgt,
-                       float *row_loss, float *row_acc, float *out2, int B, int Bp, int S, hipStream_t st);
+                       float *row_loss, float *row_acc, float *out2, int B, int Bp, int S, float inv_rows,
+                       hipStream_t st);
 int proj_bwd_chunks(int Bp);
 hipError_t launch_proj_bwd(const float *hT, const float *d, const float *M, int Bp, int H, int Hp, int S, float *dM,
                            float *dh, float *dm_part /* [proj_bwd_chunks(Bp)][H*S] */, hipStream_t st);
@@ -17,6 +18,7 @@ hipError_t launch_db_reduce(const float *db_part, int NT32, int H, int Hp, int a
 hipError_t launch_dx(const float *dg_a, const float *KxT, const int32_t *ids, float *d_emb, float *sq_part, int T,
                      int NT32, int KGn, int B, int E, int V, hipStream_t st);
 hipError_t launch_sumsq(const float *g, int64_t n, float *part, int nblocks, hipStream_t st);
+hipError_t launch_sum(const float *part, int n, float tag, float *out /* out[0]=sum, out[3]=tag */, hipStream_t st);
 hipError_t launch_clip_scale(const float *part, int n, float clip, float *scal, hipStream_t st);
 hipError_t launch_adagrad(float *w, float *accum, const float *grad, const float *scal, float lr, int64_t n,
                           hipStream_t st);

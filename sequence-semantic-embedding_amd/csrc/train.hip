@@ -30,6 +30,7 @@ struct LossArgs {
   float *d_src, *d_tgt;            // [Bp][S] gradients w.r.t. the raw encodings (rows >= B zeroed)
   float *row_loss, *row_acc;       // [B]
   int32_t B, Bp, S;
+  float inv_rows;                  // 1 / rows of the (global) batch: the loss is a mean over all ranks' rows
 };
 
 __global__ void loss_kernel(LossArgs a) {
@@ -68,7 +69,7 @@ __global__ void loss_kernel(LossArgs a) {
     a.row_loss[row] = (1.0f - z) * x + log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.0f);
     a.row_acc[row] = z * floorf(sg + 0.1f) + (1.0f - z) * floorf(1.1f - sg);
   }
-  const float dcos = 64.0f * (sg - z) / (float)a.B;
+  const float dcos = 64.0f * (sg - z) * a.inv_rows;
   // l2_normalize backward: d raw = r * (dn - n * (n . dn)), dn_s = dcos * nt; the max(., eps)
   // clamp passes no gradient to the norm when sum(x^2) < eps
   const bool cs = ss < 1e-12f, ct = tt < 1e-12f;
@@ -79,8 +80,8 @@ __global__ void loss_kernel(LossArgs a) {
   }
 }
 
-// mean over rows, fixed order (deterministic); out[0] = loss, out[1] = train_acc
-__global__ void loss_reduce_kernel(const float *row_loss, const float *row_acc, int B, float *out) {
+// sum over rows / rows_global, fixed order (deterministic); out[0] = loss, out[1] = train_acc
+__global__ void loss_reduce_kernel(const float *row_loss, const float *row_acc, int B, float inv_rows, float *out) {
   __shared__ float sl[256], sa[256];
   float l = 0.0f, c = 0.0f;
   for (int i = threadIdx.x; i < B; i += 256) {
@@ -98,8 +99,8 @@ __global__ void loss_reduce_kernel(const float *row_loss, const float *row_acc, 
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    out[0] = sl[0] / (float)B;
-    out[1] = sa[0] / (float)B;
+    out[0] = sl[0] * inv_rows;
+    out[1] = sa[0] * inv_rows;
   }
 }
 
@@ -489,6 +490,23 @@ __global__ void sumsq_kernel(const float *g, int64_t n, float *part /*[gridDim.x
   if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
 }
 
+// out[0] = sum of n floats (fixed order), out[3] = tag
+__global__ void sum_kernel(const float *part, int n, float tag, float *out) {
+  __shared__ double sh[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += (double)part[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = (float)sh[0];
+    out[3] = tag;
+  }
+}
+
 // scal[0] = global norm, scal[1] = clip scale = clip * min(1/norm, 1/clip)
 __global__ void clip_scale_kernel(const float *part, int n, float clip, float *scal) {
   __shared__ double sh[256];
@@ -523,10 +541,10 @@ __global__ void adagrad_kernel(float *w, float *accum, const float *grad, const 
 static inline int gridn(int64_t n, int cap = 4096) { return (int)((n + 255) / 256 < cap ? (n + 255) / 256 : cap); }
 
 hipError_t launch_loss(const float *src_raw, const float *tgt_raw, const float *labels, float *d_src, float *d_tgt,
-                       float *row_loss, float *row_acc, float *out2, int B, int Bp, int S, hipStream_t st) {
-  LossArgs a{src_raw, tgt_raw, labels, d_src, d_tgt, row_loss, row_acc, B, Bp, S};
+                       float *row_loss, float *row_acc, float *out2, int B, int Bp, int S, float inv_rows, hipStream_t st) {
+  LossArgs a{src_raw, tgt_raw, labels, d_src, d_tgt, row_loss, row_acc, B, Bp, S, inv_rows};
   hipLaunchKernelGGL(loss_kernel, dim3((Bp + 3) / 4), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, row_loss, row_acc, B, out2);
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, row_loss, row_acc, B, inv_rows, out2);
   return hipGetLastError();
 }
 
@@ -595,6 +613,11 @@ hipError_t launch_dx(const float *dg_a, const float *KxT, const int32_t *ids, fl
 
 hipError_t launch_sumsq(const float *g, int64_t n, float *part, int nblocks, hipStream_t st) {
   hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks), dim3(256), 0, st, g, n, part);
+  return hipGetLastError();
+}
+
+hipError_t launch_sum(const float *part, int n, float tag, float *out, hipStream_t st) {
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, part, n, tag, out);
   return hipGetLastError();
 }
 

@@ -69,3 +69,112 @@ def test_two_rank_sharded_topk_equals_unsharded(tmp_path):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
         assert np.array_equal(z["i"], wids)
         assert np.array_equal(z["s"], wsc)
+
+
+# --------------------------------------------------------------------------
+# data-parallel train step (sequence-semantic-embedding_amd/data_parallel.py): the product's exchange logic with
+# the numpy oracle as the gradient engine (on the GPU the engine is the HIP handle:
+# tests/test_gpu_train.py::test_data_parallel_two_logical_ranks)
+# --------------------------------------------------------------------------
+
+class OracleEngine(object):
+    """train_grad_count / train_bind_arena / train_grads / train_apply on top of oracle/sse_oracle.py."""
+
+    def __init__(self, params, cfg, lr):
+        from oracle import sse_oracle as O
+        self.O, self.p, self.cfg, self.lr = O, params, cfg, np.float32(lr)
+        self.acc = O.new_optimizer_state(params)
+        self.names = sorted(params)
+
+    def train_grad_count(self):
+        return sum(self.p[n].size for n in self.names) + 4
+
+    def train_bind_arena(self, tensor):
+        self.arena = tensor.numpy()                                # shares memory with the torch tensor
+
+    def train_grads(self, src, tgt, labels, rows_global):
+        O = self.O
+        loss, acc, grads = O.gradients(self.p, self.cfg, src, tgt, labels)
+        w = np.float32(len(labels)) / np.float32(rows_global)      # oracle gradients are means over the local rows
+        off, slices_sq = 0, 0.0
+        for n in self.names:
+            g = grads[n]
+            if isinstance(g, tuple):
+                slices_sq += float(np.sum(np.square(g[1] * w, dtype=np.float64)))
+                g = O.dense_embedding_grad(g, self.p[n].shape[0])
+            self.arena[off:off + g.size] = (g * w).ravel()
+            off += g.size
+        self.arena[off:off + 4] = (slices_sq, loss * w, acc * w, len(labels))
+
+    def train_apply(self):
+        O = self.O
+        tail = self.arena[-4:]
+        tot, off, dense = float(tail[0]), 0, {}
+        for n in self.names:
+            g = self.arena[off:off + self.p[n].size].reshape(self.p[n].shape).copy()
+            off += g.size
+            dense[n] = g
+            if n != "word_embedding":
+                tot += float(np.sum(np.square(g, dtype=np.float64)))
+        gn = np.float32(np.sqrt(tot))
+        scale = O.MAX_GRAD_NORM * min(np.float32(1.0) / gn, np.float32(1.0) / O.MAX_GRAD_NORM) if gn > 0 else np.float32(1)
+        for n in self.names:
+            g = (dense[n] * np.float32(scale)).astype(np.float32)
+            self.acc[n] += g * g                                    # rows with zero gradient: acc, w unchanged
+            self.p[n] -= self.lr * g / np.sqrt(self.acc[n])
+        return float(tail[1]), float(tail[2])
+
+
+def _dp_cfg():
+    from util import model_params
+    return model_params("dual-encoder", 60, 8, 12, 16, 16, 6)
+
+
+def _dp_batch(seed, rows):
+    rng = np.random.RandomState(seed)
+    src = rng.randint(2, 60, size=(rows, 6)).astype(np.int32)
+    tgt = rng.randint(2, 60, size=(rows, 6)).astype(np.int32)
+    return src, tgt, (np.arange(rows) % 2 == 0).astype(np.float32)
+
+
+def _dp_worker(rank, world, port, out_dir, uneven):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["SSE_NO_TORCH"] = "1"
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sse_amd
+    from oracle import sse_oracle as O
+    cfg = _dp_cfg()
+    eng = OracleEngine(O.init_params(cfg, seed=3), cfg, 0.9)
+    tr = sse_amd.DataParallelTrainer(eng)
+    hist = []
+    for step in range(3):
+        src, tgt, z = _dp_batch(step, 22)
+        if uneven:                                                  # rank 0: 15 rows, rank 1: 7
+            sl = slice(0, 15) if rank == 0 else slice(15, 22)
+            hist.append(tr.train_step(src[sl], tgt[sl], z[sl]))
+        else:
+            hist.append(tr.train_step(*sse_amd.split_batch(src, tgt, z, rank, world), rows_global=22))
+    np.savez(os.path.join(out_dir, "dp%d.npz" % rank), hist=np.array(hist), **eng.p)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("uneven", [False, True])
+def test_two_rank_data_parallel_step_equals_single_process(tmp_path, uneven):
+    """2 gloo ranks x half a batch == the oracle's single-process step on the whole batch
+    (loss, train_acc and every parameter after 3 steps), and both ranks end bit-identical."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import sse_oracle as O
+    world, port = 2, _free_port()
+    mp.spawn(_dp_worker, args=(world, port, str(tmp_path), uneven), nprocs=world, join=True)
+    cfg = _dp_cfg()
+    p = O.init_params(cfg, seed=3)
+    acc = O.new_optimizer_state(p)
+    want = [O.train_step(p, acc, cfg, *_dp_batch(step, 22), 0.9) for step in range(3)]
+    z0, z1 = (np.load(os.path.join(str(tmp_path), "dp%d.npz" % r)) for r in range(2))
+    assert np.allclose(z0["hist"], np.array(want), rtol=1e-5, atol=1e-6)
+    for n in p:
+        assert np.array_equal(z0[n], z1[n]), n                     # ranks stay in lock-step, bit for bit
+        assert np.abs(z0[n] - p[n]).max() < 2e-5, n

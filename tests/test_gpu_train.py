@@ -121,3 +121,64 @@ def test_checkpoint_roundtrip(tmp_path):
     assert m2.handle.global_step == 1
     ids = random_ids(rng, 3, 4, 60)
     assert np.array_equal(m.encode_target(ids), m2.encode_target(ids))
+
+
+def test_data_parallel_two_logical_ranks():
+    """SURVEY 8e "Training": grads on two half batches (two handles = two logical ranks on one GPU), the flat gradient
+    arenas summed (what the RCCL all-reduce does), apply on both -> same loss/acc/weights as the single-process step on
+    the whole batch (oracle and HIP), and the two ranks end bit-identical."""
+    import torch
+    import sse_amd
+    params = model_params("dual-encoder", 300, 50, 128, 128, 64, 10, lr=0.9)
+    rng = np.random.RandomState(4)
+    src, tgt, z = _batch(rng, 96, 10, 300)
+    (m0, p), (m1, _), (mf, _) = make_pair(params, seed=7), make_pair(params, seed=7), make_pair(params, seed=7)
+    st = O.new_optimizer_state(p)
+    want = O.train_step(p, st, params, src, tgt, z, 0.9)
+    full = mf.train_step(src, tgt, z)
+    arenas = []
+    for r, m in enumerate((m0, m1)):
+        n = m.handle.train_grad_count()
+        a = torch.zeros(n, dtype=torch.float32, device="cuda:0")
+        m.handle.train_bind_arena(a)
+        s, t, l = sse_amd.split_batch(src, tgt, z, r, 2) if r == 0 else (src[48:], tgt[48:], z[48:])
+        m.handle.train_grads(s, t, l, rows_global=96)
+        arenas.append(a)
+    torch.cuda.synchronize()
+    total = arenas[0] + arenas[1]
+    assert float(total[-1]) == 96.0                                # rows
+    for a in arenas:
+        a.copy_(total)
+    torch.cuda.synchronize()
+    res = [m.handle.train_apply() for m in (m0, m1)]
+    assert res[0] == res[1]
+    assert res[0][0] == pytest.approx(float(want[0]), rel=1e-5) and res[0][1] == pytest.approx(float(want[1]), abs=1e-6)
+    assert res[0][0] == pytest.approx(full[0], rel=1e-5)
+    g0, g1, gf = (m.get_variables(with_slots=True) for m in (m0, m1, mf))
+    for name, w in p.items():
+        assert np.array_equal(g0[name], g1[name]), name
+        assert np.abs(g0[name].reshape(w.shape) - w).max() < 2e-4, name
+        assert np.abs(g0[name] - gf[name]).max() < 2e-5, name
+        assert np.abs(g0[name + "/Adagrad"].reshape(w.shape) - st[name]).max() < 2e-4, name
+    assert m0.handle.global_step == 1
+
+
+def test_data_parallel_trainer_world1_and_arena_ownership():
+    import sse_amd
+    params = model_params("shared-encoder", 80, 16, 32, 32, 16, 5, lr=0.5)
+    rng = np.random.RandomState(8)
+    src, tgt, z = _batch(rng, 12, 5, 80)
+    (ma, _), (mb, _) = make_pair(params, seed=2), make_pair(params, seed=2)
+    tr = sse_amd.DataParallelTrainer(ma.handle, device="cuda:0")
+    got = [tr.train_step(src, tgt, z) for _ in range(2)]
+    want = [mb.train_step(src, tgt, z) for _ in range(2)]
+    # same kernels either way; the embedding gradient is a float atomicAdd scatter, so runs agree to rounding only
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-7)
+    va, vb = ma.get_variables(with_slots=True), mb.get_variables(with_slots=True)
+    assert all(np.abs(va[k] - vb[k]).max() < 1e-6 for k in va)
+    ma.handle.train_set_grad_arena(None, 0)                        # back to a library-owned arena
+    assert np.allclose(ma.train_step(src, tgt, z), mb.train_step(src, tgt, z), rtol=1e-6, atol=1e-7)
+    with pytest.raises(sse_amd.SSEError):
+        ma.handle.train_apply()                                    # nothing pending
+    with pytest.raises(sse_amd.SSEError):
+        ma.handle.train_set_grad_arena(tr.arena.data_ptr(), 5)     # wrong size
