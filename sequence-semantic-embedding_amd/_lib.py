@@ -189,12 +189,27 @@ class Handle(object):
         self.check(self.lib.sse_merge_topk_dev(self._h, in_s, in_i, P, Q, k, out_s, out_i, stream))
 
     # -- training ------------------------------------------------------------
-    def train_step(self, src_ids, tgt_ids, labels):
+    @staticmethod
+    def _train_batch(src_ids, tgt_ids, labels):
+        """src [B,T] int32; tgt [B,T] token ids -- or, for source_only_cnn, [B] rows of the free target matrix
+        (the library checks which one the network mode wants); labels float32 [B]."""
         s = np.ascontiguousarray(src_ids, dtype=np.int32)
         t = np.ascontiguousarray(tgt_ids, dtype=np.int32)
         z = np.ascontiguousarray(labels, dtype=np.float32)
-        if s.shape != t.shape or s.ndim != 2 or z.shape != (s.shape[0],):
-            raise ValueError("train batch shapes: src/tgt [B,T], labels [B]")
+        if t.ndim == 2 and t.shape[1] == 1 and s.ndim == 2 and s.shape[1] != 1:
+            t = np.ascontiguousarray(t[:, 0])
+        if s.ndim != 2 or z.shape != (s.shape[0],) or not (t.shape == s.shape or t.shape == (s.shape[0],)):
+            raise ValueError("train batch shapes: src [B,T], tgt [B,T] (or [B] target rows), labels [B]")
+        return s, t, z
+
+    def _check_tgt_kind(self, t):
+        cnn = self.cfg.network_mode == 3
+        if cnn != (t.ndim == 1):
+            raise ValueError("source_only_cnn trains on [B] target-matrix rows, the LSTM modes on [B,T] target token ids")
+
+    def train_step(self, src_ids, tgt_ids, labels):
+        s, t, z = self._train_batch(src_ids, tgt_ids, labels)
+        self._check_tgt_kind(t)
         loss, acc = C.c_float(), C.c_float()
         self.check(self.lib.sse_train_step(self._h, _ptr(s), _ptr(t), _ptr(z), s.shape[0], s.shape[1],
                                            C.byref(loss), C.byref(acc)))
@@ -219,11 +234,8 @@ class Handle(object):
         self.train_set_grad_arena(tensor.data_ptr(), tensor.numel())
 
     def train_grads(self, src_ids, tgt_ids, labels, rows_global=None):
-        s = np.ascontiguousarray(src_ids, np.int32)
-        t = np.ascontiguousarray(tgt_ids, np.int32)
-        z = np.ascontiguousarray(labels, np.float32)
-        if s.shape != t.shape or s.ndim != 2 or z.shape != (s.shape[0],):
-            raise ValueError("train batch shapes: src/tgt [B,T], labels [B]")
+        s, t, z = self._train_batch(src_ids, tgt_ids, labels)
+        self._check_tgt_kind(t)
         self.check(self.lib.sse_train_grads(self._h, _ptr(s), _ptr(t), _ptr(z), s.shape[0], s.shape[1],
                                             int(rows_global if rows_global is not None else s.shape[0])))
 

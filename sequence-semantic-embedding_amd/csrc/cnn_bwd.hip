@@ -1,0 +1,217 @@
+// Backward pass of the text-CNN encoder (network_mode 'source_only_cnn') for gfx950.
+//
+// BUILDER-DEFINED training path (BASELINE configs[4]): the reference's CNN graph does not build
+// (sse_model.py:206) and its loss is ill-shaped for this mode (:213-214,290); the pair loss of
+// :279-302 is applied with the target side read as embedding_lookup(tgt_seq_embedding, rows)
+// (oracle/sse_oracle.py::_cnn_gradients is the restatement these kernels are checked against).
+//
+// After max-over-time pooling only ONE position per (sequence, filter) carries gradient, so the
+// convolution backward is not a GEMM: it is 576 weighted window copies per sequence (~100 k MAC,
+// 2 % of the forward).  These kernels are gather/scatter-shaped and LDS/HBM-latency bound:
+//   cnn_dw_kernel   dW[k][f] = sum_b g[b][f] * window(b, pos[b][f])[k], db[f] = sum_b g[b][f];
+//                   a thread owns (filter, k-range) accumulators in registers, sequences are staged
+//                   through LDS (double-buffered), the batch is split into chunks whose partials are
+//                   summed in fixed order (deterministic);
+//   cnn_dx_kernel   dX[b][t][:] += g[b][f] * W[:, f] over the winning windows -> LDS tile (ds_add_f32),
+//                   then one float atomicAdd per element into the dense d word_embedding, and
+//                   sum dX^2 per sequence for TF's global norm over the raw IndexedSlices;
+//   rows_gather / rows_scatter: target-table lookup and its gradient.
+#include "sse_kernels.h"
+#include "train.h"
+
+namespace {
+
+__constant__ int b_fs[4] = {2, 3, 4, 5};
+__constant__ int b_nf[4] = {256, 128, 128, 64};
+__constant__ int b_foff[4] = {0, 256, 384, 512};
+
+struct CnnBwdArgs {
+  const int32_t *ids;   // [B][T]
+  const float *emb;     // [V][E] master copy
+  const float *dfeat;   // [Bp][576] d loss / d pooled features
+  const float *feat;    // [Bp][576] pooled features (ReLU mask: > 0)
+  const int32_t *pos;   // [B][576] arg-max positions
+  const float *W[4];    // master filters, row-major [fs*E][nf]
+  float *dw_part[4];    // [NCH][fs*E*nf]
+  float *db_part;       // [NCH][576]
+  float *d_emb;         // [V][E] dense embedding gradient (zeroed by the caller)
+  float *sq_part;       // [B]
+  int32_t B, T, E, NCH;
+};
+
+template <int FS, int NF>
+__device__ void dw_body(const CnnBwdArgs &a, float *xs) {
+  constexpr int PARTS = 256 / NF;
+  constexpr int KMAX = (FS * 64 + PARTS - 1) / PARTS;  // E <= 64
+  const int tid = threadIdx.x, f = tid % NF, part = tid / NF;
+  const int T = a.T, E = a.E, K = FS * E, KPT = (K + PARTS - 1) / PARTS, k0 = part * KPT;
+  const int wi = FS - 2, fo = b_foff[wi] + f;
+  const int chunk = blockIdx.x, per = (a.B + a.NCH - 1) / a.NCH;
+  const int b_begin = chunk * per, b_end = min(a.B, b_begin + per);
+  float acc[KMAX];
+#pragma unroll
+  for (int kk = 0; kk < KMAX; ++kk) acc[kk] = 0.0f;
+  float bsum = 0.0f;
+  int buf = 0;
+  for (int b = b_begin; b < b_end; ++b, buf ^= 1) {
+    float *xb = xs + buf * T * E;
+    for (int i = tid; i < T * E; i += 256) xb[i] = a.emb[(size_t)a.ids[(size_t)b * T + i / E] * E + i % E];
+    __syncthreads();
+    float g = a.dfeat[(size_t)b * 576 + fo];
+    if (!(a.feat[(size_t)b * 576 + fo] > 0.0f)) g = 0.0f;
+    if (g != 0.0f) {
+      const float *xw = xb + a.pos[(size_t)b * 576 + fo] * E + k0;
+#pragma unroll
+      for (int kk = 0; kk < KMAX; ++kk)
+        if (kk < KPT && k0 + kk < K) acc[kk] += g * xw[kk];
+      bsum += g;
+    }
+  }
+  float *out = a.dw_part[wi] + (size_t)chunk * K * NF;
+#pragma unroll
+  for (int kk = 0; kk < KMAX; ++kk)
+    if (kk < KPT && k0 + kk < K) out[(size_t)(k0 + kk) * NF + f] = acc[kk];
+  if (part == 0) a.db_part[(size_t)chunk * 576 + fo] = bsum;
+}
+
+__global__ __launch_bounds__(256) void cnn_dw_kernel(CnnBwdArgs a) {
+  extern __shared__ float xs[];  // [2][T*E]
+  switch (blockIdx.y) {
+    case 0: dw_body<2, 256>(a, xs); break;
+    case 1: dw_body<3, 128>(a, xs); break;
+    case 2: dw_body<4, 128>(a, xs); break;
+    default: dw_body<5, 64>(a, xs); break;
+  }
+}
+
+__global__ void chunk_reduce_kernel(const float *part, int nch, int n, float *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float acc = 0.0f;
+  for (int c = 0; c < nch; ++c) acc += part[(size_t)c * n + i];
+  out[i] = acc;
+}
+
+__global__ void strided_reduce_kernel(const float *part, int nch, int stride, int n, float *out) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float acc = 0.0f;
+    for (int c = 0; c < nch; ++c) acc += part[(size_t)c * stride + i];
+    out[i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void cnn_dx_kernel(CnnBwdArgs a) {
+  extern __shared__ float dX[];  // [T*E]
+  __shared__ float red[256];
+  const int tid = threadIdx.x, b = blockIdx.x, T = a.T, E = a.E;
+  for (int i = tid; i < T * E; i += 256) dX[i] = 0.0f;
+  __syncthreads();
+  for (int f = tid; f < 576; f += 256) {
+    float g = a.dfeat[(size_t)b * 576 + f];
+    if (!(a.feat[(size_t)b * 576 + f] > 0.0f) || g == 0.0f) continue;
+    const int wi = f < 256 ? 0 : f < 384 ? 1 : f < 512 ? 2 : 3;
+    const int nf = b_nf[wi], fl = f - b_foff[wi], K = b_fs[wi] * E;
+    const float *W = a.W[wi] + fl;
+    float *dst = dX + a.pos[(size_t)b * 576 + f] * E;  // the window is the contiguous run (p+j)*E+e = p*E + k
+    for (int k = 0; k < K; ++k) atomicAdd(dst + k, g * W[(size_t)k * nf]);
+  }
+  __syncthreads();
+  float sq = 0.0f;
+  for (int i = tid; i < T * E; i += 256) {
+    const float v = dX[i];
+    sq += v * v;
+    if (v != 0.0f) atomicAdd(a.d_emb + (size_t)a.ids[(size_t)b * T + i / E] * E + i % E, v);
+  }
+  red[tid] = sq;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) a.sq_part[b] = red[0];
+}
+
+// out[b][:] = table[rows[b]][:] (b < B), 0 for the padding rows; one wave per row
+__global__ void rows_gather_kernel(const float *table, const int32_t *rows, int B, int Bp, int N, int S, float *out,
+                                   int32_t *err) {
+  const int lane = threadIdx.x & 63, b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (b >= Bp) return;
+  int r = (b < B) ? rows[b] : -1;
+  if (b < B && (r < 0 || r >= N)) {
+    if (lane == 0) atomicOr(err, 1);
+    r = -1;
+  }
+  for (int s = lane; s < S; s += 64) out[(size_t)b * S + s] = (r >= 0) ? table[(size_t)r * S + s] : 0.0f;
+}
+
+// d_table[rows[b]][:] += d[b][:]; sq[b] = |d[b]|^2 (raw slice norm)
+__global__ void rows_scatter_kernel(const float *d, const int32_t *rows, int B, int S, float *d_table, float *sq) {
+  const int lane = threadIdx.x & 63, b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (b >= B) return;
+  const int r = rows[b];
+  float acc = 0.0f;
+  for (int s = lane; s < S; s += 64) {
+    const float v = d[(size_t)b * S + s];
+    acc += v * v;
+    atomicAdd(d_table + (size_t)r * S + s, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) sq[b] = acc;
+}
+
+}  // namespace
+
+int cnn_bwd_chunks(int B) {
+  int n = (B + 31) / 32;
+  return n < 1 ? 1 : n > 128 ? 128 : n;
+}
+
+size_t cnn_dw_part_floats(int E, int B) { return (size_t)cnn_bwd_chunks(B) * (size_t)E * 1728; }  // sum fs*nf = 1728
+
+hipError_t launch_rows_gather(const float *table, const int32_t *rows, int B, int Bp, int N, int S, float *out,
+                              int32_t *err, hipStream_t st) {
+  hipLaunchKernelGGL(rows_gather_kernel, dim3((Bp + 3) / 4), dim3(256), 0, st, table, rows, B, Bp, N, S, out, err);
+  return hipGetLastError();
+}
+
+hipError_t launch_rows_scatter(const float *d, const int32_t *rows, int B, int S, float *d_table, float *sq,
+                               hipStream_t st) {
+  hipLaunchKernelGGL(rows_scatter_kernel, dim3((B + 3) / 4), dim3(256), 0, st, d, rows, B, S, d_table, sq);
+  return hipGetLastError();
+}
+
+hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfeat, const float *feat, const int32_t *pos,
+                          const float *const W[4], float *const dW[4], float *const db[4], float *dw_part,
+                          float *db_part, float *d_emb, float *sq_part, int B, int T, int E, hipStream_t st) {
+  static const int fs[4] = {2, 3, 4, 5}, nf[4] = {256, 128, 128, 64}, foff[4] = {0, 256, 384, 512};
+  CnnBwdArgs a;
+  a.ids = ids;
+  a.emb = emb;
+  a.dfeat = dfeat;
+  a.feat = feat;
+  a.pos = pos;
+  a.db_part = db_part;
+  a.d_emb = d_emb;
+  a.sq_part = sq_part;
+  a.B = B;
+  a.T = T;
+  a.E = E;
+  a.NCH = cnn_bwd_chunks(B);
+  size_t off = 0;
+  for (int i = 0; i < 4; ++i) {
+    a.W[i] = W[i];
+    a.dw_part[i] = dw_part + off;
+    off += (size_t)a.NCH * fs[i] * E * nf[i];
+  }
+  hipLaunchKernelGGL(cnn_dw_kernel, dim3(a.NCH, 4), dim3(256), (size_t)2 * T * E * sizeof(float), st, a);
+  for (int i = 0; i < 4; ++i) {
+    const int n = fs[i] * E * nf[i];
+    hipLaunchKernelGGL(chunk_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a.dw_part[i], a.NCH, n, dW[i]);
+  }
+  // db: the four bias vectors are disjoint slices of the 576 features
+  for (int i = 0; i < 4; ++i)
+    hipLaunchKernelGGL(strided_reduce_kernel, dim3(1), dim3(256), 0, st, db_part + foff[i], a.NCH, 576, nf[i], db[i]);
+  hipLaunchKernelGGL(cnn_dx_kernel, dim3(B), dim3(256), (size_t)T * E * sizeof(float), st, a);
+  return hipGetLastError();
+}

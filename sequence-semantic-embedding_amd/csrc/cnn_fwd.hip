@@ -25,12 +25,18 @@ struct CnnArgs {
   float *featp;        // frag32(rows = b, red = feature): [ceil(B/32)][72][256]
   int32_t *err;
   int32_t B, T, V, Ep, wbytes;
+  float *feat_rm;      // TRAIN: [B][576] pooled features, row-major
+  int32_t *pos;        // TRAIN: [B][576] first arg-max position of each pooled feature
 };
 
 __constant__ int c_fs[4] = {2, 3, 4, 5};
 __constant__ int c_nt[4] = {8, 4, 4, 2};          // 32-filter tiles per width (256,128,128,64 filters)
 __constant__ int c_foff[4] = {0, 256, 384, 512};  // feature offset of each width in the 576-vector
 
+// TRAIN additionally records WHERE each maximum sits (the backward pass routes the gradient there):
+// the running maximum becomes a 64-bit key (value bits << 32 | ~position), so equal values keep the
+// first position, as numpy/TF arg-max do (all-PAD windows tie exactly).
+template <bool TRAIN>
 __global__ __launch_bounds__(CNN_THREADS) void conv_pool_kernel(CnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float xs[];  // [NB][T][Ep] + 5*Ep pad + work counter
   const int tid = threadIdx.x, lane = tid & 63;
@@ -38,7 +44,8 @@ __global__ __launch_bounds__(CNN_THREADS) void conv_pool_kernel(CnnArgs a) {
   const int b0 = blockIdx.x * CNN_NB;
   // all LDS in the dynamic region (16-B aligned base): xs | 5*Ep pad | feat[NB][576] | work counter
   int *feat = reinterpret_cast<int *>(xs + CNN_NB * T * Ep + 5 * Ep);  // running max as int bits (values >= 0)
-  int *s_next = feat + CNN_NB * 576;
+  unsigned long long *featk = reinterpret_cast<unsigned long long *>(feat);  // TRAIN: 64-bit keys
+  int *s_next = feat + CNN_NB * 576 * (TRAIN ? 2 : 1);
 
   // stage the embedded sequences (row-major, Ep-padded rows: 16-byte aligned windows)
   for (int i = tid; i < CNN_NB * T * E4; i += CNN_THREADS) {
@@ -52,7 +59,7 @@ __global__ __launch_bounds__(CNN_THREADS) void conv_pool_kernel(CnnArgs a) {
     reinterpret_cast<f32x4 *>(xs)[i] = *reinterpret_cast<const f32x4 *>(a.emb + (size_t)id * Ep + q * 4);
   }
   for (int i = tid; i < 5 * Ep; i += CNN_THREADS) xs[CNN_NB * T * Ep + i] = 0.0f;  // windows of the last rows read past the tile
-  for (int i = tid; i < CNN_NB * 576; i += CNN_THREADS) feat[i] = 0;
+  for (int i = tid; i < CNN_NB * 576 * (TRAIN ? 2 : 1); i += CNN_THREADS) feat[i] = 0;
   if (tid == 0) *s_next = 0;
   __syncthreads();
 
@@ -128,15 +135,29 @@ __global__ __launch_bounds__(CNN_THREADS) void conv_pool_kernel(CnnArgs a) {
       // bias + ReLU + max over this tile's valid positions (row = position, column = filter)
 #pragma unroll
       for (int s = 0; s < CNN_SG; ++s) {
-        float m = 0.0f;
+        if constexpr (TRAIN) {
+          unsigned long long key = 0;  // below every valid position's key
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int p = pt * 32 + mfma_row(r, lane);
-          const float v = fmaxf(acc[s][r] + bias, 0.0f);
-          m = fmaxf(m, (p < P) ? v : 0.0f);
+          for (int r = 0; r < 16; ++r) {
+            const int p = pt * 32 + mfma_row(r, lane);
+            const float v = fmaxf(acc[s][r] + bias, 0.0f);
+            const unsigned long long kv = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(~p);
+            if (p < P && kv > key) key = kv;
+          }
+          const unsigned long long other = __shfl_xor(key, 32);
+          if (other > key) key = other;
+          if (lane < 32) atomicMax(&featk[(sg * CNN_SG + s) * 576 + c_foff[wi] + tile * 32 + lane], key);
+        } else {
+          float m = 0.0f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int p = pt * 32 + mfma_row(r, lane);
+            const float v = fmaxf(acc[s][r] + bias, 0.0f);
+            m = fmaxf(m, (p < P) ? v : 0.0f);
+          }
+          m = fmaxf(m, __shfl_xor(m, 32));
+          if (lane < 32) atomicMax(&feat[(sg * CNN_SG + s) * 576 + c_foff[wi] + tile * 32 + lane], __float_as_int(m));
         }
-        m = fmaxf(m, __shfl_xor(m, 32));
-        if (lane < 32) atomicMax(&feat[(sg * CNN_SG + s) * 576 + c_foff[wi] + tile * 32 + lane], __float_as_int(m));
       }
     }
   }
@@ -144,8 +165,18 @@ __global__ __launch_bounds__(CNN_THREADS) void conv_pool_kernel(CnnArgs a) {
   // features -> global, frag32(rows = b, red = feature)
   for (int i = tid; i < CNN_NB * 576; i += CNN_THREADS) {
     const int j = i % 576, b = b0 + i / 576;
-    if (b < a.B)
-      a.featp[((size_t)(b >> 5) * 72 + (j >> 3)) * 256 + ((((j >> 2) & 1) * 32 + (b & 31)) << 2) + (j & 3)] = __int_as_float(feat[i]);
+    if (b < a.B) {
+      float v;
+      if constexpr (TRAIN) {
+        const unsigned long long key = featk[i];
+        v = __uint_as_float((unsigned)(key >> 32));
+        a.feat_rm[(size_t)b * 576 + j] = v;
+        a.pos[(size_t)b * 576 + j] = (int32_t)(~(unsigned)key);
+      } else {
+        v = __int_as_float(feat[i]);
+      }
+      a.featp[((size_t)(b >> 5) * 72 + (j >> 3)) * 256 + ((((j >> 2) & 1) * 32 + (b & 31)) << 2) + (j & 3)] = v;
+    }
   }
 }
 
@@ -239,7 +270,9 @@ __global__ void pack_conv_kernel_k(const float *__restrict__ W, int fs, int E, i
   }
 }
 
-size_t cnn_lds_bytes(int T, int Ep) { return (size_t)(CNN_NB * T * Ep + 5 * Ep + CNN_NB * 576) * sizeof(float) + 16; }
+size_t cnn_lds_bytes(int T, int Ep, int train) {
+  return (size_t)(CNN_NB * T * Ep + 5 * Ep + CNN_NB * 576 * (train ? 2 : 1)) * sizeof(float) + 16;
+}
 
 size_t cnn_packed_weight_floats(int Ep) {
   static const int fs[4] = {2, 3, 4, 5}, nt[4] = {8, 4, 4, 2};
@@ -263,13 +296,19 @@ hipError_t launch_pack_conv(const float *const W[4], int E, int Ep, float *out, 
 
 hipError_t launch_cnn_fwd(const int32_t *ids, const float *emb, const float *Wc, const float *bias, const float *Mp,
                           float *featp, float *out, int32_t *err, int B, int T, int V, int Ep, int S, int normalize,
-                          hipStream_t stream) {
-  const size_t lds = cnn_lds_bytes(T, Ep);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pool_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                          float *feat_rm, int32_t *pos, hipStream_t stream) {
+  const bool train = feat_rm != nullptr;
+  const size_t lds = cnn_lds_bytes(T, Ep, train);
+  const void *fn = train ? reinterpret_cast<const void *>(conv_pool_kernel<true>)
+                         : reinterpret_cast<const void *>(conv_pool_kernel<false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  CnnArgs a{ids, emb, Wc, bias, featp, err, B, T, V, Ep, (int32_t)(cnn_packed_weight_floats(Ep) * sizeof(float))};
-  hipLaunchKernelGGL(conv_pool_kernel, dim3((B + CNN_NB - 1) / CNN_NB), dim3(CNN_THREADS), lds, stream, a);
+  CnnArgs a{ids, emb, Wc, bias, featp, err, B, T, V, Ep, (int32_t)(cnn_packed_weight_floats(Ep) * sizeof(float)),
+            feat_rm, pos};
+  if (train)
+    hipLaunchKernelGGL(conv_pool_kernel<true>, dim3((B + CNN_NB - 1) / CNN_NB), dim3(CNN_THREADS), lds, stream, a);
+  else
+    hipLaunchKernelGGL(conv_pool_kernel<false>, dim3((B + CNN_NB - 1) / CNN_NB), dim3(CNN_THREADS), lds, stream, a);
   ProjArgs p{featp, Mp, out, B, S, 72, (S + 31) / 32, normalize};
   hipLaunchKernelGGL(proj_norm_kernel, dim3((B + 31) / 32), dim3(256), 0, stream, p);
   return hipGetLastError();

@@ -46,6 +46,7 @@ struct DevBuf {
 struct TrainState {
   DevBuf ids[2], labels, raw[2], draw[2], tape_g[2], tape_a[2], h_last[2], dh_last[2], dg_a[2], dg_b[2], db_part[2],
       dk_part[2], dm_part[2], sq_part, norm_part, row_loss, row_acc, scal;
+  DevBuf feat_rm, pos, dfeat, dw_part, dbias_part;  // text-CNN training
   hipStream_t side[2] = {nullptr, nullptr};  // the two encoders run concurrently (forward and backward)
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   float *KhT[2] = {nullptr, nullptr}, *KxT[2] = {nullptr, nullptr};
@@ -282,11 +283,11 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
     if (ensure_packed(h, st)) return 1;
     const int Ep = round_up(c.embedding_size, 8);
     if (T < 5) return fail(h, "source_only_cnn needs max_seq_length >= 5 (widest filter)");
-    if (cnn_lds_bytes(T, Ep) > 160 * 1024)
+    if (cnn_lds_bytes(T, Ep, 0) > 160 * 1024)
       return fail(h, "source_only_cnn: T*E = %d*%d does not fit the LDS tile of the gfx950 kernel", T, c.embedding_size);
     if (reserve(h, h->s_feat, (size_t)((B + 31) / 32) * 72 * 256 * sizeof(float))) return 1;
     HIPCHECK(h, launch_cnn_fwd(ids, h->emb_pad, h->cnn_Wc, h->cnn_bias, h->cnn_Mp, (float *)h->s_feat.p, out, h->err_flag, B,
-                               T, c.vocab_size, Ep, c.encoding_size, normalize ? 1 : 0, st));
+                               T, c.vocab_size, Ep, c.encoding_size, normalize ? 1 : 0, nullptr, nullptr, st));
     return 0;
   }
   Encoder &e = h->enc[side];
@@ -775,17 +776,105 @@ int sse_train_set_grad_arena(sse_handle *h, float *arena_dev, int64_t count) {
   return 0;
 }
 
+static int ensure_arena(sse_handle *h) {
+  TrainState &ts = *h->train;
+  if (!ts.arena) {
+    float *p = nullptr;
+    HIPCHECK(h, hipMalloc((void **)&p, grad_arena_count(h) * sizeof(float)));
+    bind_arena(h, p, false);
+  }
+  ts.grads_ready = false;
+  return 0;
+}
+
+// source_only_cnn (BUILDER-DEFINED, see cnn_bwd.hip): row b pairs source sequence b with row tgt_rows[b]
+// of the free target matrix; same loss kernel, CNN forward with arg-max tape, gather/scatter backward.
+static int cnn_train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const int32_t *tgt_rows_host,
+                                  const float *labels_host, int32_t B, int32_t T, int64_t rows_global) {
+  const sse_config &c = h->cfg;
+  hipStream_t st = nullptr;
+  TrainState &ts = *h->train;
+  const int E = c.embedding_size, S = c.encoding_size, V = c.vocab_size, Ep = round_up(E, 8);
+  const int Bp = round_up(B, 64);
+  if (T < 5) return fail(h, "source_only_cnn needs max_seq_length >= 5 (widest filter)");
+  if (E > 64) return fail(h, "train step: embedding_size %d > 64 not supported yet", E);
+  if (cnn_lds_bytes(T, Ep, 1) > 160 * 1024)
+    return fail(h, "source_only_cnn training: T*E = %d*%d does not fit the LDS tile of the gfx950 kernel", T, E);
+  if (ensure_arena(h)) return 1;
+  if (ensure_packed(h, st)) return 1;
+  float *tail = ts.arena + grad_arena_count(h) - 4;
+  const float inv_rows = 1.0f / (float)rows_global;
+  Variable &emb = h->vars[0], &table = h->vars[h->tgt_table], &M = h->vars[h->cnn_M];
+
+  if (reserve(h, ts.ids[0], (size_t)B * T * sizeof(int32_t))) return 1;
+  if (reserve(h, ts.ids[1], (size_t)B * sizeof(int32_t))) return 1;
+  if (reserve(h, ts.labels, (size_t)B * sizeof(float))) return 1;
+  HIPCHECK(h, hipMemcpyAsync(ts.ids[0].p, src_ids_host, (size_t)B * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  HIPCHECK(h, hipMemcpyAsync(ts.ids[1].p, tgt_rows_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  HIPCHECK(h, hipMemcpyAsync(ts.labels.p, labels_host, (size_t)B * sizeof(float), hipMemcpyHostToDevice, st));
+  for (int s = 0; s < 2; ++s) {
+    if (reserve(h, ts.raw[s], (size_t)Bp * S * sizeof(float))) return 1;
+    if (reserve(h, ts.draw[s], (size_t)Bp * S * sizeof(float))) return 1;
+  }
+  if (reserve(h, h->s_feat, (size_t)((B + 31) / 32) * 72 * 256 * sizeof(float))) return 1;
+  if (reserve(h, ts.feat_rm, (size_t)Bp * 576 * sizeof(float))) return 1;
+  if (reserve(h, ts.pos, (size_t)Bp * 576 * sizeof(int32_t))) return 1;
+  if (reserve(h, ts.dfeat, (size_t)Bp * 576 * sizeof(float))) return 1;
+  if (reserve(h, ts.dw_part, cnn_dw_part_floats(E, B) * sizeof(float))) return 1;
+  if (reserve(h, ts.dbias_part, (size_t)cnn_bwd_chunks(B) * 576 * sizeof(float))) return 1;
+  if (reserve(h, ts.dm_part[0], (size_t)proj_bwd_chunks(Bp) * 576 * S * sizeof(float))) return 1;
+  if (reserve(h, ts.sq_part, (size_t)2 * B * sizeof(float))) return 1;
+  if (reserve(h, ts.row_loss, (size_t)B * sizeof(float))) return 1;
+  if (reserve(h, ts.row_acc, (size_t)B * sizeof(float))) return 1;
+
+  // ---- forward with the arg-max tape; target rows looked up from the free matrix
+  HIPCHECK(h, hipMemsetAsync(ts.feat_rm.p, 0, (size_t)Bp * 576 * sizeof(float), st));  // padding rows feed the dM GEMM
+  HIPCHECK(h, launch_cnn_fwd((const int32_t *)ts.ids[0].p, h->emb_pad, h->cnn_Wc, h->cnn_bias, h->cnn_Mp,
+                             (float *)h->s_feat.p, (float *)ts.raw[0].p, h->err_flag, B, T, V, Ep, S, 0,
+                             (float *)ts.feat_rm.p, (int32_t *)ts.pos.p, st));
+  HIPCHECK(h, launch_rows_gather(table.dev, (const int32_t *)ts.ids[1].p, B, Bp, table.rows, S, (float *)ts.raw[1].p,
+                                 h->err_flag, st));
+  if (check_err_flag(h, st)) return 1;
+  HIPCHECK(h, launch_loss((const float *)ts.raw[0].p, (const float *)ts.raw[1].p, (const float *)ts.labels.p,
+                          (float *)ts.draw[0].p, (float *)ts.draw[1].p, (float *)ts.row_loss.p, (float *)ts.row_acc.p,
+                          tail + 1, B, Bp, S, inv_rows, st));
+
+  // ---- backward
+  HIPCHECK(h, hipMemsetAsync(emb.grad, 0, emb.count * sizeof(float), st));
+  HIPCHECK(h, hipMemsetAsync(table.grad, 0, table.count * sizeof(float), st));
+  HIPCHECK(h, launch_proj_bwd((const float *)ts.feat_rm.p, (const float *)ts.draw[0].p, M.dev, Bp, 576, 576, S, M.grad,
+                              (float *)ts.dfeat.p, (float *)ts.dm_part[0].p, st));
+  const float *W[4];
+  float *dW[4], *db[4];
+  for (int i = 0; i < 4; ++i) {
+    W[i] = h->vars[h->cnn_W[i]].dev;
+    dW[i] = h->vars[h->cnn_W[i]].grad;
+    db[i] = h->vars[h->cnn_b[i]].grad;
+  }
+  float *sq = (float *)ts.sq_part.p;
+  HIPCHECK(h, launch_cnn_bwd((const int32_t *)ts.ids[0].p, emb.dev, (const float *)ts.dfeat.p, (const float *)ts.feat_rm.p,
+                             (const int32_t *)ts.pos.p, W, dW, db, (float *)ts.dw_part.p, (float *)ts.dbias_part.p,
+                             emb.grad, sq, B, T, E, st));
+  HIPCHECK(h, launch_rows_scatter((const float *)ts.draw[1].p, (const int32_t *)ts.ids[1].p, B, S, table.grad, sq + B, st));
+  // tail[0]: both lookups are IndexedSlices -> raw slice norms
+  HIPCHECK(h, launch_sum(sq, 2 * B, (float)B, tail, st));
+  ts.grads_ready = true;
+  return 0;
+}
+
 // Forward, loss and backward of one batch of pair rows; gradients are scaled by 1/rows_global and left in
 // the arena (with the tail sums), nothing is updated.
 static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const int32_t *tgt_ids_host,
                               const float *labels_host, int32_t B, int32_t T, int64_t rows_global) {
   const sse_config &c = h->cfg;
-  if (c.network_mode != SSE_MODE_DUAL_ENCODER && c.network_mode != SSE_MODE_SHARED_ENCODER)
-    return fail(h, "train step: the reference loss is ill-shaped for this network mode (sse_model.py:233,290)");
   if (B < 1 || T < 1 || !src_ids_host || !tgt_ids_host || !labels_host || rows_global < B)
     return fail(h, "bad arguments to the train step");
-  hipStream_t st = nullptr;
   if (!h->train) h->train = new TrainState();
+  if (c.network_mode == SSE_MODE_SOURCE_ONLY_CNN)
+    return cnn_train_grads_locked(h, src_ids_host, tgt_ids_host, labels_host, B, T, rows_global);
+  if (c.network_mode != SSE_MODE_DUAL_ENCODER && c.network_mode != SSE_MODE_SHARED_ENCODER)
+    return fail(h, "train step: the reference loss is ill-shaped for this network mode (sse_model.py:233,290)");
+  hipStream_t st = nullptr;
   TrainState &ts = *h->train;
   if (!ts.side[0]) {
     for (int s = 0; s < 2; ++s) {
@@ -797,12 +886,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   const int E = c.embedding_size, S = c.encoding_size, V = c.vocab_size;
   const int Bp = round_up(B, 64), NT32 = Bp / 32;
   const bool shared = c.network_mode == SSE_MODE_SHARED_ENCODER;
-  if (!ts.arena) {
-    float *p = nullptr;
-    HIPCHECK(h, hipMalloc((void **)&p, grad_arena_count(h) * sizeof(float)));
-    bind_arena(h, p, false);
-  }
-  ts.grads_ready = false;
+  if (ensure_arena(h)) return 1;
   float *tail = ts.arena + grad_arena_count(h) - 4;
   const float inv_rows = 1.0f / (float)rows_global;
 
@@ -936,6 +1020,7 @@ static int train_apply_locked(sse_handle *h, float *loss, float *train_acc) {
   if (reserve(h, ts.norm_part, (size_t)(h->vars.size() * NORM_BLOCKS + 1) * sizeof(float))) return 1;
   float *np_ = (float *)ts.norm_part.p;
   for (size_t i = 1; i < h->vars.size(); ++i) {
+    if ((int)i == h->tgt_table) continue;  // a lookup table like word_embedding: its raw slices are in tail[0]
     Variable &v = h->vars[i];
     HIPCHECK(h, launch_sumsq(v.grad, v.count, np_ + nparts, NORM_BLOCKS, st));
     nparts += NORM_BLOCKS;

@@ -110,9 +110,10 @@ hipError_t launch_exact_topk(const float *q, const float *idxp, const double *id
                              int k, hipStream_t stream);
 
 // ------------------------------ CNN encoder --------------------------------
-size_t cnn_lds_bytes(int T, int Ep);
+size_t cnn_lds_bytes(int T, int Ep, int train);
 size_t cnn_packed_weight_floats(int Ep);
 hipError_t launch_pack_conv(const float *const W[4], int E, int Ep, float *out, hipStream_t stream);
 hipError_t launch_cnn_fwd(const int32_t *ids, const float *emb, const float *Wc, const float *bias, const float *Mp,
                           float *featp, float *out, int32_t *err, int B, int T, int V, int Ep, int S, int normalize,
+                          float *feat_rm /* training: [B][576], else NULL */, int32_t *pos /* training: [B][576] */,
                           hipStream_t stream);

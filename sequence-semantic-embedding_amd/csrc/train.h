@@ -23,3 +23,14 @@ hipError_t launch_clip_scale(const float *part, int n, float clip, float *scal, 
 hipError_t launch_adagrad(float *w, float *accum, const float *grad, const float *scal, float lr, int64_t n,
                           hipStream_t st);
 hipError_t launch_pack_kT(const float *K, int row0, int nrows, int RT, int H, int Hp, float *out, hipStream_t stream);
+
+// text-CNN training path (cnn_bwd.hip)
+int cnn_bwd_chunks(int B);
+size_t cnn_dw_part_floats(int E, int B);
+hipError_t launch_rows_gather(const float *table, const int32_t *rows, int B, int Bp, int N, int S, float *out,
+                              int32_t *err, hipStream_t st);
+hipError_t launch_rows_scatter(const float *d, const int32_t *rows, int B, int S, float *d_table, float *sq,
+                               hipStream_t st);
+hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfeat, const float *feat, const int32_t *pos,
+                          const float *const W[4], float *const dW[4], float *const db[4], float *dw_part,
+                          float *db_part, float *d_emb, float *sq_part, int B, int T, int E, hipStream_t st);

@@ -36,3 +36,82 @@ def test_free_target_matrix_is_the_target_encoding(mode):
     assert np.array_equal(m.encode_target(dummy, normalize=False), p["target_embedding/tgt_seq_embedding"])
     with pytest.raises(sse_amd.SSEError):
         m.encode_target(np.zeros((5, 8), np.int32))
+
+
+def _cnn_batch(rng, B, T, V, N, pad_frac=0.5):
+    src = np.repeat(random_ids(rng, B // 2, T, V, pad_frac), 2, axis=0)       # pos,neg rows share the source
+    rows = rng.randint(0, N, size=B).astype(np.int32)
+    return src, rows, np.tile(np.array([1.0, 0.0], np.float32), B // 2)
+
+
+@pytest.mark.parametrize("V,E,S,T,B,N", [(300, 50, 512, 64, 48, 571), (90, 24, 64, 20, 10, 17), (60, 8, 16, 5, 4, 5)])
+def test_cnn_train_step_matches_oracle(V, E, S, T, B, N):
+    """BUILDER-DEFINED CNN pair loss (BASELINE configs[4]; oracle._cnn_gradients): one step of forward with arg-max
+    tape, gather/scatter backward, clip, Adagrad vs the oracle.  Tolerances as for the LSTM step; a near-tie of two
+    pooled positions (|dv| ~ 1e-7) may legitimately route one filter's gradient elsewhere, hence 5e-4."""
+    params = model_params("source_only_cnn", V, E, 96, 96, S, T, N=N, lr=0.9)
+    m, p = make_pair(params, seed=6)
+    st = O.new_optimizer_state(p)
+    src, rows, z = _cnn_batch(np.random.RandomState(3), B, T, V, N)
+    want_loss, want_acc = O.train_step(p, st, params, src, rows, z, 0.9)
+    loss, acc = m.train_step(src, rows, z)
+    assert loss == pytest.approx(float(want_loss), rel=1e-5, abs=1e-6)
+    assert acc == pytest.approx(float(want_acc), abs=1e-6)
+    got = m.get_variables(with_slots=True)
+    for name, w in p.items():
+        assert np.abs(got[name].reshape(w.shape) - w).max() < 5e-4, name
+        assert np.abs(got[name + "/Adagrad"].reshape(w.shape) - st[name]).max() < 5e-4, name + "/Adagrad"
+    assert m.handle.global_step == 1
+    # the encoder sees the updated weights (layouts refreshed)
+    ids = random_ids(np.random.RandomState(1), 5, T, V, 0.3)
+    assert np.abs(m.encode_source(ids) - O.encode(p, params, "src", ids)).max() < 2e-3
+
+
+def test_cnn_training_learns_and_rejects_bad_rows():
+    import sse_amd
+    V, E, S, T, N = 120, 16, 32, 12, 9
+    params = model_params("source_only_cnn", V, E, 96, 96, S, T, N=N, lr=0.1)
+    m, p = make_pair(params, seed=1)
+    m.handle.learning_rate = 0.1
+    st = O.new_optimizer_state(p)
+    src, rows, z = _cnn_batch(np.random.RandomState(5), 24, T, V, N)
+    got, want = [], []
+    for _ in range(12):
+        want.append(float(O.train_step(p, st, params, src, rows, z, 0.1)[0]))
+        got.append(m.train_step(src, rows, z)[0])
+    assert min(got) < got[0]
+    assert np.allclose(got, want, rtol=5e-3, atol=1e-4)
+    bad = rows.copy()
+    bad[3] = N
+    with pytest.raises(sse_amd.SSEError):
+        m.train_step(src, bad, z)
+    with pytest.raises(ValueError):
+        m.train_step(src, np.zeros_like(src), z)                   # token ids where target rows are expected
+
+
+def test_cnn_data_parallel_two_logical_ranks():
+    import torch
+    V, E, S, T, N, B = 150, 20, 48, 16, 31, 40
+    params = model_params("source_only_cnn", V, E, 96, 96, S, T, N=N, lr=0.9)
+    (m0, p), (m1, _) = make_pair(params, seed=3), make_pair(params, seed=3)
+    st = O.new_optimizer_state(p)
+    src, rows, z = _cnn_batch(np.random.RandomState(9), B, T, V, N)
+    want = O.train_step(p, st, params, src, rows, z, 0.9)
+    arenas = []
+    for m, sl in ((m0, slice(0, 26)), (m1, slice(26, B))):       # uneven split
+        a = torch.zeros(m.handle.train_grad_count(), dtype=torch.float32, device="cuda:0")
+        m.handle.train_bind_arena(a)
+        m.handle.train_grads(src[sl], rows[sl], z[sl], rows_global=B)
+        arenas.append(a)
+    torch.cuda.synchronize()
+    total = arenas[0] + arenas[1]
+    for a in arenas:
+        a.copy_(total)
+    torch.cuda.synchronize()
+    res = [m.handle.train_apply() for m in (m0, m1)]
+    assert res[0] == res[1]
+    assert res[0][0] == pytest.approx(float(want[0]), rel=1e-5)
+    g0, g1 = m0.get_variables(), m1.get_variables()
+    for name, w in p.items():
+        assert np.array_equal(g0[name], g1[name]), name
+        assert np.abs(g0[name].reshape(w.shape) - w).max() < 5e-4, name

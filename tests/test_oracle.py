@@ -108,6 +108,69 @@ def test_gradients_finite_difference(mode):
         O.FORGET_BIAS, O.L2_EPS, O.LOGIT_SCALE = old(1.0), old(1e-12), old(64.0)
 
 
+def test_cnn_gradients_finite_difference():
+    """Builder-defined CNN pair loss (oracle._cnn_gradients): analytic gradients vs central differences, float64.
+    All-PAD windows make exact max-pool ties; FD is taken at points where the arg-max is stable."""
+    cfg = _cfg(mode="source_only_cnn", V=19, E=4, H=6, S=5)
+    cfg["targetSpaceSize"] = 7
+    p = {k: v.astype(np.float64) for k, v in O.init_params(cfg, seed=2).items()}
+    rng = np.random.RandomState(3)
+    B, T = 6, 7
+    src = rng.randint(0, 19, size=(B, T)).astype(np.int32)
+    src[0, :4] = 0                                                   # left padding: tied windows
+    rows = rng.randint(0, 7, size=B).astype(np.int32)
+    rows[1] = rows[0]                                                # duplicate target row: slices are summed
+    z = np.array([1, 0] * 3, np.float64)
+    old = O.F32
+    try:
+        O.F32 = np.float64
+        O.L2_EPS, O.LOGIT_SCALE = np.float64(1e-12), np.float64(64.0)
+
+        def f(pp):
+            ns = O.encode(pp, cfg, "src", src)
+            nt = O.l2_normalize(pp["target_embedding/tgt_seq_embedding"][rows])
+            return float(O.loss_and_acc(ns, nt, z)[0])
+
+        loss, _, grads = O.gradients(p, cfg, src, rows, z)
+        assert abs(loss - f(p)) < 1e-9
+        assert set(grads) == set(p)
+        for name, g in grads.items():
+            if isinstance(g, tuple):
+                g = O.dense_embedding_grad(g, p[name].shape[0])
+            for _ in range(8):
+                idx = tuple(rng.randint(0, s) for s in p[name].shape)
+                q = {k: v.copy() for k, v in p.items()}
+                eps = 1e-7
+                q[name][idx] += eps
+                up = f(q)
+                q[name][idx] -= 2 * eps
+                dn = f(q)
+                num = (up - dn) / (2 * eps)
+                assert abs(num - g[idx]) < 2e-5 * max(1.0, abs(num)), (name, idx, num, g[idx])
+    finally:
+        O.F32 = old
+        O.L2_EPS, O.LOGIT_SCALE = old(1e-12), old(64.0)
+
+
+def test_cnn_train_step_runs_and_updates_only_touched_rows():
+    cfg = _cfg(mode="source_only_cnn", V=40, E=6, H=6, S=8)
+    cfg["targetSpaceSize"] = 9
+    p = O.init_params(cfg, seed=4)
+    before = {k: v.copy() for k, v in p.items()}
+    st = O.new_optimizer_state(p)
+    rng = np.random.RandomState(0)
+    src = rng.randint(2, 30, size=(8, 9)).astype(np.int32)
+    rows = np.array([0, 3, 3, 5, 0, 1, 2, 8], np.int32)
+    z = np.array([1, 0] * 4, np.float32)
+    losses = [float(O.train_step(p, st, cfg, src, rows, z, 0.1)[0]) for _ in range(15)]
+    assert min(losses) < losses[0]
+    tbl = "target_embedding/tgt_seq_embedding"
+    untouched = [r for r in range(9) if r not in set(rows.tolist())]
+    assert np.array_equal(p[tbl][untouched], before[tbl][untouched])
+    assert np.array_equal(p["word_embedding"][30:], before["word_embedding"][30:])
+    assert not np.array_equal(p[tbl][3], before[tbl][3])
+
+
 def test_train_step_reduces_loss_and_dedups_embedding_rows():
     cfg = _cfg(V=31, E=6, H=8, S=6)
     p = O.init_params(cfg, seed=2)
