@@ -22,7 +22,6 @@
 namespace {
 
 __constant__ int b_fs[4] = {2, 3, 4, 5};
-__constant__ int b_nf[4] = {256, 128, 128, 64};
 __constant__ int b_foff[4] = {0, 256, 384, 512};
 
 struct CnnBwdArgs {
@@ -32,6 +31,7 @@ struct CnnBwdArgs {
   const float *feat;    // [Bp][576] pooled features (ReLU mask: > 0)
   const int32_t *pos;   // [B][576] arg-max positions
   const float *W[4];    // master filters, row-major [fs*E][nf]
+  const float *Wt[4];   // transposed copies [nf][fs*E] (made per step by launch_cnn_bwd)
   float *dw_part[4];    // [NCH][fs*E*nf]
   float *db_part;       // [NCH][576]
   float *d_emb;         // [V][E] dense embedding gradient (zeroed by the caller)
@@ -100,27 +100,64 @@ __global__ void strided_reduce_kernel(const float *part, int nch, int stride, in
   }
 }
 
+// dX[t][e] = sum over the filters whose winning window covers t.  LDS float atomics run ~1 lane/clock on
+// gfx950 (a scatter formulation took 3.5 ms at 8192 sequences), so this is a GATHER: the 576 filters are
+// bucketed by winning position (ascending filter order: deterministic), thread (t,e) walks the buckets of
+// positions t, t-1, .. t-4 and reads the TRANSPOSED filters Wt[f][j*E+e] (lanes = e: coalesced).
 __global__ __launch_bounds__(256) void cnn_dx_kernel(CnnBwdArgs a) {
-  extern __shared__ float dX[];  // [T*E]
+  __shared__ float g_s[576];
+  __shared__ int pos_s[576], list_s[576], start_s[72];
+  __shared__ int woff_s[576], fs_s[576];  // per list entry: row offset into the transposed filters, width
+  __shared__ float gl_s[576];
   __shared__ float red[256];
   const int tid = threadIdx.x, b = blockIdx.x, T = a.T, E = a.E;
-  for (int i = tid; i < T * E; i += 256) dX[i] = 0.0f;
-  __syncthreads();
   for (int f = tid; f < 576; f += 256) {
     float g = a.dfeat[(size_t)b * 576 + f];
-    if (!(a.feat[(size_t)b * 576 + f] > 0.0f) || g == 0.0f) continue;
-    const int wi = f < 256 ? 0 : f < 384 ? 1 : f < 512 ? 2 : 3;
-    const int nf = b_nf[wi], fl = f - b_foff[wi], K = b_fs[wi] * E;
-    const float *W = a.W[wi] + fl;
-    float *dst = dX + a.pos[(size_t)b * 576 + f] * E;  // the window is the contiguous run (p+j)*E+e = p*E + k
-    for (int k = 0; k < K; ++k) atomicAdd(dst + k, g * W[(size_t)k * nf]);
+    if (!(a.feat[(size_t)b * 576 + f] > 0.0f)) g = 0.0f;
+    g_s[f] = g;
+    pos_s[f] = (g != 0.0f) ? a.pos[(size_t)b * 576 + f] : -1;
   }
   __syncthreads();
+  int cnt = 0;
+  if (tid < T)
+    for (int f = 0; f < 576; ++f) cnt += (pos_s[f] == tid);
+  if (tid < 72) start_s[tid] = (tid < T) ? cnt : 0;
+  __syncthreads();
+  int st = 0;
+  if (tid < T)
+    for (int q = 0; q < tid; ++q) st += start_s[q];
+  __syncthreads();
+  if (tid < T) {
+    start_s[tid] = st;
+    if (tid == T - 1) start_s[T] = st + cnt;
+    for (int f = 0; f < 576; ++f)
+      if (pos_s[f] == tid) list_s[st++] = f;
+  }
+  __syncthreads();
+  const int n_list = start_s[T];
+  for (int x = tid; x < n_list; x += 256) {
+    const int f = list_s[x];
+    const int wi = f < 256 ? 0 : f < 384 ? 1 : f < 512 ? 2 : 3;
+    woff_s[x] = (int)(a.Wt[wi] - a.Wt[0]) + (f - b_foff[wi]) * (b_fs[wi] * E);
+    fs_s[x] = b_fs[wi];
+    gl_s[x] = g_s[f];
+  }
+  __syncthreads();
+  const float *Wt = a.Wt[0];
   float sq = 0.0f;
   for (int i = tid; i < T * E; i += 256) {
-    const float v = dX[i];
-    sq += v * v;
-    if (v != 0.0f) atomicAdd(a.d_emb + (size_t)a.ids[(size_t)b * T + i / E] * E + i % E, v);
+    const int t = i / E, e = i % E;
+    float acc = 0.0f;
+    for (int j = 0; j < 5 && j <= t; ++j) {
+      const int p = t - j, i1 = start_s[p + 1], je = j * E + e;
+#pragma unroll 4
+      for (int x = start_s[p]; x < i1; ++x) {  // branch-free: filters narrower than j+1 contribute 0 * (a valid element)
+        const bool in = j < fs_s[x];
+        acc += (in ? gl_s[x] : 0.0f) * Wt[woff_s[x] + (in ? je : e)];
+      }
+    }
+    sq += acc * acc;
+    if (acc != 0.0f) atomicAdd(a.d_emb + (size_t)a.ids[(size_t)b * T + t] * E + e, acc);
   }
   red[tid] = sq;
   __syncthreads();
@@ -129,6 +166,12 @@ __global__ __launch_bounds__(256) void cnn_dx_kernel(CnnBwdArgs a) {
     __syncthreads();
   }
   if (tid == 0) a.sq_part[b] = red[0];
+}
+
+// Wt[f][k] = W[k][f]
+__global__ void transpose_kernel(const float *W, int K, int NF, float *Wt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < K * NF) Wt[(size_t)(i % NF) * K + i / NF] = W[i];
 }
 
 // out[b][:] = table[rows[b]][:] (b < B), 0 for the padding rows; one wave per row
@@ -183,7 +226,8 @@ hipError_t launch_rows_scatter(const float *d, const int32_t *rows, int B, int S
 
 hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfeat, const float *feat, const int32_t *pos,
                           const float *const W[4], float *const dW[4], float *const db[4], float *dw_part,
-                          float *db_part, float *d_emb, float *sq_part, int B, int T, int E, hipStream_t st) {
+                          float *db_part, float *wt_scratch /* [E*1728] */, float *d_emb, float *sq_part, int B, int T,
+                          int E, hipStream_t st) {
   static const int fs[4] = {2, 3, 4, 5}, nf[4] = {256, 128, 128, 64}, foff[4] = {0, 256, 384, 512};
   CnnBwdArgs a;
   a.ids = ids;
@@ -198,11 +242,15 @@ hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfe
   a.T = T;
   a.E = E;
   a.NCH = cnn_bwd_chunks(B);
-  size_t off = 0;
+  size_t off = 0, toff = 0;
   for (int i = 0; i < 4; ++i) {
+    const int n = fs[i] * E * nf[i];
     a.W[i] = W[i];
+    a.Wt[i] = wt_scratch + toff;
+    hipLaunchKernelGGL(transpose_kernel, dim3((n + 255) / 256), dim3(256), 0, st, W[i], fs[i] * E, nf[i], wt_scratch + toff);
+    toff += n;
     a.dw_part[i] = dw_part + off;
-    off += (size_t)a.NCH * fs[i] * E * nf[i];
+    off += (size_t)a.NCH * n;
   }
   hipLaunchKernelGGL(cnn_dw_kernel, dim3(a.NCH, 4), dim3(256), (size_t)2 * T * E * sizeof(float), st, a);
   for (int i = 0; i < 4; ++i) {
@@ -212,6 +260,6 @@ hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfe
   // db: the four bias vectors are disjoint slices of the 576 features
   for (int i = 0; i < 4; ++i)
     hipLaunchKernelGGL(strided_reduce_kernel, dim3(1), dim3(256), 0, st, db_part + foff[i], a.NCH, 576, nf[i], db[i]);
-  hipLaunchKernelGGL(cnn_dx_kernel, dim3(B), dim3(256), (size_t)T * E * sizeof(float), st, a);
+  hipLaunchKernelGGL(cnn_dx_kernel, dim3(B), dim3(256), 0, st, a);
   return hipGetLastError();
 }

@@ -33,4 +33,5 @@ hipError_t launch_rows_scatter(const float *d, const int32_t *rows, int B, int S
                                hipStream_t st);
 hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfeat, const float *feat, const int32_t *pos,
                           const float *const W[4], float *const dW[4], float *const db[4], float *dw_part,
-                          float *db_part, float *d_emb, float *sq_part, int B, int T, int E, hipStream_t st);
+                          float *db_part, float *wt_scratch, float *d_emb, float *sq_part, int B, int T, int E,
+                          hipStream_t st);

@@ -135,7 +135,17 @@ class Data(object):
         self.vocab_size = self.encoder.vocab_size
         log("Vocab size: %d unique words; max allowed sequence length: %d" % (self.vocab_size, self.max_seq_length))
 
-    def get_train_batch(self, batch_size):
+    def target_row(self, tgt_id):
+        """Row of a target id in the free target matrix of source_only_cnn / source-encoder-only (builder-defined:
+        the position of the id in fullSetTargetIds, i.e. the order of the targetIDs file)."""
+        if getattr(self, "_row_of", None) is None:
+            self._row_of = {t: i for i, t in enumerate(self.fullSetTargetIds)}
+        return self._row_of[tgt_id]
+
+    def get_train_batch(self, batch_size, target_rows=False):
+        """data.py:95-115.  target_rows=True (source_only_cnn): the target side of each pair is the row of the
+        target id in the free target matrix instead of its token sequence."""
+        tgt_of = self.target_row if target_rows else self.encodedFullTargetSpace.__getitem__
         n = len(self.rawTrainPosCorpus)
         start = self.rng.randint(0, n - batch_size) + batch_size     # data.py:97 (window may be cut at the end)
         src, tgt, labels = [], [], []
@@ -143,12 +153,12 @@ class Data(object):
             pos = verified[self.rng.randint(0, len(verified))]
             positives = set(verified)
             src.append(tokens)
-            tgt.append(self.encodedFullTargetSpace[pos])
+            tgt.append(tgt_of(pos))
             labels.append(1.0)
             neg = self.fullSetTargetIds[self.rng.randint(0, self.rawnegSetLen)]
             while neg in positives:
                 neg = self.fullSetTargetIds[self.rng.randint(0, self.rawnegSetLen)]
             src.append(tokens)
-            tgt.append(self.encodedFullTargetSpace[neg])
+            tgt.append(tgt_of(neg))
             labels.append(0.0)
         return src, tgt, labels

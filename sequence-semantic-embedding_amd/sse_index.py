@@ -19,12 +19,33 @@ FLAGS = flags.FlagSet("sse_index", [
 ])
 
 
-def createIndexFile(model, encoder, rawfile, max_seq_len, encodeIndexFile, session, batchsize=10000):
+def createIndexFile(model, encoder, rawfile, max_seq_len, encodeIndexFile, session, batchsize=10000, row_of=None):
     if not os.path.exists(rawfile):
         raise FileNotFoundError("Error!! Could not find raw target file to be indexed!! :%s" % rawfile)
     lines = codecs.open(rawfile, "r", "utf-8").readlines()
     cnt = 0
     print("Start indexing whole target space entries with current model ...")
+    if model.network_mode in ("source_only_cnn", "source-encoder-only"):
+        # no target sequence encoder: norm_tgt_seq_embedding IS the [N,S] variable (sse_model.py:214,233,283);
+        # row r belongs to the r-th well-formed line of the target file (or row_of(id) when the caller knows better)
+        n_rows = int(model.targetSpaceSize)
+        table = np.vstack(session.run([model.norm_tgt_seq_embedding],
+                                      feed_dict=model.get_target_encoding_feed_dict(np.zeros((n_rows, max_seq_len), np.int32))))
+        with codecs.open(encodeIndexFile, "w", "utf-8") as out:
+            r = 0
+            for line in lines:
+                cnt += 1
+                info = line.strip().split("\t")
+                if len(info) != 2:
+                    print("Missing field with error line in raw target file: %s " % line)
+                    continue
+                row = row_of(info[1]) if row_of else r
+                r += 1
+                if row >= n_rows:
+                    raise ValueError("target file has more entries than the model's target matrix (%d rows)" % n_rows)
+                out.write(info[1] + "\t" + info[0] + "\t" + ",".join([str(n) for n in table[row]]) + "\n")
+        print("Done of all indexing total count:%d" % cnt)
+        return
     with codecs.open(encodeIndexFile, "w", "utf-8") as out:
         for b in range(int(math.ceil(len(lines) / float(batchsize)))):
             ids, tids, sents = [], [], []

@@ -31,7 +31,7 @@ FLAGS = flags.FlagSet("sse_train", [
     ("rawfilename", str, "targetIDs", "raw target sequence file to be indexed"),
     ("encodedIndexFile", str, "targetEncodingIndex.tsv", "target sequece encoding index file."),
     ("device", str, "0", "GPU ordinal."),
-    ("network_mode", str, "dual-encoder", "source-encoder-only, dual-encoder, shared-encoder"),
+    ("network_mode", str, "dual-encoder", "source-encoder-only, dual-encoder, shared-encoder, source_only_cnn"),
     ("steps_per_checkpoint", int, 200, "How many training steps to do per checkpoint."),
     ("seed", int, -1, "seed for batch sampling and initialisation (-1: unseeded, like the reference)"),
     ("max_steps", int, 0, "stop after this many steps (0: no limit; for smoke runs)"),
@@ -91,7 +91,7 @@ def train(f):
         epoc_start = time.time()
         for _ in range(int(epoc_steps)):
             start = time.time()
-            src, tgt, labels = data.get_train_batch(f.batch_size)
+            src, tgt, labels = data.get_train_batch(f.batch_size, target_rows=(f.network_mode == "source_only_cnn"))
             model.set_forward_only(False)
             d = model.get_train_feed_dict(src, tgt, labels)
             _, _, step_loss, step_train_acc = sess.run([model.train, summary_op, model.loss, model.train_acc], feed_dict=d)
@@ -127,7 +127,7 @@ def train(f):
             model.set_forward_only(True)
             idx_file = os.path.join(f.model_dir, f.encodedIndexFile)
             sse_index.createIndexFile(model, data.encoder, os.path.join(f.model_dir, f.rawfilename), f.max_seq_length,
-                                      idx_file, sess, batchsize=1000)
+                                      idx_file, sess, batchsize=1000, row_of=data.target_row)
             acc1, acc3, acc10 = Evaluator(model, data.rawEvalCorpus, idx_file, sess).eval()
             logging.info("epoc#%d, task specific evaluation: top 1/3/10 accuracies: %f / %f / %f \n\n\n" % (epoch, acc1, acc3, acc10))
         model.save(sess, checkpoint_path + "-epoch-%d" % epoch)

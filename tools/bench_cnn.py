@@ -30,3 +30,22 @@ h.timer_record(1)
 ms = h.timer_elapsed_ms(0, 1) / n
 print("CNN encode B=%d T=%d S=%d: %.3f ms  %.0f seq/s  %.1f TFLOP/s algorithmic (%.1f%% of fp32 MFMA peak)"
       % (B, T, S, ms, B / ms * 1e3, B * flop / ms / 1e9, B * flop / ms / 1e9 / 157.3 * 100))
+
+# ---- training step (builder-defined CNN pair loss, configs[4]): host ids in, loss/acc out
+import time  # noqa: E402
+import numpy as np  # noqa: E402
+
+rng = np.random.RandomState(0)
+for Bt in (1024, 8192):
+    src = np.repeat(rng.randint(2, V, size=(Bt // 2, T)).astype(np.int32), 2, axis=0)
+    rows = rng.randint(0, 571, size=Bt).astype(np.int32)
+    z = np.tile(np.array([1.0, 0.0], np.float32), Bt // 2)
+    for _ in range(2):
+        m.train_step(src, rows, z)
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        loss, acc = m.train_step(src, rows, z)
+    dt = (time.perf_counter() - t0) / n
+    print("CNN train step B_rows=%d: %.3f ms/step  %.0f pair-rows/s  (forward share %.2f ms at the encode rate above), loss %.4f"
+          % (Bt, dt * 1e3, Bt / dt, Bt * ms / B, loss))
