@@ -370,6 +370,25 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
     nsplit = 1;
     while (nsplit < 8 && QB * nsplit < 256 && NT / (nsplit * 2) >= 8) nsplit *= 2;
   }
+  // one workgroup per CU is resident (the query block fills LDS): the launch runs in ceil(WGs/256) rounds and the
+  // last round may be nearly empty (782 query blocks = 3.05 rounds ran at 76 % of the 64-block rate).  Split
+  // further while that evens the rounds out by more than the extra per-split cost (~1 % per doubling).
+  if (NQ == 4) {
+    auto eff = [&](int ns) {
+      const double r = (double)QB * ns / 256.0;
+      return r / std::ceil(r);
+    };
+    int best = nsplit;
+    double best_score = eff(nsplit);
+    for (int ns = nsplit * 2, d = 1; ns <= 128 && NT / ns >= 256; ns *= 2, ++d) {
+      const double sc = eff(ns) - 0.01 * d;
+      if (sc > best_score + 0.01) {
+        best = ns;
+        best_score = sc;
+      }
+    }
+    nsplit = best;
+  }
   // the 16 per-wave lists of a workgroup are always merged in-kernel (a few tens of microseconds per
   // workgroup): the re-scoring pass then ranks 16 candidates per split instead of 256
   const int merge = 1;
