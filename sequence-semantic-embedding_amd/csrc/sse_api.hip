@@ -68,6 +68,7 @@ struct sse_handle {
   Encoder enc[2];
   bool packed_dirty = true;
   bool pad_skip = true;      // option "pad_skip": exact left-pad prefix skip in inference encodes
+  bool train_serial = false; // option "train_serial": both encoders on one stream (profiling: isolated kernel times)
   float *emb_pad = nullptr;  // [V][Ep]
   // source_only_cnn
   int cnn_W[4] = {-1, -1, -1, -1}, cnn_b[4] = {-1, -1, -1, -1}, cnn_M = -1, tgt_table = -1;
@@ -657,6 +658,10 @@ int sse_encode(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int3
 int sse_set_option(sse_handle *h, const char *name, int32_t value) {
   if (!h || !name) return 1;
   std::lock_guard<std::mutex> lk(h->mu);
+  if (strcmp(name, "train_serial") == 0) {
+    h->train_serial = value != 0;
+    return 0;
+  }
   if (strcmp(name, "pad_skip") == 0) {
     h->pad_skip = value != 0;
     return 0;
@@ -944,7 +949,8 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   // encoders are independent: fork onto two side streams, join before the loss
   HIPCHECK(h, hipEventRecord(ts.ev_fork, st));
   for (int s = 0; s < 2; ++s) {
-    HIPCHECK(h, hipStreamWaitEvent(ts.side[s], ts.ev_fork, 0));
+    hipStream_t fs = h->train_serial ? ts.side[0] : ts.side[s];
+    HIPCHECK(h, hipStreamWaitEvent(fs, ts.ev_fork, 0));
     Encoder &e = h->enc[s];
     const int KT = 2 + e.Hp / 32;
     if (reserve(h, ts.raw[s], (size_t)Bp * S * sizeof(float))) return 1;
@@ -973,8 +979,8 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     a.tape_g = (float *)ts.tape_g[s].p;
     a.tape_a = (float *)ts.tape_a[s].p;
     a.h_last = (float *)ts.h_last[s].p;
-    HIPCHECK(h, launch_lstm_fwd(a, e.Hp, ts.side[s]));
-    HIPCHECK(h, hipEventRecord(ts.ev_join[s], ts.side[s]));
+    HIPCHECK(h, launch_lstm_fwd(a, e.Hp, fs));
+    HIPCHECK(h, hipEventRecord(ts.ev_join[s], fs));
     HIPCHECK(h, hipStreamWaitEvent(st, ts.ev_join[s], 0));
   }
   if (check_err_flag(h, st)) return 1;
@@ -997,7 +1003,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     const int SL = dk_slices(RG);
     // dual-encoder: the two backward chains are independent -> side streams; shared-encoder: the
     // target side accumulates onto the source side's kernel/bias gradient -> one stream, in order
-    hipStream_t bs = shared ? ts.side[0] : ts.side[s];
+    hipStream_t bs = (shared || h->train_serial) ? ts.side[0] : ts.side[s];
     if (!shared || s == 0) HIPCHECK(h, hipStreamWaitEvent(bs, ts.ev_fork, 0));
     if (reserve(h, ts.dh_last[s], (size_t)Bp * Hp * sizeof(float))) return 1;
     if (reserve(h, ts.dg_a[s], (size_t)T * NT32 * KGn * 256 * sizeof(float))) return 1;

@@ -17,7 +17,6 @@
 
 #include "sse_kernels.h"
 
-#define BW_THREADS 256
 
 __device__ __forceinline__ float fast_tanh_t(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008178f * x)); }
 __device__ __forceinline__ float fast_sigmoid_t(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504089f * x)); }
@@ -210,15 +209,29 @@ struct LstmBwdArgs {
   int32_t T, NT32, Hp;
 };
 
-template <int UB>
-__global__ __launch_bounds__(BW_THREADS) void lstm_bwd_kernel(LstmBwdArgs a) {
+template <int UB, int NW>
+__global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float dgs[];  // [KGn][256]: dg tile, frag32(rows = b, red = n)
-  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  constexpr int NTHR = NW * 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform (SGPR): the tape descriptor depends on it
   const int tile = blockIdx.x, Hp = a.Hp, KGn = Hp / 2, NTn = Hp / 8, T = a.T;
   const int half = lane >> 5;
 
   f32x16 dh[UB], dc[UB];
   float dbacc[UB][4];
+  // gate tape of the step about to be processed, held in registers and refilled (for step t-1) while the
+  // recurrent GEMM of step t runs: the HBM latency of the tape never sits on the critical path
+  float tg[UB][4][16], tcn[UB][16], tcp[UB][16];
+  // tape reads go through a buffer descriptor: address = SGPR base + SGPR offset + (4*lane), so the 80
+  // loads of a refill cost no address VGPRs (per-lane 64-bit pointers spilled this kernel)
+  const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(a.tape_g + ((size_t)tile * NW + wn) * UB * 5 * 1024), 0, 0x7fffffff, 0x00020000);
+  const int tvo = lane * 4;
+  const int tstep = a.NT32 * NW * UB * 5 * 1024 * 4;  // bytes between consecutive steps (T*tstep < 2^31 checked by the launcher)
+  auto tld = [&](int t, int u, int word) -> float {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(trs, tvo, t * tstep + (u * 5 * 1024 + word) * 4, 0));
+  };
 #pragma unroll
   for (int u = 0; u < UB; ++u) {
     const int unit = (wn * UB + u) * 32 + (lane & 31);
@@ -226,6 +239,10 @@ __global__ __launch_bounds__(BW_THREADS) void lstm_bwd_kernel(LstmBwdArgs a) {
     for (int r = 0; r < 16; ++r) {
       dh[u][r] = a.dh_last[(size_t)(tile * 32 + mfma_row(r, lane)) * Hp + unit];
       dc[u][r] = 0.0f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) tg[u][g][r] = tld(T - 1, u, g * 1024 + r * 64);
+      tcn[u][r] = tld(T - 1, u, 4096 + r * 64);
+      tcp[u][r] = tld(T > 1 ? T - 2 : 0, u, 4096 + r * 64);  // unused when T == 1
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) dbacc[u][g] = 0.0f;
@@ -235,14 +252,12 @@ __global__ __launch_bounds__(BW_THREADS) void lstm_bwd_kernel(LstmBwdArgs a) {
     // ---- elementwise gate backward, results into the LDS dg tile
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
-      const float *tp = a.tape_g + ((((size_t)t * a.NT32 + tile) * 4 + wn) * UB + u) * 5 * 1024 + lane;
-      const float *tprev = a.tape_g + ((((size_t)(t > 0 ? t - 1 : 0) * a.NT32 + tile) * 4 + wn) * UB + u) * 5 * 1024 + 4096 + lane;
       const int unit = (wn * UB + u) * 32 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float si = tp[r * 64], tj = tp[1024 + r * 64], sf = tp[2048 + r * 64], so = tp[3072 + r * 64];
-        const float cn = tp[4096 + r * 64];
-        const float cprev = (t > 0) ? tprev[r * 64] : 0.0f;
+        const float si = tg[u][0][r], tj = tg[u][1][r], sf = tg[u][2][r], so = tg[u][3][r];
+        const float cn = tcn[u][r];
+        const float cprev = (t > 0) ? tcp[u][r] : 0.0f;
         const float tc = fast_tanh_t(cn);
         const float dhv = dh[u][r];
         const float dov = dhv * tc;
@@ -263,18 +278,43 @@ __global__ __launch_bounds__(BW_THREADS) void lstm_bwd_kernel(LstmBwdArgs a) {
         dst[(size_t)(1 * Hp / 8) * 256] = g_j;
         dst[(size_t)(2 * Hp / 8) * 256] = g_f;
         dst[(size_t)(3 * Hp / 8) * 256] = g_o;
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the interleaving (register pressure)
+      }
+    }
+    // refill the tape registers for step t-1 (c_{t-1} is already here: it was this step's c_prev); the fence
+    // keeps the scheduler from hoisting these loads above the last use of the old values (two live copies spill)
+    __builtin_amdgcn_sched_barrier(0);
+    if (t > 0) {
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) tg[u][g][r] = tld(t - 1, u, g * 1024 + r * 64);
+          tcn[u][r] = tcp[u][r];
+          tcp[u][r] = tld(t > 1 ? t - 2 : 0, u, 4096 + r * 64);  // step 0 ignores it (c_{-1} = 0)
+        }
       }
     }
     __syncthreads();
 
-    // ---- dump the tile: linear copy (A-operand layout) and transposed (B-operand layout)
-    {
+    // ---- dump the tile: linear copy (A-operand layout) and transposed (B-operand layout).  Both the dump
+    // and the recurrent GEMM only READ the LDS tile, so the two waves that share a SIMD run them in
+    // opposite order (waves < NW/2: dump then GEMM; the others: GEMM then dump): one wave's global stores
+    // overlap its partner's MFMA stream.  Each group dumps its half of the tile.
+    auto dump = [&]() {
+      constexpr int GTHR = NTHR / 2;
+      const int grp = (wn >= NW / 2) ? 1 : 0, gt = tid - grp * GTHR;
       f32x4 *ga = reinterpret_cast<f32x4 *>(a.dg_a + ((size_t)t * a.NT32 + tile) * KGn * 256);
       const f32x4 *ls = reinterpret_cast<const f32x4 *>(dgs);
-      for (int i = tid; i < KGn * 64; i += BW_THREADS) ga[i] = ls[i];
+      const int n4 = KGn * 64, h4 = n4 / 2;
+#pragma unroll 4
+      for (int i = grp * h4 + gt; i < (grp + 1) * h4; i += GTHR) ga[i] = ls[i];
       // (n, 4 consecutive rows) -> one float4 of block (rg, n/32)
       const size_t rg0 = ((size_t)t * a.NT32 + tile) * 4;
-      for (int i = tid; i < 4 * Hp * 8; i += BW_THREADS) {
+      const int nb = 4 * Hp * 8, hb = nb / 2;
+#pragma unroll 4
+      for (int i = grp * hb + gt; i < (grp + 1) * hb; i += GTHR) {
         const int n = i % (4 * Hp), b4 = i / (4 * Hp);  // rows 4*b4 .. 4*b4+3
         const int bl = b4 * 4;
         const float *src = dgs + (size_t)(n >> 3) * 256 + ((((n >> 2) & 1) * 32 + bl) << 2) + (n & 3);
@@ -282,7 +322,9 @@ __global__ __launch_bounds__(BW_THREADS) void lstm_bwd_kernel(LstmBwdArgs a) {
         float *dst = a.dg_b + ((rg0 + (bl >> 3)) * NTn + (n >> 5)) * 256 + ((((bl >> 2) & 1) * 32 + (n & 31)) << 2);
         *reinterpret_cast<f32x4 *>(dst) = v;
       }
-    }
+    };
+    const bool dump_first = wn < NW / 2;
+    if (dump_first) dump();
 
     // ---- recurrent GEMM: dh_{t-1}[b][j] = sum_n dg[b][n] * Kh[j][n]
     if (t > 0) {
@@ -292,32 +334,35 @@ __global__ __launch_bounds__(BW_THREADS) void lstm_bwd_kernel(LstmBwdArgs a) {
         for (int r = 0; r < 16; ++r) dh[u][r] = 0.0f;
       const float *la = dgs + lane * 4;
       const float *kb = a.KhT + (size_t)(wn * UB) * KGn * 256 + lane * 4;
-      f32x4 b0[UB], b1[UB];
+      // Kh^T fragments come from L2 (~1-2 k cycles): keep PF k-groups (PF*4*UB MFMAs) of them in flight
+      // in a register ring; the dg fragments come from LDS one k-group ahead.  KGn % PF == 0.
+      constexpr int PF = 2;
+      f32x4 bq[PF][UB], aq[2];
 #pragma unroll
-      for (int u = 0; u < UB; ++u) b0[u] = *reinterpret_cast<const f32x4 *>(kb + (size_t)u * KGn * 256);
-      f32x4 a0 = *reinterpret_cast<const f32x4 *>(la);
-      for (int kg = 0; kg < KGn; kg += 2) {  // KGn is even (Hp/2)
+      for (int p = 0; p < PF; ++p)
 #pragma unroll
-        for (int u = 0; u < UB; ++u) b1[u] = *reinterpret_cast<const f32x4 *>(kb + ((size_t)u * KGn + kg + 1) * 256);
-        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(la + (kg + 1) * 256);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < UB; ++u) bq[p][u] = *reinterpret_cast<const f32x4 *>(kb + ((size_t)u * KGn + p) * 256);
+      aq[0] = *reinterpret_cast<const f32x4 *>(la);
+      __builtin_amdgcn_s_setprio(1);
+      for (int kg = 0; kg < KGn; kg += PF) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int p = 0; p < PF; ++p) {
+          const int kn = (kg + p + 1 < KGn) ? kg + p + 1 : kg + p;
+          aq[(p + 1) & 1] = *reinterpret_cast<const f32x4 *>(la + kn * 256);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int u = 0; u < UB; ++u) dh[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[u][e], dh[u], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        const int k2 = (kg + 2 < KGn) ? kg + 2 : kg;
+          for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int u = 0; u < UB; ++u) b0[u] = *reinterpret_cast<const f32x4 *>(kb + ((size_t)u * KGn + k2) * 256);
-        a0 = *reinterpret_cast<const f32x4 *>(la + k2 * 256);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int u = 0; u < UB; ++u) dh[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[p & 1][e], bq[p][u][e], dh[u], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          const int kp = (kg + p + PF < KGn) ? kg + p + PF : kg + p;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int u = 0; u < UB; ++u) dh[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[u][e], dh[u], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int u = 0; u < UB; ++u) bq[p][u] = *reinterpret_cast<const f32x4 *>(kb + ((size_t)u * KGn + kp) * 256);
+        }
       }
+      __builtin_amdgcn_s_setprio(0);
     }
+    if (!dump_first) dump();
     __syncthreads();
   }
 
@@ -333,9 +378,12 @@ __global__ __launch_bounds__(BW_THREADS) void lstm_bwd_kernel(LstmBwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// dK partials: out[slice][k'][n] = sum_{r in slice} A[r][k'] * dG[r][n]
-// wave tile = 2 k'-tiles x 4 n-tiles; workgroup = 4 waves covering 4 consecutive
-// n-quads; grid = (NTn/16 * KT/2, slices).
+// dK partials: out[slice][k'][n] = sum_{r in slice} A[r][k'] * dG[r][n]   (the time-batched A^T dG GEMM,
+// 2*(E+H)*4H*T*B flop: as much work as the forward pass).
+// Workgroup = 8 waves = all KT k'-tiles x 8 consecutive n-tiles; wave w owns n-tile w for every k'-tile
+// (KT accumulators), so per r-group it loads KT A fragments -- the same ones its 7 siblings load, served
+// by L1 -- and ONE dG fragment for 4*KT MFMAs; dG is read from HBM exactly once, A once per 8 n-tiles.
+// The r loop is software-pipelined by hand (two named operand sets).  grid = (NTn/8, slices).
 struct DkArgs {
   const float *tape_a;  // [(RG)][KT][256]
   const float *dg_b;    // [(RG)][NTn][256]
@@ -343,54 +391,54 @@ struct DkArgs {
   int32_t RG, KT, NTn, SL;
 };
 
-__global__ __launch_bounds__(256) void dk_gemm_kernel(DkArgs a) {
+template <int KT>
+__global__ __launch_bounds__(512) void dk_gemm_kernel(DkArgs a) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int nquads = a.NTn / 4;               // n-quads in total
-  const int nqg = (nquads + 3) / 4;           // groups of 4 quads (one per wave)
-  const int kpair = blockIdx.x / nqg, qg = blockIdx.x % nqg;
-  const int quad = qg * 4 + w;
+  const int nt = blockIdx.x * 8 + w;
   const int slice = blockIdx.y;
   const int per = (a.RG + a.SL - 1) / a.SL;
   const int rg0 = slice * per, rg1 = min(a.RG, rg0 + per);
-  const bool active = quad < nquads;
-  const int kt0 = kpair * 2;
-  const bool k1 = (kt0 + 1) < a.KT;
-  f32x16 acc[2][4];
+  if (nt >= a.NTn) return;
+  f32x16 acc[KT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < KT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  const float *pa = a.tape_a + lane * 4;
+  const float *pb = a.dg_b + (size_t)nt * 256 + lane * 4;
+  auto load = [&](int rg, f32x4 (&av)[KT], f32x4 &bv) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  if (active) {
-    for (int rg = rg0; rg < rg1; ++rg) {
-      const float *pa = a.tape_a + ((size_t)rg * a.KT + kt0) * 256 + lane * 4;
-      const float *pb = a.dg_b + ((size_t)rg * a.NTn + quad * 4) * 256 + lane * 4;
-      const f32x4 a0 = *reinterpret_cast<const f32x4 *>(pa);
-      const f32x4 a1 = k1 ? *reinterpret_cast<const f32x4 *>(pa + 256) : f32x4{0, 0, 0, 0};
-      f32x4 b[4];
+    for (int i = 0; i < KT; ++i) av[i] = *reinterpret_cast<const f32x4 *>(pa + ((size_t)rg * KT + i) * 256);
+    bv = *reinterpret_cast<const f32x4 *>(pb + (size_t)rg * a.NTn * 256);
+  };
+  auto mac = [&](const f32x4 (&av)[KT], const f32x4 &bv) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f32x4 *>(pb + j * 256);
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b[j][e], acc[0][j], 0, 0, 0);
-          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b[j][e], acc[1][j], 0, 0, 0);
-        }
+      for (int i = 0; i < KT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[e], acc[i], 0, 0, 0);
+  };
+  if (rg0 < rg1) {
+    f32x4 ax[KT], ay[KT], bx, by;
+    load(rg0, ax, bx);
+    int rg = rg0;
+    for (; rg + 1 < rg1; rg += 2) {
+      load(rg + 1, ay, by);
+      __builtin_amdgcn_sched_barrier(0);
+      mac(ax, bx);
+      __builtin_amdgcn_sched_barrier(0);
+      load(rg + 2 < rg1 ? rg + 2 : rg, ax, bx);
+      __builtin_amdgcn_sched_barrier(0);
+      mac(ay, by);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    const int ldn = a.NTn * 32;
-    float *out = a.part + (size_t)slice * a.KT * 32 * ldn;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (i == 1 && !k1) break;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          out[(size_t)((kt0 + i) * 32 + mfma_row(r, lane)) * ldn + (quad * 4 + j) * 32 + (lane & 31)] = acc[i][j][r];
-    }
+    if (rg < rg1) mac(ax, bx);
   }
+  const int ldn = a.NTn * 32;
+  float *out = a.part + (size_t)slice * KT * 32 * ldn;
+#pragma unroll
+  for (int i = 0; i < KT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(size_t)(i * 32 + mfma_row(r, lane)) * ldn + nt * 32 + (lane & 31)] = acc[i][r];
 }
 
 // sum the slices and write/accumulate into the variable-shaped gradient dK [(E+H)][4H]
@@ -567,15 +615,16 @@ hipError_t launch_lstm_bwd(const float *tape_g, const float *dh_last, const floa
                            float *db_part, int T, int NT32, int Hp, hipStream_t st) {
   LstmBwdArgs a{tape_g, dh_last, KhT, dg_a, dg_b, db_part, T, NT32, Hp};
   const size_t lds = (size_t)(Hp / 2) * 256 * sizeof(float);
+  if ((size_t)T * NT32 * (Hp / 32) * 5 * 1024 * sizeof(float) >= ((size_t)1 << 31)) return hipErrorInvalidValue;  // 32-bit tape offsets
   hipError_t e;
   if (Hp == 128) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_bwd_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(lstm_bwd_kernel<1>, dim3(NT32), dim3(BW_THREADS), lds, st, a);
+    hipLaunchKernelGGL((lstm_bwd_kernel<1, 4>), dim3(NT32), dim3(256), lds, st, a);
   } else if (Hp == 256) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_bwd_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(lstm_bwd_kernel<2>, dim3(NT32), dim3(BW_THREADS), lds, st, a);
+    hipLaunchKernelGGL((lstm_bwd_kernel<1, 8>), dim3(NT32), dim3(512), lds, st, a);
   } else {
     return hipErrorInvalidValue;
   }
@@ -585,15 +634,17 @@ hipError_t launch_lstm_bwd(const float *tape_g, const float *dh_last, const floa
 int dk_slices(int RG) {
   int sl = RG / 16;  // >= 16 r-groups (128 rows) per slice
   if (sl < 1) sl = 1;
-  if (sl > 24) sl = 24;
+  if (sl > 64) sl = 64;  // x NTn/8 n-groups (4 at H=256) = 256 workgroups
   return sl;
 }
 
 hipError_t launch_dk(const float *tape_a, const float *dg_b, float *part, int RG, int KT, int NTn, int SL, int E, int H,
                      int Hp, int accumulate, float *dK, hipStream_t st) {
   DkArgs a{tape_a, dg_b, part, RG, KT, NTn, SL};
-  const int nqg = (NTn / 4 + 3) / 4, kpairs = (KT + 1) / 2;
-  hipLaunchKernelGGL(dk_gemm_kernel, dim3(nqg * kpairs, SL), dim3(256), 0, st, a);
+  const dim3 grid((NTn + 7) / 8, SL);
+  if (KT == 10) hipLaunchKernelGGL(dk_gemm_kernel<10>, grid, dim3(512), 0, st, a);
+  else if (KT == 6) hipLaunchKernelGGL(dk_gemm_kernel<6>, grid, dim3(512), 0, st, a);
+  else return hipErrorInvalidValue;
   hipLaunchKernelGGL(dk_reduce_kernel, dim3(((E + H) * 4 * H + 255) / 256), dim3(256), 0, st, part, SL, KT, NTn, E, H, Hp,
                      accumulate, dK);
   return hipGetLastError();

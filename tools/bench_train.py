@@ -16,6 +16,8 @@ params = dict(forward_only=False, network_mode="dual-encoder", predict_nbest=10,
               learning_rate_decay_factor=0.99, targetSpaceSize=571)
 m = sse_amd.SSEModel(params)
 m.init_variables(seed=0)
+if os.environ.get("SSE_TRAIN_SERIAL"):                 # profiling aid: isolated kernel durations
+    m.handle.set_option("train_serial", 1)
 rng = np.random.RandomState(0)
 for B in [int(x) for x in (sys.argv[1:] or ["128", "1024", "8192"])]:
     src = rng.randint(2, V, size=(B, T)).astype(np.int32)
