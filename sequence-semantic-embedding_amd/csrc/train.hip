@@ -393,12 +393,17 @@ struct DkArgs {
 
 template <int KT>
 __global__ __launch_bounds__(512) void dk_gemm_kernel(DkArgs a) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int nt = blockIdx.x * 8 + w;
+  // The KT A fragments of an r-group are the same for all 8 waves: they are fetched ONCE per workgroup
+  // (each wave brings 1-2 of the KT 1-KB blocks) into a double-buffered LDS stage, one barrier per r-group;
+  // without it every wave pulled them through L1/L2 itself (17 B/clk/CU of L2 traffic, kernel at 50 %).
+  __shared__ __attribute__((aligned(16))) float stage[2][KT][256];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nt = min(blockIdx.x * 8 + w, a.NTn - 1);  // surplus waves recompute the last tile (no divergent barriers)
+  const bool live = blockIdx.x * 8 + w < a.NTn;
   const int slice = blockIdx.y;
   const int per = (a.RG + a.SL - 1) / a.SL;
   const int rg0 = slice * per, rg1 = min(a.RG, rg0 + per);
-  if (nt >= a.NTn) return;
   f32x16 acc[KT];
 #pragma unroll
   for (int i = 0; i < KT; ++i)
@@ -406,33 +411,58 @@ __global__ __launch_bounds__(512) void dk_gemm_kernel(DkArgs a) {
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
   const float *pa = a.tape_a + lane * 4;
   const float *pb = a.dg_b + (size_t)nt * 256 + lane * 4;
-  auto load = [&](int rg, f32x4 (&av)[KT], f32x4 &bv) {
-#pragma unroll
-    for (int i = 0; i < KT; ++i) av[i] = *reinterpret_cast<const f32x4 *>(pa + ((size_t)rg * KT + i) * 256);
-    bv = *reinterpret_cast<const f32x4 *>(pb + (size_t)rg * a.NTn * 256);
+  constexpr bool TWO = KT > 8;  // waves 0 .. KT-9 bring a second block
+  const bool second = TWO && (8 + w < KT);
+  auto gload_a = [&](int rg, f32x4 &s0, f32x4 &s1) {
+    if (w < KT) s0 = *reinterpret_cast<const f32x4 *>(pa + ((size_t)rg * KT + w) * 256);
+    if (second) s1 = *reinterpret_cast<const f32x4 *>(pa + ((size_t)rg * KT + 8 + w) * 256);
   };
-  auto mac = [&](const f32x4 (&av)[KT], const f32x4 &bv) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int i = 0; i < KT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[e], acc[i], 0, 0, 0);
+  auto stash = [&](int buf, const f32x4 &s0, const f32x4 &s1) {
+    if (w < KT) *reinterpret_cast<f32x4 *>(&stage[buf][w][lane * 4]) = s0;
+    if (second) *reinterpret_cast<f32x4 *>(&stage[buf][8 + w][lane * 4]) = s1;
   };
   if (rg0 < rg1) {
-    f32x4 ax[KT], ay[KT], bx, by;
-    load(rg0, ax, bx);
-    int rg = rg0;
-    for (; rg + 1 < rg1; rg += 2) {
-      load(rg + 1, ay, by);
-      __builtin_amdgcn_sched_barrier(0);
-      mac(ax, bx);
-      __builtin_amdgcn_sched_barrier(0);
-      load(rg + 2 < rg1 ? rg + 2 : rg, ax, bx);
-      __builtin_amdgcn_sched_barrier(0);
-      mac(ay, by);
-      __builtin_amdgcn_sched_barrier(0);
+    f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, bc, bn;
+    gload_a(rg0, s0, s1);
+    bc = *reinterpret_cast<const f32x4 *>(pb + (size_t)rg0 * a.NTn * 256);
+    stash(0, s0, s1);
+    const int r1 = (rg0 + 1 < rg1) ? rg0 + 1 : rg0;
+    gload_a(r1, s0, s1);
+    bn = *reinterpret_cast<const f32x4 *>(pb + (size_t)r1 * a.NTn * 256);
+    __syncthreads();
+    for (int rg = rg0; rg < rg1; ++rg) {
+      const int cur = (rg - rg0) & 1;
+      const float *sa = &stage[cur][0][lane * 4];
+      // KT fragments from LDS, software-pipelined one fragment ahead of its 4 MFMAs
+      f32x4 ax = *reinterpret_cast<const f32x4 *>(sa), ay;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < KT; i += 2) {
+        if (i + 1 < KT) ay = *reinterpret_cast<const f32x4 *>(sa + (i + 1) * 256);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bc[e], acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 2 < KT) ax = *reinterpret_cast<const f32x4 *>(sa + (i + 2) * 256);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < KT) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[e], bc[e], acc[i + 1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      // hand over: the r-group fetched one iteration ago goes into the other stage, the next one is requested
+      if (rg + 1 < rg1) stash(cur ^ 1, s0, s1);
+      bc = bn;
+      if (rg + 2 < rg1) {
+        gload_a(rg + 2, s0, s1);
+        bn = *reinterpret_cast<const f32x4 *>(pb + (size_t)(rg + 2) * a.NTn * 256);
+      }
+      __syncthreads();
     }
-    if (rg < rg1) mac(ax, bx);
   }
+  if (!live) return;
   const int ldn = a.NTn * 32;
   float *out = a.part + (size_t)slice * KT * 32 * ldn;
 #pragma unroll
