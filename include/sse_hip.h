@@ -158,6 +158,23 @@ int sse_timer_elapsed_ms(sse_handle *h, int32_t a, int32_t b, float *ms);
  * range seen by an asynchronous sse_encode_dev). */
 int sse_synchronize(sse_handle *h);
 
+
+/* ---- targetEncodingIndex.tsv text I/O, host only (no handle, no GPU) --------
+ * sse_format_rows_f32: the vector field of sse_index.py:93-95,
+ *   ",".join([str(n) for n in row]) with n a numpy.float32, byte-identical
+ *   (shortest round-trip digits; positional for 1e-4 <= |x| < 1e16, else
+ *   scientific).  Row r is written at out + r * sse_format_rows_stride(S)
+ *   (no terminator) and its length stored in lengths[r].  Multi-threaded.
+ * sse_parse_rows_f64: the inverse as sse_evaluator.py:87 / sse_demo.py:87 do it,
+ *   [float(f) for f in field.split(",")] -> float64; row r is
+ *   text[offsets[r] .. offsets[r+1]) (trailing newline / blanks ignored) and
+ *   must hold exactly S numbers, else the call returns 2 and *bad_row is the
+ *   first offending row. */
+int64_t sse_format_rows_stride(int32_t S);
+int sse_format_rows_f32(const float *rows, int64_t n_rows, int32_t S, char *out, int64_t *lengths);
+int sse_parse_rows_f64(const char *text, const int64_t *offsets, int64_t n_rows, int32_t S, double *out,
+                       int64_t *bad_row);
+
 #ifdef __cplusplus
 }
 #endif

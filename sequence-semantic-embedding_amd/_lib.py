@@ -57,6 +57,9 @@ SYMBOLS = {
     "sse_timer_record": (C.c_int, [_P, C.c_int32, _P]),
     "sse_timer_elapsed_ms": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
     "sse_synchronize": (C.c_int, [_P]),
+    "sse_format_rows_stride": (C.c_int64, [C.c_int32]),
+    "sse_format_rows_f32": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P]),
+    "sse_parse_rows_f64": (C.c_int, [C.c_char_p, _P, C.c_int64, C.c_int32, _P, C.POINTER(C.c_int64)]),
 }
 
 _lib = None

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsse_hip.so")
-SOURCES = ["sse_api.hip", "lstm_fwd.hip", "cnn_fwd.hip", "score_topk.hip", "pack.hip", "train.hip", "cnn_bwd.hip"]
+SOURCES = ["sse_api.hip", "lstm_fwd.hip", "cnn_fwd.hip", "score_topk.hip", "pack.hip", "train.hip", "cnn_bwd.hip", "index_io.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 
 
@@ -37,16 +37,17 @@ def build(force=False, verbose=False):
     objs, rebuilt = [], False
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        o = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_mtime):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            flags = FLAGS if src.endswith(".hip") else [f for f in FLAGS if not f.startswith("--offload-arch")] + ["-pthread"]
+            cmd = [hipcc] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
             rebuilt = True
     if rebuilt or not os.path.exists(LIB):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -10,11 +10,13 @@ import math
 
 import numpy as np
 
+from . import index_io
+
 
 def load_index_file(path):
     """Parse targetEncodingIndex.tsv as Evaluator.__init__ does (sse_evaluator.py:80-92):
     lines without exactly 3 fields are skipped; float() per component -> float64."""
-    ids, names, enc, id_map = [], [], [], {}
+    ids, names, fields, id_map = [], [], [], {}
     for line in codecs.open(path, "r", "utf-8").readlines():
         info = line.strip().split("\t")
         if len(info) != 3:
@@ -23,8 +25,9 @@ def load_index_file(path):
         id_map[info[0]] = len(ids)
         ids.append(info[0])
         names.append(info[1])
-        enc.append([float(f) for f in info[2].strip().split(",")])
-    return ids, names, np.array(enc), id_map
+        fields.append(info[2].strip())
+    # [float(f) for f in field.split(",")] per row, in C (csrc/index_io.cpp): same float64 values
+    return ids, names, index_io.parse_rows(fields), id_map
 
 
 def topk_tight_accuracy(topk, labels, ranked_idx):

@@ -8,7 +8,7 @@ import sys
 
 import numpy as np
 
-from . import flags, sse_data, sse_text
+from . import flags, index_io, sse_data, sse_text
 from .sse_model import Session, SSEModel, get_checkpoint_state
 
 FLAGS = flags.FlagSet("sse_index", [
@@ -43,7 +43,7 @@ def createIndexFile(model, encoder, rawfile, max_seq_len, encodeIndexFile, sessi
                 r += 1
                 if row >= n_rows:
                     raise ValueError("target file has more entries than the model's target matrix (%d rows)" % n_rows)
-                out.write(info[1] + "\t" + info[0] + "\t" + ",".join([str(n) for n in table[row]]) + "\n")
+                out.write(info[1] + "\t" + info[0] + "\t" + index_io.format_rows(table[row:row + 1])[0] + "\n")
         print("Done of all indexing total count:%d" % cnt)
         return
     with codecs.open(encodeIndexFile, "w", "utf-8") as out:
@@ -62,8 +62,9 @@ def createIndexFile(model, encoder, rawfile, max_seq_len, encodeIndexFile, sessi
                 continue
             enc = np.vstack(session.run([model.norm_tgt_seq_embedding],
                                         feed_dict=model.get_target_encoding_feed_dict(ids)))
+            vecs = index_io.format_rows(enc)          # == ",".join([str(n) for n in enc[i]]), sse_index.py:95
             for i in range(len(sents)):
-                out.write(tids[i] + "\t" + sents[i] + "\t" + ",".join([str(n) for n in enc[i]]) + "\n")
+                out.write(tids[i] + "\t" + sents[i] + "\t" + vecs[i] + "\n")
     print("Done of all indexing total count:%d" % cnt)
 
 
