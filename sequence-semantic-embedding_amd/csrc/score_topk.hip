@@ -141,11 +141,23 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   for (int tile = t0 + w; tile < t1; tile += SC_THREADS / 64) {
     // index tile through a buffer descriptor (base = this tile: stays below the 4 GiB
     // descriptor range for any index size); per-lane offset is the constant 16*lane
+    // The descriptor also spans this wave's NEXT tile (8 tiles on) so that the loop can touch index bytes PD
+    // k-groups ahead of their use: the fragment load proper is issued only one k-group (16 MFMAs, ~1-2 k cycles)
+    // early, which does not cover an HBM miss; the touch pulls the lines into L2 first.
+    const int utile = __builtin_amdgcn_readfirstlane(tile);
+    const int span = min(a.NT - utile, SC_THREADS / 64 + 1);
     const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.idxp) + (size_t)__builtin_amdgcn_readfirstlane(tile) * KG * 256, 0, KG * 1024, 0x00020000);
+        const_cast<float *>(a.idxp) + (size_t)utile * KG * 256, 0, span * KG * 1024, 0x00020000);
     auto iload = [&](int kg) -> f32x4 {
       return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ir, voff, kg * 1024, 0));
     };
+    constexpr int PD = 8;
+    auto touch = [&](int kg) -> int {  // one dword per 16-byte segment of k-group kg+PD (next tile past the end)
+      const int kp = kg + PD;
+      const int off = (kp < KG) ? kp : kp + (SC_THREADS / 64 - 1) * KG;
+      return __builtin_amdgcn_raw_buffer_load_b32(ir, voff, off * 1024, 0);
+    };
+    int tch0 = 0, tch1 = 0;
     f32x16 acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
@@ -162,7 +174,12 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
     __builtin_amdgcn_s_setprio(1);
     int kg = 0;
     for (; kg + 1 < KG; kg += 2) {
+      asm volatile("" ::"v"(tch0), "v"(tch1));  // last iteration's touches (long since returned: in-order)
       ay = iload(kg + 1);
+      if constexpr (NQ > 1) {  // the single-query-tile sweep is HBM-bound already: extra requests only cost
+        tch0 = touch(kg);
+        tch1 = touch(kg + 1);
+      }
 #pragma unroll
       for (int q = 0; q < NQ; ++q) by[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG + kg + 1) * 256);
       __builtin_amdgcn_sched_barrier(0);
