@@ -172,6 +172,33 @@ def test_large_index_properties():
     assert np.abs(s[:8] - wsc).max() < 1e-12
 
 
+def test_many_queries_round_balanced_splits():
+    """Q = 20,000 (157 query blocks): the launch policy splits the index further so that the workgroups fill the
+    256 CUs in whole rounds (sse_api.hip score_dev_locked).  Every query is independent, so a sample of them is
+    checked exactly against the float64 oracle; all are checked for planted top-1 / sortedness / uniqueness."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    N, S, Q, k = 70_000, 64, 20_000, 10
+    t = torch.nn.functional.normalize(torch.randn((N, S), generator=g, device=dev), dim=1)
+    q = torch.nn.functional.normalize(torch.randn((Q, S), generator=g, device=dev), dim=1)
+    rows = torch.randperm(N, generator=g, device=dev)[:Q]
+    t[rows] = torch.nn.functional.normalize(q + 0.05 * torch.randn((Q, S), generator=g, device=dev), dim=1)
+    h = _scorer()
+    h.index_set_dev(t.data_ptr(), N, S)
+    out_s = torch.empty((Q, k), dtype=torch.float64, device=dev)
+    out_i = torch.empty((Q, k), dtype=torch.int64, device=dev)
+    h.score_topk_dev(q.data_ptr(), Q, k, out_s.data_ptr(), out_i.data_ptr())
+    torch.cuda.synchronize()
+    s, i = out_s.cpu().numpy(), out_i.cpu().numpy()
+    assert np.array_equal(i[:, 0], rows.cpu().numpy())
+    assert np.all(np.diff(s, axis=1) <= 0)
+    sample = np.random.RandomState(0).choice(Q, 200, replace=False)
+    wsc, wids = O.topk(O.scores_f64(q.cpu().numpy()[sample], t.cpu().numpy().astype(np.float64)), k)
+    assert np.array_equal(i[sample], wids)
+    assert np.abs(s[sample] - wsc).max() < 1e-12
+
+
 @pytest.mark.parametrize("Q,N,S", [(1, 200_000, 64), (7, 150_000, 256), (40, 300_000, 64), (32, 5000, 50)])
 def test_few_queries_many_splits_merged_lists(Q, N, S):
     """Demo / web regime (sse_demo.py:121-134): a handful of queries against a large index uses the
