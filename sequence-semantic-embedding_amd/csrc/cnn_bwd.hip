@@ -106,7 +106,8 @@ __global__ void strided_reduce_kernel(const float *part, int nch, int stride, in
 // positions t, t-1, .. t-4 and reads the TRANSPOSED filters Wt[f][j*E+e] (lanes = e: coalesced).
 __global__ __launch_bounds__(256) void cnn_dx_kernel(CnnBwdArgs a) {
   __shared__ float g_s[576];
-  __shared__ int pos_s[576], list_s[576], start_s[72];
+  __shared__ int pos_s[576], list_s[576];
+  extern __shared__ int start_s[];  // [T + 1] bucket starts (dynamic: any T)
   __shared__ int woff_s[576], fs_s[576];  // per list entry: row offset into the transposed filters, width
   __shared__ float gl_s[576];
   __shared__ float red[256];
@@ -118,20 +119,22 @@ __global__ __launch_bounds__(256) void cnn_dx_kernel(CnnBwdArgs a) {
     pos_s[f] = (g != 0.0f) ? a.pos[(size_t)b * 576 + f] : -1;
   }
   __syncthreads();
-  int cnt = 0;
-  if (tid < T)
-    for (int f = 0; f < 576; ++f) cnt += (pos_s[f] == tid);
-  if (tid < 72) start_s[tid] = (tid < T) ? cnt : 0;
+  // bucket sizes, then (thread 0) their exclusive prefix, then the fill -- every bucket in ascending filter order
+  for (int p = tid; p < T; p += 256) {
+    int cnt = 0;
+    for (int f = 0; f < 576; ++f) cnt += (pos_s[f] == p);
+    start_s[p + 1] = cnt;
+  }
   __syncthreads();
-  int st = 0;
-  if (tid < T)
-    for (int q = 0; q < tid; ++q) st += start_s[q];
+  if (tid == 0) {
+    start_s[0] = 0;
+    for (int p = 0; p < T; ++p) start_s[p + 1] += start_s[p];
+  }
   __syncthreads();
-  if (tid < T) {
-    start_s[tid] = st;
-    if (tid == T - 1) start_s[T] = st + cnt;
+  for (int p = tid; p < T; p += 256) {
+    int st = start_s[p];
     for (int f = 0; f < 576; ++f)
-      if (pos_s[f] == tid) list_s[st++] = f;
+      if (pos_s[f] == p) list_s[st++] = f;
   }
   __syncthreads();
   const int n_list = start_s[T];
@@ -260,6 +263,6 @@ hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfe
   // db: the four bias vectors are disjoint slices of the 576 features
   for (int i = 0; i < 4; ++i)
     hipLaunchKernelGGL(strided_reduce_kernel, dim3(1), dim3(256), 0, st, db_part + foff[i], a.NCH, 576, nf[i], db[i]);
-  hipLaunchKernelGGL(cnn_dx_kernel, dim3(B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(cnn_dx_kernel, dim3(B), dim3(256), (size_t)(T + 1) * sizeof(int), st, a);
   return hipGetLastError();
 }

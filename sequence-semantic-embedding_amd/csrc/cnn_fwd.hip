@@ -14,7 +14,8 @@
 #include "sse_kernels.h"
 
 #define CNN_THREADS 512
-#define CNN_NB 8   // sequences per workgroup
+// sequences per workgroup: 8, or 4 when 8 embedded sequences (+ the training keys) do not fit the 160 KB of LDS
+// (e.g. the reference's default T = 80 with the arg-max tape)
 #define CNN_SG 4   // sequences per wave work item (one B fragment feeds 4 MFMAs)
 
 struct CnnArgs {
@@ -36,7 +37,7 @@ __constant__ int c_foff[4] = {0, 256, 384, 512};  // feature offset of each widt
 // TRAIN additionally records WHERE each maximum sits (the backward pass routes the gradient there):
 // the running maximum becomes a 64-bit key (value bits << 32 | ~position), so equal values keep the
 // first position, as numpy/TF arg-max do (all-PAD windows tie exactly).
-template <bool TRAIN>
+template <bool TRAIN, int CNN_NB>
 __global__ __launch_bounds__(CNN_THREADS) void conv_pool_kernel(CnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float xs[];  // [NB][T][Ep] + 5*Ep pad + work counter
   const int tid = threadIdx.x, lane = tid & 63;
@@ -270,9 +271,13 @@ __global__ void pack_conv_kernel_k(const float *__restrict__ W, int fs, int E, i
   }
 }
 
-size_t cnn_lds_bytes(int T, int Ep, int train) {
-  return (size_t)(CNN_NB * T * Ep + 5 * Ep + CNN_NB * 576 * (train ? 2 : 1)) * sizeof(float) + 16;
+static size_t cnn_lds_bytes_nb(int T, int Ep, int train, int nb) {
+  return (size_t)(nb * T * Ep + 5 * Ep + nb * 576 * (train ? 2 : 1)) * sizeof(float) + 16;
 }
+
+static int cnn_pick_nb(int T, int Ep, int train) { return cnn_lds_bytes_nb(T, Ep, train, 8) <= 160 * 1024 ? 8 : 4; }
+
+size_t cnn_lds_bytes(int T, int Ep, int train) { return cnn_lds_bytes_nb(T, Ep, train, cnn_pick_nb(T, Ep, train)); }
 
 size_t cnn_packed_weight_floats(int Ep) {
   static const int fs[4] = {2, 3, 4, 5}, nt[4] = {8, 4, 4, 2};
@@ -298,17 +303,21 @@ hipError_t launch_cnn_fwd(const int32_t *ids, const float *emb, const float *Wc,
                           float *featp, float *out, int32_t *err, int B, int T, int V, int Ep, int S, int normalize,
                           float *feat_rm, int32_t *pos, hipStream_t stream) {
   const bool train = feat_rm != nullptr;
-  const size_t lds = cnn_lds_bytes(T, Ep, train);
-  const void *fn = train ? reinterpret_cast<const void *>(conv_pool_kernel<true>)
-                         : reinterpret_cast<const void *>(conv_pool_kernel<false>);
+  const int nb = cnn_pick_nb(T, Ep, train);
+  const size_t lds = cnn_lds_bytes_nb(T, Ep, train, nb);
+  const void *fn = train ? (nb == 8 ? reinterpret_cast<const void *>(conv_pool_kernel<true, 8>)
+                                    : reinterpret_cast<const void *>(conv_pool_kernel<true, 4>))
+                         : (nb == 8 ? reinterpret_cast<const void *>(conv_pool_kernel<false, 8>)
+                                    : reinterpret_cast<const void *>(conv_pool_kernel<false, 4>));
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   CnnArgs a{ids, emb, Wc, bias, featp, err, B, T, V, Ep, (int32_t)(cnn_packed_weight_floats(Ep) * sizeof(float)),
             feat_rm, pos};
-  if (train)
-    hipLaunchKernelGGL(conv_pool_kernel<true>, dim3((B + CNN_NB - 1) / CNN_NB), dim3(CNN_THREADS), lds, stream, a);
-  else
-    hipLaunchKernelGGL(conv_pool_kernel<false>, dim3((B + CNN_NB - 1) / CNN_NB), dim3(CNN_THREADS), lds, stream, a);
+  const dim3 grid((B + nb - 1) / nb), block(CNN_THREADS);
+  if (train && nb == 8) hipLaunchKernelGGL((conv_pool_kernel<true, 8>), grid, block, lds, stream, a);
+  else if (train) hipLaunchKernelGGL((conv_pool_kernel<true, 4>), grid, block, lds, stream, a);
+  else if (nb == 8) hipLaunchKernelGGL((conv_pool_kernel<false, 8>), grid, block, lds, stream, a);
+  else hipLaunchKernelGGL((conv_pool_kernel<false, 4>), grid, block, lds, stream, a);
   ProjArgs p{featp, Mp, out, B, S, 72, (S + 31) / 32, normalize};
   hipLaunchKernelGGL(proj_norm_kernel, dim3((B + 31) / 32), dim3(256), 0, stream, p);
   return hipGetLastError();

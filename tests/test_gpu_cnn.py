@@ -11,7 +11,8 @@ from tests.util import make_pair, model_params, random_ids
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("V,E,S,T,B", [(300, 50, 512, 64, 37), (100, 30, 64, 80, 9), (60, 8, 16, 5, 3), (200, 50, 64, 33, 70)])
+@pytest.mark.parametrize("V,E,S,T,B", [(300, 50, 512, 64, 37), (100, 30, 64, 80, 9), (60, 8, 16, 5, 3), (200, 50, 64, 33, 70),
+                                       (150, 64, 64, 80, 21), (120, 50, 32, 150, 6)])   # 4 sequences per workgroup
 def test_cnn_encode_matches_oracle(V, E, S, T, B):
     params = model_params("source_only_cnn", V, E, 96, 96, S, T, N=11)
     m, p = make_pair(params, seed=2)
@@ -44,7 +45,8 @@ def _cnn_batch(rng, B, T, V, N, pad_frac=0.5):
     return src, rows, np.tile(np.array([1.0, 0.0], np.float32), B // 2)
 
 
-@pytest.mark.parametrize("V,E,S,T,B,N", [(300, 50, 512, 64, 48, 571), (90, 24, 64, 20, 10, 17), (60, 8, 16, 5, 4, 5)])
+@pytest.mark.parametrize("V,E,S,T,B,N", [(300, 50, 512, 64, 48, 571), (90, 24, 64, 20, 10, 17), (60, 8, 16, 5, 4, 5),
+                                         (200, 50, 64, 80, 26, 33)])     # reference default T=80: 4-sequence tiles
 def test_cnn_train_step_matches_oracle(V, E, S, T, B, N):
     """BUILDER-DEFINED CNN pair loss (BASELINE configs[4]; oracle._cnn_gradients): one step of forward with arg-max
     tape, gather/scatter backward, clip, Adagrad vs the oracle.  Tolerances as for the LSTM step; a near-tie of two

@@ -1,0 +1,82 @@
+#!/usr/bin/env python
+"""Randomised parity sweep (GPU vs CPU oracle) over model shapes, batch sizes and padding patterns: encode (both
+sides, normalised and raw), score/top-k, and one training step.  Not part of the test suite (minutes of oracle time);
+run on the GPU box:  python tools/fuzz_parity.py [n_cases] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import sse_amd  # noqa: E402
+from oracle import sse_oracle as O  # noqa: E402
+from tests.util import make_pair, model_params, random_ids  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+worst = dict(enc=0.0, raw=0.0, score=0.0, train=0.0)
+t_start = time.time()
+for case in range(n_cases):
+    mode = rng.choice(["dual-encoder", "shared-encoder", "source_only_cnn"], p=[0.5, 0.3, 0.2])
+    V = int(rng.choice([17, 90, 500, 3000]))
+    E = int(rng.choice([3, 8, 30, 40, 50, 64]))
+    Hs = int(rng.choice([5, 32, 96, 128, 200, 256]))
+    Ht = Hs if mode == "shared-encoder" else int(rng.choice([7, 64, 96, 128, 256]))
+    S = int(rng.choice([2, 16, 50, 64, 100, 256]))
+    T = int(rng.choice([5, 6, 13, 32, 50, 80]))
+    B = int(rng.choice([1, 2, 3, 31, 33, 64, 65, 200]))
+    N = int(rng.choice([1, 5, 33, 571]))
+    pad = float(rng.choice([0.0, 0.5, 0.95]))
+    params = model_params(mode, V, E, Hs, Ht, S, T, N=N, lr=0.5)
+    tag = "%s V=%d E=%d Hs=%d Ht=%d S=%d T=%d B=%d N=%d pad=%.2f" % (mode, V, E, Hs, Ht, S, T, B, N, pad)
+    try:
+        m, p = make_pair(params, seed=int(rng.randint(1 << 30)))
+        src = random_ids(rng, B, T, V, pad)
+        for normalize in (True, False):
+            want = O.encode(p, params, "src", src, normalize=normalize)
+            got = m.encode_source(src, normalize=normalize)
+            err = float(np.abs(got - want).max() / max(1.0, np.abs(want).max()))
+            worst["enc" if normalize else "raw"] = max(worst["enc" if normalize else "raw"], err)
+            assert err < 1e-4, ("encode src", normalize, err)
+        if mode != "source_only_cnn":
+            tgt = random_ids(rng, N, T, V, pad)
+            want_t = O.encode(p, params, "tgt", tgt)
+            got_t = m.encode_target(tgt)
+            assert np.abs(got_t - want_t).max() < 1e-4, "encode tgt"
+        else:
+            got_t = m.encode_target(np.zeros((N, T), np.int32))
+        # scoring on the GPU's own encodings (identical inputs on both sides)
+        k = min(10, N)
+        ns = m.encode_source(src)
+        idx64 = got_t.astype(np.float64)
+        m.handle.index_upload(idx64)
+        sc, ids = m.handle.score_topk(ns, k)
+        wsc, wids = O.topk(O.scores_f64(ns, idx64), k)
+        assert np.array_equal(ids, wids), "top-k ids"
+        worst["score"] = max(worst["score"], float(np.abs(sc - wsc).max()))
+        assert np.abs(sc - wsc).max() < 1e-12
+        # one training step
+        if Hs <= 256 and Ht <= 256 and B >= 2:
+            Bt = B - B % 2
+            z = np.tile(np.array([1.0, 0.0], np.float32), Bt // 2)
+            tsrc = src[:Bt]
+            ttgt = rng.randint(0, N, size=Bt).astype(np.int32) if mode == "source_only_cnn" else random_ids(rng, Bt, T, V, pad)
+            st = O.new_optimizer_state(p)
+            wl, wa = O.train_step(p, st, params, tsrc, ttgt, z, 0.5)
+            m.handle.learning_rate = 0.5
+            gl, ga = m.train_step(tsrc, ttgt, z)
+            assert abs(gl - float(wl)) < 1e-4 * max(1.0, abs(float(wl))), ("loss", gl, wl)
+            got = m.get_variables()
+            for name, w in p.items():
+                d = float(np.abs(got[name].reshape(w.shape) - w).max())
+                worst["train"] = max(worst["train"], d)
+                assert d < 1e-3, ("train", name, d)
+        print("ok   %s" % tag)
+    except Exception as ex:                                       # keep sweeping; the summary line reports
+        print("FAIL %s: %r" % (tag, ex))
+        worst.setdefault("failures", 0)
+        worst["failures"] += 1
+    sys.stdout.flush()
+print("fuzz summary: %d cases in %.0f s, failures %d, worst errors %s" % (n_cases, time.time() - t_start, worst.get("failures", 0), worst))
