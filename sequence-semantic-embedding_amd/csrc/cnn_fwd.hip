@@ -82,8 +82,8 @@ __global__ __launch_bounds__(CNN_THREADS) void conv_pool_kernel(CnnArgs a) {
       tile -= c_nt[wi];
       --wi;
     }
-    for (int j = 0; j < wi; ++j) woff_tiles += c_nt[j] * (c_fs[j] * Ep / 8);
-    const int fs = c_fs[wi], KG = fs * Ep / 8, P = T - fs + 1;
+    for (int j = 0; j < wi; ++j) woff_tiles += c_nt[j] * ((c_fs[j] * Ep + 7) / 8);
+    const int fs = c_fs[wi], KG = (fs * Ep + 7) / 8, P = T - fs + 1;  // a last half k-group reads 4 floats past the window: their weights are 0
     const int wsoff = (woff_tiles + tile * KG) * 1024;  // byte offset of this filter tile in the packed weights
     const float bias = a.bias[c_foff[wi] + tile * 32 + (lane & 31)];
     const float *xb = xs + (size_t)(sg * CNN_SG) * T * Ep + (lane & 31) * Ep + (lane >> 5) * 4;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void proj_norm_kernel(ProjArgs a) {
 // conv filter W [fs][E][1][nf] (row-major [fs*E][nf]) -> frag32(rows = filter, red = k' = d*Ep + e)
 __global__ void pack_conv_kernel_k(const float *__restrict__ W, int fs, int E, int Ep, int nf, int64_t total4,
                                    f32x4 *__restrict__ out) {
-  const int KG = fs * Ep / 8;
+  const int KG = (fs * Ep + 7) / 8;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
     const int l = (int)(i & 63);
     const int64_t blk = i >> 6;
@@ -265,7 +265,7 @@ __global__ void pack_conv_kernel_k(const float *__restrict__ W, int fs, int E, i
     for (int e4 = 0; e4 < 4; ++e4) {
       const int kp = kg * 8 + (l >> 5) * 4 + e4;
       const int d = kp / Ep, e = kp % Ep;
-      if (f < nf && e < E) v[e4] = W[(size_t)(d * E + e) * nf + f];
+      if (f < nf && e < E && d < fs) v[e4] = W[(size_t)(d * E + e) * nf + f];
     }
     out[i] = v;
   }
@@ -282,7 +282,7 @@ size_t cnn_lds_bytes(int T, int Ep, int train) { return cnn_lds_bytes_nb(T, Ep, 
 size_t cnn_packed_weight_floats(int Ep) {
   static const int fs[4] = {2, 3, 4, 5}, nt[4] = {8, 4, 4, 2};
   size_t n = 0;
-  for (int i = 0; i < 4; ++i) n += (size_t)nt[i] * (fs[i] * Ep / 8) * 256;
+  for (int i = 0; i < 4; ++i) n += (size_t)nt[i] * ((fs[i] * Ep + 7) / 8) * 256;
   return n;
 }
 
@@ -290,7 +290,7 @@ hipError_t launch_pack_conv(const float *const W[4], int E, int Ep, float *out, 
   static const int fs[4] = {2, 3, 4, 5}, nf[4] = {256, 128, 128, 64};
   size_t off = 0;
   for (int i = 0; i < 4; ++i) {
-    const int KG = fs[i] * Ep / 8;
+    const int KG = (fs[i] * Ep + 7) / 8;
     const int64_t total4 = (int64_t)(nf[i] / 32) * KG * 64;
     hipLaunchKernelGGL(pack_conv_kernel_k, dim3((int)((total4 + 255) / 256)), dim3(256), 0, stream, W[i], fs[i], E, Ep,
                        nf[i], total4, reinterpret_cast<f32x4 *>(out + off));

@@ -166,11 +166,17 @@ int geometry(sse_handle *h, Encoder &e) {
   return 0;
 }
 
+// row stride of the padded embedding table: the LSTM kernels consume k in groups of 8; the CNN only needs
+// 16-byte aligned window starts (E = 50: 52 instead of 56 -> 7 % fewer MFMAs)
+static int emb_cols(const sse_config &c) {
+  return round_up(c.embedding_size, c.network_mode == SSE_MODE_SOURCE_ONLY_CNN ? 4 : 8);
+}
+
 // (re)build the kernel-facing layouts from the master variables
 int ensure_packed(sse_handle *h, hipStream_t st) {
   if (!h->packed_dirty) return 0;
   const sse_config &c = h->cfg;
-  const int Ep = round_up(c.embedding_size, 8);
+  const int Ep = emb_cols(c);
   if (!h->emb_pad) HIPCHECK(h, hipMalloc((void **)&h->emb_pad, (size_t)c.vocab_size * Ep * sizeof(float)));
   HIPCHECK(h, launch_pad_rows(h->vars[0].dev, c.vocab_size, c.embedding_size, Ep, h->emb_pad, st));
   for (int s = 0; s < 2; ++s) {
@@ -282,7 +288,7 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
   }
   if (c.network_mode == SSE_MODE_SOURCE_ONLY_CNN) {
     if (ensure_packed(h, st)) return 1;
-    const int Ep = round_up(c.embedding_size, 8);
+    const int Ep = emb_cols(c);
     if (T < 5) return fail(h, "source_only_cnn needs max_seq_length >= 5 (widest filter)");
     if (cnn_lds_bytes(T, Ep, 0) > 160 * 1024)
       return fail(h, "source_only_cnn: T*E = %d*%d does not fit the LDS tile of the gfx950 kernel", T, c.embedding_size);
@@ -818,7 +824,7 @@ static int cnn_train_grads_locked(sse_handle *h, const int32_t *src_ids_host, co
   const sse_config &c = h->cfg;
   hipStream_t st = nullptr;
   TrainState &ts = *h->train;
-  const int E = c.embedding_size, S = c.encoding_size, V = c.vocab_size, Ep = round_up(E, 8);
+  const int E = c.embedding_size, S = c.encoding_size, V = c.vocab_size, Ep = emb_cols(c);
   const int Bp = round_up(B, 64);
   if (T < 5) return fail(h, "source_only_cnn needs max_seq_length >= 5 (widest filter)");
   if (E > 64) return fail(h, "train step: embedding_size %d > 64 not supported yet", E);
