@@ -37,9 +37,15 @@ struct Encoder {
   bool pad_valid = false;
 };
 
-struct DevBuf {
+struct DevBuf {  // grow-only device scratch; freed with its owner (handle / TrainState)
   void *p = nullptr;
   size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
 };
 
 // device buffers of the training path, grown on demand
@@ -542,19 +548,11 @@ void sse_destroy(sse_handle *h) {
   if (h->err_flag) hipFree(h->err_flag);
   if (h->idxp) hipFree(h->idxp);
   if (h->idx64) hipFree(h->idx64);
-  DevBuf *bufs[] = {&h->s_ids, &h->s_out, &h->s_q, &h->s_qp, &h->s_ps, &h->s_pi, &h->s_cert, &h->s_os, &h->s_oi, &h->s_tmp, &h->s_tmp2, &h->s_feat, &h->s_zero, &h->s_map};
   if (h->cnn_Wc) (void)hipFree(h->cnn_Wc);
   if (h->cnn_bias) (void)hipFree(h->cnn_bias);
   if (h->cnn_Mp) (void)hipFree(h->cnn_Mp);
-  for (DevBuf *b : bufs)
-    if (b->p) hipFree(b->p);
   if (h->train) {
     TrainState *t = h->train;
-    DevBuf *tb[] = {&t->ids[0], &t->ids[1], &t->labels, &t->raw[0], &t->raw[1], &t->draw[0], &t->draw[1], &t->tape_g[0],
-                    &t->tape_g[1], &t->tape_a[0], &t->tape_a[1], &t->h_last[0], &t->h_last[1], &t->dh_last[0], &t->dh_last[1], &t->dg_a[0], &t->dg_a[1],
-                    &t->dg_b[0], &t->dg_b[1], &t->db_part[0], &t->db_part[1], &t->dk_part[0], &t->dk_part[1], &t->dm_part[0], &t->dm_part[1], &t->sq_part, &t->norm_part, &t->row_loss, &t->row_acc, &t->scal};
-    for (DevBuf *b : tb)
-      if (b->p) (void)hipFree(b->p);
     for (int s = 0; s < 2; ++s) {
       if (t->side[s]) (void)hipStreamDestroy(t->side[s]);
       if (t->ev_join[s]) (void)hipEventDestroy(t->ev_join[s]);

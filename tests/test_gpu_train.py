@@ -182,3 +182,33 @@ def test_data_parallel_trainer_world1_and_arena_ownership():
         ma.handle.train_apply()                                    # nothing pending
     with pytest.raises(sse_amd.SSEError):
         ma.handle.train_set_grad_arena(tr.arena.data_ptr(), 5)     # wrong size
+
+
+def test_handles_release_their_device_memory():
+    """Create / train / encode / destroy repeatedly: free device memory does not drift (scratch, tapes, arena)."""
+    import gc
+    import torch
+    params = model_params("dual-encoder", 500, 50, 128, 128, 64, 16, lr=0.5)
+    cparams = model_params("source_only_cnn", 500, 50, 96, 96, 64, 16, N=9, lr=0.5)
+    rng = np.random.RandomState(0)
+    src, tgt, z = _batch(rng, 256, 16, 500)
+    rows = rng.randint(0, 9, size=256).astype(np.int32)
+
+    def cycle():
+        m, _ = make_pair(params, seed=1)
+        m.train_step(src, tgt, z)
+        m.encode_source(src)
+        m.handle.close()
+        c, _ = make_pair(cparams, seed=1)
+        c.train_step(src, rows, z)
+        c.handle.close()
+        del m, c
+        gc.collect()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(8):
+        cycle()
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < 8 << 20
