@@ -14,9 +14,10 @@ torch / torch.distributed are plumbing only.
 
 
 class DataParallelTrainer(object):
-    def __init__(self, engine, device=None, group=None):
+    def __init__(self, engine, device=None, group=None, always_reduce=False):
+        """always_reduce: issue the collective even in a 1-rank group (exercises the RCCL path on one GPU)."""
         import torch
-        self.engine, self.group = engine, group
+        self.engine, self.group, self.always_reduce = engine, group, bool(always_reduce)
         self.arena = torch.zeros(engine.train_grad_count(), dtype=torch.float32, device=device or "cpu")
         engine.train_bind_arena(self.arena)
 
@@ -43,7 +44,7 @@ class DataParallelTrainer(object):
         if rows_global is None:
             rows_global = self.global_rows(len(labels))
         self.engine.train_grads(src_ids, tgt_ids, labels, rows_global)
-        if self.world > 1:
+        if self.world > 1 or self.always_reduce:
             dist.all_reduce(self.arena, group=self.group)          # ONE collective per step (sum)
         return self.engine.train_apply()
 

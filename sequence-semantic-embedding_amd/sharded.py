@@ -21,7 +21,7 @@ def shard_bounds(n_rows, world):
     return out
 
 
-def all_gather_topk(local_scores, local_ids, group=None):
+def all_gather_topk(local_scores, local_ids, group=None, force=False):
     """All-gather the per-shard lists.  local_* are [Q,k] tensors (CUDA with the
     nccl backend, CPU with gloo); returns ([P,Q,k] scores, [P,Q,k] ids), shard-major."""
     import torch
@@ -29,7 +29,7 @@ def all_gather_topk(local_scores, local_ids, group=None):
     world = dist.get_world_size(group)
     gs = torch.empty((world,) + tuple(local_scores.shape), dtype=local_scores.dtype, device=local_scores.device)
     gi = torch.empty((world,) + tuple(local_ids.shape), dtype=local_ids.dtype, device=local_ids.device)
-    if world == 1:
+    if world == 1 and not force:
         gs[0].copy_(local_scores)
         gi[0].copy_(local_ids)
         return gs, gi
@@ -45,8 +45,10 @@ def all_gather_topk(local_scores, local_ids, group=None):
 class ShardedIndex(object):
     """One rank's view of the sharded index.  `handle` is an sse_amd Handle."""
 
-    def __init__(self, handle, rank, world, n_total, group=None):
+    def __init__(self, handle, rank, world, n_total, group=None, always_gather=False):
+        """always_gather: run the all-gather + merge even with one shard (exercises the RCCL path on one GPU)."""
         self.handle, self.rank, self.world, self.group = handle, int(rank), int(world), group
+        self.always_gather = bool(always_gather)
         self.n_total = int(n_total)
         self.start, self.end = shard_bounds(n_total, world)[rank]
 
@@ -64,9 +66,9 @@ class ShardedIndex(object):
         ls = torch.empty((Q, k), dtype=torch.float64, device=queries.device)
         li = torch.empty((Q, k), dtype=torch.int64, device=queries.device)
         self.handle.score_topk_dev(queries.data_ptr(), Q, k, ls.data_ptr(), li.data_ptr())
-        if self.world == 1:
+        if self.world == 1 and not self.always_gather:
             return ls, li
-        gs, gi = all_gather_topk(ls, li, self.group)
+        gs, gi = all_gather_topk(ls, li, self.group, force=self.always_gather)
         fs, fi = torch.empty_like(ls), torch.empty_like(li)
         self.handle.merge_topk_dev(gs.data_ptr(), gi.data_ptr(), self.world, Q, k, fs.data_ptr(), fi.data_ptr())
         return fs, fi

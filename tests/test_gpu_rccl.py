@@ -1,0 +1,66 @@
+"""The real RCCL collectives of the N>1 paths, on the one GPU a test box has: a 1-rank `nccl` process group
+(127.0.0.1 rendezvous) and the product's DataParallelTrainer / ShardedIndex with the collectives forced on.
+Checks what the CPU `gloo` tests cannot: RCCL on buffers the HIP library writes through raw pointers (stream
+ordering between the library's streams and torch's), float64 / int64 all-gather, float32 all-reduce in place."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import sse_oracle as O
+from tests.util import make_pair, model_params, random_ids
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nccl_group():
+    import torch
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_through_rccl_all_reduce(nccl_group):
+    import sse_amd
+    params = model_params("dual-encoder", 200, 50, 128, 128, 64, 12, lr=0.9)
+    m, p = make_pair(params, seed=4)
+    st = O.new_optimizer_state(p)
+    rng = np.random.RandomState(1)
+    src = np.repeat(random_ids(rng, 24, 12, 200, 0.5), 2, axis=0)
+    tgt = random_ids(rng, 48, 12, 200, 0.5)
+    z = np.tile(np.array([1.0, 0.0], np.float32), 24)
+    tr = sse_amd.DataParallelTrainer(m.handle, device="cuda:0", always_reduce=True)
+    for _ in range(3):
+        want = O.train_step(p, st, params, src, tgt, z, 0.9)
+        got = tr.train_step(src, tgt, z)
+        assert got[0] == pytest.approx(float(want[0]), rel=1e-4)
+    got_vars = m.get_variables()
+    for name, w in p.items():
+        assert np.abs(got_vars[name].reshape(w.shape) - w).max() < 1e-3, name
+    assert tr.global_rows(48) == 48
+
+
+def test_sharded_scoring_through_rccl_all_gather(nccl_group):
+    import torch
+    import sse_amd
+    params = model_params("dual-encoder", 50, 8, 16, 16, 32, 4)
+    m, _ = make_pair(params)
+    rng = np.random.RandomState(3)
+    t = rng.standard_normal((5000, 32)).astype(np.float32)
+    q = rng.standard_normal((300, 32)).astype(np.float32)
+    sh = sse_amd.ShardedIndex(m.handle, 0, 1, 5000, always_gather=True)
+    sh.set_local_rows(torch.from_numpy(t).cuda())
+    s, i = sh.score_topk(torch.from_numpy(q).cuda(), 10)
+    wsc, wids = O.topk(O.scores_f64(q, t.astype(np.float64)), 10)
+    assert np.array_equal(i.cpu().numpy(), wids)
+    assert np.abs(s.cpu().numpy() - wsc).max() < 1e-12
