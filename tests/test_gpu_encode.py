@@ -156,3 +156,37 @@ def test_in_graph_predict_and_similarity():
     assert np.abs(scores - want_sc).max() < 1e-5
     got_sim = sess.run(m.similarity, feed_dict=m.get_predict_feed_dict(src, tgt))
     assert np.abs(got_sim - sim).max() < 1e-5
+
+
+def test_concurrent_encode_and_score_from_threads():
+    """webserver.py:108 calls sess.run from Flask worker threads on ONE session; the handle serialises
+    encode / score calls internally (include/sse_hip.h): results equal the single-threaded ones."""
+    import threading
+    params = model_params("dual-encoder", 300, 50, 96, 96, 64, 20)
+    m, _ = make_pair(params, seed=12)
+    rng = np.random.RandomState(5)
+    tgt = random_ids(rng, 400, 20, 300, 0.5)
+    m.handle.index_upload(m.encode_target(tgt).astype(np.float64))
+    batches = [random_ids(rng, b, 20, 300, 0.5) for b in (1, 7, 64, 130, 600, 33, 2, 257)]
+    want = []
+    for ids in batches:
+        enc = m.encode_source(ids)
+        want.append((enc, m.handle.score_topk(enc, 10)))
+    got, errs = [None] * len(batches), []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                enc = m.encode_source(batches[i])
+                got[i] = (enc, m.handle.score_topk(enc, 10))
+        except Exception as ex:                                 # pragma: no cover
+            errs.append(ex)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(batches))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs
+    for (we, (ws, wi)), (ge, (gs, gi)) in zip(want, got):
+        assert np.array_equal(we, ge) and np.array_equal(wi, gi) and np.array_equal(ws, gs)
