@@ -26,11 +26,66 @@ __global__ void pack_rows_kernel(const float *__restrict__ rows, int64_t R, int 
   }
 }
 
+// Same re-layout for C % 4 == 0, at HBM speed: a wave moves 8 rows x 8 float4 columns per step -- loads are
+// 128-byte row segments, and because a float4 of 4 consecutive k of one row stays a float4 in fragment order
+// ((k%8)/4 picks the half, k/8 the block) the stores are 128-byte runs too; no LDS transpose.  A wave owns its 8
+// rows for all columns, so the row norms needed for the scoring error bound (max over rows of sum x^2) come for free
+// (norm_bits != nullptr: atomicMax on the float bits).
+__global__ __launch_bounds__(256) void pack_rows_vec_kernel(const f32x4 *__restrict__ rows, int64_t R, int C4, int KG,
+                                                            int64_t groups, f32x4 *__restrict__ out,
+                                                            unsigned *__restrict__ norm_bits) {
+  const int lane = threadIdx.x & 63, rs = lane >> 3, qq = lane & 7;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int Q4 = KG * 2;
+  float best = 0.0f;
+  for (int64_t g = wave0; g < groups; g += nwaves) {
+    const int64_t r = g * 8 + rs;
+    const int64_t rt = r >> 5;
+    const int rl = (int)(r & 31);
+    float ss = 0.0f;
+#pragma unroll 8
+    for (int q = qq; q < Q4; q += 8) {
+      f32x4 v = {0, 0, 0, 0};
+      if (r < R && q < C4) v = rows[(size_t)r * C4 + q];
+      ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+      out[((size_t)rt * KG + (q >> 1)) * 64 + (q & 1) * 32 + rl] = v;
+    }
+    ss += __shfl_xor(ss, 1);
+    ss += __shfl_xor(ss, 2);
+    ss += __shfl_xor(ss, 4);
+    best = fmaxf(best, ss);
+  }
+  if (norm_bits) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o));
+    if (lane == 0) atomicMax(norm_bits, __float_as_uint(best));
+  }
+}
+
+hipError_t launch_pack_rows_norm(const float *rows, int64_t R, int C, float *out, float *norm_bits, hipStream_t stream) {
+  const int KG = (C + 7) / 8;
+  const int64_t RT = (R + 31) / 32;
+  if (RT == 0) return hipSuccess;
+  if ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(rows) & 15) == 0) {
+    const int64_t groups = RT * 4;  // 8-row groups, padding rows of the last tile included (zero-filled)
+    const int64_t blocks = (groups + 3) / 4;
+    hipLaunchKernelGGL(pack_rows_vec_kernel, dim3((int)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, stream,
+                       reinterpret_cast<const f32x4 *>(rows), R, C / 4, KG, groups, reinterpret_cast<f32x4 *>(out),
+                       reinterpret_cast<unsigned *>(norm_bits));
+    return hipGetLastError();
+  }
+  hipError_t e = launch_pack_rows(rows, R, C, out, stream);
+  if (e != hipSuccess || !norm_bits) return e;
+  return launch_row_norm2_max(rows, R, C, norm_bits, stream);
+}
+
 hipError_t launch_pack_rows(const float *rows, int64_t R, int C, float *out, hipStream_t stream) {
   const int KG = (C + 7) / 8;
   const int64_t RT = (R + 31) / 32;
   const int64_t total4 = RT * KG * 64;
   if (total4 == 0) return hipSuccess;
+  if ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(rows) & 15) == 0) return launch_pack_rows_norm(rows, R, C, out, nullptr, stream);
   const int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
   hipLaunchKernelGGL(pack_rows_kernel, dim3(grid), dim3(256), 0, stream, rows, R, C, KG, total4,
                      reinterpret_cast<f32x4 *>(out));
@@ -65,8 +120,50 @@ __global__ void l2_normalize_kernel(const float *__restrict__ x, float *__restri
   }
 }
 
+// cols % 4 == 0 and cols <= 1024: LPR = lanes per row (power of two, cols/4 rounded up, <= 64), 64/LPR rows per wave,
+// NV float4 per lane; every element is read once (16-byte loads) and kept in registers.
+template <int NV>
+__global__ __launch_bounds__(256) void l2_normalize_vec_kernel(const f32x4 *__restrict__ x, f32x4 *__restrict__ out,
+                                                               int64_t rows, int C4, int LPR) {
+  const int lane = threadIdx.x & 63, sub = lane & (LPR - 1), rsub = lane / LPR, RPW = 64 / LPR;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r0 = wave0 * RPW; r0 < rows; r0 += nwaves * RPW) {
+    const int64_t r = r0 + rsub;
+    f32x4 v[NV];
+    float ss = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = sub + j * LPR;
+      v[j] = (r < rows && c < C4) ? x[(size_t)r * C4 + c] : f32x4{0, 0, 0, 0};
+      ss += v[j][0] * v[j][0] + v[j][1] * v[j][1] + v[j][2] * v[j][2] + v[j][3] * v[j][3];
+    }
+    for (int o = LPR >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float sc = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = sub + j * LPR;
+      if (r < rows && c < C4) out[(size_t)r * C4 + c] = f32x4{v[j][0] * sc, v[j][1] * sc, v[j][2] * sc, v[j][3] * sc};
+    }
+  }
+}
+
 hipError_t launch_l2_normalize(const float *x, float *out, int64_t rows, int cols, hipStream_t stream) {
   if (rows == 0) return hipSuccess;
+  if ((cols & 3) == 0 && cols <= 1024 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    const int C4 = cols / 4;
+    int LPR = 1;
+    while (LPR < C4 && LPR < 64) LPR <<= 1;
+    const int NV = (C4 + LPR - 1) / LPR;  // 1 unless cols > 256
+    const int64_t waves = (rows + 64 / LPR - 1) / (64 / LPR), blk = (waves + 3) / 4;
+    const dim3 grid((int)(blk < 32768 ? blk : 32768));
+    const f32x4 *xi = reinterpret_cast<const f32x4 *>(x);
+    f32x4 *xo = reinterpret_cast<f32x4 *>(out);
+    if (NV == 1) hipLaunchKernelGGL(l2_normalize_vec_kernel<1>, grid, dim3(256), 0, stream, xi, xo, rows, C4, LPR);
+    else if (NV == 2) hipLaunchKernelGGL(l2_normalize_vec_kernel<2>, grid, dim3(256), 0, stream, xi, xo, rows, C4, LPR);
+    else hipLaunchKernelGGL(l2_normalize_vec_kernel<4>, grid, dim3(256), 0, stream, xi, xo, rows, C4, LPR);
+    return hipGetLastError();
+  }
   const int64_t blocks = (rows + 3) / 4;
   hipLaunchKernelGGL(l2_normalize_kernel, dim3((int)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream, x, out,
                      rows, cols);

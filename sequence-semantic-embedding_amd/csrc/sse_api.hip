@@ -82,6 +82,7 @@ struct sse_handle {
   int32_t *err_flag = nullptr;
   // index
   float *idxp = nullptr;
+  size_t idxp_cap = 0;
   double *idx64 = nullptr;
   int64_t idx_N = 0, idx_base = 0;
   int idx_S = 0;
@@ -341,13 +342,18 @@ int index_from_dev_rows(sse_handle *h, const float *rows_dev, int64_t N, int S, 
   if (N > (int64_t)2147483000) return fail(h, "index shard too large for int32 row ids");
   const int KG = (S + 7) / 8;
   const int64_t NT = (N + 31) / 32;
-  if (h->idxp) HIPCHECK(h, hipFree(h->idxp));
-  h->idxp = nullptr;
-  HIPCHECK(h, hipMalloc((void **)&h->idxp, (size_t)NT * KG * 256 * sizeof(float)));
-  HIPCHECK(h, launch_pack_rows(rows_dev, N, S, h->idxp, st));
+  // fragment-order copy of the index: grow-only (re-indexing with the same or a smaller shard reuses the allocation)
+  const size_t need = (size_t)NT * KG * 256 * sizeof(float);
+  if (need > h->idxp_cap) {
+    if (h->idxp) HIPCHECK(h, hipFree(h->idxp));
+    h->idxp = nullptr;
+    h->idxp_cap = 0;
+    HIPCHECK(h, hipMalloc((void **)&h->idxp, need));
+    h->idxp_cap = need;
+  }
   if (reserve(h, h->s_tmp2, 16)) return 1;
   HIPCHECK(h, hipMemsetAsync(h->s_tmp2.p, 0, 4, st));
-  HIPCHECK(h, launch_row_norm2_max(rows_dev, N, S, (float *)h->s_tmp2.p, st));
+  HIPCHECK(h, launch_pack_rows_norm(rows_dev, N, S, h->idxp, (float *)h->s_tmp2.p, st));
   float n2 = 0;
   HIPCHECK(h, hipMemcpyAsync(&n2, h->s_tmp2.p, 4, hipMemcpyDeviceToHost, st));
   HIPCHECK(h, hipStreamSynchronize(st));

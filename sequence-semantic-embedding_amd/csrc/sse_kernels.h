@@ -96,6 +96,8 @@ hipError_t launch_merge_topk(const double *in_s, const int64_t *in_i, int P, int
 // ------------------------------ packing / misc -----------------------------
 // rows [R][C] f32 row-major -> frag32 [ceil(R/32)][ceil(C/8)][256], zero padded
 hipError_t launch_pack_rows(const float *rows, int64_t R, int C, float *out, hipStream_t stream);
+// pack + max over rows of sum(x^2) (float bits, atomicMax into *norm_bits which the caller zeroed) in one pass
+hipError_t launch_pack_rows_norm(const float *rows, int64_t R, int C, float *out, float *norm_bits, hipStream_t stream);
 hipError_t launch_f64_to_f32(const double *in, float *out, int64_t n, hipStream_t stream);
 hipError_t launch_l2_normalize(const float *x, float *out, int64_t rows, int cols, hipStream_t stream);
 
