@@ -138,6 +138,23 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   const float *qs = smem + lane * 4;
   const int voff = lane * 16;
 
+  // NQ == 1 (<= 32 queries) is an HBM-bound sweep: 4 MFMAs per KiB of index.  Two loads in flight per wave
+  // (the pipelined loop below) cover only ~4 MB chip-wide where 8 TB/s x ~1.5 us wants >= 12 MB, so this variant
+  // keeps a ring of RING k-group fragments per wave in registers (32 VGPRs), running across tile boundaries.
+  constexpr int RING = 8;
+  constexpr int WSTEP = SC_THREADS / 64;
+  const bool use_ring = (NQ == 1) && (KG % RING == 0) && ((int64_t)tps * KG * 1024 < ((int64_t)1 << 31));
+  f32x4 ring[RING];
+  const int tile0 = t0 + w;
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(a.idxp) + (size_t)__builtin_amdgcn_readfirstlane(tile0 < t1 ? tile0 : t0) * KG * 256, 0,
+      (tile0 < t1 ? (t1 - tile0) : 0) * KG * 1024, 0x00020000);  // this wave's whole tile stream (< 2 GiB, else use_ring is off)
+  if (use_ring && tile0 < t1) {
+#pragma unroll
+    for (int d = 0; d < RING; ++d)
+      ring[d] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, voff, d * 1024, 0));
+  }
+
   for (int tile = t0 + w; tile < t1; tile += SC_THREADS / 64) {
     // index tile through a buffer descriptor (base = this tile: stays below the 4 GiB
     // descriptor range for any index size); per-lane offset is the constant 16*lane
@@ -164,46 +181,69 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
 
-    // k-loop, hand software-pipelined with two named operand sets (X / Y): the index
-    // fragment of k-group kg+1 (global) and the query fragments (LDS) are in flight while
-    // kg's 4*NQ MFMAs issue; no register copies.
-    f32x4 ax = iload(0), ay;
-    f32x4 bx[NQ], by[NQ];
+    if (use_ring) {
+      if constexpr (NQ == 1) {
+        const int tbase = (tile - tile0) * KG;                       // k-group index of this tile in the wave's stream
+        const bool more = tile + WSTEP < t1;                          // a next tile exists
+        f32x4 bq = *reinterpret_cast<const f32x4 *>(qs), bqn;
+        __builtin_amdgcn_s_setprio(1);
+        for (int kg0 = 0; kg0 < KG; kg0 += RING) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) bx[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG) * 256);
-    __builtin_amdgcn_s_setprio(1);
-    int kg = 0;
-    for (; kg + 1 < KG; kg += 2) {
-      asm volatile("" ::"v"(tch0), "v"(tch1));  // last iteration's touches (long since returned: in-order)
-      ay = iload(kg + 1);
-      if constexpr (NQ > 1) {  // the single-query-tile sweep is HBM-bound already: extra requests only cost
-        tch0 = touch(kg);
-        tch1 = touch(kg + 1);
+          for (int d = 0; d < RING; ++d) {
+            const int kg = kg0 + d;
+            bqn = *reinterpret_cast<const f32x4 *>(qs + ((kg + 1 < KG) ? kg + 1 : 0) * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[d][e], bq[e], acc[0], 0, 0, 0);
+            // refill the slot with the fragment RING k-groups on: same tile, or the head of this wave's next tile
+            const int kn = kg + RING;
+            const int off = (kn < KG) ? tbase + kn : (more ? tbase + WSTEP * KG + (kn - KG) : tbase + kg);
+            ring[d] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, voff, off * 1024, 0));
+            bq = bqn;
+          }
+        }
       }
+    } else {
+      // k-loop, hand software-pipelined with two named operand sets (X / Y): the index
+      // fragment of k-group kg+1 (global) and the query fragments (LDS) are in flight while
+      // kg's 4*NQ MFMAs issue; no register copies.
+      f32x4 ax = iload(0), ay;
+      f32x4 bx[NQ], by[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) by[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG + kg + 1) * 256);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int q = 0; q < NQ; ++q) bx[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG) * 256);
+      __builtin_amdgcn_s_setprio(1);
+      int kg = 0;
+      for (; kg + 1 < KG; kg += 2) {
+        asm volatile("" ::"v"(tch0), "v"(tch1));  // last iteration's touches (long since returned: in-order)
+        ay = iload(kg + 1);
+        if constexpr (NQ > 1) {  // the single-query-tile sweep is HBM-bound already: extra requests only cost
+          tch0 = touch(kg);
+          tch1 = touch(kg + 1);
+        }
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+        for (int q = 0; q < NQ; ++q) by[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG + kg + 1) * 256);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[q][e], acc[q], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      const int k2 = (kg + 2 < KG) ? kg + 2 : kg;
-      ax = iload(k2);
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) bx[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG + k2) * 256);
-      __builtin_amdgcn_sched_barrier(0);
+          for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[q][e], acc[q], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int k2 = (kg + 2 < KG) ? kg + 2 : kg;
+        ax = iload(k2);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+        for (int q = 0; q < NQ; ++q) bx[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG + k2) * 256);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[e], by[q][e], acc[q], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (kg < KG) {
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+          for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[e], by[q][e], acc[q], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (kg < KG) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[q][e], acc[q], 0, 0, 0);
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[q][e], acc[q], 0, 0, 0);
+      }
     }
     __builtin_amdgcn_s_setprio(0);
 
@@ -398,7 +438,6 @@ __device__ __forceinline__ bool before(double sa, int64_t ia, double sb, int64_t
 #define RS_MAXWIN 256
 #define RS_MAXNC 4096  // candidates per query the re-scoring pass accepts
 __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
-  __shared__ float s_thr[RS_THREADS / 64];
   __shared__ int s_cnt;
   __shared__ int s_win[RS_MAXWIN];
   __shared__ double s_ex[RS_MAXWIN];
@@ -433,19 +472,52 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
     s_key[c] = (id < 0) ? 0ull : (((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)id));
   }
   __syncthreads();
+  // k-th largest key: every slot of KC candidates is a sorted list (descending), so k rounds of "largest list head
+  // wins and advances" find it -- O(k * slots / 256) instead of ranking all NC candidates against each other
+  // (NC = 4096 for a single query over 256 index splits: that ranking was a third of the whole pass).
   float kth = NEG_INF;
-  for (int c = tid; c < a.NC; c += RS_THREADS) {
-    const unsigned long long key = s_key[c];
-    if (key == 0ull) continue;
-    int rank = 0;
-    for (int j = 0; j < a.NC; ++j) rank += (s_key[j] > key) ? 1 : 0;
-    if (rank == a.k - 1) kth = ps[c];
-  }
+  {
+    __shared__ unsigned long long s_best[RS_THREADS / 64];
+    const int nslots = a.NC / SC_KC;
+    int head[RS_MAXNC / SC_KC / RS_THREADS];   // this thread's slots: tid, tid + 256, ...
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) kth = fmaxf(kth, __shfl_xor(kth, o));
-  if (lane == 0) s_thr[w] = kth;
-  __syncthreads();
-  kth = fmaxf(fmaxf(s_thr[0], s_thr[1]), fmaxf(s_thr[2], s_thr[3]));
+    for (int j = 0; j < RS_MAXNC / SC_KC / RS_THREADS; ++j) head[j] = 0;
+    unsigned long long kkey = 0ull;
+    for (int it = 0; it < a.k; ++it) {
+      unsigned long long best = 0ull;
+#pragma unroll
+      for (int j = 0; j < RS_MAXNC / SC_KC / RS_THREADS; ++j) {
+        const int slot = tid + j * RS_THREADS;
+        if (slot < nslots && head[j] < SC_KC) {
+          const unsigned long long key = s_key[slot * SC_KC + head[j]];
+          best = key > best ? key : best;
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(best, o);
+        best = other > best ? other : best;
+      }
+      if (lane == 0) s_best[w] = best;
+      __syncthreads();
+      unsigned long long win = s_best[0];
+#pragma unroll
+      for (int i = 1; i < RS_THREADS / 64; ++i) win = s_best[i] > win ? s_best[i] : win;
+      __syncthreads();
+      kkey = win;
+      if (win == 0ull) break;                  // fewer than k candidates
+#pragma unroll
+      for (int j = 0; j < RS_MAXNC / SC_KC / RS_THREADS; ++j) {  // keys are unique (row id): exactly one head matches
+        const int slot = tid + j * RS_THREADS;
+        if (slot < nslots && head[j] < SC_KC && s_key[slot * SC_KC + head[j]] == win) ++head[j];
+      }
+    }
+    if (kkey != 0ull) {  // decode the score bits of the k-th key
+      unsigned u = (unsigned)(kkey >> 32);
+      u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+      kth = __uint_as_float(u);
+    }
+  }
 
   // window: candidates whose fp32 score is within 2*eps of the k-th (the only ones
   // that can be in the exact top-k); largest slot minimum M over full slots
