@@ -476,7 +476,20 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
   // wins and advances" find it -- O(k * slots / 256) instead of ranking all NC candidates against each other
   // (NC = 4096 for a single query over 256 index splits: that ranking was a third of the whole pass).
   float kth = NEG_INF;
-  {
+  if (a.NC <= 256) {
+    // few candidates (many-queries launches: 16 per index split): every thread ranks its candidate by counting
+    // larger keys (LDS broadcast reads) -- cheaper than the barriers of the tournament below
+    const unsigned long long key = (tid < a.NC) ? s_key[tid] : 0ull;
+    int rank = 0;
+    for (int j = 0; j < a.NC; ++j) rank += (s_key[j] > key) ? 1 : 0;
+    float mine = (key != 0ull && rank == a.k - 1) ? ps[tid] : NEG_INF;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine = fmaxf(mine, __shfl_xor(mine, o));
+    __shared__ float s_thr[RS_THREADS / 64];
+    if (lane == 0) s_thr[w] = mine;
+    __syncthreads();
+    kth = fmaxf(fmaxf(s_thr[0], s_thr[1]), fmaxf(s_thr[2], s_thr[3]));
+  } else {
     __shared__ unsigned long long s_best[RS_THREADS / 64];
     const int nslots = a.NC / SC_KC;
     int head[RS_MAXNC / SC_KC / RS_THREADS];   // this thread's slots: tid, tid + 256, ...
