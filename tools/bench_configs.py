@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import sse_amd  # noqa: E402
 
-which = set(sys.argv[1:]) or {"c2", "c4"}
+which = set(sys.argv[1:]) or {"c2", "c4", "shapes"}
 dev = torch.device("cuda:0")
 V, E, H, S, T = 32000, 50, 256, 256, 32
 params = dict(forward_only=True, network_mode="dual-encoder", predict_nbest=10, max_seq_length=T, vocab_size=V,
@@ -40,6 +40,31 @@ if "c2" in which:
             ms = h.timer_elapsed_ms(0, 1) / n
             print("C2 %s B=%-6d %.3f ms/call  %.0f seq/s  %.1f TFLOP/s (%.1f%% of fp32 MFMA peak)"
                   % (name, B, ms, B / ms * 1e3, B * FLOP / ms / 1e9, B * FLOP / ms / 1e9 / 157.3 * 100))
+
+if "shapes" in which:
+    # other model shapes at B = 16384: the reference's defaults (sse_train.py:60-74: E=50, H=96, S=64, T=80),
+    # configs[0] (shared-encoder H=128), the crosslingual recipe shape, and a wide cell (H=512: inference only)
+    for (mode, E2, H2, S2, T2) in (("dual-encoder", 50, 96, 64, 80), ("shared-encoder", 50, 128, 64, 80),
+                                   ("dual-encoder", 40, 50, 50, 50), ("dual-encoder", 50, 256, 256, 50),
+                                   ("dual-encoder", 50, 512, 512, 32)):
+        p2 = dict(params, network_mode=mode, embedding_size=E2, src_cell_size=H2, tgt_cell_size=H2, encoding_size=S2,
+                  max_seq_length=T2)
+        m2 = sse_amd.SSEModel(p2)
+        m2.init_variables(seed=0)
+        B = 16384
+        ids = torch.randint(2, V, (B, T2), device=dev, dtype=torch.int32)
+        out = torch.empty((B, S2), device=dev)
+        for _ in range(2):
+            m2.handle.encode_dev(0, ids.data_ptr(), B, T2, True, out.data_ptr())
+        m2.handle.timer_record(0)
+        for _ in range(10):
+            m2.handle.encode_dev(0, ids.data_ptr(), B, T2, True, out.data_ptr())
+        m2.handle.timer_record(1)
+        ms = m2.handle.timer_elapsed_ms(0, 1) / 10
+        fl = T2 * 8 * H2 * (E2 + H2) + 2 * H2 * S2
+        print("shape %s E=%d H=%d S=%d T=%d B=%d: %.3f ms  %.0f seq/s  %.1f TFLOP/s algorithmic (%.1f%% of fp32 MFMA peak)"
+              % (mode, E2, H2, S2, T2, B, ms, B / ms * 1e3, B * fl / ms / 1e9, B * fl / ms / 1e9 / 157.3 * 100))
+        m2.handle.close()
 
 if "c4" in which:
     Q, NS, P, k = 100000, 1250000, 8, 10
