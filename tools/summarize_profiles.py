@@ -32,11 +32,11 @@ def main():
         dur = collections.defaultdict(list)
         for r in csv.DictReader(open(os.path.join(d, "p_counter_collection.csv"))):
             if any(k in r["Kernel_Name"] for k in ("lstm_fwd", "score_topk", "rescore_kernel")):
-                key = (r["Kernel_Name"].split("(")[0][:40], r["Grid_Size"])
+                key = (r["Kernel_Name"].split("(")[0][:64], r["Grid_Size"])
                 agg[key + (r["Counter_Name"],)].append(float(r["Counter_Value"]))
                 dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         for (k, g, c), v in sorted(agg.items()):
-            out.append("%-42s grid=%-8s %-26s n=%-3d avg=%.5g  (avg dispatch %.3f ms)"
+            out.append("%-56s grid=%-8s %-26s n=%-3d avg=%.5g  (avg dispatch %.3f ms)"
                        % (k, g, c, len(v), sum(v) / len(v), sum(dur[(k, g)]) / len(dur[(k, g)]) / 1e6))
     open(os.path.join(root, "%s_pmc.txt" % tag), "w").write("\n".join(out) + "\n")
     # HBM traffic of the dominant kernel's full-size launches for bench.py's roofline.traffic:
@@ -45,7 +45,9 @@ def main():
     traffic = {}
     for d in pmc_dirs:
         for r in csv.DictReader(open(os.path.join(d, "p_counter_collection.csv"))):
-            if "lstm_fwd" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE") and int(r["Grid_Size"]) >= 65536:
+            # the inference configuration of the headline launches (<2, 2, 1, false, ..>), not the training-leg forward
+            if ("lstm_fwd_kernel<2, 2, 1, false" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE")
+                    and int(r["Grid_Size"]) >= 65536):
                 traffic.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
         f = sum(traffic["FETCH_SIZE"]) / len(traffic["FETCH_SIZE"])
