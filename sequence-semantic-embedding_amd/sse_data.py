@@ -142,6 +142,38 @@ class Data(object):
             self._row_of = {t: i for i, t in enumerate(self.fullSetTargetIds)}
         return self._row_of[tgt_id]
 
+    def _corpus_arrays(self):
+        """The padded corpora as int32 matrices (built once): sources [n_pos, T], targets [N, T] in
+        fullSetTargetIds order; plus the positives of every source as target rows."""
+        if getattr(self, "_arr", None) is None:
+            src = np.array([tokens for tokens, _ in self.rawTrainPosCorpus], dtype=np.int32)
+            tgt = np.array([self.encodedFullTargetSpace[t] for t in self.fullSetTargetIds], dtype=np.int32)
+            self._arr = (src, tgt)
+        return self._arr
+
+    def get_train_batch_arrays(self, batch_size, target_rows=False):
+        """get_train_batch with the same random draws in the same order (same seed -> same batch), returning
+        ndarrays gathered from pre-built corpus matrices instead of lists of token lists: the list -> ndarray
+        conversion of the feed dict (sse_model.py:419-421) was 0.5 ms of a 3 ms train step."""
+        src_arr, tgt_arr = self._corpus_arrays()
+        n = len(self.rawTrainPosCorpus)
+        start = self.rng.randint(0, n - batch_size) + batch_size     # data.py:97 (window may be cut at the end)
+        stop = min(n, start + batch_size)
+        rows = np.empty(2 * (stop - start), np.int64)
+        for i in range(start, stop):
+            verified = self.rawTrainPosCorpus[i][1]
+            pos = verified[self.rng.randint(0, len(verified))]
+            positives = set(verified)
+            neg = self.fullSetTargetIds[self.rng.randint(0, self.rawnegSetLen)]
+            while neg in positives:
+                neg = self.fullSetTargetIds[self.rng.randint(0, self.rawnegSetLen)]
+            rows[2 * (i - start)] = self.target_row(pos)
+            rows[2 * (i - start) + 1] = self.target_row(neg)
+        src = src_arr[np.repeat(np.arange(start, stop), 2)]
+        tgt = rows.astype(np.int32) if target_rows else tgt_arr[rows]
+        labels = np.tile(np.array([1.0, 0.0], np.float32), stop - start)
+        return src, tgt, labels
+
     def get_train_batch(self, batch_size, target_rows=False):
         """data.py:95-115.  target_rows=True (source_only_cnn): the target side of each pair is the row of the
         target id in the free target matrix instead of its token sequence."""
