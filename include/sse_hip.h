@@ -83,7 +83,9 @@ int sse_encode_dev(sse_handle *h, int side, const int32_t *ids_dev, int32_t B, i
 /* Library options.  "pad_skip" (default 1): inference encodes skip the left-PAD prefix of
  * every 64-row tile exactly -- the LSTM state after p leading PAD (id 0) steps is
  * sequence-independent (sse_index.py:79-85 left-pads; sse_model.py:240-242 runs all T steps),
- * so it is precomputed per p with the same kernel; results are bit-identical to pad_skip = 0. */
+ * so it is precomputed per p with the same kernel; results are bit-identical to pad_skip = 0.
+ * "train_serial" (default 0): run both encoders of a train step on one stream (profiling aid:
+ * isolated kernel durations; same results). */
 int sse_set_option(sse_handle *h, const char *name, int32_t value);
 
 /* tf.nn.l2_normalize(x, dim=-1) on device rows (sse_model.py:282-283). */
@@ -117,7 +119,11 @@ int sse_merge_topk_dev(sse_handle *h, const double *in_scores_dev, const int64_t
 
 /* session.run([model.train, model.loss, model.train_acc], feed) --
  * sse_train.py:170-172; loss/acc are evaluated before the update.  labels
- * float32 [B] (sse_model.py:420). */
+ * float32 [B] (sse_model.py:420).  tgt_ids_host is int32 [B,T] token ids in the
+ * LSTM modes; in source_only_cnn (builder-defined training: the reference's
+ * graph for that mode does not build) it is int32 [B] rows of the free target
+ * matrix.  Limits (rejected with an error, never silently): cell size <= 256
+ * and embedding_size <= 64 for training, cell size <= 512 for inference. */
 int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tgt_ids_host,
                    const float *labels_host, int32_t B, int32_t T, float *loss, float *train_acc);
 
