@@ -120,9 +120,10 @@ int sse_merge_topk_dev(sse_handle *h, const double *in_scores_dev, const int64_t
 /* session.run([model.train, model.loss, model.train_acc], feed) --
  * sse_train.py:170-172; loss/acc are evaluated before the update.  labels
  * float32 [B] (sse_model.py:420).  tgt_ids_host is int32 [B,T] token ids in the
- * LSTM modes; in source_only_cnn (builder-defined training: the reference's
- * graph for that mode does not build) it is int32 [B] rows of the free target
- * matrix.  Limits (rejected with an error, never silently): cell size <= 256
+ * dual- and shared-encoder modes; in source-encoder-only and source_only_cnn
+ * (builder-defined training: the reference's loss is ill-shaped for the free
+ * target matrix and its CNN graph does not build) it is int32 [B] rows of the
+ * free target matrix.  Limits (rejected with an error, never silently): cell size <= 256
  * and embedding_size <= 64 for training, cell size <= 512 for inference. */
 int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tgt_ids_host,
                    const float *labels_host, int32_t B, int32_t T, float *loss, float *train_acc);

@@ -206,9 +206,10 @@ class Handle(object):
         return s, t, z
 
     def _check_tgt_kind(self, t):
-        cnn = self.cfg.network_mode == 3
-        if cnn != (t.ndim == 1):
-            raise ValueError("source_only_cnn trains on [B] target-matrix rows, the LSTM modes on [B,T] target token ids")
+        table = self.cfg.network_mode in (2, 3)                    # source-encoder-only, source_only_cnn
+        if table != (t.ndim == 1):
+            raise ValueError("source-encoder-only / source_only_cnn train on [B] target-matrix rows, "
+                             "dual- and shared-encoder on [B,T] target token ids")
 
     def train_step(self, src_ids, tgt_ids, labels):
         s, t, z = self._train_batch(src_ids, tgt_ids, labels)

@@ -907,8 +907,11 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   if (!h->train) h->train = new TrainState();
   if (c.network_mode == SSE_MODE_SOURCE_ONLY_CNN)
     return cnn_train_grads_locked(h, src_ids_host, tgt_ids_host, labels_host, B, T, rows_global);
-  if (c.network_mode != SSE_MODE_DUAL_ENCODER && c.network_mode != SSE_MODE_SHARED_ENCODER)
-    return fail(h, "train step: the reference loss is ill-shaped for this network mode (sse_model.py:233,290)");
+  // source-encoder-only (BUILDER-DEFINED like the CNN mode: the reference's loss is ill-shaped there,
+  // sse_model.py:233,290): LSTM source encoder, target side = embedding_lookup(tgt_seq_embedding, rows);
+  // tgt_ids_host is int32 [B] rows of the free target matrix.  nside = sequence encoders in the step.
+  const bool table_tgt = c.network_mode == SSE_MODE_SOURCE_ENCODER_ONLY;
+  const int nside = table_tgt ? 1 : 2;
   hipStream_t st = nullptr;
   TrainState &ts = *h->train;
   if (!ts.side[0]) {
@@ -928,7 +931,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   if (ensure_packed(h, st)) return 1;
   // transposed kernel slices for the backward GEMMs
   if (ts.packed_dirty) {
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < nside; ++s) {
       Encoder &e = h->enc[s];
       if (e.shares_lstm_with >= 0) {
         ts.KhT[s] = ts.KhT[e.shares_lstm_with];
@@ -943,14 +946,15 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     ts.packed_dirty = false;
   }
   if (E > 64) return fail(h, "train step: embedding_size %d > 64 not supported yet", E);
-  for (int s = 0; s < 2; ++s)
+  for (int s = 0; s < nside; ++s)
     if (h->enc[s].Hp > 256) return fail(h, "train step: LSTM cell size %d > 256 not supported yet (inference only)", h->enc[s].H);
 
   // ---- inputs
   const int32_t *ids_host[2] = {src_ids_host, tgt_ids_host};
   for (int s = 0; s < 2; ++s) {
-    if (reserve(h, ts.ids[s], (size_t)B * T * sizeof(int32_t))) return 1;
-    HIPCHECK(h, hipMemcpyAsync(ts.ids[s].p, ids_host[s], (size_t)B * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    const size_t n_ids = (s == 1 && table_tgt) ? (size_t)B : (size_t)B * T;
+    if (reserve(h, ts.ids[s], n_ids * sizeof(int32_t))) return 1;
+    HIPCHECK(h, hipMemcpyAsync(ts.ids[s].p, ids_host[s], n_ids * sizeof(int32_t), hipMemcpyHostToDevice, st));
   }
   if (reserve(h, ts.labels, (size_t)B * sizeof(float))) return 1;
   HIPCHECK(h, hipMemcpyAsync(ts.labels.p, labels_host, (size_t)B * sizeof(float), hipMemcpyHostToDevice, st));
@@ -958,7 +962,14 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   // ---- forward with tapes (un-normalised encodings; the loss kernel normalises); the two
   // encoders are independent: fork onto two side streams, join before the loss
   HIPCHECK(h, hipEventRecord(ts.ev_fork, st));
-  for (int s = 0; s < 2; ++s) {
+  if (table_tgt) {
+    Variable &table = h->vars[h->tgt_table];
+    if (reserve(h, ts.raw[1], (size_t)Bp * S * sizeof(float))) return 1;
+    if (reserve(h, ts.draw[1], (size_t)Bp * S * sizeof(float))) return 1;
+    HIPCHECK(h, launch_rows_gather(table.dev, (const int32_t *)ts.ids[1].p, B, Bp, table.rows, S, (float *)ts.raw[1].p,
+                                   h->err_flag, st));
+  }
+  for (int s = 0; s < nside; ++s) {
     hipStream_t fs = h->train_serial ? ts.side[0] : ts.side[s];
     HIPCHECK(h, hipStreamWaitEvent(fs, ts.ev_fork, 0));
     Encoder &e = h->enc[s];
@@ -1005,9 +1016,16 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   // ---- backward
   Variable &emb = h->vars[0];
   HIPCHECK(h, hipMemsetAsync(emb.grad, 0, emb.count * sizeof(float), st));
-  if (reserve(h, ts.sq_part, (size_t)2 * T * NT32 * sizeof(float))) return 1;
+  const int n_sq = table_tgt ? T * NT32 + B : 2 * T * NT32;  // dx partials per side (+ one per target row)
+  if (reserve(h, ts.sq_part, (size_t)n_sq * sizeof(float))) return 1;
+  if (table_tgt) {
+    Variable &table = h->vars[h->tgt_table];
+    HIPCHECK(h, hipMemsetAsync(table.grad, 0, table.count * sizeof(float), st));
+    HIPCHECK(h, launch_rows_scatter((const float *)ts.draw[1].p, (const int32_t *)ts.ids[1].p, B, S, table.grad,
+                                    (float *)ts.sq_part.p + (size_t)T * NT32, st));
+  }
   HIPCHECK(h, hipEventRecord(ts.ev_fork, st));  // loss + zeroed embedding gradient are ready
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < nside; ++s) {
     Encoder &e = h->enc[s];
     const int Hp = e.Hp, KGn = Hp / 2, NTn = Hp / 8, KT = 2 + Hp / 32, RG = T * NT32 * 4;
     const int SL = dk_slices(RG);
@@ -1038,7 +1056,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   }
 
   // tail[0] = sum of squares of the raw (un-deduplicated) embedding-gradient slices, tail[3] = rows
-  HIPCHECK(h, launch_sum((const float *)ts.sq_part.p, 2 * T * NT32, (float)B, tail, st));
+  HIPCHECK(h, launch_sum((const float *)ts.sq_part.p, n_sq, (float)B, tail, st));
   ts.grads_ready = true;
   return 0;
 }

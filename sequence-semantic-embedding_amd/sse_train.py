@@ -91,7 +91,7 @@ def train(f):
         epoc_start = time.time()
         for _ in range(int(epoc_steps)):
             start = time.time()
-            src, tgt, labels = data.get_train_batch_arrays(f.batch_size, target_rows=(f.network_mode == "source_only_cnn"))
+            src, tgt, labels = data.get_train_batch_arrays(f.batch_size, target_rows=(f.network_mode in ("source_only_cnn", "source-encoder-only")))
             model.set_forward_only(False)
             d = model.get_train_feed_dict(src, tgt, labels)
             _, _, step_loss, step_train_acc = sess.run([model.train, summary_op, model.loss, model.train_acc], feed_dict=d)

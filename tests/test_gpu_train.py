@@ -212,3 +212,30 @@ def test_handles_release_their_device_memory():
         cycle()
     torch.cuda.synchronize()
     assert free0 - torch.cuda.mem_get_info()[0] < 8 << 20
+
+
+@pytest.mark.parametrize("V,E,H,S,T,B,N", [(200, 50, 128, 64, 12, 40, 17), (80, 16, 32, 8, 5, 6, 3)])
+def test_source_encoder_only_train_step_matches_oracle(V, E, H, S, T, B, N):
+    """source-encoder-only (BUILDER-DEFINED training, as for the CNN mode): LSTM source encoder + rows of the free
+    target matrix; one step vs oracle._source_only_gradients."""
+    import sse_amd
+    params = model_params("source-encoder-only", V, E, H, H, S, T, N=N, lr=0.9)
+    m, p = make_pair(params, seed=2)
+    st = O.new_optimizer_state(p)
+    rng = np.random.RandomState(7)
+    src = np.repeat(random_ids(rng, B // 2, T, V, 0.5), 2, axis=0)
+    rows = rng.randint(0, N, size=B).astype(np.int32)
+    z = np.tile(np.array([1.0, 0.0], np.float32), B // 2)
+    want = O.train_step(p, st, params, src, rows, z, 0.9)
+    got = m.train_step(src, rows, z)
+    assert got[0] == pytest.approx(float(want[0]), rel=1e-5, abs=1e-6) and got[1] == pytest.approx(float(want[1]), abs=1e-6)
+    vars_ = m.get_variables(with_slots=True)
+    for name, w in p.items():
+        assert np.abs(vars_[name].reshape(w.shape) - w).max() < 2e-4, name
+        assert np.abs(vars_[name + "/Adagrad"].reshape(w.shape) - st[name]).max() < 2e-4, name
+    with pytest.raises(ValueError):
+        m.train_step(src, np.zeros_like(src), z)
+    bad = rows.copy()
+    bad[0] = N
+    with pytest.raises(sse_amd.SSEError):
+        m.train_step(src, bad, z)

@@ -223,3 +223,40 @@ def test_sorted_results_ties_lower_index_first():
     s = np.array([[0.5, 0.9, 0.9, 0.1]])
     sc, idx = O.sorted_results(s)
     assert idx.tolist() == [[1, 2, 0, 3]] and sc.tolist() == [[0.9, 0.9, 0.5, 0.1]]
+
+
+def test_source_encoder_only_gradients_finite_difference():
+    """Builder-defined source-encoder-only pair loss (oracle._source_only_gradients) vs central differences."""
+    cfg = _cfg(mode="source-encoder-only", V=21, E=4, H=5, S=4)
+    cfg["targetSpaceSize"] = 6
+    p = {k: v.astype(np.float64) for k, v in O.init_params(cfg, seed=3).items()}
+    rng = np.random.RandomState(1)
+    src = rng.randint(0, 21, size=(6, 5)).astype(np.int32)
+    rows = np.array([0, 2, 2, 5, 1, 3], np.int32)
+    z = np.array([1, 0] * 3, np.float64)
+    old = O.F32
+    try:
+        O.F32 = np.float64
+        O.FORGET_BIAS, O.L2_EPS, O.LOGIT_SCALE = np.float64(1.0), np.float64(1e-12), np.float64(64.0)
+
+        def f(pp):
+            ns = O.encode(pp, cfg, "src", src)
+            nt = O.l2_normalize(pp["target_embedding/tgt_seq_embedding"][rows])
+            return float(O.loss_and_acc(ns, nt, z)[0])
+
+        loss, _, grads = O.gradients(p, cfg, src, rows, z)
+        assert abs(loss - f(p)) < 1e-9 and set(grads) == set(p)
+        for name, g in grads.items():
+            if isinstance(g, tuple):
+                g = O.dense_embedding_grad(g, p[name].shape[0])
+            for _ in range(6):
+                idx = tuple(rng.randint(0, s) for s in p[name].shape)
+                q = {k: v.copy() for k, v in p.items()}
+                q[name][idx] += 1e-6
+                up = f(q)
+                q[name][idx] -= 2e-6
+                num = (up - f(q)) / 2e-6
+                assert abs(num - g[idx]) < 1e-5 * max(1.0, abs(num)), (name, idx, num, g[idx])
+    finally:
+        O.F32 = old
+        O.FORGET_BIAS, O.L2_EPS, O.LOGIT_SCALE = old(1.0), old(1e-12), old(64.0)

@@ -19,7 +19,7 @@ rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 worst = dict(enc=0.0, raw=0.0, score=0.0, train=0.0)
 t_start = time.time()
 for case in range(n_cases):
-    mode = rng.choice(["dual-encoder", "shared-encoder", "source_only_cnn"], p=[0.5, 0.3, 0.2])
+    mode = rng.choice(["dual-encoder", "shared-encoder", "source_only_cnn", "source-encoder-only"], p=[0.4, 0.25, 0.2, 0.15])
     V = int(rng.choice([17, 90, 500, 3000]))
     E = int(rng.choice([3, 8, 30, 40, 50, 64]))
     Hs = int(rng.choice([5, 32, 96, 128, 200, 256]))
@@ -40,7 +40,7 @@ for case in range(n_cases):
             err = float(np.abs(got - want).max() / max(1.0, np.abs(want).max()))
             worst["enc" if normalize else "raw"] = max(worst["enc" if normalize else "raw"], err)
             assert err < 1e-4, ("encode src", normalize, err)
-        if mode != "source_only_cnn":
+        if mode in ("dual-encoder", "shared-encoder"):
             tgt = random_ids(rng, N, T, V, pad)
             want_t = O.encode(p, params, "tgt", tgt)
             got_t = m.encode_target(tgt)
@@ -69,7 +69,8 @@ for case in range(n_cases):
             Bt = B - B % 2
             z = np.tile(np.array([1.0, 0.0], np.float32), Bt // 2)
             tsrc = src[:Bt]
-            ttgt = rng.randint(0, N, size=Bt).astype(np.int32) if mode == "source_only_cnn" else random_ids(rng, Bt, T, V, pad)
+            ttgt = (rng.randint(0, N, size=Bt).astype(np.int32) if mode in ("source_only_cnn", "source-encoder-only")
+                    else random_ids(rng, Bt, T, V, pad))
             st = O.new_optimizer_state(p)
             wl, wa = O.train_step(p, st, params, tsrc, ttgt, z, 0.5)
             m.handle.learning_rate = 0.5
