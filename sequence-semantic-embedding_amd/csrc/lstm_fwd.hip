@@ -395,11 +395,27 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
     for (int r = 0; r < 16; ++r) pacc[i][r] = 0.0f;
     if (nt < a.NTS) {
       const float *mp = a.Mp + (size_t)nt * KGh * 256 + lane * 4;
-      for (int kg = 0; kg < KGh; ++kg) {
-        const f32x4 a4 = *reinterpret_cast<const f32x4 *>(hp + kg * 256);
-        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(mp + kg * 256);
+      // two named operand sets (as in gemm_pass): M fragments come from L2, keep the next one in flight
+      f32x4 ax = *reinterpret_cast<const f32x4 *>(hp), bx = *reinterpret_cast<const f32x4 *>(mp), ay, by;
+      int kg = 0;
+      for (; kg + 1 < KGh; kg += 2) {
+        ay = *reinterpret_cast<const f32x4 *>(hp + (kg + 1) * 256);
+        by = *reinterpret_cast<const f32x4 *>(mp + (kg + 1) * 256);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], pacc[i], 0, 0, 0);
+        for (int e = 0; e < 4; ++e) pacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[e], pacc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int k2 = (kg + 2 < KGh) ? kg + 2 : kg;
+        ax = *reinterpret_cast<const f32x4 *>(hp + k2 * 256);
+        bx = *reinterpret_cast<const f32x4 *>(mp + k2 * 256);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[e], by[e], pacc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (kg < KGh) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[e], pacc[i], 0, 0, 0);
       }
       if (a.normalize) {
 #pragma unroll
