@@ -519,14 +519,27 @@ __global__ __launch_bounds__(64) void dx_kernel(DxArgs a) {
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-  for (int kg = 0; kg < a.KGn; ++kg) {
-    const f32x4 a4 = *reinterpret_cast<const f32x4 *>(pa + kg * 256);
-    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(pb + kg * 256);
-    const f32x4 b1 = *reinterpret_cast<const f32x4 *>(pb + (size_t)(a.KGn + kg) * 256);
+  // the dG tile streams from HBM: a ring of 4 k-groups of operands in flight (KGn = Hp/2 is a multiple of 4)
+  constexpr int RING = 4;
+  f32x4 ra[RING], rb0[RING], rb1[RING];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b0[e], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b1[e], acc[1], 0, 0, 0);
+  for (int d = 0; d < RING; ++d) {
+    ra[d] = *reinterpret_cast<const f32x4 *>(pa + d * 256);
+    rb0[d] = *reinterpret_cast<const f32x4 *>(pb + d * 256);
+    rb1[d] = *reinterpret_cast<const f32x4 *>(pb + (size_t)(a.KGn + d) * 256);
+  }
+  for (int kg0 = 0; kg0 < a.KGn; kg0 += RING) {
+#pragma unroll
+    for (int d = 0; d < RING; ++d) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[d][e], rb0[d][e], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[d][e], rb1[d][e], acc[1], 0, 0, 0);
+      }
+      const int kn = (kg0 + d + RING < a.KGn) ? kg0 + d + RING : kg0 + d;  // clamped: harmless reload at the end
+      ra[d] = *reinterpret_cast<const f32x4 *>(pa + kn * 256);
+      rb0[d] = *reinterpret_cast<const f32x4 *>(pb + kn * 256);
+      rb1[d] = *reinterpret_cast<const f32x4 *>(pb + (size_t)(a.KGn + kn) * 256);
     }
   }
   float sq = 0.0f;
