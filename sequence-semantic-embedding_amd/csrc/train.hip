@@ -391,6 +391,29 @@ struct DkArgs {
   int32_t RG, KT, NTn, SL;
 };
 
+// KT fragments of one LDS stage, software-pipelined one fragment ahead of its 4 MFMAs (used twice in the kernel)
+#define DK_COMPUTE(CUR)                                                                                       \
+  {                                                                                                             \
+    const float *sa = &stage[CUR][0][lane * 4];                                                                 \
+    f32x4 ax = *reinterpret_cast<const f32x4 *>(sa), ay;                                                        \
+    __builtin_amdgcn_s_setprio(1);                                                                              \
+    _Pragma("unroll") for (int i = 0; i < KT; i += 2) {                                                         \
+      if (i + 1 < KT) ay = *reinterpret_cast<const f32x4 *>(sa + (i + 1) * 256);                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                             \
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bc[e], acc[i], 0, 0, 0);                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+      if (i + 2 < KT) ax = *reinterpret_cast<const f32x4 *>(sa + (i + 2) * 256);                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+      if (i + 1 < KT) {                                                                                         \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                           \
+            acc[i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[e], bc[e], acc[i + 1], 0, 0, 0);               \
+      }                                                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+    }                                                                                                           \
+    __builtin_amdgcn_s_setprio(0);                                                                              \
+  }
+
 template <int KT>
 __global__ __launch_bounds__(512) void dk_gemm_kernel(DkArgs a) {
   // The KT A fragments of an r-group are the same for all 8 waves: they are fetched ONCE per workgroup
@@ -402,7 +425,7 @@ __global__ __launch_bounds__(512) void dk_gemm_kernel(DkArgs a) {
   const int nt = min(blockIdx.x * 8 + w, a.NTn - 1);  // surplus waves recompute the last tile (no divergent barriers)
   const bool live = blockIdx.x * 8 + w < a.NTn;
   const int slice = blockIdx.y;
-  const int per = (a.RG + a.SL - 1) / a.SL;
+  const int per = ((a.RG + a.SL - 1) / a.SL + 1) & ~1;  // even; RG = T*NT32*4 is a multiple of 4: every slice is even
   const int rg0 = slice * per, rg1 = min(a.RG, rg0 + per);
   f32x16 acc[KT];
 #pragma unroll
@@ -422,43 +445,33 @@ __global__ __launch_bounds__(512) void dk_gemm_kernel(DkArgs a) {
     if (second) *reinterpret_cast<f32x4 *>(&stage[buf][8 + w][lane * 4]) = s1;
   };
   if (rg0 < rg1) {
-    f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, bc, bn;
-    gload_a(rg0, s0, s1);
+    // Operands are requested TWO r-groups ahead (two named register sets, X and Y, used alternately): under the
+    // streaming load of this kernel an HBM access takes longer than one r-group of MFMAs (clock64: the hand-over
+    // below waited 20-30 % of the kernel when the distance was one).
+    f32x4 xs0 = {0, 0, 0, 0}, xs1 = {0, 0, 0, 0}, xb, ys0 = {0, 0, 0, 0}, ys1 = {0, 0, 0, 0}, yb, bc;
+    auto clampr = [&](int rg) { return rg < rg1 ? rg : rg1 - 1; };
+    gload_a(rg0, xs0, xs1);
     bc = *reinterpret_cast<const f32x4 *>(pb + (size_t)rg0 * a.NTn * 256);
-    stash(0, s0, s1);
-    const int r1 = (rg0 + 1 < rg1) ? rg0 + 1 : rg0;
-    gload_a(r1, s0, s1);
-    bn = *reinterpret_cast<const f32x4 *>(pb + (size_t)r1 * a.NTn * 256);
+    stash(0, xs0, xs1);
+    gload_a(clampr(rg0 + 1), xs0, xs1);
+    xb = *reinterpret_cast<const f32x4 *>(pb + (size_t)clampr(rg0 + 1) * a.NTn * 256);
+    gload_a(clampr(rg0 + 2), ys0, ys1);
+    yb = *reinterpret_cast<const f32x4 *>(pb + (size_t)clampr(rg0 + 2) * a.NTn * 256);
     __syncthreads();
-    for (int rg = rg0; rg < rg1; ++rg) {
-      const int cur = (rg - rg0) & 1;
-      const float *sa = &stage[cur][0][lane * 4];
-      // KT fragments from LDS, software-pipelined one fragment ahead of its 4 MFMAs
-      f32x4 ax = *reinterpret_cast<const f32x4 *>(sa), ay;
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < KT; i += 2) {
-        if (i + 1 < KT) ay = *reinterpret_cast<const f32x4 *>(sa + (i + 1) * 256);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bc[e], acc[i], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i + 2 < KT) ax = *reinterpret_cast<const f32x4 *>(sa + (i + 2) * 256);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i + 1 < KT) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[e], bc[e], acc[i + 1], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      __builtin_amdgcn_s_setprio(0);
-      // hand over: the r-group fetched one iteration ago goes into the other stage, the next one is requested
-      if (rg + 1 < rg1) stash(cur ^ 1, s0, s1);
-      bc = bn;
-      if (rg + 2 < rg1) {
-        gload_a(rg + 2, s0, s1);
-        bn = *reinterpret_cast<const f32x4 *>(pb + (size_t)(rg + 2) * a.NTn * 256);
-      }
+    for (int rg = rg0; rg < rg1; rg += 2) {
+      // even step: stage 0 holds r-group rg; set X holds rg+1 (to stage 1), then refetches rg+3
+      DK_COMPUTE(0)
+      if (rg + 1 < rg1) stash(1, xs0, xs1);
+      bc = xb;
+      gload_a(clampr(rg + 3), xs0, xs1);
+      xb = *reinterpret_cast<const f32x4 *>(pb + (size_t)clampr(rg + 3) * a.NTn * 256);
+      __syncthreads();
+      // odd step: stage 1 holds rg+1; set Y holds rg+2 (to stage 0), then refetches rg+4
+      DK_COMPUTE(1)
+      if (rg + 2 < rg1) stash(0, ys0, ys1);
+      bc = yb;
+      gload_a(clampr(rg + 4), ys0, ys1);
+      yb = *reinterpret_cast<const f32x4 *>(pb + (size_t)clampr(rg + 4) * a.NTn * 256);
       __syncthreads();
     }
   }
