@@ -146,11 +146,17 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # SSE_BENCH_FORCE_DIST=1: run every N>1 code path (process group, barriers, max-over-ranks, all-gather + merge,
+    # gradient all-reduce) in a 1-rank RCCL group -- a single-GPU box can then check the multi-GPU branches
+    force_dist = os.environ.get("SSE_BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -196,7 +202,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     h.synchronize()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -230,7 +236,7 @@ def main():
         noise = torch.randn((Q, S), generator=gq, device=dev)
         mine = torch.arange(Q, device=dev)[torch.arange(Q, device=dev) % world == rank]
         shard[mine] = torch.nn.functional.normalize(q[mine] + 0.1 * noise[mine], dim=1)   # planted: query j -> shard j%world, row j
-        sharded = sse_amd.ShardedIndex(h, rank, world, Ns * world)
+        sharded = sse_amd.ShardedIndex(h, rank, world, Ns * world, always_gather=force_dist)
         sharded.set_local_rows(shard)
         del shard
         state = {}
@@ -245,7 +251,7 @@ def main():
             score_step()
         barrier()
         sdt = (time.perf_counter() - ts) / args.score_iters
-        if world > 1:
+        if use_dist:
             t = torch.tensor([sdt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             sdt = float(t.item())
@@ -269,7 +275,7 @@ def main():
         tsrc[:, -1] = 1
         ttgt[:, -1] = 1
         tz = np.tile(np.array([1.0, 0.0], np.float32), Bt // 2)
-        trainer = sse_amd.DataParallelTrainer(h, device=dev)
+        trainer = sse_amd.DataParallelTrainer(h, device=dev, always_reduce=force_dist)
         tl = trainer.train_step(tsrc, ttgt, tz, rows_global=Bt * world)
         barrier()
         ts = time.perf_counter()
@@ -277,7 +283,7 @@ def main():
             tl = trainer.train_step(tsrc, ttgt, tz, rows_global=Bt * world)
         barrier()
         tdt = (time.perf_counter() - ts) / args.train_iters
-        if world > 1:
+        if use_dist:
             t = torch.tensor([tdt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             tdt = float(t.item())
@@ -316,8 +322,15 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
-        print(json.dumps(line))
-    if world > 1:
+        # RCCL (NCCL_DEBUG=VERSION on the GPU boxes) prints its banner through C stdio, which would otherwise be
+        # flushed at exit, AFTER this line: push it out first so that the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
+    if use_dist:
         dist.destroy_process_group()
 
 
