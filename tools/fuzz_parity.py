@@ -14,79 +14,87 @@ import sse_amd  # noqa: E402
 from oracle import sse_oracle as O  # noqa: E402
 from tests.util import make_pair, model_params, random_ids  # noqa: E402
 
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-worst = dict(enc=0.0, raw=0.0, score=0.0, train=0.0)
-t_start = time.time()
-for case in range(n_cases):
-    mode = rng.choice(["dual-encoder", "shared-encoder", "source_only_cnn", "source-encoder-only"], p=[0.4, 0.25, 0.2, 0.15])
-    V = int(rng.choice([17, 90, 500, 3000]))
-    E = int(rng.choice([3, 8, 30, 40, 50, 64]))
-    Hs = int(rng.choice([5, 32, 96, 128, 200, 256]))
-    Ht = Hs if mode == "shared-encoder" else int(rng.choice([7, 64, 96, 128, 256]))
-    S = int(rng.choice([2, 16, 50, 64, 100, 256]))
-    T = int(rng.choice([5, 6, 13, 32, 50, 80]))
-    B = int(rng.choice([1, 2, 3, 31, 33, 64, 65, 200]))
-    N = int(rng.choice([1, 5, 33, 571]))
-    pad = float(rng.choice([0.0, 0.5, 0.95]))
-    params = model_params(mode, V, E, Hs, Ht, S, T, N=N, lr=0.5)
-    tag = "%s V=%d E=%d Hs=%d Ht=%d S=%d T=%d B=%d N=%d pad=%.2f" % (mode, V, E, Hs, Ht, S, T, B, N, pad)
-    try:
-        m, p = make_pair(params, seed=int(rng.randint(1 << 30)))
-        src = random_ids(rng, B, T, V, pad)
-        for normalize in (True, False):
-            want = O.encode(p, params, "src", src, normalize=normalize)
-            got = m.encode_source(src, normalize=normalize)
-            err = float(np.abs(got - want).max() / max(1.0, np.abs(want).max()))
-            worst["enc" if normalize else "raw"] = max(worst["enc" if normalize else "raw"], err)
-            assert err < 1e-4, ("encode src", normalize, err)
-        if mode in ("dual-encoder", "shared-encoder"):
-            tgt = random_ids(rng, N, T, V, pad)
-            want_t = O.encode(p, params, "tgt", tgt)
-            got_t = m.encode_target(tgt)
-            assert np.abs(got_t - want_t).max() < 1e-4, "encode tgt"
-        else:
-            got_t = m.encode_target(np.zeros((N, T), np.int32))
-        # scoring on the GPU's own encodings (identical inputs on both sides)
-        k = min(10, N)
-        ns = m.encode_source(src)
-        idx64 = got_t.astype(np.float64)
-        m.handle.index_upload(idx64)
-        sc, ids = m.handle.score_topk(ns, k)
-        wsc, wids = O.topk(O.scores_f64(ns, idx64), k)
-        worst["score"] = max(worst["score"], float(np.abs(sc - wsc).max()))
-        assert np.abs(sc - wsc).max() < 1e-12
-        # duplicate target rows (heavy padding) tie exactly on the GPU; numpy's BLAS may order them by last-bit noise:
-        # ids must agree wherever the neighbouring scores are distinct
-        tie = np.zeros_like(ids, bool)
-        tie[:, 1:] |= np.abs(np.diff(wsc, axis=1)) < 1e-12
-        tie[:, :-1] |= np.abs(np.diff(wsc, axis=1)) < 1e-12
-        if k == N:
-            assert all(sorted(a) == sorted(b) for a, b in zip(ids.tolist(), wids.tolist())), "top-k id sets"
-        assert np.array_equal(ids[~tie], wids[~tie]), "top-k ids"
-        # one training step
-        if Hs <= 256 and Ht <= 256 and B >= 2:
-            Bt = B - B % 2
-            z = np.tile(np.array([1.0, 0.0], np.float32), Bt // 2)
-            tsrc = src[:Bt]
-            ttgt = (rng.randint(0, N, size=Bt).astype(np.int32) if mode in ("source_only_cnn", "source-encoder-only")
-                    else random_ids(rng, Bt, T, V, pad))
-            st = O.new_optimizer_state(p)
-            wl, wa = O.train_step(p, st, params, tsrc, ttgt, z, 0.5)
-            m.handle.learning_rate = 0.5
-            gl, ga = m.train_step(tsrc, ttgt, z)
-            assert abs(gl - float(wl)) < 1e-4 * max(1.0, abs(float(wl))), ("loss", gl, wl)
-            got = m.get_variables()
-            for name, w in p.items():
-                d = float(np.abs(got[name].reshape(w.shape) - w).max())
-                worst["train"] = max(worst["train"], d)
-                # CNN: two pooled positions within fp32 rounding of each other may route one filter's gradient to a
-                # different window (gradients otherwise agree to 1e-7, tools/dbg_cnn_grads.py): looser bound there
-                assert d < (5e-3 if mode == "source_only_cnn" else 1e-3), ("train", name, d)
-        print("ok   %s" % tag)
-    except Exception as ex:                                       # keep sweeping; the summary line reports
-        print("FAIL %s: %r" % (tag, ex))
-        worst.setdefault("failures", 0)
-        worst["failures"] += 1
-    sys.stdout.flush()
-print("fuzz summary: %d cases in %.0f s, failures %d, worst errors %s" % (n_cases, time.time() - t_start, worst.get("failures", 0), worst))
+
+def main(n_cases=40, seed=0, verbose=True):
+    """Runs the sweep; returns (failures, worst-error dict)."""
+    rng = np.random.RandomState(seed)
+    worst = dict(enc=0.0, raw=0.0, score=0.0, train=0.0)
+    t_start = time.time()
+    for case in range(n_cases):
+        mode = rng.choice(["dual-encoder", "shared-encoder", "source_only_cnn", "source-encoder-only"], p=[0.4, 0.25, 0.2, 0.15])
+        V = int(rng.choice([17, 90, 500, 3000]))
+        E = int(rng.choice([3, 8, 30, 40, 50, 64]))
+        Hs = int(rng.choice([5, 32, 96, 128, 200, 256]))
+        Ht = Hs if mode == "shared-encoder" else int(rng.choice([7, 64, 96, 128, 256]))
+        S = int(rng.choice([2, 16, 50, 64, 100, 256]))
+        T = int(rng.choice([5, 6, 13, 32, 50, 80]))
+        B = int(rng.choice([1, 2, 3, 31, 33, 64, 65, 200]))
+        N = int(rng.choice([1, 5, 33, 571]))
+        pad = float(rng.choice([0.0, 0.5, 0.95]))
+        params = model_params(mode, V, E, Hs, Ht, S, T, N=N, lr=0.5)
+        tag = "%s V=%d E=%d Hs=%d Ht=%d S=%d T=%d B=%d N=%d pad=%.2f" % (mode, V, E, Hs, Ht, S, T, B, N, pad)
+        try:
+            m, p = make_pair(params, seed=int(rng.randint(1 << 30)))
+            src = random_ids(rng, B, T, V, pad)
+            for normalize in (True, False):
+                want = O.encode(p, params, "src", src, normalize=normalize)
+                got = m.encode_source(src, normalize=normalize)
+                err = float(np.abs(got - want).max() / max(1.0, np.abs(want).max()))
+                worst["enc" if normalize else "raw"] = max(worst["enc" if normalize else "raw"], err)
+                assert err < 1e-4, ("encode src", normalize, err)
+            if mode in ("dual-encoder", "shared-encoder"):
+                tgt = random_ids(rng, N, T, V, pad)
+                want_t = O.encode(p, params, "tgt", tgt)
+                got_t = m.encode_target(tgt)
+                assert np.abs(got_t - want_t).max() < 1e-4, "encode tgt"
+            else:
+                got_t = m.encode_target(np.zeros((N, T), np.int32))
+            # scoring on the GPU's own encodings (identical inputs on both sides)
+            k = min(10, N)
+            ns = m.encode_source(src)
+            idx64 = got_t.astype(np.float64)
+            m.handle.index_upload(idx64)
+            sc, ids = m.handle.score_topk(ns, k)
+            wsc, wids = O.topk(O.scores_f64(ns, idx64), k)
+            worst["score"] = max(worst["score"], float(np.abs(sc - wsc).max()))
+            assert np.abs(sc - wsc).max() < 1e-12
+            # duplicate target rows (heavy padding) tie exactly on the GPU; numpy's BLAS may order them by last-bit noise:
+            # ids must agree wherever the neighbouring scores are distinct
+            tie = np.zeros_like(ids, bool)
+            tie[:, 1:] |= np.abs(np.diff(wsc, axis=1)) < 1e-12
+            tie[:, :-1] |= np.abs(np.diff(wsc, axis=1)) < 1e-12
+            if k == N:
+                assert all(sorted(a) == sorted(b) for a, b in zip(ids.tolist(), wids.tolist())), "top-k id sets"
+            assert np.array_equal(ids[~tie], wids[~tie]), "top-k ids"
+            # one training step
+            if Hs <= 256 and Ht <= 256 and B >= 2:
+                Bt = B - B % 2
+                z = np.tile(np.array([1.0, 0.0], np.float32), Bt // 2)
+                tsrc = src[:Bt]
+                ttgt = (rng.randint(0, N, size=Bt).astype(np.int32) if mode in ("source_only_cnn", "source-encoder-only")
+                        else random_ids(rng, Bt, T, V, pad))
+                st = O.new_optimizer_state(p)
+                wl, wa = O.train_step(p, st, params, tsrc, ttgt, z, 0.5)
+                m.handle.learning_rate = 0.5
+                gl, ga = m.train_step(tsrc, ttgt, z)
+                assert abs(gl - float(wl)) < 1e-4 * max(1.0, abs(float(wl))), ("loss", gl, wl)
+                got = m.get_variables()
+                for name, w in p.items():
+                    d = float(np.abs(got[name].reshape(w.shape) - w).max())
+                    worst["train"] = max(worst["train"], d)
+                    # CNN: two pooled positions within fp32 rounding of each other may route one filter's gradient to a
+                    # different window (gradients otherwise agree to 1e-7, tools/dbg_cnn_grads.py): looser bound there
+                    assert d < (5e-3 if mode == "source_only_cnn" else 1e-3), ("train", name, d)
+            if verbose:
+                print("ok   %s" % tag)
+        except Exception as ex:                                       # keep sweeping; the summary line reports
+            print("FAIL %s: %r" % (tag, ex))
+            worst.setdefault("failures", 0)
+            worst["failures"] += 1
+        sys.stdout.flush()
+    print("fuzz summary: %d cases in %.0f s, failures %d, worst errors %s" % (n_cases, time.time() - t_start, worst.get("failures", 0), worst))
+    return worst.get("failures", 0), worst
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
