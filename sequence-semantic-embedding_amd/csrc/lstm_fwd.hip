@@ -122,9 +122,13 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   constexpr int NWR = 8 / RT;                   // waves sharing one row tile (projection tail)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // first unit block owned by this wave (further ones at +8), and its first row tile
-  const int ub0 = (RT == 2 && MT == 1) ? (w & 3) : w;
-  const int mt0 = (RT == 2 && MT == 1) ? (w >> 2) : 0;
+  // <2,1,1>: wave w -> unit block w>>1, row tile w&1.  Waves are placed on SIMD w%4, so the live unit blocks of a
+  // small cell (H <= 64: blocks 0,1 -> waves 0..3) land on four different SIMDs and the padding-only blocks, which
+  // are not computed at all in inference, leave no SIMD with two busy waves.
+  const int ub0 = (RT == 2 && MT == 1) ? (w >> 1) : w;
+  const int mt0 = (RT == 2 && MT == 1) ? (w & 1) : 0;
   const int KGx = a.KGx, KGh = a.KGh, KG = KGx + KGh, T = a.T;
+  const int KGhe = (a.KGhe > 0 && a.KGhe < KGh) ? a.KGhe : KGh;
   // LDS.  LIN (x double-buffered, fits 160 KiB): A tiles [2 bufs][RT][KG][256], the x part of
   // a row tile followed by its h part, so a k-loop walks one linear array.  Otherwise:
   // x [RT][KGx][256] single-buffered, then h [2 bufs][RT][KGh][256].
@@ -267,11 +271,26 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
         *reinterpret_cast<f32x4 *>(dst) = v;
       }
     }
-    const int kend = (t == 0) ? KGx : KG;  // h_{-1} = 0: skip the recurrent part of step 0
+    // h_{-1} = 0: skip the recurrent part of step 0; hidden units >= H are padding whose state stays exactly 0,
+    // so their k-groups are skipped in every step (H = 96 in 128 slots: 19 instead of 23 k-groups)
+    const int kend = (t == 0) ? KGx : KGx + KGhe;
 
 #pragma unroll
     for (int u = 0; u < UBW; ++u) {
       const int ub = ub0 + 8 * u;
+      // a unit block made only of padding (units >= H) keeps c = h = 0 and its h slots are never read (k-groups
+      // >= KGhe are skipped): nothing to compute.  Training keeps it (the tapes cover all Hp units).
+      if (!TRAIN && a.H > 0 && ub * 32 >= a.H) {
+        // (the wave still delivers its share of the x_{t+1} gather, which normally rides between the two passes)
+        if (u == 0 && XD && have_next) {
+          if (xq < KGx) x_store(nxt, xq, nlo, nhi);
+          for (int kg = xq + TPR; kg < KGx; kg += TPR) {
+            const float *src = a.emb + (size_t)nid * a.Ep + kg * 8;
+            x_store(nxt, kg, *reinterpret_cast<const f32x4 *>(src), *reinterpret_cast<const f32x4 *>(src + 4));
+          }
+        }
+        continue;
+      }
       const int unit = ub * 32 + (lane & 31);
       const int hoff = (unit >> 3) * 256 + ((((unit >> 2) & 1) * 32) << 2) + (unit & 3);  // h element (row 0, k = unit) in a row tile
       const int wsoff = __builtin_amdgcn_readfirstlane(ub) * KG * 4096;
@@ -398,14 +417,14 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       // two named operand sets (as in gemm_pass): M fragments come from L2, keep the next one in flight
       f32x4 ax = *reinterpret_cast<const f32x4 *>(hp), bx = *reinterpret_cast<const f32x4 *>(mp), ay, by;
       int kg = 0;
-      for (; kg + 1 < KGh; kg += 2) {
+      for (; kg + 1 < KGhe; kg += 2) {
         ay = *reinterpret_cast<const f32x4 *>(hp + (kg + 1) * 256);
         by = *reinterpret_cast<const f32x4 *>(mp + (kg + 1) * 256);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) pacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[e], pacc[i], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        const int k2 = (kg + 2 < KGh) ? kg + 2 : kg;
+        const int k2 = (kg + 2 < KGhe) ? kg + 2 : kg;
         ax = *reinterpret_cast<const f32x4 *>(hp + k2 * 256);
         bx = *reinterpret_cast<const f32x4 *>(mp + k2 * 256);
         __builtin_amdgcn_sched_barrier(0);
@@ -413,7 +432,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
         for (int e = 0; e < 4; ++e) pacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[e], by[e], pacc[i], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (kg < KGh) {
+      if (kg < KGhe) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) pacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[e], pacc[i], 0, 0, 0);
       }

@@ -235,6 +235,8 @@ void fill_fwd_args(sse_handle *h, Encoder &e, LstmFwdArgs &a) {
   a.Ep = e.Ep;
   a.KGx = e.KGx;
   a.KGh = e.KGh;
+  a.H = e.H;
+  a.KGhe = (e.H + 7) / 8;
   a.S = c.encoding_size;
   a.NTS = (c.encoding_size + 31) / 32;
 }
@@ -993,6 +995,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     a.Ep = e.Ep;
     a.KGx = e.KGx;
     a.KGh = e.KGh;
+    a.KGhe = (e.H + 7) / 8;
     a.S = S;
     a.NTS = (S + 31) / 32;
     a.normalize = 0;

@@ -40,6 +40,8 @@ struct LstmFwdArgs {
   float *out;           // [B][S]
   int32_t *err;         // bit 0: token id out of range
   int32_t B, T, V, Ep, KGx, KGh, S, NTS, normalize;
+  int32_t H = 0;        // real cell size (0: Hp); unit blocks made only of padding are not computed in inference
+  int32_t KGhe = 0;     // k-groups of h that can be non-zero = ceil(H/8) (0: all KGh); units >= H stay exactly 0
   int32_t NT32 = 0;     // training: number of 32-row tiles the tapes are laid out for (0: from the grid)
   int32_t xdouble = 1;  // set by launch_lstm_fwd from lstm_fwd_x_double()
   // Left-pad prefix skip (exact): the state after p leading PAD (id 0) steps does not depend on
