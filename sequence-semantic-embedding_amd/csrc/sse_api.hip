@@ -1045,13 +1045,13 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     HIPCHECK(h, launch_proj_bwd((const float *)ts.h_last[s].p, (const float *)ts.draw[s].p, h->vars[e.proj].dev, Bp, e.H, Hp,
                                 S, h->vars[e.proj].grad, (float *)ts.dh_last[s].p, (float *)ts.dm_part[s].p, bs));
     HIPCHECK(h, launch_lstm_bwd((const float *)ts.tape_g[s].p, (const float *)ts.dh_last[s].p, ts.KhT[s],
-                                (float *)ts.dg_a[s].p, (float *)ts.dg_b[s].p, (float *)ts.db_part[s].p, T, NT32, Hp, bs));
+                                (float *)ts.dg_a[s].p, (float *)ts.dg_b[s].p, (float *)ts.db_part[s].p, T, NT32, Hp, e.H, bs));
     const int accumulate = (shared && s == 1) ? 1 : 0;
     HIPCHECK(h, launch_dk((const float *)ts.tape_a[s].p, (const float *)ts.dg_b[s].p, (float *)ts.dk_part[s].p, RG, KT, NTn, SL,
                           E, e.H, Hp, accumulate, h->vars[e.kernel].grad, bs));
     HIPCHECK(h, launch_db_reduce((const float *)ts.db_part[s].p, NT32, e.H, Hp, accumulate, h->vars[e.bias].grad, bs));
     HIPCHECK(h, launch_dx((const float *)ts.dg_a[s].p, ts.KxT[s], (const int32_t *)ts.ids[s].p, emb.grad,
-                          (float *)ts.sq_part.p + (size_t)s * T * NT32, T, NT32, KGn, B, E, V, bs));
+                          (float *)ts.sq_part.p + (size_t)s * T * NT32, T, NT32, KGn, B, E, V, e.H, bs));
     if (!shared || s == 1) {
       HIPCHECK(h, hipEventRecord(ts.ev_join[s], bs));
       HIPCHECK(h, hipStreamWaitEvent(st, ts.ev_join[s], 0));

@@ -207,6 +207,7 @@ struct LstmBwdArgs {
   float *dg_b;          // [(T*NT32*4)][NTn][256]
   float *db_part;       // [NT32][4*Hp] per-tile bias-gradient partials
   int32_t T, NT32, Hp;
+  int32_t H;            // real cell size: dG columns of padded units are exactly 0, their k-groups are skipped
 };
 
 template <int UB, int NW>
@@ -338,16 +339,20 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
       // in a register ring; the dg fragments come from LDS one k-group ahead.  KGn % PF == 0.
       constexpr int PF = 2;
       f32x4 bq[PF][UB], aq[2];
+      // reduction index n = gate*Hp + unit: only the k-groups of units < H can be non-zero -> walk
+      // 4 gates x KGl live k-groups (logical index i -> physical k-group); 4*KGl is even
+      const int KGg = Hp / 8, KGl = min(KGg, (a.H + 7) / 8), NL = 4 * KGl;
+      auto phys = [&](int i) { return (i / KGl) * KGg + i % KGl; };
 #pragma unroll
       for (int p = 0; p < PF; ++p)
 #pragma unroll
-        for (int u = 0; u < UB; ++u) bq[p][u] = *reinterpret_cast<const f32x4 *>(kb + ((size_t)u * KGn + p) * 256);
+        for (int u = 0; u < UB; ++u) bq[p][u] = *reinterpret_cast<const f32x4 *>(kb + ((size_t)u * KGn + phys(p)) * 256);
       aq[0] = *reinterpret_cast<const f32x4 *>(la);
       __builtin_amdgcn_s_setprio(1);
-      for (int kg = 0; kg < KGn; kg += PF) {
+      for (int kg = 0; kg < NL; kg += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-          const int kn = (kg + p + 1 < KGn) ? kg + p + 1 : kg + p;
+          const int kn = phys((kg + p + 1 < NL) ? kg + p + 1 : kg + p);
           aq[(p + 1) & 1] = *reinterpret_cast<const f32x4 *>(la + kn * 256);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
 #pragma unroll
             for (int u = 0; u < UB; ++u) dh[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[p & 1][e], bq[p][u][e], dh[u], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          const int kp = (kg + p + PF < KGn) ? kg + p + PF : kg + p;
+          const int kp = phys((kg + p + PF < NL) ? kg + p + PF : kg + p);
 #pragma unroll
           for (int u = 0; u < UB; ++u) bq[p][u] = *reinterpret_cast<const f32x4 *>(kb + ((size_t)u * KGn + kp) * 256);
         }
@@ -389,6 +394,7 @@ struct DkArgs {
   const float *dg_b;    // [(RG)][NTn][256]
   float *part;          // [SL][KT*32][NTn*32]
   int32_t RG, KT, NTn, SL;
+  uint32_t live_k;      // bit i: k'-tile i has non-padding rows (x: 2 tiles of 32 up to E; h: one per 32 units up to H)
 };
 
 // KT fragments of one LDS stage, software-pipelined one fragment ahead of its 4 MFMAs (used twice in the kernel)
@@ -400,12 +406,14 @@ struct DkArgs {
     _Pragma("unroll") for (int i = 0; i < KT; i += 2) {                                                         \
       if (i + 1 < KT) ay = *reinterpret_cast<const f32x4 *>(sa + (i + 1) * 256);                                \
       __builtin_amdgcn_sched_barrier(0);                                                                        \
-      _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                             \
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bc[e], acc[i], 0, 0, 0);                         \
+      if ((live_k >> i) & 1) {                                                                                  \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                           \
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bc[e], acc[i], 0, 0, 0);                       \
+      }                                                                                                         \
       __builtin_amdgcn_sched_barrier(0);                                                                        \
       if (i + 2 < KT) ax = *reinterpret_cast<const f32x4 *>(sa + (i + 2) * 256);                                \
       __builtin_amdgcn_sched_barrier(0);                                                                        \
-      if (i + 1 < KT) {                                                                                         \
+      if (i + 1 < KT && ((live_k >> (i + 1)) & 1)) {                                                            \
         _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                           \
             acc[i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[e], bc[e], acc[i + 1], 0, 0, 0);               \
       }                                                                                                         \
@@ -422,6 +430,7 @@ __global__ __launch_bounds__(512) void dk_gemm_kernel(DkArgs a) {
   __shared__ __attribute__((aligned(16))) float stage[2][KT][256];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t live_k = a.live_k;  // all-padding k'-tiles have all-zero A rows: their accumulators stay 0
   const int nt = min(blockIdx.x * 8 + w, a.NTn - 1);  // surplus waves recompute the last tile (no divergent barriers)
   const bool live = blockIdx.x * 8 + w < a.NTn;
   const int slice = blockIdx.y;
@@ -520,6 +529,7 @@ struct DxArgs {
   float *d_emb;        // [V][E] zero-initialised
   float *sq_part;      // [T*NT32] partial sums of dx^2
   int32_t T, NT32, KGn, B, E, V;
+  int32_t KGl;         // live k-groups per gate = ceil(H/8) (dG columns of padded units are 0)
 };
 
 __global__ __launch_bounds__(64) void dx_kernel(DxArgs a) {
@@ -535,13 +545,17 @@ __global__ __launch_bounds__(64) void dx_kernel(DxArgs a) {
   // the dG tile streams from HBM: a ring of 4 k-groups of operands in flight (KGn = Hp/2 is a multiple of 4)
   constexpr int RING = 4;
   f32x4 ra[RING], rb0[RING], rb1[RING];
+  // logical index over 4 gates x KGl live k-groups -> physical k-group (padding skipped); NL is a multiple of 4
+  const int KGg = a.KGn / 4, KGl = a.KGl, NL = 4 * KGl;
+  auto phys = [&](int i) { return (i / KGl) * KGg + i % KGl; };
 #pragma unroll
   for (int d = 0; d < RING; ++d) {
-    ra[d] = *reinterpret_cast<const f32x4 *>(pa + d * 256);
-    rb0[d] = *reinterpret_cast<const f32x4 *>(pb + d * 256);
-    rb1[d] = *reinterpret_cast<const f32x4 *>(pb + (size_t)(a.KGn + d) * 256);
+    const int k = phys(d < NL ? d : NL - 1);
+    ra[d] = *reinterpret_cast<const f32x4 *>(pa + k * 256);
+    rb0[d] = *reinterpret_cast<const f32x4 *>(pb + k * 256);
+    rb1[d] = *reinterpret_cast<const f32x4 *>(pb + (size_t)(a.KGn + k) * 256);
   }
-  for (int kg0 = 0; kg0 < a.KGn; kg0 += RING) {
+  for (int kg0 = 0; kg0 < NL; kg0 += RING) {
 #pragma unroll
     for (int d = 0; d < RING; ++d) {
 #pragma unroll
@@ -549,7 +563,7 @@ __global__ __launch_bounds__(64) void dx_kernel(DxArgs a) {
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[d][e], rb0[d][e], acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[d][e], rb1[d][e], acc[1], 0, 0, 0);
       }
-      const int kn = (kg0 + d + RING < a.KGn) ? kg0 + d + RING : kg0 + d;  // clamped: harmless reload at the end
+      const int kn = phys((kg0 + d + RING < NL) ? kg0 + d + RING : kg0 + d);  // clamped: harmless reload at the end
       ra[d] = *reinterpret_cast<const f32x4 *>(pa + kn * 256);
       rb0[d] = *reinterpret_cast<const f32x4 *>(pb + kn * 256);
       rb1[d] = *reinterpret_cast<const f32x4 *>(pb + (size_t)(a.KGn + kn) * 256);
@@ -668,8 +682,8 @@ hipError_t launch_proj_bwd(const float *hT, const float *d, const float *M, int 
 }
 
 hipError_t launch_lstm_bwd(const float *tape_g, const float *dh_last, const float *KhT, float *dg_a, float *dg_b,
-                           float *db_part, int T, int NT32, int Hp, hipStream_t st) {
-  LstmBwdArgs a{tape_g, dh_last, KhT, dg_a, dg_b, db_part, T, NT32, Hp};
+                           float *db_part, int T, int NT32, int Hp, int H, hipStream_t st) {
+  LstmBwdArgs a{tape_g, dh_last, KhT, dg_a, dg_b, db_part, T, NT32, Hp, H};
   const size_t lds = (size_t)(Hp / 2) * 256 * sizeof(float);
   if ((size_t)T * NT32 * (Hp / 32) * 5 * 1024 * sizeof(float) >= ((size_t)1 << 31)) return hipErrorInvalidValue;  // 32-bit tape offsets
   hipError_t e;
@@ -696,7 +710,12 @@ int dk_slices(int RG) {
 
 hipError_t launch_dk(const float *tape_a, const float *dg_b, float *part, int RG, int KT, int NTn, int SL, int E, int H,
                      int Hp, int accumulate, float *dK, hipStream_t st) {
-  DkArgs a{tape_a, dg_b, part, RG, KT, NTn, SL};
+  uint32_t live = 0;
+  for (int i = 0; i < KT; ++i) {
+    const bool on = (i < 2) ? (i * 32 < E) : ((i - 2) * 32 < H);
+    if (on) live |= 1u << i;
+  }
+  DkArgs a{tape_a, dg_b, part, RG, KT, NTn, SL, live};
   const dim3 grid((NTn + 7) / 8, SL);
   if (KT == 10) hipLaunchKernelGGL(dk_gemm_kernel<10>, grid, dim3(512), 0, st, a);
   else if (KT == 6) hipLaunchKernelGGL(dk_gemm_kernel<6>, grid, dim3(512), 0, st, a);
@@ -712,8 +731,9 @@ hipError_t launch_db_reduce(const float *db_part, int NT32, int H, int Hp, int a
 }
 
 hipError_t launch_dx(const float *dg_a, const float *KxT, const int32_t *ids, float *d_emb, float *sq_part, int T,
-                     int NT32, int KGn, int B, int E, int V, hipStream_t st) {
-  DxArgs a{dg_a, KxT, ids, d_emb, sq_part, T, NT32, KGn, B, E, V};
+                     int NT32, int KGn, int B, int E, int V, int H, hipStream_t st) {
+  const int KGg = KGn / 4;
+  DxArgs a{dg_a, KxT, ids, d_emb, sq_part, T, NT32, KGn, B, E, V, (H + 7) / 8 < KGg ? (H + 7) / 8 : KGg};
   hipLaunchKernelGGL(dx_kernel, dim3(T * NT32), dim3(64), 0, st, a);
   return hipGetLastError();
 }
