@@ -84,6 +84,9 @@ int sse_encode_dev(sse_handle *h, int side, const int32_t *ids_dev, int32_t B, i
  * every 64-row tile exactly -- the LSTM state after p leading PAD (id 0) steps is
  * sequence-independent (sse_index.py:79-85 left-pads; sse_model.py:240-242 runs all T steps),
  * so it is precomputed per p with the same kernel; results are bit-identical to pad_skip = 0.
+ * "cnn_bf16" (default 0; source_only_cnn only): the convolution of inference encodes reads embeddings and
+ * filters rounded to bf16 (fp32 accumulation, fp32 bias/ReLU/pool/projection) on the bf16 matrix pipe -- the
+ * reference has no reduced-precision behaviour; BASELINE configs[4] names bf16.  Training stays fp32.
  * "train_serial" (default 0): run both encoders of a train step on one stream (profiling aid:
  * isolated kernel durations; same results). */
 int sse_set_option(sse_handle *h, const char *name, int32_t value);

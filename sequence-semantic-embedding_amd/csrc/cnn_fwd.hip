@@ -315,6 +315,13 @@ hipError_t launch_pack_conv(const float *const W[4], int E, int Ep, float *out, 
   return hipGetLastError();
 }
 
+// projection tail alone (the bf16-storage convolution of cnn_fwd_bf16.hip feeds the same fp32 tail)
+hipError_t launch_cnn_proj(const float *featp, const float *Mp, float *out, int B, int S, int normalize, hipStream_t stream) {
+  ProjArgs p{featp, Mp, out, B, S, 72, (S + 31) / 32, normalize};
+  hipLaunchKernelGGL(proj_norm_kernel, dim3((B + 31) / 32), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
 hipError_t launch_cnn_fwd(const int32_t *ids, const float *emb, const float *Wc, const float *bias, const float *Mp,
                           float *featp, float *out, int32_t *err, int B, int T, int V, int Ep, int S, int normalize,
                           float *feat_rm, int32_t *pos, hipStream_t stream) {

@@ -74,6 +74,8 @@ struct sse_handle {
   Encoder enc[2];
   bool packed_dirty = true;
   bool pad_skip = true;      // option "pad_skip": exact left-pad prefix skip in inference encodes
+  bool cnn_bf16 = false;     // option "cnn_bf16": source_only_cnn inference with bf16 storage / fp32 accumulation
+  unsigned short *emb_bf16 = nullptr, *cnn_Wc16 = nullptr;
   bool train_serial = false; // option "train_serial": both encoders on one stream (profiling: isolated kernel times)
   float *emb_pad = nullptr;  // [V][Ep]
   // source_only_cnn
@@ -218,6 +220,12 @@ int ensure_packed(sse_handle *h, hipStream_t st) {
                                  hipMemcpyDeviceToDevice, st));
     }
     HIPCHECK(h, launch_pack_conv(W, c.embedding_size, Ep, h->cnn_Wc, st));
+    if (h->cnn_bf16) {
+      const int Ep8 = round_up(c.embedding_size, 8);
+      if (!h->emb_bf16) HIPCHECK(h, hipMalloc((void **)&h->emb_bf16, (size_t)c.vocab_size * Ep8 * sizeof(unsigned short)));
+      if (!h->cnn_Wc16) HIPCHECK(h, hipMalloc((void **)&h->cnn_Wc16, cnn_bf16_packed_weight_elems(Ep8) * sizeof(unsigned short)));
+      HIPCHECK(h, launch_cnn_bf16_pack(h->vars[0].dev, c.vocab_size, c.embedding_size, Ep8, h->emb_bf16, W, h->cnn_Wc16, st));
+    }
     HIPCHECK(h, launch_pack_kn(h->vars[h->cnn_M].dev, 576, c.encoding_size, 72, h->cnn_Mp, st));
   }
   h->packed_dirty = false;
@@ -302,6 +310,15 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
     if (cnn_lds_bytes(T, Ep, 0) > 160 * 1024)
       return fail(h, "source_only_cnn: T*E = %d*%d does not fit the LDS tile of the gfx950 kernel", T, c.embedding_size);
     if (reserve(h, h->s_feat, (size_t)((B + 31) / 32) * 72 * 256 * sizeof(float))) return 1;
+    if (h->cnn_bf16) {
+      const int Ep8 = round_up(c.embedding_size, 8);
+      if (cnn_bf16_lds_bytes(T, Ep8) > 160 * 1024)
+        return fail(h, "source_only_cnn (bf16): T*E = %d*%d does not fit the LDS tile of the gfx950 kernel", T, c.embedding_size);
+      HIPCHECK(h, launch_cnn_fwd_bf16(ids, h->emb_bf16, h->cnn_Wc16, h->cnn_bias, (float *)h->s_feat.p, h->err_flag, B, T,
+                                      c.vocab_size, Ep8, st));
+      HIPCHECK(h, launch_cnn_proj((const float *)h->s_feat.p, h->cnn_Mp, out, B, c.encoding_size, normalize ? 1 : 0, st));
+      return 0;
+    }
     HIPCHECK(h, launch_cnn_fwd(ids, h->emb_pad, h->cnn_Wc, h->cnn_bias, h->cnn_Mp, (float *)h->s_feat.p, out, h->err_flag, B,
                                T, c.vocab_size, Ep, c.encoding_size, normalize ? 1 : 0, nullptr, nullptr, st));
     return 0;
@@ -557,6 +574,8 @@ void sse_destroy(sse_handle *h) {
   if (h->idxp) hipFree(h->idxp);
   if (h->idx64) hipFree(h->idx64);
   if (h->cnn_Wc) (void)hipFree(h->cnn_Wc);
+  if (h->emb_bf16) (void)hipFree(h->emb_bf16);
+  if (h->cnn_Wc16) (void)hipFree(h->cnn_Wc16);
   if (h->cnn_bias) (void)hipFree(h->cnn_bias);
   if (h->cnn_Mp) (void)hipFree(h->cnn_Mp);
   if (h->train) {
@@ -670,6 +689,12 @@ int sse_encode(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int3
 int sse_set_option(sse_handle *h, const char *name, int32_t value) {
   if (!h || !name) return 1;
   std::lock_guard<std::mutex> lk(h->mu);
+  if (strcmp(name, "cnn_bf16") == 0) {
+    if (h->cfg.network_mode != SSE_MODE_SOURCE_ONLY_CNN) return fail(h, "option cnn_bf16 needs network_mode source_only_cnn");
+    h->cnn_bf16 = value != 0;
+    h->packed_dirty = true;  // (re)build the bf16 copies with the next encode
+    return 0;
+  }
   if (strcmp(name, "train_serial") == 0) {
     h->train_serial = value != 0;
     return 0;

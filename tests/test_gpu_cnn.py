@@ -117,3 +117,33 @@ def test_cnn_data_parallel_two_logical_ranks():
     for name, w in p.items():
         assert np.array_equal(g0[name], g1[name]), name
         assert np.abs(g0[name].reshape(w.shape) - w).max() < 5e-4, name
+
+
+@pytest.mark.parametrize("V,E,S,T,B", [(300, 50, 512, 64, 37), (100, 30, 64, 80, 9), (60, 8, 16, 5, 3), (150, 64, 64, 80, 21)])
+def test_cnn_bf16_storage_variant_matches_bf16_oracle(V, E, S, T, B):
+    """Option cnn_bf16 (BASELINE configs[4] names bf16; builder-defined precision): embeddings and filters rounded
+    to bf16, fp32 accumulation -> equals the oracle with the same rounding to fp32 accumulation error, and stays
+    within bf16 storage error of the fp32 encoding."""
+    params = model_params("source_only_cnn", V, E, 96, 96, S, T, N=11)
+    m, p = make_pair(params, seed=2)
+    ids = random_ids(np.random.RandomState(4), B, T, V, pad_frac=0.5)
+    exact = m.encode_source(ids)
+    m.handle.set_option("cnn_bf16", 1)
+    for normalize in (True, False):
+        want = O.encode(p, params, "src", ids, normalize=normalize, cnn_bf16=True)
+        got = m.encode_source(ids, normalize=normalize)
+        scale = 1.0 if normalize else max(1.0, float(np.abs(want).max()))
+        assert np.abs(got - want).max() <= 1e-4 * scale
+    got = m.encode_source(ids)
+    assert 0 < np.abs(got - exact).max() < 3e-2                      # genuinely a different precision, and a close one
+    cos = np.sum(got * exact, axis=1)
+    assert cos.min() > 0.9995
+    m.handle.set_option("cnn_bf16", 0)
+    assert np.array_equal(m.encode_source(ids), exact)               # back to the exact fp32 path
+
+
+def test_cnn_bf16_option_is_rejected_outside_cnn_mode():
+    import sse_amd
+    m, _ = make_pair(model_params("dual-encoder", 50, 8, 16, 16, 8, 5), seed=0)
+    with pytest.raises(sse_amd.SSEError):
+        m.handle.set_option("cnn_bf16", 1)

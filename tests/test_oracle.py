@@ -260,3 +260,13 @@ def test_source_encoder_only_gradients_finite_difference():
     finally:
         O.F32 = old
         O.FORGET_BIAS, O.L2_EPS, O.LOGIT_SCALE = old(1.0), old(1e-12), old(64.0)
+
+
+def test_bf16_round_is_round_to_nearest_even():
+    x = np.array([1.0, 1.00390625, 1.001953125, 1.005859375, -2.5, 3.0e38, 1e-30, 0.0], np.float32)
+    r = O.bf16_round(x)
+    assert r[0] == 1.0 and r[1] == np.float32(1.0) and r[2] == np.float32(1.0)      # 1 + 2^-8 ties to even (1.0); 1 + 2^-9 rounds down
+    assert r[3] == np.float32(1.0078125)                                             # 1 + 1.5 * 2^-8 rounds up to 1 + 2^-7
+    assert np.all((r.view(np.uint32) & 0xFFFF) == 0) and np.all(np.abs(r - x) <= np.abs(x) * 2.0 ** -8)
+    torch_r = torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
+    assert np.array_equal(r, torch_r)

@@ -31,6 +31,18 @@ ms = h.timer_elapsed_ms(0, 1) / n
 print("CNN encode B=%d T=%d S=%d: %.3f ms  %.0f seq/s  %.1f TFLOP/s algorithmic (%.1f%% of fp32 MFMA peak)"
       % (B, T, S, ms, B / ms * 1e3, B * flop / ms / 1e9, B * flop / ms / 1e9 / 157.3 * 100))
 
+h.set_option("cnn_bf16", 1)
+for _ in range(3):
+    h.encode_dev(0, ids.data_ptr(), B, T, True, out.data_ptr())
+h.timer_record(0)
+for _ in range(n):
+    h.encode_dev(0, ids.data_ptr(), B, T, True, out.data_ptr())
+h.timer_record(1)
+ms16 = h.timer_elapsed_ms(0, 1) / n
+print("CNN encode, bf16 storage / fp32 accumulate (option cnn_bf16): %.3f ms  %.0f seq/s  %.1f TFLOP/s algorithmic"
+      % (ms16, B / ms16 * 1e3, B * flop / ms16 / 1e9))
+h.set_option("cnn_bf16", 0)
+
 # ---- training step (builder-defined CNN pair loss, configs[4]): host ids in, loss/acc out
 import time  # noqa: E402
 import numpy as np  # noqa: E402
