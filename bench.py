@@ -257,6 +257,27 @@ def main():
             sdt = float(t.item())
         jj = torch.arange(Q, device=dev)
         planted_ok = float((state["i"][:, 0] == (jj % world) * Ns + jj).double().mean().item())
+        # same pass with the candidate selection on the bf16 matrix pipe (option score_bf16): the float64 re-scoring
+        # keeps ids and scores exact -- checked here against the fp32-candidate result
+        ref_s, ref_i = state["s"].clone(), state["i"].clone()
+        h.set_option("score_bf16", 1)
+        score_step()
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(args.score_iters):
+            score_step()
+        barrier()
+        bdt = (time.perf_counter() - ts) / args.score_iters
+        h.set_option("score_bf16", 0)
+        if use_dist:
+            t = torch.tensor([bdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            bdt = float(t.item())
+        same = bool(torch.equal(state["i"], ref_i) and torch.equal(state["s"], ref_s))
+        scoring_bf16 = {"scores_per_s": Q * Ns * world / bdt, "ms_per_pass": bdt * 1e3,
+                        "identical_to_fp32_candidates": same,
+                        "note": "candidate pass on v_mfma_f32_32x32x16_bf16, float64 re-scoring with the bound widened to "
+                                "the bf16 rounding: exact results (library default stays the fp32 candidate pass)"}
         scoring = {"scores_per_s": Q * Ns * world / sdt, "ms_per_pass": sdt * 1e3, "queries": Q,
                    "index_rows_total": Ns * world, "index_rows_per_gpu": Ns, "S": S, "k": k,
                    "collective": "rccl all_gather of per-shard top-k + k-way merge" if world > 1 else "none (1 shard)",
@@ -317,6 +338,7 @@ def main():
         }
         if scoring is not None:
             line["scoring_leg"] = scoring
+            line["scoring_leg_bf16_candidates"] = scoring_bf16
         if training is not None:
             line["train_leg"] = training
         if world == 1 and not args.no_cpu_baseline:

@@ -84,6 +84,9 @@ int sse_encode_dev(sse_handle *h, int side, const int32_t *ids_dev, int32_t B, i
  * every 64-row tile exactly -- the LSTM state after p leading PAD (id 0) steps is
  * sequence-independent (sse_index.py:79-85 left-pads; sse_model.py:240-242 runs all T steps),
  * so it is precomputed per p with the same kernel; results are bit-identical to pad_skip = 0.
+ * "score_bf16" (default 0): the candidate pass of sse_score_topk* reads bf16 copies of the index and the queries on
+ * the bf16 matrix pipe; the float64 re-scoring pass, its error bound widened to the bf16 rounding, still returns
+ * exactly the reference's ids and scores (bit-identical to score_bf16 = 0), ~5x faster; +50 % index memory.
  * "cnn_bf16" (default 0; source_only_cnn only): the convolution of inference encodes reads embeddings and
  * filters rounded to bf16 (fp32 accumulation, fp32 bias/ReLU/pool/projection) on the bf16 matrix pipe -- the
  * reference has no reduced-precision behaviour; BASELINE configs[4] names bf16.  Training stays fp32.

@@ -78,7 +78,12 @@ __device__ __forceinline__ void merge_lists(float (&ls)[KC], int (&li)[KC], cons
 //   a quarter of the MFMA work per index byte, so the sweep runs at HBM speed.
 //   MERGE: the 16 lists per query of a workgroup are merged to one (in-wave via shuffles,
 //   across waves through LDS) so that many index splits stay cheap to re-score.
-template <int KC, int NQ, bool MERGE>
+// BF: the candidate pass runs on v_mfma_f32_32x32x16_bf16 -- index and queries are bf16 copies in the same 1-KiB
+// block / 16-byte-per-lane fragment scheme (a block now holds 32 rows x 16 k, a.KG counts 16-k groups), ONE MFMA per
+// (k-group, query tile).  Only candidate SELECTION sees bf16: the float64 re-scoring pass works on the fp32 / f64
+// rows with an error bound widened to the bf16 rounding, so the results stay exact (or fall back, certified).
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+template <int KC, int NQ, bool MERGE, bool BF>
 __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // query block [NQ][KG][256]; later merge scratch
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -192,8 +197,12 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
           for (int d = 0; d < RING; ++d) {
             const int kg = kg0 + d;
             bqn = *reinterpret_cast<const f32x4 *>(qs + ((kg + 1 < KG) ? kg + 1 : 0) * 256);
+            if constexpr (BF) {
+              acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ring[d]), __builtin_bit_cast(bf16x8_t, bq), acc[0], 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[d][e], bq[e], acc[0], 0, 0, 0);
+              for (int e = 0; e < 4; ++e) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[d][e], bq[e], acc[0], 0, 0, 0);
+            }
             // refill the slot with the fragment RING k-groups on: same tile, or the head of this wave's next tile
             const int kn = kg + RING;
             const int off = (kn < KG) ? tbase + kn : (more ? tbase + WSTEP * KG + (kn - KG) : tbase + kg);
@@ -222,27 +231,45 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) by[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG + kg + 1) * 256);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (BF) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+          for (int q = 0; q < NQ; ++q)
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ax), __builtin_bit_cast(bf16x8_t, bx[q]), acc[q], 0, 0, 0);
+        } else {
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[q][e], acc[q], 0, 0, 0);
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[q][e], acc[q], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         const int k2 = (kg + 2 < KG) ? kg + 2 : kg;
         ax = iload(k2);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) bx[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG + k2) * 256);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (BF) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+          for (int q = 0; q < NQ; ++q)
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ay), __builtin_bit_cast(bf16x8_t, by[q]), acc[q], 0, 0, 0);
+        } else {
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[e], by[q][e], acc[q], 0, 0, 0);
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[e], by[q][e], acc[q], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       if (kg < KG) {
+        if constexpr (BF) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+          for (int q = 0; q < NQ; ++q)
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ax), __builtin_bit_cast(bf16x8_t, bx[q]), acc[q], 0, 0, 0);
+        } else {
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[q][e], acc[q], 0, 0, 0);
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[q][e], acc[q], 0, 0, 0);
+        }
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -371,7 +398,7 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
 // candidate lists per query and index split
 int score_slots_per_split(int merge) { return merge ? 1 : (SC_THREADS / 64) * 2; }
 
-template <int NQ, bool MERGE>
+template <int NQ, bool MERGE, bool BF = false>
 static hipError_t launch_score_variant(const ScoreArgs &a_in, hipStream_t stream) {
   size_t lds = (size_t)NQ * a_in.KG * 256 * sizeof(float);
   const size_t merge_lds = (size_t)(SC_THREADS / 128) * NQ * SC_KC * 32 * 8;
@@ -388,16 +415,96 @@ static hipError_t launch_score_variant(const ScoreArgs &a_in, hipStream_t stream
   } else {
     grid = QB * a.NSPLIT;
   }
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(score_topk_kernel<SC_KC, NQ, MERGE>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(score_topk_kernel<SC_KC, NQ, MERGE, BF>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((score_topk_kernel<SC_KC, NQ, MERGE>), dim3(grid), dim3(SC_THREADS), lds, stream, a);
+  hipLaunchKernelGGL((score_topk_kernel<SC_KC, NQ, MERGE, BF>), dim3(grid), dim3(SC_THREADS), lds, stream, a);
+  return hipGetLastError();
+}
+
+// rows [R][C] fp32 -> bf16 fragment blocks [ceil(R/32)][ceil(C/16)][512 bf16]: lane (k half, row) owns 8 consecutive k
+__global__ void pack_rows_bf16_kernel(const float *__restrict__ rows, int64_t R, int C, int KG16, int64_t total8,
+                                      f32x4 *__restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(i & 63);
+    const int64_t blk = i >> 6;
+    const int kg = (int)(blk % KG16);
+    const int64_t r = (blk / KG16) * 32 + (l & 31);
+    const int k0 = kg * 16 + (l >> 5) * 8;
+    unsigned w[4] = {0, 0, 0, 0};
+    if (r < R) {
+      const float *src = rows + (size_t)r * C + k0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        unsigned short b = 0;
+        if (k0 + j < C) {
+          unsigned u = __float_as_uint(src[j]);
+          u += 0x7FFFu + ((u >> 16) & 1u);  // round to nearest even
+          b = (unsigned short)(u >> 16);
+        }
+        w[j >> 1] |= (unsigned)b << ((j & 1) * 16);
+      }
+    }
+    out[i] = __builtin_bit_cast(f32x4, u32x4{w[0], w[1], w[2], w[3]});
+  }
+}
+
+hipError_t launch_pack_rows_bf16(const float *rows, int64_t R, int C, void *out, hipStream_t stream) {
+  const int KG16 = (C + 15) / 16;
+  const int64_t total8 = ((R + 31) / 32) * KG16 * 64;
+  if (total8 == 0) return hipSuccess;
+  const int64_t blocks = (total8 + 255) / 256;
+  hipLaunchKernelGGL(pack_rows_bf16_kernel, dim3((int)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, stream, rows, R, C, KG16,
+                     total8, reinterpret_cast<f32x4 *>(out));
+  return hipGetLastError();
+}
+
+// the resident fp32 fragment index [NT][KG][256 floats] -> bf16 fragment copy [NT][ceil(KG/2)][1 KiB]
+__global__ void frag32_to_bf16_kernel(const f32x4 *__restrict__ in, int64_t NT, int KG, int KG16, int64_t total8,
+                                      f32x4 *__restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(i & 63);
+    const int64_t blk = i >> 6;
+    const int kg16 = (int)(blk % KG16);
+    const int64_t tile = blk / KG16;
+    const int kg = kg16 * 2 + (l >> 5), r = l & 31;
+    f32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+    if (kg < KG) {
+      lo = in[((size_t)tile * KG + kg) * 64 + r];
+      hi = in[((size_t)tile * KG + kg) * 64 + 32 + r];
+    }
+    unsigned w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = (j < 2) ? lo[2 * j] : hi[2 * (j - 2)], b = (j < 2) ? lo[2 * j + 1] : hi[2 * (j - 2) + 1];
+      unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+      ua += 0x7FFFu + ((ua >> 16) & 1u);
+      ub += 0x7FFFu + ((ub >> 16) & 1u);
+      w[j] = (ua >> 16) | (ub & 0xFFFF0000u);
+    }
+    out[i] = __builtin_bit_cast(f32x4, u32x4{w[0], w[1], w[2], w[3]});
+  }
+}
+
+hipError_t launch_frag32_to_bf16(const float *idxp, int64_t NT, int KG, void *out, hipStream_t stream) {
+  const int KG16 = (KG + 1) / 2;
+  const int64_t total8 = NT * KG16 * 64;
+  if (total8 == 0) return hipSuccess;
+  const int64_t blocks = (total8 + 255) / 256;
+  hipLaunchKernelGGL(frag32_to_bf16_kernel, dim3((int)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, stream,
+                     reinterpret_cast<const f32x4 *>(idxp), NT, KG, KG16, total8, reinterpret_cast<f32x4 *>(out));
   return hipGetLastError();
 }
 
 hipError_t launch_score_topk(const ScoreArgs &a, hipStream_t stream) {
   if (a.KC != SC_KC) return hipErrorInvalidValue;
   if (a.NSPLIT > 8 && (a.NSPLIT & 7)) return hipErrorInvalidValue;
+  if (a.BF) {  // bf16 candidate pass: merged lists only
+    if (!a.MERGE) return hipErrorInvalidValue;
+    if (a.NQ == 1) return launch_score_variant<1, true, true>(a, stream);
+    if (a.NQ == 4) return launch_score_variant<4, true, true>(a, stream);
+    return hipErrorInvalidValue;
+  }
   if (a.NQ == 1) return a.MERGE ? launch_score_variant<1, true>(a, stream) : launch_score_variant<1, false>(a, stream);
   if (a.NQ == 4) return a.MERGE ? launch_score_variant<4, true>(a, stream) : launch_score_variant<4, false>(a, stream);
   return hipErrorInvalidValue;

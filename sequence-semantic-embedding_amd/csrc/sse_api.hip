@@ -74,6 +74,10 @@ struct sse_handle {
   Encoder enc[2];
   bool packed_dirty = true;
   bool pad_skip = true;      // option "pad_skip": exact left-pad prefix skip in inference encodes
+  bool score_bf16 = false;   // option "score_bf16": candidate pass of many-queries scoring on the bf16 matrix pipe (results stay exact)
+  void *idxp16 = nullptr;    // bf16 fragment copy of the index (built on demand)
+  size_t idxp16_cap = 0;
+  bool idxp16_valid = false;
   bool cnn_bf16 = false;     // option "cnn_bf16": source_only_cnn inference with bf16 storage / fp32 accumulation
   unsigned short *emb_bf16 = nullptr, *cnn_Wc16 = nullptr;
   bool train_serial = false; // option "train_serial": both encoders on one stream (profiling: isolated kernel times)
@@ -377,6 +381,7 @@ int index_from_dev_rows(sse_handle *h, const float *rows_dev, int64_t N, int S, 
   HIPCHECK(h, hipMemcpyAsync(&n2, h->s_tmp2.p, 4, hipMemcpyDeviceToHost, st));
   HIPCHECK(h, hipStreamSynchronize(st));
   h->idx_norm_max = std::sqrt(n2);
+  h->idxp16_valid = false;
   h->idx_N = N;
   h->idx_S = S;
   h->idx_base = id_base;
@@ -431,19 +436,37 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   // workgroup): the re-scoring pass then ranks 16 candidates per split instead of 256
   const int merge = 1;
   const int NC = nsplit * score_slots_per_split(merge) * 16;
+  // bf16 candidate pass (option score_bf16): 16x the matrix rate for the 128-query-block variant, half the index
+  // bytes for the HBM-bound few-queries sweep
+  const bool bf = h->score_bf16;
+  const int KG16 = (S + 15) / 16;
+  if (bf && !h->idxp16_valid) {
+    const size_t need = (size_t)NT * KG16 * 1024;
+    if (need > h->idxp16_cap) {
+      if (h->idxp16) HIPCHECK(h, hipFree(h->idxp16));
+      h->idxp16 = nullptr;
+      h->idxp16_cap = 0;
+      HIPCHECK(h, hipMalloc(&h->idxp16, need));
+      h->idxp16_cap = need;
+    }
+    HIPCHECK(h, launch_frag32_to_bf16(h->idxp, NT, KG, h->idxp16, st));
+    h->idxp16_valid = true;
+  }
   if (reserve(h, h->s_qp, (size_t)QB * NQ * KG * 256 * sizeof(float))) return 1;
   if (reserve(h, h->s_ps, (size_t)Q * NC * sizeof(float))) return 1;
   if (reserve(h, h->s_pi, (size_t)Q * NC * sizeof(int32_t))) return 1;
   if (reserve(h, h->s_cert, (size_t)Q * sizeof(int32_t))) return 1;
-  HIPCHECK(h, launch_pack_rows(q, Q, S, (float *)h->s_qp.p, st));
+  if (bf) HIPCHECK(h, launch_pack_rows_bf16(q, Q, S, h->s_qp.p, st));
+  else HIPCHECK(h, launch_pack_rows(q, Q, S, (float *)h->s_qp.p, st));
   ScoreArgs a;
-  a.idxp = h->idxp;
+  a.BF = bf ? 1 : 0;
+  a.idxp = bf ? (const float *)h->idxp16 : h->idxp;
   a.qp = (const float *)h->s_qp.p;
   a.part_scores = (float *)h->s_ps.p;
   a.part_ids = (int32_t *)h->s_pi.p;
   a.N = h->idx_N;
   a.Q = Q;
-  a.KG = KG;
+  a.KG = bf ? KG16 : KG;
   a.NT = (int)NT;
   a.QT = QT;
   a.NSPLIT = nsplit;
@@ -468,6 +491,8 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   r.k = k;
   // |fp32 fma-chain dot - exact| <= S * 2^-24 * |q||t| (+ the f32 rounding of f64 rows); use 2x margin
   r.eps = (float)(2.0 * (S + 2) * 5.97e-8 * h->idx_norm_max);
+  // bf16 operands: |q^.t^ - q.t| <= ((1+u)^2 - 1) sum|q_i t_i| <= (2^-8 + 2^-18) |q||t|, u = 2^-9 (round to nearest)
+  if (bf) r.eps += (float)(1.02 * (1.0 / 256.0 + 1.0 / 262144.0) * h->idx_norm_max);
   HIPCHECK(h, launch_rescore(r, st));
   HIPCHECK(h, launch_exact_topk(q, h->idxp, h->idx64, r.cert, out_s, out_i, h->idx_base, h->idx_N, Q, S, k, st));
   return 0;
@@ -572,6 +597,7 @@ void sse_destroy(sse_handle *h) {
   if (h->emb_pad) hipFree(h->emb_pad);
   if (h->err_flag) hipFree(h->err_flag);
   if (h->idxp) hipFree(h->idxp);
+  if (h->idxp16) (void)hipFree(h->idxp16);
   if (h->idx64) hipFree(h->idx64);
   if (h->cnn_Wc) (void)hipFree(h->cnn_Wc);
   if (h->emb_bf16) (void)hipFree(h->emb_bf16);
@@ -689,6 +715,10 @@ int sse_encode(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int3
 int sse_set_option(sse_handle *h, const char *name, int32_t value) {
   if (!h || !name) return 1;
   std::lock_guard<std::mutex> lk(h->mu);
+  if (strcmp(name, "score_bf16") == 0) {
+    h->score_bf16 = value != 0;
+    return 0;
+  }
   if (strcmp(name, "cnn_bf16") == 0) {
     if (h->cfg.network_mode != SSE_MODE_SOURCE_ONLY_CNN) return fail(h, "option cnn_bf16 needs network_mode source_only_cnn");
     h->cnn_bf16 = value != 0;

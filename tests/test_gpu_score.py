@@ -235,3 +235,54 @@ def test_large_k_exact_paging(Q, N, S, k):
     wsc, wids = O.topk(O.scores_f64(q, t.astype(np.float64)), k)
     assert np.array_equal(ids, wids)
     assert np.abs(sc - wsc).max() < 1e-12
+
+
+# --------------------------------------------------------------------------
+# option "score_bf16": the candidate pass of the 128-query-block kernel runs on the bf16 matrix pipe; the float64
+# re-scoring (with the bound widened to the bf16 rounding) keeps ids and scores EXACT -- same assertions as above
+# --------------------------------------------------------------------------
+
+def _scorer_bf16(S=8):
+    h = _scorer(S)
+    h.set_option("score_bf16", 1)
+    return h
+
+
+@pytest.mark.parametrize("Q,N,S", [(300, 5000, 64), (129, 33, 256), (600, 32060, 64), (200, 4000, 50), (4000, 70000, 256),
+                                   (1, 64, 32), (1, 200000, 256), (7, 150000, 256), (32, 5000, 64), (3, 300000, 64)])
+def test_bf16_candidate_pass_keeps_results_exact(Q, N, S):
+    rng = np.random.RandomState(Q + N)
+    q, t = _unit(rng, Q, S), _unit(rng, N, S)
+    h = _scorer_bf16()
+    h.index_upload(t)
+    k = min(10, N)
+    sc, ids = h.score_topk(q, k)
+    sub = np.arange(Q) if Q <= 600 else np.random.RandomState(1).choice(Q, 300, replace=False)
+    wsc, wids = O.topk(O.scores_f64(q[sub], t.astype(np.float64)), k)
+    assert np.array_equal(ids[sub], wids)
+    assert np.abs(sc[sub] - wsc).max() < 1e-12
+    # and identical to the fp32 candidate pass everywhere
+    h.set_option("score_bf16", 0)
+    sc32, ids32 = h.score_topk(q, k)
+    assert np.array_equal(ids, ids32) and np.array_equal(sc, sc32)
+
+
+def test_bf16_candidate_pass_golden_ties_and_near_ties():
+    z = np.load(os.path.join(G, "scoring_eval.npz"))
+    h = _scorer_bf16()
+    h.index_upload(z["tgt64"])
+    sc, ids = h.score_topk(z["src"], 10)
+    assert np.array_equal(ids, z["ranked_idx"][:, :10]) and np.abs(sc - z["ranked_score"][:, :10]).max() < 1e-12
+    # exact ties + rows that differ below fp32 (let alone bf16) resolution: the certificate fails over to exact paths
+    rng = np.random.RandomState(8)
+    S, N = 64, 3000
+    t = _unit(rng, N, S).astype(np.float64)
+    base = t[10].copy()
+    for j, r in enumerate((500, 20, 2500, 1234)):
+        t[r] = base * (1.0 - (j + 1) * 1e-9)
+    t[2999] = t[77]
+    q = np.concatenate([base[None, :], t[77:78], _unit(rng, 70, S)]).astype(np.float32)
+    h.index_upload(t)
+    sc, ids = h.score_topk(q, 5)
+    wsc, wids = O.topk(O.scores_f64(q, t), 5)
+    assert np.array_equal(ids, wids) and np.abs(sc - wsc).max() < 1e-12
