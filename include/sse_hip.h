@@ -84,15 +84,20 @@ int sse_encode_dev(sse_handle *h, int side, const int32_t *ids_dev, int32_t B, i
  * every 64-row tile exactly -- the LSTM state after p leading PAD (id 0) steps is
  * sequence-independent (sse_index.py:79-85 left-pads; sse_model.py:240-242 runs all T steps),
  * so it is precomputed per p with the same kernel; results are bit-identical to pad_skip = 0.
- * "score_bf16" (default 0): the candidate pass of sse_score_topk* reads bf16 copies of the index and the queries on
+ * "score_bf16" (default 1): the candidate pass of sse_score_topk* reads bf16 copies of the index and the queries on
  * the bf16 matrix pipe; the float64 re-scoring pass, its error bound widened to the bf16 rounding, still returns
- * exactly the reference's ids and scores (bit-identical to score_bf16 = 0), ~5x faster; +50 % index memory.
+ * exactly the reference's ids and scores (bit-identical to score_bf16 = 0), ~5x faster; +50 % index memory.  Queries
+ * whose result misses the certificate (top scores packed closer than the bf16 bound) are swept again with fp32
+ * candidates on the device before anything reaches the float64 brute force.  0 = fp32 candidates only.
  * "cnn_bf16" (default 0; source_only_cnn only): the convolution of inference encodes reads embeddings and
  * filters rounded to bf16 (fp32 accumulation, fp32 bias/ReLU/pool/projection) on the bf16 matrix pipe -- the
  * reference has no reduced-precision behaviour; BASELINE configs[4] names bf16.  Training stays fp32.
  * "train_serial" (default 0): run both encoders of a train step on one stream (profiling aid:
  * isolated kernel durations; same results). */
 int sse_set_option(sse_handle *h, const char *name, int32_t value);
+/* Diagnostic counters.  "score_bf16_second_chance_queries": queries (cumulative) whose bf16-candidate result missed
+ * its certificate and were re-run with fp32 candidates. */
+int sse_get_counter(sse_handle *h, const char *name, int64_t *value);
 
 /* tf.nn.l2_normalize(x, dim=-1) on device rows (sse_model.py:282-283). */
 int sse_l2_normalize_dev(sse_handle *h, const float *x_dev, float *out_dev, int64_t rows, int32_t cols,

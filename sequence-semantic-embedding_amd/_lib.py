@@ -37,6 +37,7 @@ SYMBOLS = {
     "sse_encode": (C.c_int, [_P, C.c_int, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "sse_encode_dev": (C.c_int, [_P, C.c_int, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "sse_set_option": (C.c_int, [_P, C.c_char_p, C.c_int32]),
+    "sse_get_counter": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     "sse_l2_normalize_dev": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P]),
     "sse_index_upload": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int64]),
     "sse_index_upload_f64": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int64]),
@@ -156,6 +157,11 @@ class Handle(object):
 
     def set_option(self, name, value):
         self.check(self.lib.sse_set_option(self._h, name.encode(), int(value)))
+
+    def get_counter(self, name):
+        v = C.c_int64()
+        self.check(self.lib.sse_get_counter(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
 
     def l2_normalize_dev(self, x_ptr, out_ptr, rows, cols, stream=0):
         self.check(self.lib.sse_l2_normalize_dev(self._h, x_ptr, out_ptr, rows, cols, stream))

@@ -106,6 +106,14 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   }
   const int QB = (a.QT + NQ - 1) / NQ;
   if (qb >= QB) return;
+  if (a.skip_cert) {  // fp32 second chance after a bf16 candidate pass: only blocks with an uncertified query run
+    int open_q = 0;
+    for (int i = tid; i < NQ * 32; i += SC_THREADS) {
+      const int qq = qb * NQ * 32 + i;
+      if (qq < a.Q && a.skip_cert[qq] == 0) open_q = 1;
+    }
+    if (!__syncthreads_or(open_q)) return;
+  }
 
   // stage the query block (already frag32-packed) into LDS
   {
@@ -422,6 +430,17 @@ static hipError_t launch_score_variant(const ScoreArgs &a_in, hipStream_t stream
   return hipGetLastError();
 }
 
+// diagnostic: number of queries of this call left uncertified by the bf16 pass, accumulated on the device
+__global__ void count_uncert_kernel(const int32_t *cert, int Q, unsigned long long *count) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long m = __ballot(q < Q && cert[q] == 0);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+}
+hipError_t launch_count_uncert(const int32_t *cert, int Q, unsigned long long *count, hipStream_t st) {
+  hipLaunchKernelGGL(count_uncert_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, cert, Q, count);
+  return hipGetLastError();
+}
+
 // rows [R][C] fp32 -> bf16 fragment blocks [ceil(R/32)][ceil(C/16)][512 bf16]: lane (k half, row) owns 8 consecutive k
 __global__ void pack_rows_bf16_kernel(const float *__restrict__ rows, int64_t R, int C, int KG16, int64_t total8,
                                       f32x4 *__restrict__ out) {
@@ -552,6 +571,7 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
   __shared__ double s_qn[RS_THREADS / 64];
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_key[];  // [NC] (dynamic: keeps occupancy for small NC)
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (a.skip && a.skip[q] != 0) return;  // (uniform per workgroup) already final
   const float *ps = a.part_scores + (size_t)q * a.NC;
   const int32_t *pi = a.part_ids + (size_t)q * a.NC;
   const float *qrow = a.q + (size_t)q * a.S;
@@ -706,6 +726,7 @@ __global__ __launch_bounds__(256) void rescore_small_kernel(RescoreArgs a) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= a.Q) return;
+  if (a.skip && a.skip[q] != 0) return;  // already final (uniform per wave)
   const float *qrow = a.q + (size_t)q * a.S;
   const int KG = (a.S + 7) / 8;
   double qn = 0.0;

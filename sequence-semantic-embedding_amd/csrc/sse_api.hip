@@ -74,10 +74,11 @@ struct sse_handle {
   Encoder enc[2];
   bool packed_dirty = true;
   bool pad_skip = true;      // option "pad_skip": exact left-pad prefix skip in inference encodes
-  bool score_bf16 = false;   // option "score_bf16": candidate pass of many-queries scoring on the bf16 matrix pipe (results stay exact)
+  bool score_bf16 = true;    // option "score_bf16" (default on): candidate pass on the bf16 matrix pipe; results stay exact
   void *idxp16 = nullptr;    // bf16 fragment copy of the index (built on demand)
   size_t idxp16_cap = 0;
   bool idxp16_valid = false;
+  bool fb_cnt_init = false;
   bool cnn_bf16 = false;     // option "cnn_bf16": source_only_cnn inference with bf16 storage / fp32 accumulation
   unsigned short *emb_bf16 = nullptr, *cnn_Wc16 = nullptr;
   bool train_serial = false; // option "train_serial": both encoders on one stream (profiling: isolated kernel times)
@@ -95,6 +96,7 @@ struct sse_handle {
   float idx_norm_max = 1.0f;
   // scratch
   DevBuf s_ids, s_out, s_q, s_qp, s_ps, s_pi, s_cert, s_os, s_oi, s_tmp, s_tmp2, s_feat, s_zero, s_map;
+  DevBuf s_qp32, s_fb_cnt;  // fp32 second chance of the bf16 candidate pass: fp32 query fragments, counter
   const int32_t *cur_row_map = nullptr;  // set by sse_encode around its launch
   // training
   float lr = 0.9f;
@@ -438,7 +440,8 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   const int NC = nsplit * score_slots_per_split(merge) * 16;
   // bf16 candidate pass (option score_bf16): 16x the matrix rate for the 128-query-block variant, half the index
   // bytes for the HBM-bound few-queries sweep
-  const bool bf = h->score_bf16;
+  // (small indexes stay on the fp32 pass: nothing to win, and no bf16 copy / second-chance launches to pay for)
+  const bool bf = h->score_bf16 && h->idx_N >= 8192;
   const int KG16 = (S + 15) / 16;
   if (bf && !h->idxp16_valid) {
     const size_t need = (size_t)NT * KG16 * 1024;
@@ -494,6 +497,31 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   // bf16 operands: |q^.t^ - q.t| <= ((1+u)^2 - 1) sum|q_i t_i| <= (2^-8 + 2^-18) |q||t|, u = 2^-9 (round to nearest)
   if (bf) r.eps += (float)(1.02 * (1.0 / 256.0 + 1.0 / 262144.0) * h->idx_norm_max);
   HIPCHECK(h, launch_rescore(r, st));
+  if (bf) {
+    // Second chance, entirely on the device (the call stays asynchronous): queries whose bf16-candidate result missed
+    // its certificate (top scores packed closer than the bf16 bound) are swept again with fp32 candidates -- the same
+    // kernels, where a workgroup whose whole query block is certified returns at once and a certified query is left
+    // alone -- before anything falls through to the float64 brute force.
+    if (reserve(h, h->s_qp32, (size_t)QB * NQ * KG * 256 * sizeof(float))) return 1;
+    if (reserve(h, h->s_fb_cnt, sizeof(unsigned long long))) return 1;
+    if (h->s_fb_cnt.cap && !h->fb_cnt_init) {
+      HIPCHECK(h, hipMemsetAsync(h->s_fb_cnt.p, 0, sizeof(unsigned long long), st));
+      h->fb_cnt_init = true;
+    }
+    HIPCHECK(h, launch_count_uncert(r.cert, Q, (unsigned long long *)h->s_fb_cnt.p, st));
+    HIPCHECK(h, launch_pack_rows(q, Q, S, (float *)h->s_qp32.p, st));
+    ScoreArgs a2 = a;
+    a2.BF = 0;
+    a2.idxp = h->idxp;
+    a2.qp = (const float *)h->s_qp32.p;
+    a2.KG = KG;
+    a2.skip_cert = r.cert;
+    HIPCHECK(h, launch_score_topk(a2, st));
+    RescoreArgs r2 = r;
+    r2.eps = (float)(2.0 * (S + 2) * 5.97e-8 * h->idx_norm_max);
+    r2.skip = r.cert;
+    HIPCHECK(h, launch_rescore(r2, st));
+  }
   HIPCHECK(h, launch_exact_topk(q, h->idxp, h->idx64, r.cert, out_s, out_i, h->idx_base, h->idx_N, Q, S, k, st));
   return 0;
 }
@@ -710,6 +738,22 @@ int sse_encode(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int3
   if (check_err_flag(h, st)) return 1;
   HIPCHECK(h, hipMemcpy(out_host, h->s_out.p, (size_t)B * S * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
+}
+
+int sse_get_counter(sse_handle *h, const char *name, int64_t *value) {
+  if (!h || !name || !value) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (strcmp(name, "score_bf16_second_chance_queries") == 0) {
+    unsigned long long v = 0;
+    if (h->s_fb_cnt.p && h->fb_cnt_init) {
+      HIPCHECK(h, hipSetDevice(h->cfg.device));
+      HIPCHECK(h, hipDeviceSynchronize());
+      HIPCHECK(h, hipMemcpy(&v, h->s_fb_cnt.p, sizeof v, hipMemcpyDeviceToHost));
+    }
+    *value = (int64_t)v;
+    return 0;
+  }
+  return fail(h, "unknown counter '%s'", name);
 }
 
 int sse_set_option(sse_handle *h, const char *name, int32_t value) {

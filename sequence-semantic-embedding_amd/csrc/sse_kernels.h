@@ -73,11 +73,13 @@ struct ScoreArgs {
   int32_t NQ = 4;     // query tiles (of 32) per workgroup: 4 (128-query blocks) or 1 (Q <= 32)
   int32_t MERGE = 0;  // 1: one merged list per (query, split); 0: 16 lists (waves x lane halves)
   int32_t thr_off = 0;  // set by the launcher: LDS offset (floats) of the shared per-query thresholds
+  const int32_t *skip_cert = nullptr;  // second-chance pass: a workgroup whose whole query block is already certified returns
   int32_t BF = 0;       // 1: idxp / qp are bf16 fragment copies, KG counts 16-k groups (candidate pass on bf16 MFMA)
 };
 hipError_t launch_score_topk(const ScoreArgs &a, hipStream_t stream);
 // rows [R][C] fp32 -> bf16 fragment blocks [ceil(R/32)][ceil(C/16)][1 KiB]; fp32 frag32 index -> the same
 hipError_t launch_pack_rows_bf16(const float *rows, int64_t R, int C, void *out, hipStream_t stream);
+hipError_t launch_count_uncert(const int32_t *cert, int Q, unsigned long long *count, hipStream_t st);
 hipError_t launch_frag32_to_bf16(const float *idxp, int64_t NT, int KG, void *out, hipStream_t stream);
 int score_slots_per_split(int merge);  // candidate lists per query and index split
 
@@ -93,6 +95,7 @@ struct RescoreArgs {
   int64_t id_base, N;
   int32_t Q, S, NC, k;     // NC = NSPLIT*KC candidates per query
   float eps;               // bound on |f32 score - exact score|
+  const int32_t *skip = nullptr;  // second-chance pass: queries with skip[q] != 0 are already final
 };
 hipError_t launch_rescore(const RescoreArgs &a, hipStream_t stream);
 

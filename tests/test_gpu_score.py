@@ -248,8 +248,8 @@ def _scorer_bf16(S=8):
     return h
 
 
-@pytest.mark.parametrize("Q,N,S", [(300, 5000, 64), (129, 33, 256), (600, 32060, 64), (200, 4000, 50), (4000, 70000, 256),
-                                   (1, 64, 32), (1, 200000, 256), (7, 150000, 256), (32, 5000, 64), (3, 300000, 64)])
+@pytest.mark.parametrize("Q,N,S", [(300, 9000, 64), (129, 8192, 256), (600, 32060, 64), (200, 10000, 50), (4000, 70000, 256),
+                                   (1, 8200, 32), (1, 200000, 256), (7, 150000, 256), (32, 9000, 64), (3, 300000, 64)])
 def test_bf16_candidate_pass_keeps_results_exact(Q, N, S):
     rng = np.random.RandomState(Q + N)
     q, t = _unit(rng, Q, S), _unit(rng, N, S)
@@ -286,3 +286,30 @@ def test_bf16_candidate_pass_golden_ties_and_near_ties():
     sc, ids = h.score_topk(q, 5)
     wsc, wids = O.topk(O.scores_f64(q, t), 5)
     assert np.array_equal(ids, wids) and np.abs(sc - wsc).max() < 1e-12
+
+
+def test_bf16_candidates_second_chance_on_densely_packed_scores():
+    """400 index rows whose cosine to a query steps down by 2e-5 -- far closer than the bf16 bound (4e-3), far apart
+    for the fp32 one (3e-5): those queries miss the bf16 certificate and take the fp32 second chance (not the float64
+    brute force); results stay exact and the ordinary queries are untouched."""
+    rng = np.random.RandomState(12)
+    S, N, Q = 64, 40000, 300
+    t = _unit(rng, N, S).astype(np.float64)
+    q = _unit(rng, Q, S)
+    for qi in (0, 7, 150):
+        rows = rng.choice(N, 400, replace=False)
+        base = q[qi].astype(np.float64)
+        base /= np.linalg.norm(base)
+        for j, r in enumerate(rows):
+            u = rng.standard_normal(S)
+            u -= u.dot(base) * base
+            u /= np.linalg.norm(u)
+            c = 1.0 - 2e-5 * j
+            t[r] = c * base + np.sqrt(1.0 - c * c) * u
+    h = _scorer_bf16()
+    h.index_upload(t)
+    sc, ids = h.score_topk(q, 10)
+    wsc, wids = O.topk(O.scores_f64(q, t), 10)
+    assert np.array_equal(ids, wids) and np.abs(sc - wsc).max() < 1e-12
+    n = h.get_counter("score_bf16_second_chance_queries")
+    assert 3 <= n <= 30, n                                   # the crowded queries took it; the ordinary ones did not
