@@ -21,6 +21,7 @@ for i in range(0, N, 1_000_000):
     t[i:i + 1_000_000] = torch.nn.functional.normalize(torch.randn((min(1_000_000, N - i), S), device=dev), dim=1)
 h.index_set_dev(t.data_ptr(), N, S)
 del t
+h.set_option("score_bf16", 0)                      # first the fp32-candidate sweep (4 bytes per index element)
 for Q in (1, 8, 32):
     q = torch.nn.functional.normalize(torch.randn((Q, S), device=dev), dim=1)
     os_ = torch.empty((Q, 10), dtype=torch.float64, device=dev)
@@ -35,7 +36,7 @@ for Q in (1, 8, 32):
     print("Q=%d N=%d S=%d: %.3f ms/pass, %.2f TB/s of index streamed, %.3g scores/s"
           % (Q, N, S, dt * 1e3, N * S * 4 / dt / 1e12, Q * N / dt))
 
-# the same with the bf16 candidate pass (option score_bf16): half the index bytes to stream, exact results
+# the library default: bf16 candidate pass (option score_bf16 = 1): half the index bytes to stream, exact results
 h.set_option("score_bf16", 1)
 for Q in (1, 32):
     q = torch.nn.functional.normalize(torch.randn((Q, S), device=dev), dim=1)
