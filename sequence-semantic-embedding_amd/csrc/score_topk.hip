@@ -144,6 +144,13 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   auto enc = [](float f) -> int { const int i = __float_as_int(f); return i >= 0 ? i : (i ^ 0x7FFFFFFF); };
   auto dec = [](int i) -> float { return __int_as_float(i >= 0 ? i : (i ^ 0x7FFFFFFF)); };
   for (int i = tid; i < NQ * 32; i += SC_THREADS) thr_s[i] = enc(NEG_INF);
+  // A second, much tighter lower bound of the workgroup's KC-th best per query: the SMALLEST of its 16 lists' best
+  // entries (16 distinct rows score at least that).  Every list keeps its current best in mx_s[query][list]
+  // (monotone, plain stores); wave 0 folds the minimum into thr_s every few tiles.  Racy reads only see older,
+  // smaller -- still valid -- values.  With 16 lists of 1/16 of the rows each, the list minima alone let a lane insert
+  // on practically every tile (~150 instructions per round): at bf16 matrix speed that cost more than the MFMAs.
+  float *mx_s = reinterpret_cast<float *>(thr_s + NQ * 32);  // [NQ*32][16]
+  for (int i = tid; i < NQ * 32 * 16; i += SC_THREADS) mx_s[i] = NEG_INF;
   __syncthreads();
 
   const int tps = (a.NT + a.NSPLIT - 1) / a.NSPLIT;  // n-tiles per split
@@ -288,6 +295,16 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
     // insert it (1-2 rounds in practice) -- no per-score branches.
     const int nrow0 = tile * 32;
     const bool tail = (nrow0 + 32) > a.N;  // only the last tile has rows >= N (zero padding)
+    if (w == 0 && (((tile - t0) / (SC_THREADS / 64)) & 3) == 3 && lane < 32) {
+#pragma nounroll
+      for (int q = 0; q < NQ; ++q) {  // rolled on purpose: runs once per 4 tiles, must not cost registers
+        const float *mp = mx_s + (q * 32 + lane) * 16;
+        float f = mp[0];
+#pragma nounroll
+        for (int j = 1; j < 16; ++j) f = fminf(f, mp[j]);
+        if (f > NEG_INF) atomicMax(&thr_s[q * 32 + lane], enc(f));
+      }
+    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       float m = NEG_INF;
@@ -319,6 +336,7 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
           if (!__any(m > thr)) break;
         }
         atomicMax(&thr_s[q * 32 + (lane & 31)], enc(ls[q][KC - 1]));  // publish this list's minimum
+        mx_s[(q * 32 + (lane & 31)) * 16 + w * 2 + (lane >> 5)] = ls[q][0];  // and its best
       }
     }
   }
@@ -413,7 +431,7 @@ static hipError_t launch_score_variant(const ScoreArgs &a_in, hipStream_t stream
   if (MERGE && merge_lds > lds) lds = merge_lds;
   ScoreArgs a = a_in;
   a.thr_off = (int32_t)(lds / sizeof(float));  // shared thresholds live behind the query block / merge scratch
-  lds += (size_t)NQ * 32 * sizeof(int);
+  lds += (size_t)NQ * 32 * sizeof(int) + (size_t)NQ * 32 * 16 * sizeof(float);  // thresholds + per-list best entries
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const int QB = (a.QT + NQ - 1) / NQ;
   int grid;
