@@ -76,3 +76,22 @@ def test_index_file_written_and_loaded_identically(tmp_path):
     ids, names, got, id_map = sse_evaluator.load_index_file(path)
     assert ids == ["id%d" % i for i in range(300)] and id_map["id7"] == 7 and names[3] == "Sentence 3"
     assert np.array_equal(got, _ref_parse(_ref_format(enc)))
+
+
+def test_format_and_parse_property_based():
+    """hypothesis: any float32 bit pattern formats exactly like numpy's str() and, when finite, parses back to itself."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.lists(st.integers(min_value=0, max_value=2 ** 32 - 1), min_size=1, max_size=40))
+    def check(bits):
+        row = np.array(bits, np.uint32).view(np.float32)[None, :]
+        got = index_io.format_rows(row)
+        assert got == _ref_format(row)
+        back = index_io.parse_rows(got, row.shape[1])
+        want = _ref_parse(got)
+        assert np.array_equal(back, want, equal_nan=True)
+        fin = np.isfinite(row[0])
+        assert np.array_equal(back[0][fin].astype(np.float32), row[0][fin])
+
+    check()
