@@ -239,7 +239,7 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
       for (; kg + 1 < KG; kg += 2) {
         asm volatile("" ::"v"(tch0), "v"(tch1));  // last iteration's touches (long since returned: in-order)
         ay = iload(kg + 1);
-        if constexpr (NQ > 1) {  // the single-query-tile sweep is HBM-bound already: extra requests only cost
+        if constexpr (NQ > 1 && !BF) {  // the single-query-tile sweep is HBM-bound already: extra requests only cost
           tch0 = touch(kg);
           tch1 = touch(kg + 1);
         }
