@@ -307,12 +307,16 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
+      if (tail) {
+        // only the last tile of the index: a real (wave-uniform) branch -- the empty asm keeps the compiler from
+        // if-converting it into 16 selects per query tile on EVERY tile (it did: ~300 instructions per tile)
+        asm volatile("");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = (nrow0 + mfma_row(r, lane) >= a.N) ? NEG_INF : acc[q][r];
+      }
       float m = NEG_INF;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (tail) acc[q][r] = (nrow0 + mfma_row(r, lane) >= a.N) ? NEG_INF : acc[q][r];
-        m = fmaxf(m, acc[q][r]);
-      }
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[q][r]);
       float thr = fmaxf(ls[q][KC - 1], dec(thr_s[q * 32 + (lane & 31)]));
       if (__any(m > thr)) {
         for (;;) {
