@@ -20,6 +20,18 @@
 //   MT = 1 (Hp = 128): wave w: units [32(w&3), +32), row half w>>2.
 // Per unit block the four gates are computed in two passes (i,j then f,o) so
 // that only 2*MT accumulators are live.
+//
+// Operand roles (inference, SWAP): the WEIGHT fragment is the MFMA's A operand (M = hidden
+// units) and the x/h fragment its B operand (N = sequences), so an accumulator lane holds ONE
+// sequence (lane & 31) and 16 units -- registers 4g..4g+3 are four consecutive units, i.e. exactly
+// one float4 of the frag32 h tile: h_t (and the parked sigmoid(i)*tanh(j)) leave the wave as four
+// contiguous, conflict-free ds_write_b128 per row tile.  (The other orientation -- lane = unit,
+// registers = sequences -- scatters 16 dwords per lane into 4 banks: 8-way conflicts,
+// SQ_LDS_BANK_CONFLICT = 9.4e7 per 16384-sequence launch in round 1.)  Both operands use the same
+// frag32 layout, so the swap is free.  The training forward keeps the old orientation: its gate tape
+// is re-read lane-privately by the BPTT kernel in that layout.
+// The bias is not added separately: the padded embedding table carries a constant 1.0 in column E
+// and the packed kernel the bias (forget-bias folded in) in k-row E, so it rides in the GEMM.
 #include "sse_kernels.h"
 
 #define LSTM_THREADS 512
@@ -53,7 +65,7 @@ __device__ __forceinline__ f32x4 wload(__amdgpu_buffer_rsrc_t r, int voff, int s
 // A fragments: LIN -> x and h parts are contiguous in LDS (xa[m] + kg*256); otherwise x tile
 // for kg < KGx, h tile after.  Hand software-pipelined with two named operand sets (no
 // register copies): the operands of k-group kg+1 are in flight while kg's 8*MT MFMAs issue.
-template <int MT, bool LIN>
+template <int MT, bool LIN, bool SWAP>
 __device__ __forceinline__ void gemm_pass(__amdgpu_buffer_rsrc_t wr, int voff, int soff, const float *const (&xa)[MT],
                                           const float *const (&ha)[MT], int KGx, int kend, f32x16 (&acc)[MT][2]) {
   auto a_frag = [&](int m, int kg) -> f32x4 {
@@ -76,8 +88,10 @@ __device__ __forceinline__ void gemm_pass(__amdgpu_buffer_rsrc_t wr, int voff, i
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][e], p0[e], acc[m][0], 0, 0, 0);
-        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][e], p1[e], acc[m][1], 0, 0, 0);
+        acc[m][0] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(p0[e], a0[m][e], acc[m][0], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][e], p0[e], acc[m][0], 0, 0, 0);
+        acc[m][1] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(p1[e], a0[m][e], acc[m][1], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][e], p1[e], acc[m][1], 0, 0, 0);
       }
     __builtin_amdgcn_sched_barrier(0);
     const int k2 = (kg + 2 < kend) ? kg + 2 : kg;  // clamped: harmless reload on the last pair
@@ -90,8 +104,10 @@ __device__ __forceinline__ void gemm_pass(__amdgpu_buffer_rsrc_t wr, int voff, i
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m][e], q0[e], acc[m][0], 0, 0, 0);
-        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m][e], q1[e], acc[m][1], 0, 0, 0);
+        acc[m][0] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(q0[e], a1[m][e], acc[m][0], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m][e], q0[e], acc[m][0], 0, 0, 0);
+        acc[m][1] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(q1[e], a1[m][e], acc[m][1], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m][e], q1[e], acc[m][1], 0, 0, 0);
       }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -100,8 +116,10 @@ __device__ __forceinline__ void gemm_pass(__amdgpu_buffer_rsrc_t wr, int voff, i
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][e], p0[e], acc[m][0], 0, 0, 0);
-        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][e], p1[e], acc[m][1], 0, 0, 0);
+        acc[m][0] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(p0[e], a0[m][e], acc[m][0], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][e], p0[e], acc[m][0], 0, 0, 0);
+        acc[m][1] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(p1[e], a0[m][e], acc[m][1], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][e], p1[e], acc[m][1], 0, 0, 0);
       }
   }
   __builtin_amdgcn_s_setprio(0);
@@ -120,6 +138,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   constexpr int ROWS = RT * 32;                 // sequences per workgroup
   constexpr int TPR = LSTM_THREADS / ROWS;      // threads per sequence row in the x gather
   constexpr int NWR = 8 / RT;                   // waves sharing one row tile (projection tail)
+  constexpr bool SWAP = !TRAIN;                 // weights as the MFMA A operand (see the file header)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // first unit block owned by this wave (further ones at +8), and its first row tile
   // <2,1,1>: wave w -> unit block w>>1, row tile w&1.  Waves are placed on SIMD w%4, so the live unit blocks of a
@@ -143,8 +162,10 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   float *red = smem + (size_t)(LIN ? 2 * RT * KG : RT * KGx + 2 * RT * KGh) * 256;  // [ROWS][NWR] (>= 8 floats)
   const int b0 = blockIdx.x * ROWS;
 
-  // --- x gather assignment: TPR threads per sequence row, 8 floats (one k-group) each
-  const int xr = tid / TPR, xq = tid % TPR;
+  // --- x gather assignment: TPR threads per sequence row, 8 floats (one k-group) each.  Consecutive lanes take
+  // consecutive ROWS of the same k-group, so a 16-byte x_store of 8 adjacent lanes covers 128 contiguous bytes
+  // (with tid / TPR the 8 lanes of a store group wrote k-groups 1 KiB apart: the same banks, 8-way conflict)
+  const int xr = tid % ROWS, xq = tid / ROWS;
   const bool row_ok = (b0 + xr) < a.B;
   const int32_t *id_row = a.ids + (size_t)(row_ok ? (a.row_map ? a.row_map[b0 + xr] : b0 + xr) : 0) * T;
   auto fetch_id = [&](int t) -> int {
@@ -201,20 +222,18 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
     }
   }
 
-  float bias[UBW][4];
-#pragma unroll
-  for (int u = 0; u < UBW; ++u)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bias[u][g] = a.bias[((ub0 + 8 * u) * 4 + g) * 32 + (lane & 31)];
-
+  // cell state, accumulator layout: SWAP: lane = sequence, register r = unit mfma_row(r, lane) of the block;
+  // otherwise lane = unit, register = sequence
   f32x16 c[UBW][MT];
 #pragma unroll
   for (int u = 0; u < UBW; ++u) {
-    const float c0 = (t0 > 0) ? a.pad_c[(size_t)t0 * (KGh * 8) + (ub0 + 8 * u) * 32 + (lane & 31)] : 0.0f;
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int r = 0; r < 16; ++r) {
+      const int un = (ub0 + 8 * u) * 32 + (SWAP ? mfma_row(r, lane) : (lane & 31));
+      const float c0 = (t0 > 0) ? a.pad_c[(size_t)t0 * (KGh * 8) + un] : 0.0f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) c[u][m][r] = c0;
+      for (int m = 0; m < MT; ++m) c[u][m][r] = c0;
+    }
   }
 
   __syncthreads();
@@ -291,8 +310,11 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
         }
         continue;
       }
-      const int unit = ub * 32 + (lane & 31);
-      const int hoff = (unit >> 3) * 256 + ((((unit >> 2) & 1) * 32) << 2) + (unit & 3);  // h element (row 0, k = unit) in a row tile
+      const int unit = ub * 32 + (lane & 31);   // !SWAP: this lane's hidden unit
+      // !SWAP: h element (row 0, k = unit) in a row tile.  SWAP: this lane's float4 (4 consecutive units of its
+      // sequence) in k-group 4*ub of a row tile; registers 4g..4g+3 go to k-group 4*ub + g.
+      const int hoff = SWAP ? (ub * 4) * 256 + lane * 4
+                            : (unit >> 3) * 256 + ((((unit >> 2) & 1) * 32) << 2) + (unit & 3);
       const int wsoff = __builtin_amdgcn_readfirstlane(ub) * KG * 4096;
       // gate tape, accumulator layout: [t][tile32][unit block][q][reg][lane], q = si,tj,sf,so,c
       float *tp[MT];
@@ -305,6 +327,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       // pass A: gates i, j  ->  pij = sigmoid(i) * tanh(j)      (BasicLSTMCell, TF 1.x)
       // pij is parked in the (still unused) h_t slots of the other h buffer -- same (row, unit)
       // coordinates -- instead of 16*MT registers held across pass B.
+      // (accumulators start at 0: the bias arrives through the constant-1 column of x, see the file header)
       f32x16 g[MT][2];
       float *hdst[MT];
 #pragma unroll
@@ -312,23 +335,34 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
         hdst[m] = hptr(nxt, mt0 + m) + hoff;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          g[m][0][r] = bias[u][0];
-          g[m][1][r] = bias[u][1];
+          g[m][0][r] = 0.0f;
+          g[m][1][r] = 0.0f;
         }
       }
-      gemm_pass<MT, LIN>(wr, wvoff, wsoff, xa, ha, KGx, kend, g);
+      gemm_pass<MT, LIN, SWAP>(wr, wvoff, wsoff, xa, ha, KGx, kend, g);
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m) {
+        if constexpr (SWAP) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float si = fast_sigmoid(g[m][0][r]);
-          const float tj = fast_tanh(g[m][1][r]);
-          hdst[m][mfma_row(r, lane) << 2] = si * tj;
-          if constexpr (TRAIN) {
-            tp[m][r * 64] = si;
-            tp[m][1024 + r * 64] = tj;
+          for (int q4 = 0; q4 < 4; ++q4) {
+            f32x4 pij;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pij[e] = fast_sigmoid(g[m][0][q4 * 4 + e]) * fast_tanh(g[m][1][q4 * 4 + e]);
+            *reinterpret_cast<f32x4 *>(hdst[m] + q4 * 256) = pij;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float si = fast_sigmoid(g[m][0][r]);
+            const float tj = fast_tanh(g[m][1][r]);
+            hdst[m][mfma_row(r, lane) << 2] = si * tj;
+            if constexpr (TRAIN) {
+              tp[m][r * 64] = si;
+              tp[m][1024 + r * 64] = tj;
+            }
           }
         }
+      }
       if (u == 0 && XD && have_next) {
         // x_{t+1}: its buffer was last read in step t-1, so it can be written as soon as the
         // prefetch has landed (frees the staging registers before pass B)
@@ -343,29 +377,47 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          g[m][0][r] = bias[u][2];
-          g[m][1][r] = bias[u][3];
+          g[m][0][r] = 0.0f;
+          g[m][1][r] = 0.0f;
         }
-      gemm_pass<MT, LIN>(wr, wvoff, wsoff + 2048, xa, ha, KGx, kend, g);
+      gemm_pass<MT, LIN, SWAP>(wr, wvoff, wsoff + 2048, xa, ha, KGx, kend, g);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
+        if constexpr (SWAP) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float sf = fast_sigmoid(g[m][0][r]);
-          const float so = fast_sigmoid(g[m][1][r]);
-          const float cn = c[u][m][r] * sf + hdst[m][mfma_row(r, lane) << 2];
-          c[u][m][r] = cn;
-          const float hv = fast_tanh(cn) * so;
-          hdst[m][mfma_row(r, lane) << 2] = hv;  // h_t, A-fragment order
-          if (!TRAIN && a.rec_h != nullptr && blockIdx.x == 0 && mt0 + m == 0 && r == 0 && lane < 32) {
-            // row 0 of the launch: state after t+1 steps (used to build the pad-prefix table)
-            a.rec_h[(size_t)(t + 1) * (KGh * 8) + unit] = hv;
-            a.rec_c[(size_t)(t + 1) * (KGh * 8) + unit] = cn;
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 pij = *reinterpret_cast<const f32x4 *>(hdst[m] + q4 * 256);
+            f32x4 hv4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = q4 * 4 + e;
+              const float sf = fast_sigmoid(g[m][0][r]);
+              const float so = fast_sigmoid(g[m][1][r]);
+              const float cn = c[u][m][r] * sf + pij[e];
+              c[u][m][r] = cn;
+              hv4[e] = fast_tanh(cn) * so;
+              if (a.rec_h != nullptr && blockIdx.x == 0 && mt0 + m == 0 && (lane & 31) == 0) {
+                // sequence 0 of the launch: state after t+1 steps (used to build the pad-prefix table)
+                a.rec_h[(size_t)(t + 1) * (KGh * 8) + ub * 32 + mfma_row(r, lane)] = hv4[e];
+                a.rec_c[(size_t)(t + 1) * (KGh * 8) + ub * 32 + mfma_row(r, lane)] = cn;
+              }
+            }
+            *reinterpret_cast<f32x4 *>(hdst[m] + q4 * 256) = hv4;  // h_t, A-fragment order: one 16-byte piece per k-group
           }
-          if constexpr (TRAIN) {
-            tp[m][2048 + r * 64] = sf;
-            tp[m][3072 + r * 64] = so;
-            tp[m][4096 + r * 64] = cn;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float sf = fast_sigmoid(g[m][0][r]);
+            const float so = fast_sigmoid(g[m][1][r]);
+            const float cn = c[u][m][r] * sf + hdst[m][mfma_row(r, lane) << 2];
+            c[u][m][r] = cn;
+            const float hv = fast_tanh(cn) * so;
+            hdst[m][mfma_row(r, lane) << 2] = hv;  // h_t, A-fragment order
+            if constexpr (TRAIN) {
+              tp[m][2048 + r * 64] = sf;
+              tp[m][3072 + r * 64] = so;
+              tp[m][4096 + r * 64] = cn;
+            }
           }
         }
       }

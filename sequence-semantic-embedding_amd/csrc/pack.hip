@@ -176,8 +176,11 @@ hipError_t launch_l2_normalize(const float *x, float *out, int64_t rows, int col
 // BasicLSTMCell kernel [(E+H)][4H] (TF 1.x: rows [x | h], columns [i | j | f | o])
 // -> Wp[wn][u][kg][gate][256]: for hidden-unit block ub = wn*UB + u the four gate
 // tiles of one k-group are contiguous (4 KiB), k = [x padded to Ep | h padded to Hp].
-__global__ void pack_lstm_kernel_k(const float *__restrict__ K, int E, int H, int Ep, int Hp, int UB,
-                                   int64_t total4, f32x4 *__restrict__ out) {
+// k-row E (the first padding row of the x part, Ep > E always) carries the BIAS: the padded embedding table
+// holds a constant 1.0 in column E, so the gate GEMM adds it -- forget_bias = 1.0 folded into the f block
+// (BasicLSTMCell adds it at run time, it is not stored in the variable).
+__global__ void pack_lstm_kernel_k(const float *__restrict__ K, const float *__restrict__ b, int E, int H, int Ep,
+                                   int Hp, int UB, int64_t total4, f32x4 *__restrict__ out) {
   const int KG = (Ep + Hp) / 8;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -197,6 +200,7 @@ __global__ void pack_lstm_kernel_k(const float *__restrict__ K, int E, int H, in
         int row = -1;
         if (kk < Ep) {
           if (kk < E) row = kk;
+          else if (kk == E) v[e] = b[col] + (g == 2 ? 1.0f : 0.0f);
         } else if (kk - Ep < H) {
           row = E + (kk - Ep);
         }
@@ -206,18 +210,6 @@ __global__ void pack_lstm_kernel_k(const float *__restrict__ K, int E, int H, in
     out[i] = v;
   }
   (void)UB;
-}
-
-// bias [4H] -> [Hp/32][4][32]; forget_bias = 1.0 folded into the f block
-// (BasicLSTMCell adds it at run time, it is not stored in the variable).
-__global__ void pack_lstm_bias_k(const float *__restrict__ b, int H, int Hp, float *__restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Hp * 4) return;
-  const int r = i & 31, g = (i >> 5) & 3, ub = i >> 7;
-  const int unit = ub * 32 + r;
-  float v = (unit < H) ? b[g * H + unit] : 0.0f;
-  if (g == 2) v += 1.0f;
-  out[i] = v;
 }
 
 // X[K][N] row-major -> frag32 with rows = n (columns of X), k = rows of X, zero padded to KGp groups
@@ -242,24 +234,25 @@ __global__ void pack_kn_kernel_k(const float *__restrict__ X, int K, int N, int 
   }
 }
 
-__global__ void pad_rows_kernel_k(const float *__restrict__ in, int64_t R, int C, int Cp, float *__restrict__ out) {
+// rows [R][C] -> [R][Cp] zero padded; one_col >= 0: that padding column holds 1.0 (the LSTM bias rides on it)
+__global__ void pad_rows_kernel_k(const float *__restrict__ in, int64_t R, int C, int Cp, int one_col, float *__restrict__ out) {
   const int64_t total = R * Cp;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % Cp);
     const int64_t r = i / Cp;
-    out[i] = (c < C) ? in[r * C + c] : 0.0f;
+    out[i] = (c < C) ? in[r * C + c] : (c == one_col ? 1.0f : 0.0f);
   }
 }
 
 static inline int grid_for(int64_t n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
 
 hipError_t launch_pack_lstm(const float *K, const float *b, int E, int H, int Ep, int Hp, int UB, float *Wp,
-                            float *biasp, hipStream_t stream) {
+                            hipStream_t stream) {
+  if (Ep <= E) return hipErrorInvalidValue;  // the bias needs a padding k-row
   const int KG = (Ep + Hp) / 8;
   const int64_t total4 = (int64_t)(Hp / 32) * KG * 4 * 64;
-  hipLaunchKernelGGL(pack_lstm_kernel_k, dim3(grid_for(total4)), dim3(256), 0, stream, K, E, H, Ep, Hp, UB, total4,
+  hipLaunchKernelGGL(pack_lstm_kernel_k, dim3(grid_for(total4)), dim3(256), 0, stream, K, b, E, H, Ep, Hp, UB, total4,
                      reinterpret_cast<f32x4 *>(Wp));
-  hipLaunchKernelGGL(pack_lstm_bias_k, dim3((Hp * 4 + 255) / 256), dim3(256), 0, stream, b, H, Hp, biasp);
   return hipGetLastError();
 }
 
@@ -270,8 +263,8 @@ hipError_t launch_pack_kn(const float *X, int K, int N, int KGp, float *out, hip
   return hipGetLastError();
 }
 
-hipError_t launch_pad_rows(const float *in, int64_t R, int C, int Cp, float *out, hipStream_t stream) {
-  hipLaunchKernelGGL(pad_rows_kernel_k, dim3(grid_for(R * Cp)), dim3(256), 0, stream, in, R, C, Cp, out);
+hipError_t launch_pad_rows(const float *in, int64_t R, int C, int Cp, int one_col, float *out, hipStream_t stream) {
+  hipLaunchKernelGGL(pad_rows_kernel_k, dim3(grid_for(R * Cp)), dim3(256), 0, stream, in, R, C, Cp, one_col, out);
   return hipGetLastError();
 }
 

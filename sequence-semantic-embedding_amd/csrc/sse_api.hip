@@ -29,7 +29,7 @@ struct Variable {
 struct Encoder {
   int kernel = -1, bias = -1, proj = -1;  // variable indices
   int H = 0, Hp = 0, UB = 0, KGx = 0, KGh = 0, Ep = 0;
-  float *Wp = nullptr, *biasp = nullptr, *Mp = nullptr;
+  float *Wp = nullptr, *Mp = nullptr;
   int shares_lstm_with = -1;  // shared-encoder: target reuses the source LSTM packing
   // pad-prefix table: state after p leading PAD steps, p = 0..pad_T ([pad_T+1][Hp] each)
   float *pad_h = nullptr, *pad_c = nullptr;
@@ -172,7 +172,7 @@ int geometry(sse_handle *h, Encoder &e) {
   if (e.H > 512) return fail(h, "LSTM cell size %d > 512 is not supported by the gfx950 kernel yet", e.H);
   e.Hp = e.H <= 128 ? 128 : e.H <= 256 ? 256 : 512;
   e.UB = e.Hp / 128;
-  e.Ep = round_up(c.embedding_size, 8);
+  e.Ep = round_up(c.embedding_size + 1, 8);  // at least one padding column: it holds the constant 1 of the bias row
   e.KGx = e.Ep / 8;
   e.KGh = e.Hp / 8;
   if (lstm_fwd_lds_bytes(e.KGx, e.KGh, e.Hp == 512 ? 1 : 2) > 160 * 1024)
@@ -181,10 +181,11 @@ int geometry(sse_handle *h, Encoder &e) {
   return 0;
 }
 
-// row stride of the padded embedding table: the LSTM kernels consume k in groups of 8; the CNN only needs
-// 16-byte aligned window starts (E = 50: 52 instead of 56 -> 7 % fewer MFMAs)
+// row stride of the padded embedding table: the LSTM kernels consume k in groups of 8 and need one padding column
+// for the constant 1 that carries the bias; the CNN only needs 16-byte aligned window starts (E = 50: 52 instead of
+// 56 -> 7 % fewer MFMAs)
 static int emb_cols(const sse_config &c) {
-  return round_up(c.embedding_size, c.network_mode == SSE_MODE_SOURCE_ONLY_CNN ? 4 : 8);
+  return c.network_mode == SSE_MODE_SOURCE_ONLY_CNN ? round_up(c.embedding_size, 4) : round_up(c.embedding_size + 1, 8);
 }
 
 // (re)build the kernel-facing layouts from the master variables
@@ -193,7 +194,8 @@ int ensure_packed(sse_handle *h, hipStream_t st) {
   const sse_config &c = h->cfg;
   const int Ep = emb_cols(c);
   if (!h->emb_pad) HIPCHECK(h, hipMalloc((void **)&h->emb_pad, (size_t)c.vocab_size * Ep * sizeof(float)));
-  HIPCHECK(h, launch_pad_rows(h->vars[0].dev, c.vocab_size, c.embedding_size, Ep, h->emb_pad, st));
+  HIPCHECK(h, launch_pad_rows(h->vars[0].dev, c.vocab_size, c.embedding_size, Ep,
+                              c.network_mode == SSE_MODE_SOURCE_ONLY_CNN ? -1 : c.embedding_size, h->emb_pad, st));
   for (int s = 0; s < 2; ++s) {
     Encoder &e = h->enc[s];
     if (e.H <= 0 || e.kernel < 0) continue;
@@ -201,12 +203,10 @@ int ensure_packed(sse_handle *h, hipStream_t st) {
     const int KG = e.KGx + e.KGh;
     if (e.shares_lstm_with < 0) {
       if (!e.Wp) HIPCHECK(h, hipMalloc((void **)&e.Wp, (size_t)(e.Hp / 32) * KG * 4 * 256 * sizeof(float)));
-      if (!e.biasp) HIPCHECK(h, hipMalloc((void **)&e.biasp, (size_t)e.Hp * 4 * sizeof(float)));
       HIPCHECK(h, launch_pack_lstm(h->vars[e.kernel].dev, h->vars[e.bias].dev, c.embedding_size, e.H, e.Ep, e.Hp, e.UB,
-                                   e.Wp, e.biasp, st));
+                                   e.Wp, st));
     } else {
       e.Wp = h->enc[e.shares_lstm_with].Wp;
-      e.biasp = h->enc[e.shares_lstm_with].biasp;
     }
     const int NTS = (c.encoding_size + 31) / 32;
     if (!e.Mp) HIPCHECK(h, hipMalloc((void **)&e.Mp, (size_t)NTS * e.KGh * 256 * sizeof(float)));
@@ -242,7 +242,6 @@ void fill_fwd_args(sse_handle *h, Encoder &e, LstmFwdArgs &a) {
   const sse_config &c = h->cfg;
   a.emb = h->emb_pad;
   a.Wp = e.Wp;
-  a.bias = e.biasp;
   a.Mp = e.Mp;
   a.err = h->err_flag;
   a.V = c.vocab_size;
@@ -616,7 +615,6 @@ void sse_destroy(sse_handle *h) {
     Encoder &e = h->enc[s];
     if (e.shares_lstm_with < 0) {
       if (e.Wp) hipFree(e.Wp);
-      if (e.biasp) hipFree(e.biasp);
       if (e.pad_h) (void)hipFree(e.pad_h);
       if (e.pad_c) (void)hipFree(e.pad_c);
     }
@@ -1084,8 +1082,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     a.ids = (const int32_t *)ts.ids[s].p;
     a.emb = h->emb_pad;
     a.Wp = e.Wp;
-    a.bias = e.biasp;
-    a.Mp = e.Mp;
+      a.Mp = e.Mp;
     a.out = (float *)ts.raw[s].p;
     a.err = h->err_flag;
     a.B = B;

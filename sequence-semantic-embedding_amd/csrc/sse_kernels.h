@@ -33,9 +33,8 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // ------------------------------ LSTM forward -------------------------------
 struct LstmFwdArgs {
   const int32_t *ids;   // [B][T]
-  const float *emb;     // [V][Ep] zero-padded word_embedding
-  const float *Wp;      // packed kernel, see pack_lstm_kernel()
-  const float *bias;    // [Hp/32][4][32], forget bias folded into the f block
+  const float *emb;     // [V][Ep] word_embedding, zero padded, column E = 1.0 (carries the bias through the GEMM)
+  const float *Wp;      // packed kernel, see pack_lstm_kernel(): k-row E = bias, forget bias folded into the f block
   const float *Mp;      // packed projection [Sp/32][KGh][256]
   float *out;           // [B][S]
   int32_t *err;         // bit 0: token id out of range
@@ -111,9 +110,9 @@ hipError_t launch_f64_to_f32(const double *in, float *out, int64_t n, hipStream_
 hipError_t launch_l2_normalize(const float *x, float *out, int64_t rows, int cols, hipStream_t stream);
 
 hipError_t launch_pack_lstm(const float *K, const float *b, int E, int H, int Ep, int Hp, int UB, float *Wp,
-                            float *biasp, hipStream_t stream);
+                            hipStream_t stream);
 hipError_t launch_pack_kn(const float *X, int K, int N, int KGp, float *out, hipStream_t stream);
-hipError_t launch_pad_rows(const float *in, int64_t R, int C, int Cp, float *out, hipStream_t stream);
+hipError_t launch_pad_rows(const float *in, int64_t R, int C, int Cp, int one_col, float *out, hipStream_t stream);
 hipError_t launch_row_norm2_max(const float *x, int64_t rows, int cols, float *out_bits, hipStream_t stream);
 hipError_t launch_fill(float *p, int64_t n, float v, hipStream_t stream);
 hipError_t launch_exact_topk(const float *q, const float *idxp, const double *idx64, const int32_t *cert,
