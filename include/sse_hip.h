@@ -95,8 +95,11 @@ int sse_encode_dev(sse_handle *h, int side, const int32_t *ids_dev, int32_t B, i
  * "train_serial" (default 0): run both encoders of a train step on one stream (profiling aid:
  * isolated kernel durations; same results). */
 int sse_set_option(sse_handle *h, const char *name, int32_t value);
-/* Diagnostic counters.  "score_bf16_second_chance_queries": queries (cumulative) whose bf16-candidate result missed
- * its certificate and were re-run with fp32 candidates. */
+/* Diagnostic counters (cumulative).  "score_bf16_second_chance_queries": queries whose bf16-candidate result missed
+ * its certificate and were re-run with fp32 candidates.  "score_collect_queries": queries served by the collect path
+ * (k > 16, or a k-th score tied with rows outside the candidate lists: one more grid-wide sweep gathers every row that
+ * can be in the exact top-k).  "score_bruteforce_queries": queries that fell through to the one-workgroup-per-query
+ * float64 sweep (k > 1024, or more than 4096 rows within the fp32 bound of the k-th score). */
 int sse_get_counter(sse_handle *h, const char *name, int64_t *value);
 
 /* tf.nn.l2_normalize(x, dim=-1) on device rows (sse_model.py:282-283). */

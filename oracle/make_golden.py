@@ -10,7 +10,9 @@ What the reference can pin (it has no tests and TensorFlow cannot run here):
                        sample raw lines and the token-id rows the reference
                        produced (data_utils.py:115-213), which pin pad_tokens and
                        the drop-in tokenizer;
-  * prep_crosslingual.json -- same on a sample of rawdata-crosslingual.
+  * prep_crosslingual.json -- same on a sample of rawdata-crosslingual;
+  * qna_full_ids.npz / crosslingual_full_ids.npz -- ALL token-id rows (eval sources, every target) and eval labels
+                       of the two datasets, for the full-size GPU parity tests (C3: 32,060 x 16,491; qna: T = 1000).
 """
 import argparse
 import contextlib
@@ -119,6 +121,20 @@ def golden_prep(data_utils, ref, task, vocab_size, max_seq_length, n_sample):
                             src_ids=np.array([evalc[i][0] for i in pick], np.int32),
                             tgt_ids=np.array([full_tgt[t] for t in tids], np.int32), labels=lab,
                             vocab_size=np.int32(encoder.vocab_size))
+    # full-size parity fixtures (SURVEY 8d C3 as specified: every target indexed, every eval query scored; qna at
+    # T = 1000): the token-id rows exactly as the reference's prepare_raw_data produced them, uint16 (vocab < 65536),
+    # eval labels as rows of the target matrix in `full_tgt` order, -1 padded
+    assert encoder.vocab_size < 65536
+    tid_list = list(full_tgt.keys())
+    row_of_all = {t: r for r, t in enumerate(tid_list)}
+    width = max(len(e[1]) for e in evalc)
+    lab_all = np.full((len(evalc), width), -1, np.int32)
+    for r, e in enumerate(evalc):
+        lab_all[r, :len(e[1])] = [row_of_all[t] for t in e[1]]
+    np.savez_compressed(os.path.join(OUT, "%s_full_ids.npz" % task),
+                        src_ids=np.array([e[0] for e in evalc], np.uint16),
+                        tgt_ids=np.array([full_tgt[t] for t in tid_list], np.uint16), labels=lab_all,
+                        vocab_size=np.int32(encoder.vocab_size))
     out = {"task": task, "vocab_size_flag": vocab_size, "max_seq_length": max_seq_length,
            "encoder_vocab_size": encoder.vocab_size, "n_train": len(train), "n_eval": len(evalc),
            "n_targets": len(full_tgt), "vocabulary_txt": vocab, "src_cases": src_cases, "tgt_cases": tgt_cases,

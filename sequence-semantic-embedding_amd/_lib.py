@@ -10,7 +10,8 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsse_hip.so")
+# SSE_HIP_LIB: developer knob for A/B timing of two builds of the same C ABI (tools/ab); never a CPU fallback
+LIB_PATH = os.environ.get("SSE_HIP_LIB") or os.path.join(HERE, "libsse_hip.so")
 
 MODE_IDS = {"dual-encoder": 0, "shared-encoder": 1, "source-encoder-only": 2, "source_only_cnn": 3}
 SIDE_SOURCE, SIDE_TARGET = 0, 1

@@ -71,22 +71,69 @@ __device__ __forceinline__ void merge_lists(float (&ls)[KC], int (&li)[KC], cons
       }
 }
 
+// merge of two sorted (descending) 8-lists held by a lane pair into one sorted 16-list: [A0..A7, B7..B0] is bitonic
+// (in the list order), four compare-exchange stages sort it
+__device__ __forceinline__ void merge8_to16(const float (&as)[8], const int (&ai)[8], const float (&bs)[8], const int (&bi)[8],
+                                            float (&os)[16], int (&oi)[16]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    os[i] = as[i];
+    oi[i] = ai[i];
+    os[8 + i] = bs[7 - i];
+    oi[8 + i] = bi[7 - i];
+  }
+#pragma unroll
+  for (int stride = 8; stride > 0; stride >>= 1)
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if ((i & stride) == 0) {
+        const bool sw = entry_before(os[i + stride], oi[i + stride], os[i], oi[i]);
+        const float ts = os[i];
+        const int ti = oi[i];
+        os[i] = sw ? os[i + stride] : ts;
+        oi[i] = sw ? oi[i + stride] : ti;
+        os[i + stride] = sw ? ts : os[i + stride];
+        oi[i + stride] = sw ? ti : oi[i + stride];
+      }
+}
+
 // 8 waves per workgroup = 2 per SIMD: there is no barrier in the sweep, so the waves drift
 // apart and one wave's top-k epilogue (VALU) overlaps its partner's MFMA stream.
 // Wave tile: 1 index tile (32 rows, M) x NQ query tiles (N): NQ accumulators + NQ private lists.
 //   NQ = 4: 128-query block (MFMA-bound regime).  NQ = 1: <= 32 queries (demo / web, Q = 1):
 //   a quarter of the MFMA work per index byte, so the sweep runs at HBM speed.
-//   MERGE: the 16 lists per query of a workgroup are merged to one (in-wave via shuffles,
-//   across waves through LDS) so that many index splits stay cheap to re-score.
+// Lists.  A lane keeps a sorted top-KL (8) list per query tile over the rows it sees (1/16 of the workgroup's rows);
+//   the 16 lane lists of a query are merged in the kernel (lane pairs via shuffles into a 16-list, then an LDS tree
+//   over the waves) into ONE list of KC = 16 candidates per (query, index split), together with a BOUND: every row of
+//   the split that is not in the merged list scores <= bound = max(16th merged entry, the 8th entry of any FULL lane
+//   list): a row a lane list evicted or refused is <= that list's final 8th entry (monotone), a row refused by the
+//   shared threshold is <= the workgroup's 16th best, a row dropped by a merge is <= the merged 16th.  The re-scoring
+//   pass certifies against that bound, so 8-entry lane lists cost no exactness: when one of them overflows with rows
+//   that mattered (probability ~1e-6 per query on unordered data) the certificate fails and the query is recomputed.
+//   (Round 1 kept 16 sorted entries per lane: 128 list registers at NQ = 4 and ~250 instructions per insertion round.)
+// Insertion: one ballot per accumulator register against the threshold; a register some lane beats it with is inserted
+//   with selects (lanes that do not take keep their list) -- ~50 instructions per hit instead of an
+//   extract-max / find-index / insert-16 round.
+// The accumulators start from the MFMA's zero C operand (first k-group), not from 16 moves per query tile.
 // BF: the candidate pass runs on v_mfma_f32_32x32x16_bf16 -- index and queries are bf16 copies in the same 1-KiB
 // block / 16-byte-per-lane fragment scheme (a block now holds 32 rows x 16 k, a.KG counts 16-k groups), ONE MFMA per
 // (k-group, query tile).  Only candidate SELECTION sees bf16: the float64 re-scoring pass works on the fp32 / f64
 // rows with an error bound widened to the bf16 rounding, so the results stay exact (or fall back, certified).
+// COLLECT: no lists at all -- every row whose score reaches the query's threshold a.col_thr[query] is appended to the
+// query's buffer (a.col_buf[slot], atomic counter a.col_cnt[slot]); queries with a.col_slot[query] < 0 are skipped.
+// This is the grid-wide exact path for what the lists cannot certify (ties / duplicates at the k-th score, k > 16):
+// the threshold is a proven lower bound of the fp32 score of every exact top-k row, so the buffer provably holds the
+// exact top-k (select_topk_kernel re-scores and sorts it in float64).
 typedef short bf16x8_t __attribute__((ext_vector_type(8)));
-template <int KC, int NQ, bool MERGE, bool BF>
+#define SC_KL 8
+struct TagZ { static constexpr bool value = true; };   // "accumulators start from zero" / "accumulate" tags of mma()
+struct TagA { static constexpr bool value = false; };
+template <int NQ, bool BF, bool COLLECT, bool RINGED>
 __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // query block [NQ][KG][256]; later merge scratch
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  constexpr int KC = SC_KC, KL = SC_KL;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform (SGPR): tile numbers and load offsets derive from it
   const int KG = a.KG;
 
   // XCD-aware decode: workgroups of one XCD (blockIdx % 8) sweep the same index
@@ -106,333 +153,340 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   }
   const int QB = (a.QT + NQ - 1) / NQ;
   if (qb >= QB) return;
-  if (a.skip_cert) {  // fp32 second chance after a bf16 candidate pass: only blocks with an uncertified query run
+  if (COLLECT || a.skip_cert) {  // fp32 second chance after a bf16 candidate pass / collect pass: only blocks with an open query run
     int open_q = 0;
     for (int i = tid; i < NQ * 32; i += SC_THREADS) {
       const int qq = qb * NQ * 32 + i;
-      if (qq < a.Q && a.skip_cert[qq] == 0) open_q = 1;
+      if (qq < a.Q && (COLLECT ? a.col_slot[qq] >= 0 : a.skip_cert[qq] == 0)) open_q = 1;
     }
     if (!__syncthreads_or(open_q)) return;
   }
 
-  // stage the query block (already frag32-packed) into LDS
+  // stage the query block (already fragment-packed, [query tile][k-group][1 KiB]) into LDS as [k-group][query tile]:
+  // the NQ fragments of one k-group are 1 KiB apart and consecutive k-groups NQ KiB, so every read in the unrolled
+  // k-loop is ONE base register + an immediate offset (with [q][kg] the NQ*KG addresses each took a VGPR)
   {
     const f32x4 *src = reinterpret_cast<const f32x4 *>(a.qp) + (size_t)qb * NQ * KG * 64;
     f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
     const int valid = min(NQ, a.QT - qb * NQ) * KG * 64;
-    for (int i = tid; i < NQ * KG * 64; i += SC_THREADS) dst[i] = (i < valid) ? src[i] : f32x4{0, 0, 0, 0};
+    for (int i = tid; i < NQ * KG * 64; i += SC_THREADS) {
+      const int blk = i >> 6, qt = blk / KG, kg = blk - qt * KG;
+      dst[(kg * NQ + qt) * 64 + (i & 63)] = (i < valid) ? src[i] : f32x4{0, 0, 0, 0};
+    }
   }
-  __syncthreads();
 
-  float ls[NQ][KC];
-  int li[NQ][KC];
+  float ls[NQ][KL];
+  int li[NQ][KL];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
 #pragma unroll
-    for (int i = 0; i < KC; ++i) {
+    for (int i = 0; i < KL; ++i) {
       ls[q][i] = NEG_INF;
       li[q][i] = -1;
     }
+  // COLLECT: this lane's query threshold and buffer slot per query tile
+  float cthr[NQ];
+  int cslot[NQ];
+  if constexpr (COLLECT) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int query = (qb * NQ + q) * 32 + (lane & 31);
+      cslot[q] = (query < a.Q) ? a.col_slot[query] : -1;
+      cthr[q] = (cslot[q] >= 0) ? a.col_thr[query] : __builtin_inff();
+    }
+  }
 
-  // Shared per-query insertion thresholds (LDS, order-preserving int encoding of the float):
-  // max over the workgroup's 16 lists of a query of their current minima.  A list minimum is
-  // the KC-th best of a subset of the rows, hence a lower bound of the workgroup's KC-th best:
-  // rows below it can never reach the merged top-KC, so every lane may use it as its
-  // threshold -- the 16 lists of a query share their progress and insertions (a
-  // wave-divergent ~100-instruction path) become ~16x rarer.
+  // Shared per-query insertion threshold (LDS, order-preserving int encoding of the float): a lower bound of the
+  // workgroup's 16th best score -- the SMALLEST of the 16 lane lists' best entries (16 distinct rows score at least
+  // that).  Every list keeps its current best in mx_s[query][list] (monotone, plain stores); wave 0 folds the minimum
+  // into thr_s every few tiles.  Racy reads only see older, smaller -- still valid -- values.  Rows below it can never
+  // reach the merged top-16, so every lane may use it as its threshold: the 16 lists of a query share their progress.
   int *thr_s = reinterpret_cast<int *>(smem + (size_t)a.thr_off);
   auto enc = [](float f) -> int { const int i = __float_as_int(f); return i >= 0 ? i : (i ^ 0x7FFFFFFF); };
   auto dec = [](int i) -> float { return __int_as_float(i >= 0 ? i : (i ^ 0x7FFFFFFF)); };
-  for (int i = tid; i < NQ * 32; i += SC_THREADS) thr_s[i] = enc(NEG_INF);
-  // A second, much tighter lower bound of the workgroup's KC-th best per query: the SMALLEST of its 16 lists' best
-  // entries (16 distinct rows score at least that).  Every list keeps its current best in mx_s[query][list]
-  // (monotone, plain stores); wave 0 folds the minimum into thr_s every few tiles.  Racy reads only see older,
-  // smaller -- still valid -- values.  With 16 lists of 1/16 of the rows each, the list minima alone let a lane insert
-  // on practically every tile (~150 instructions per round): at bf16 matrix speed that cost more than the MFMAs.
   float *mx_s = reinterpret_cast<float *>(thr_s + NQ * 32);  // [NQ*32][16]
-  for (int i = tid; i < NQ * 32 * 16; i += SC_THREADS) mx_s[i] = NEG_INF;
+  if constexpr (!COLLECT) {
+    for (int i = tid; i < NQ * 32; i += SC_THREADS) thr_s[i] = enc(NEG_INF);
+    for (int i = tid; i < NQ * 32 * 16; i += SC_THREADS) mx_s[i] = NEG_INF;
+  }
   __syncthreads();
 
   const int tps = (a.NT + a.NSPLIT - 1) / a.NSPLIT;  // n-tiles per split
   const int t0 = split * tps, t1 = min(a.NT, t0 + tps);
   const float *qs = smem + lane * 4;
   const int voff = lane * 16;
-
-  // NQ == 1 (<= 32 queries) is an HBM-bound sweep: 4 MFMAs per KiB of index.  Two loads in flight per wave
-  // (the pipelined loop below) cover only ~4 MB chip-wide where 8 TB/s x ~1.5 us wants >= 12 MB, so this variant
-  // keeps a ring of RING k-group fragments per wave in registers (32 VGPRs), running across tile boundaries.
-  constexpr int RING = 8;
   constexpr int WSTEP = SC_THREADS / 64;
-  const bool use_ring = (NQ == 1) && (KG % RING == 0) && ((int64_t)tps * KG * 1024 < ((int64_t)1 << 31));
+
+  // k-group product: acc (+)= A fragment x the NQ query fragments; ZERO: the accumulators start from the MFMA's
+  // inline-constant C operand
+  auto mma = [&](f32x16 (&acc)[NQ], const f32x4 &av, const f32x4 (&bv)[NQ], auto zero_tag) {
+    constexpr bool ZERO = decltype(zero_tag)::value;
+    const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (BF) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, bv[q]),
+                                                         ZERO ? z : acc[q], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[q][e], (ZERO && e == 0) ? z : acc[q], 0, 0, 0);
+    }
+  };
+
+  // Index fragments: a ring of RING k-groups per wave in registers, running ACROSS tile boundaries (the slot used for
+  // k-group kg is refilled with k-group kg + RING of the same tile, or the head of this wave's next tile), all through
+  // one buffer descriptor per tile (base = this tile, spanning the wave's next tile 8 tiles on: offsets stay far below
+  // the 4 GiB descriptor range for any index size; per-lane offset is the constant 16*lane).  RING k-groups in
+  // flight cover an HBM miss at either matrix rate: fp32 16 MFMAs (1 k cycles) per k-group, bf16 4 MFMAs (128 cycles).
+  // Needs KG % RING == 0 (RINGED, chosen by the launcher); other shapes (small encodings) use the two-set pipelined
+  // loop below.  A template parameter, not a run-time branch: with both loops in one kernel the compiler's wait-count
+  // bookkeeping merges their pending loads and drains the ring (vmcnt(0)) in front of every epilogue.
+  constexpr int RING = 8;
   f32x4 ring[RING];
   const int tile0 = t0 + w;
-  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(a.idxp) + (size_t)__builtin_amdgcn_readfirstlane(tile0 < t1 ? tile0 : t0) * KG * 256, 0,
-      (tile0 < t1 ? (t1 - tile0) : 0) * KG * 1024, 0x00020000);  // this wave's whole tile stream (< 2 GiB, else use_ring is off)
-  if (use_ring && tile0 < t1) {
+  const int tail_tile = (a.N & 31) ? (int)(a.N >> 5) : -1;
+  if (RINGED && tile0 < t1) {
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.idxp) + (size_t)__builtin_amdgcn_readfirstlane(tile0) * KG * 256, 0, KG * 1024, 0x00020000);
 #pragma unroll
     for (int d = 0; d < RING; ++d)
-      ring[d] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, voff, d * 1024, 0));
+      ring[d] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, voff, d * 1024, 0));
   }
 
-  for (int tile = t0 + w; tile < t1; tile += SC_THREADS / 64) {
-    // index tile through a buffer descriptor (base = this tile: stays below the 4 GiB
-    // descriptor range for any index size); per-lane offset is the constant 16*lane
-    // The descriptor also spans this wave's NEXT tile (8 tiles on) so that the loop can touch index bytes PD
-    // k-groups ahead of their use: the fragment load proper is issued only one k-group (16 MFMAs, ~1-2 k cycles)
-    // early, which does not cover an HBM miss; the touch pulls the lines into L2 first.
+  for (int tile = tile0; tile < t1; tile += WSTEP) {
     const int utile = __builtin_amdgcn_readfirstlane(tile);
-    const int span = min(a.NT - utile, SC_THREADS / 64 + 1);
+    const int span = min(a.NT - utile, WSTEP + 1);
     const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.idxp) + (size_t)utile * KG * 256, 0, span * KG * 1024, 0x00020000);
-    auto iload = [&](int kg) -> f32x4 {
-      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ir, voff, kg * 1024, 0));
+    auto iload = [&](int off_kg) -> f32x4 {
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ir, voff, off_kg * 1024, 0));
     };
-    constexpr int PD = 8;
-    auto touch = [&](int kg) -> int {  // one dword per 16-byte segment of k-group kg+PD (next tile past the end)
-      const int kp = kg + PD;
-      const int off = (kp < KG) ? kp : kp + (SC_THREADS / 64 - 1) * KG;
-      return __builtin_amdgcn_raw_buffer_load_b32(ir, voff, off * 1024, 0);
-    };
-    int tch0 = 0, tch1 = 0;
     f32x16 acc[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
 
-    if (use_ring) {
-      if constexpr (NQ == 1) {
-        const int tbase = (tile - tile0) * KG;                       // k-group index of this tile in the wave's stream
-        const bool more = tile + WSTEP < t1;                          // a next tile exists
-        f32x4 bq = *reinterpret_cast<const f32x4 *>(qs), bqn;
-        __builtin_amdgcn_s_setprio(1);
-        for (int kg0 = 0; kg0 < KG; kg0 += RING) {
+    if constexpr (RINGED) {
+      const bool more = tile + WSTEP < t1;  // this wave has a next tile
+      f32x4 bq[NQ], bqn[NQ];
 #pragma unroll
-          for (int d = 0; d < RING; ++d) {
-            const int kg = kg0 + d;
-            bqn = *reinterpret_cast<const f32x4 *>(qs + ((kg + 1 < KG) ? kg + 1 : 0) * 256);
-            if constexpr (BF) {
-              acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ring[d]), __builtin_bit_cast(bf16x8_t, bq), acc[0], 0, 0, 0);
-            } else {
+      for (int q = 0; q < NQ; ++q) bq[q] = *reinterpret_cast<const f32x4 *>(qs + q * 256);
+      __builtin_amdgcn_s_setprio(1);
+      auto ring_block = [&](int kg0, auto zero_tag) {
+        const float *qcur = qs + (size_t)kg0 * NQ * 256;                               // query fragments of k-group kg0
+        const float *qnext = (kg0 + RING < KG) ? qcur + RING * NQ * 256 : qs;          // ... of the next block (or the next tile's first)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[d][e], bq[e], acc[0], 0, 0, 0);
-            }
-            // refill the slot with the fragment RING k-groups on: same tile, or the head of this wave's next tile
-            const int kn = kg + RING;
-            const int off = (kn < KG) ? tbase + kn : (more ? tbase + WSTEP * KG + (kn - KG) : tbase + kg);
-            ring[d] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, voff, off * 1024, 0));
-            bq = bqn;
-          }
+        for (int d = 0; d < RING; ++d) {
+          const int kg = kg0 + d;
+          // next k-group's query fragments (LDS) first, then this k-group's MFMAs, then the refill of the slot
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            bqn[q] = *reinterpret_cast<const f32x4 *>(d + 1 < RING ? qcur + ((d + 1) * NQ + q) * 256 : qnext + q * 256);
+          __builtin_amdgcn_sched_barrier(0);
+          if (d == 0) mma(acc, ring[d], bq, zero_tag);
+          else mma(acc, ring[d], bq, TagA{});
+          __builtin_amdgcn_sched_barrier(0);
+          // refill the slot with the fragment RING k-groups on: same tile, or the head of this wave's next tile
+          const int kn = kg + RING;
+          const int off = (kn < KG) ? kn : (more ? WSTEP * KG + (kn - KG) : kg);
+          ring[d] = iload(off);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) bq[q] = bqn[q];
         }
-      }
+      };
+      ring_block(0, TagZ{});
+      for (int kg0 = RING; kg0 < KG; kg0 += RING) ring_block(kg0, TagA{});
     } else {
       // k-loop, hand software-pipelined with two named operand sets (X / Y): the index
       // fragment of k-group kg+1 (global) and the query fragments (LDS) are in flight while
-      // kg's 4*NQ MFMAs issue; no register copies.
+      // kg's MFMAs issue; no register copies.
       f32x4 ax = iload(0), ay;
       f32x4 bx[NQ], by[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) bx[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG) * 256);
+      for (int q = 0; q < NQ; ++q) bx[q] = *reinterpret_cast<const f32x4 *>(qs + q * 256);
       __builtin_amdgcn_s_setprio(1);
       int kg = 0;
-      for (; kg + 1 < KG; kg += 2) {
-        asm volatile("" ::"v"(tch0), "v"(tch1));  // last iteration's touches (long since returned: in-order)
-        ay = iload(kg + 1);
-        if constexpr (NQ > 1 && !BF) {  // the single-query-tile sweep is HBM-bound already: extra requests only cost
-          tch0 = touch(kg);
-          tch1 = touch(kg + 1);
-        }
+      if (KG >= 2) {  // first pair: starts the accumulators from zero
+        ay = iload(1);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) by[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG + kg + 1) * 256);
+        for (int q = 0; q < NQ; ++q) by[q] = *reinterpret_cast<const f32x4 *>(qs + (NQ + q) * 256);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (BF) {
-#pragma unroll
-          for (int q = 0; q < NQ; ++q)
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ax), __builtin_bit_cast(bf16x8_t, bx[q]), acc[q], 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[q][e], acc[q], 0, 0, 0);
-        }
+        mma(acc, ax, bx, TagZ{});
         __builtin_amdgcn_sched_barrier(0);
-        const int k2 = (kg + 2 < KG) ? kg + 2 : kg;
+        const int k2 = (2 < KG) ? 2 : 0;
         ax = iload(k2);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) bx[q] = *reinterpret_cast<const f32x4 *>(qs + (q * KG + k2) * 256);
+        for (int q = 0; q < NQ; ++q) bx[q] = *reinterpret_cast<const f32x4 *>(qs + (k2 * NQ + q) * 256);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (BF) {
-#pragma unroll
-          for (int q = 0; q < NQ; ++q)
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ay), __builtin_bit_cast(bf16x8_t, by[q]), acc[q], 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[e], by[q][e], acc[q], 0, 0, 0);
-        }
+        mma(acc, ay, by, TagA{});
         __builtin_amdgcn_sched_barrier(0);
-      }
-      if (kg < KG) {
-        if constexpr (BF) {
+        kg = 2;
+        for (; kg + 1 < KG; kg += 2) {
+          ay = iload(kg + 1);
 #pragma unroll
-          for (int q = 0; q < NQ; ++q)
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ax), __builtin_bit_cast(bf16x8_t, bx[q]), acc[q], 0, 0, 0);
-        } else {
+          for (int q = 0; q < NQ; ++q) by[q] = *reinterpret_cast<const f32x4 *>(qs + ((kg + 1) * NQ + q) * 256);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(acc, ax, bx, TagA{});
+          __builtin_amdgcn_sched_barrier(0);
+          const int k3 = (kg + 2 < KG) ? kg + 2 : kg;
+          ax = iload(k3);
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[q][e], acc[q], 0, 0, 0);
+          for (int q = 0; q < NQ; ++q) bx[q] = *reinterpret_cast<const f32x4 *>(qs + (k3 * NQ + q) * 256);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(acc, ay, by, TagA{});
+          __builtin_amdgcn_sched_barrier(0);
         }
+        if (kg < KG) mma(acc, ax, bx, TagA{});
+      } else {
+        mma(acc, ax, bx, TagZ{});
       }
     }
     __builtin_amdgcn_s_setprio(0);
 
-    // fused top-k: lane owns query column (lane & 31) of each q-tile and sees 16 index rows
-    // per n-tile.  Branch-lean: one max tree per q-tile against the (shared) threshold; only
-    // when some lane beats it, lanes repeatedly extract their best remaining score and
-    // insert it (1-2 rounds in practice) -- no per-score branches.
     const int nrow0 = tile * 32;
-    const bool tail = (nrow0 + 32) > a.N;  // only the last tile has rows >= N (zero padding)
-    if (w == 0 && (((tile - t0) / (SC_THREADS / 64)) & 3) == 3 && lane < 32) {
-#pragma nounroll
-      for (int q = 0; q < NQ; ++q) {  // rolled on purpose: runs once per 4 tiles, must not cost registers
-        const float *mp = mx_s + (q * 32 + lane) * 16;
-        float f = mp[0];
-#pragma nounroll
-        for (int j = 1; j < 16; ++j) f = fminf(f, mp[j]);
-        if (f > NEG_INF) atomicMax(&thr_s[q * 32 + lane], enc(f));
-      }
-    }
+    if constexpr (COLLECT) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      if (tail) {
-        // only the last tile of the index: a real (wave-uniform) branch -- the empty asm keeps the compiler from
-        // if-converting it into 16 selects per query tile on EVERY tile (it did: ~300 instructions per tile)
-        asm volatile("");
+      for (int q = 0; q < NQ; ++q) {
+        float m = NEG_INF;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = (nrow0 + mfma_row(r, lane) >= a.N) ? NEG_INF : acc[q][r];
-      }
-      float m = NEG_INF;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[q][r]);
-      float thr = fmaxf(ls[q][KC - 1], dec(thr_s[q * 32 + (lane & 31)]));
-      if (__any(m > thr)) {
-        for (;;) {
-          // this lane's best remaining score and its register index (first one on ties: rows
-          // ascend with r, so equal scores are taken in row order)
-          const bool take = m > thr;
-          int ridx = 0;
-          bool found = false;
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[q][r]);
+        if (__any(m >= cthr[q])) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const bool hit = !found && (acc[q][r] == m);
-            ridx = hit ? r : ridx;
-            acc[q][r] = (hit && take) ? NEG_INF : acc[q][r];
-            found = found || hit;
+            const int row = nrow0 + mfma_row(r, lane);
+            if (acc[q][r] >= cthr[q] && row < a.N) {  // rows >= N are the zero padding of the last tile
+              const int pos = atomicAdd(a.col_cnt + cslot[q], 1);
+              if (pos < a.col_cap) a.col_buf[(size_t)cslot[q] * a.col_cap + pos] = row;
+            }
           }
-          list_insert<KC>(ls[q], li[q], m, nrow0 + (ridx & 3) + 8 * (ridx >> 2) + 4 * (lane >> 5), take);
-          thr = fmaxf(thr, ls[q][KC - 1]);
-          m = NEG_INF;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[q][r]);
-          if (!__any(m > thr)) break;
         }
-        atomicMax(&thr_s[q * 32 + (lane & 31)], enc(ls[q][KC - 1]));  // publish this list's minimum
-        mx_s[(q * 32 + (lane & 31)) * 16 + w * 2 + (lane >> 5)] = ls[q][0];  // and its best
+      }
+    } else {
+      // fused top-k: lane owns query column (lane & 31) of each q-tile and sees 16 index rows per n-tile
+      const bool tail = (tile == tail_tile);  // only the last tile of the index can have rows >= N (zero padding)
+      if (w == 0 && (((tile - t0) / WSTEP) & 3) == 3 && lane < 32) {
+#pragma nounroll
+        for (int q = 0; q < NQ; ++q) {  // rolled on purpose: runs once per 4 tiles, must not cost registers
+          const float *mp = mx_s + (q * 32 + lane) * 16;
+          float f = mp[0];
+#pragma nounroll
+          for (int j = 1; j < 16; ++j) f = fminf(f, mp[j]);
+          if (f > NEG_INF) atomicMax(&thr_s[q * 32 + lane], enc(f));
+        }
+      }
+      const int rbase = nrow0 + 4 * (lane >> 5);  // row of accumulator register r: rbase + (r & 3) + 8 * (r >> 2)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        if (tail) {
+          // only the last tile of the index: a real (wave-uniform) branch -- the asm makes the row base opaque, which
+          // keeps the compiler from if-converting the masking into 16 selects per query tile on EVERY tile and from
+          // hoisting the 16 row numbers (and their registers) out of the branch
+          int nb = rbase;
+          asm volatile("" : "+v"(nb));
+          const int nlim = (int)a.N;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[q][r] = (nb + (r & 3) + 8 * (r >> 2) >= nlim) ? NEG_INF : acc[q][r];
+        }
+        float m = NEG_INF;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[q][r]);
+        float thr = fmaxf(ls[q][KL - 1], dec(thr_s[q * 32 + (lane & 31)]));
+        if (__any(m > thr)) {
+          // rare (about two hits per wave tile): per register one ballot; a register some lane takes is inserted
+          // with selects.  Registers ascend with the row number, '>' keeps the earlier row on equal scores.
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool take = acc[q][r] > thr;
+            if (__ballot(take) != 0ull) {
+              asm volatile("");  // keep it a branch (see above)
+              list_insert<KL>(ls[q], li[q], acc[q][r], rbase + (r & 3) + 8 * (r >> 2), take);
+              thr = fmaxf(thr, ls[q][KL - 1]);
+            }
+          }
+          mx_s[(q * 32 + (lane & 31)) * 16 + w * 2 + (lane >> 5)] = ls[q][0];  // publish this list's best
+        }
       }
     }
   }
+  if constexpr (COLLECT) return;
 
   constexpr int WAVES = SC_THREADS / 64;
-  if constexpr (MERGE) {
-    // (1) the two lane halves hold lists of the same query over different rows: merge into lanes 0-31
+  // (1) the two lane halves hold lists of the same query over different rows: merge into a 16-list in lanes 0-31;
+  //     bnd = largest 8th entry of a full lane list (see the header comment)
+  float ms16[NQ][KC];
+  int mi16[NQ][KC];
+  float bnd[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      float os[KC];
-      int oi[KC];
+  for (int q = 0; q < NQ; ++q) {
+    float os[KL];
+    int oi[KL];
 #pragma unroll
-      for (int i = 0; i < KC; ++i) {
-        os[i] = __shfl_xor(ls[q][i], 32);
-        oi[i] = __shfl_xor(li[q][i], 32);
-      }
-      merge_lists<KC>(ls[q], li[q], os, oi);
+    for (int i = 0; i < KL; ++i) {
+      os[i] = __shfl_xor(ls[q][i], 32);
+      oi[i] = __shfl_xor(li[q][i], 32);
     }
-    // (2) tree over the 8 waves through LDS (the query block is no longer needed):
-    // scratch [wave][q][entry][32 queries], one (score, id) plane pair per sender wave
-    __syncthreads();
-    float *ms = smem;
-    int *mi = reinterpret_cast<int *>(smem) + (WAVES / 2) * NQ * KC * 32;
-    for (int half = WAVES / 2; half >= 1; half >>= 1) {
-      if (w >= half && w < 2 * half && lane < 32) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-          for (int i = 0; i < KC; ++i) {
-            ms[(((w - half) * NQ + q) * KC + i) * 32 + lane] = ls[q][i];
-            mi[(((w - half) * NQ + q) * KC + i) * 32 + lane] = li[q][i];
-          }
-      }
-      __syncthreads();
-      if (w < half && lane < 32) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          float os[KC];
-          int oi[KC];
-#pragma unroll
-          for (int i = 0; i < KC; ++i) {
-            os[i] = ms[((w * NQ + q) * KC + i) * 32 + lane];
-            oi[i] = mi[((w * NQ + q) * KC + i) * 32 + lane];
-          }
-          merge_lists<KC>(ls[q], li[q], os, oi);
-        }
-      }
-      __syncthreads();
-    }
-    if (w == 0 && lane < 32) {
+    merge8_to16(ls[q], li[q], os, oi, ms16[q], mi16[q]);
+    bnd[q] = fmaxf(ls[q][KL - 1], os[KL - 1]);
+  }
+  // (2) tree over the 8 waves through LDS (the query block is no longer needed):
+  // scratch [wave][q][entry][32 queries], one (score, id) plane pair per sender wave, then the bounds
+  __syncthreads();
+  float *ms = smem;
+  int *mi = reinterpret_cast<int *>(smem) + (WAVES / 2) * NQ * KC * 32;
+  float *mb = smem + 2 * (WAVES / 2) * NQ * KC * 32;  // [wave][q][32]
+  for (int half = WAVES / 2; half >= 1; half >>= 1) {
+    if (w >= half && w < 2 * half && lane < 32) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const int query = (qb * NQ + q) * 32 + lane;
-        if (query < a.Q) {
-          float *ps = a.part_scores + ((size_t)query * a.NSPLIT + split) * KC;
-          int32_t *pi = a.part_ids + ((size_t)query * a.NSPLIT + split) * KC;
 #pragma unroll
-          for (int i = 0; i < KC; i += 4) {
-            *reinterpret_cast<f32x4 *>(ps + i) = f32x4{ls[q][i], ls[q][i + 1], ls[q][i + 2], ls[q][i + 3]};
-            *reinterpret_cast<int4 *>(pi + i) = int4{li[q][i], li[q][i + 1], li[q][i + 2], li[q][i + 3]};
-          }
+        for (int i = 0; i < KC; ++i) {
+          ms[(((w - half) * NQ + q) * KC + i) * 32 + lane] = ms16[q][i];
+          mi[(((w - half) * NQ + q) * KC + i) * 32 + lane] = mi16[q][i];
         }
+        mb[((w - half) * NQ + q) * 32 + lane] = bnd[q];
       }
     }
-  } else {
-    // partial lists -> global: candidate slot (split, wave, lane half)
-    const int slot = (split * WAVES + w) * 2 + (lane >> 5);
-    const int nslots = a.NSPLIT * WAVES * 2;
+    __syncthreads();
+    if (w < half && lane < 32) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        float os[KC];
+        int oi[KC];
+#pragma unroll
+        for (int i = 0; i < KC; ++i) {
+          os[i] = ms[((w * NQ + q) * KC + i) * 32 + lane];
+          oi[i] = mi[((w * NQ + q) * KC + i) * 32 + lane];
+        }
+        merge_lists<KC>(ms16[q], mi16[q], os, oi);
+        bnd[q] = fmaxf(bnd[q], mb[(w * NQ + q) * 32 + lane]);
+      }
+    }
+    __syncthreads();
+  }
+  if (w == 0 && lane < 32) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int query = (qb * NQ + q) * 32 + (lane & 31);
+      const int query = (qb * NQ + q) * 32 + lane;
       if (query < a.Q) {
-        float *ps = a.part_scores + ((size_t)query * nslots + slot) * KC;
-        int32_t *pi = a.part_ids + ((size_t)query * nslots + slot) * KC;
+        float *ps = a.part_scores + ((size_t)query * a.NSPLIT + split) * KC;
+        int32_t *pi = a.part_ids + ((size_t)query * a.NSPLIT + split) * KC;
 #pragma unroll
         for (int i = 0; i < KC; i += 4) {
-          *reinterpret_cast<f32x4 *>(ps + i) = f32x4{ls[q][i], ls[q][i + 1], ls[q][i + 2], ls[q][i + 3]};
-          *reinterpret_cast<int4 *>(pi + i) = int4{li[q][i], li[q][i + 1], li[q][i + 2], li[q][i + 3]};
+          *reinterpret_cast<f32x4 *>(ps + i) = f32x4{ms16[q][i], ms16[q][i + 1], ms16[q][i + 2], ms16[q][i + 3]};
+          *reinterpret_cast<int4 *>(pi + i) = int4{mi16[q][i], mi16[q][i + 1], mi16[q][i + 2], mi16[q][i + 3]};
         }
+        // every row of this split outside the 16 candidates scores <= this
+        a.part_bnd[(size_t)query * a.NSPLIT + split] = fmaxf(bnd[q], ms16[q][KC - 1]);
       }
     }
   }
 }
 
-// candidate lists per query and index split
-int score_slots_per_split(int merge) { return merge ? 1 : (SC_THREADS / 64) * 2; }
-
-template <int NQ, bool MERGE, bool BF = false>
-static hipError_t launch_score_variant(const ScoreArgs &a_in, hipStream_t stream) {
+template <int NQ, bool BF, bool COLLECT, bool RINGED>
+static hipError_t launch_score_ringed(const ScoreArgs &a_in, hipStream_t stream) {
   size_t lds = (size_t)NQ * a_in.KG * 256 * sizeof(float);
-  const size_t merge_lds = (size_t)(SC_THREADS / 128) * NQ * SC_KC * 32 * 8;
-  if (MERGE && merge_lds > lds) lds = merge_lds;
+  const size_t merge_lds = (size_t)(SC_THREADS / 128) * NQ * (SC_KC * 2 + 1) * 32 * 4;  // (score, id) planes + bounds
+  if (!COLLECT && merge_lds > lds) lds = merge_lds;
   ScoreArgs a = a_in;
   a.thr_off = (int32_t)(lds / sizeof(float));  // shared thresholds live behind the query block / merge scratch
   lds += (size_t)NQ * 32 * sizeof(int) + (size_t)NQ * 32 * 16 * sizeof(float);  // thresholds + per-list best entries
@@ -445,11 +499,16 @@ static hipError_t launch_score_variant(const ScoreArgs &a_in, hipStream_t stream
   } else {
     grid = QB * a.NSPLIT;
   }
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(score_topk_kernel<SC_KC, NQ, MERGE, BF>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(score_topk_kernel<NQ, BF, COLLECT, RINGED>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((score_topk_kernel<SC_KC, NQ, MERGE, BF>), dim3(grid), dim3(SC_THREADS), lds, stream, a);
+  hipLaunchKernelGGL((score_topk_kernel<NQ, BF, COLLECT, RINGED>), dim3(grid), dim3(SC_THREADS), lds, stream, a);
   return hipGetLastError();
+}
+
+template <int NQ, bool BF, bool COLLECT>
+static hipError_t launch_score_variant(const ScoreArgs &a, hipStream_t stream) {
+  return (a.KG % 8 == 0) ? launch_score_ringed<NQ, BF, COLLECT, true>(a, stream) : launch_score_ringed<NQ, BF, COLLECT, false>(a, stream);
 }
 
 // diagnostic: number of queries of this call left uncertified by the bf16 pass, accumulated on the device
@@ -540,14 +599,21 @@ hipError_t launch_frag32_to_bf16(const float *idxp, int64_t NT, int KG, void *ou
 hipError_t launch_score_topk(const ScoreArgs &a, hipStream_t stream) {
   if (a.KC != SC_KC) return hipErrorInvalidValue;
   if (a.NSPLIT > 8 && (a.NSPLIT & 7)) return hipErrorInvalidValue;
-  if (a.BF) {  // bf16 candidate pass: merged lists only
-    if (!a.MERGE) return hipErrorInvalidValue;
-    if (a.NQ == 1) return launch_score_variant<1, true, true>(a, stream);
-    if (a.NQ == 4) return launch_score_variant<4, true, true>(a, stream);
+  if (a.NSPLIT < 8 && (8 % a.NSPLIT)) return hipErrorInvalidValue;
+  if (a.COLLECT) {  // collect pass: fp32 scores only (the thresholds are fp32 bounds)
+    if (a.BF || !a.col_thr || !a.col_slot || !a.col_cnt || !a.col_buf) return hipErrorInvalidValue;
+    if (a.NQ == 1) return launch_score_variant<1, false, true>(a, stream);
+    if (a.NQ == 4) return launch_score_variant<4, false, true>(a, stream);
     return hipErrorInvalidValue;
   }
-  if (a.NQ == 1) return a.MERGE ? launch_score_variant<1, true>(a, stream) : launch_score_variant<1, false>(a, stream);
-  if (a.NQ == 4) return a.MERGE ? launch_score_variant<4, true>(a, stream) : launch_score_variant<4, false>(a, stream);
+  if (!a.part_bnd) return hipErrorInvalidValue;
+  if (a.BF) {
+    if (a.NQ == 1) return launch_score_variant<1, true, false>(a, stream);
+    if (a.NQ == 4) return launch_score_variant<4, true, false>(a, stream);
+    return hipErrorInvalidValue;
+  }
+  if (a.NQ == 1) return launch_score_variant<1, false, false>(a, stream);
+  if (a.NQ == 4) return launch_score_variant<4, false, false>(a, stream);
   return hipErrorInvalidValue;
 }
 
@@ -609,7 +675,8 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
   }
   if (tid == 0) s_cnt = 0;
   __syncthreads();
-  const float eps_q = a.eps * (float)sqrt(s_qn[0] + s_qn[1] + s_qn[2] + s_qn[3]);
+  const float qnorm = (float)sqrt(s_qn[0] + s_qn[1] + s_qn[2] + s_qn[3]);
+  const float eps_q = a.eps * qnorm;
 
   // k-th largest fp32 candidate: stage one sortable 64-bit key per candidate in LDS
   // (monotone score bits << 32 | inverted row id, 0 = empty slot), then every thread
@@ -682,9 +749,8 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
   }
 
   // window: candidates whose fp32 score is within 2*eps of the k-th (the only ones
-  // that can be in the exact top-k); largest slot minimum M over full slots
+  // that can be in the exact top-k); M = largest per-split bound (rows outside the candidates score <= M)
   float mmax = NEG_INF;
-  const int KCc = SC_KC;
   for (int c = tid; c < a.NC; c += RS_THREADS) {
     const int id = pi[c];
     if (id < 0) continue;
@@ -693,8 +759,8 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
       const int p = atomicAdd(&s_cnt, 1);
       if (p < RS_MAXWIN) s_win[p] = c;
     }
-    if ((c % KCc) == KCc - 1) mmax = fmaxf(mmax, s);  // slot is full: rows outside it score <= s
   }
+  for (int c = tid; c < a.NC / SC_KC; c += RS_THREADS) mmax = fmaxf(mmax, a.part_bnd[(size_t)q * (a.NC / SC_KC) + c]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mmax = fmaxf(mmax, __shfl_xor(mmax, o));
   if (lane == 0) s_m[w] = mmax;
@@ -736,6 +802,9 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
       t = fmax(fmax(s_ex[0], s_ex[1]), fmax(s_ex[2], s_ex[3]));
       const bool ok = (nwin_all <= RS_MAXWIN) && (nwin >= a.k) && ((double)mmax + (double)eps_q < t);
       a.cert[q] = ok ? 1 : 0;
+      // t = exact score of the k-th best candidate (-inf with fewer than k): a lower bound of the true k-th best, so
+      // every exact top-k row has fp32 score >= t - eps32*|q| (the collect pass gathers exactly those)
+      if (a.col_thr) a.col_thr[q] = ok ? __builtin_inff() : __double2float_rd(t - (double)(a.eps32 * qnorm));
     }
   }
 }
@@ -755,7 +824,8 @@ __global__ __launch_bounds__(256) void rescore_small_kernel(RescoreArgs a) {
   for (int d = lane; d < a.S; d += 64) qn += (double)qrow[d] * qrow[d];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
-  const float eps_q = a.eps * (float)sqrt(qn);
+  const float qnorm = (float)sqrt(qn);
+  const float eps_q = a.eps * qnorm;
 
   const bool have = lane < a.NC;
   const int id = have ? a.part_ids[(size_t)q * a.NC + lane] : -1;
@@ -769,9 +839,9 @@ __global__ __launch_bounds__(256) void rescore_small_kernel(RescoreArgs a) {
   float kth = (key != 0ull && rank == a.k - 1) ? sc : NEG_INF;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) kth = fmaxf(kth, __shfl_xor(kth, o));
-  // window: candidates within 2*eps of the k-th; M: largest minimum of a full slot (rows outside score <= M)
+  // window: candidates within 2*eps of the k-th; M: largest per-split bound (rows outside the candidates score <= M)
   const bool in_win = (id >= 0) && (sc >= kth - 2.0f * eps_q);
-  float mmax = (id >= 0 && (lane % SC_KC) == SC_KC - 1) ? sc : NEG_INF;
+  float mmax = (lane < a.NC / SC_KC) ? a.part_bnd[(size_t)q * (a.NC / SC_KC) + lane] : NEG_INF;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mmax = fmaxf(mmax, __shfl_xor(mmax, o));
   const unsigned long long wmask = __ballot(in_win);
@@ -796,7 +866,11 @@ __global__ __launch_bounds__(256) void rescore_small_kernel(RescoreArgs a) {
   double theta = (in_win && r2 == a.k - 1) ? ex : -__builtin_inf();
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) theta = fmax(theta, __shfl_xor(theta, o));
-  if (lane == 0) a.cert[q] = ((nwin >= a.k) && ((double)mmax + (double)eps_q < theta)) ? 1 : 0;
+  if (lane == 0) {
+    const bool ok = (nwin >= a.k) && ((double)mmax + (double)eps_q < theta);
+    a.cert[q] = ok ? 1 : 0;
+    if (a.col_thr) a.col_thr[q] = ok ? __builtin_inff() : __double2float_rd(theta - (double)(a.eps32 * qnorm));
+  }
 }
 
 hipError_t launch_rescore(const RescoreArgs &a, hipStream_t stream) {
@@ -825,6 +899,7 @@ struct ExactArgs {
   int32_t Q, S, k;  // k = entries emitted by this pass (<= 16)
   int32_t k_off, k_total;  // they land at columns [k_off, k_off + k) of rows of k_total columns; when
                            // k_off > 0 only rows ranked AFTER column k_off-1 are considered (next page)
+  unsigned long long *served;  // diagnostic counter (device) or nullptr: +1 per query computed here (first page)
 };
 
 __global__ __launch_bounds__(EX_THREADS) void exact_topk_kernel(ExactArgs a) {
@@ -832,6 +907,7 @@ __global__ __launch_bounds__(EX_THREADS) void exact_topk_kernel(ExactArgs a) {
   __shared__ int64_t s_id[EX_THREADS / 64][SC_KC];
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (a.cert && a.cert[q]) return;
+  if (a.served && tid == 0 && a.k_off == 0) atomicAdd(a.served, 1ull);
   const float *qrow = a.q + (size_t)q * a.S;
   const int KG = (a.S + 7) / 8;
   double ls[SC_KC];
@@ -893,14 +969,169 @@ __global__ __launch_bounds__(EX_THREADS) void exact_topk_kernel(ExactArgs a) {
 
 hipError_t launch_exact_topk(const float *q, const float *idxp, const double *idx64, const int32_t *cert,
                              double *out_scores, int64_t *out_ids, int64_t id_base, int64_t N, int Q, int S,
-                             int k, hipStream_t stream) {
+                             int k, hipStream_t stream, unsigned long long *served) {
   // k <= 16: one pass (the certified-failure path).  Larger k: pages of 16, each pass a full
   // float64 sweep restricted to rows ranked after the previous page (exact, slow, rarely used:
   // the reference's consumers read <= 10 columns, sse_evaluator.py:95,112)
   for (int off = 0; off < k; off += SC_KC) {
-    ExactArgs a{q, idxp, idx64, cert, out_scores, out_ids, id_base, N, Q, S, (k - off < SC_KC) ? k - off : SC_KC, off, k};
+    ExactArgs a{q, idxp, idx64, cert, out_scores, out_ids, id_base, N, Q, S, (k - off < SC_KC) ? k - off : SC_KC, off, k, served};
     hipLaunchKernelGGL(exact_topk_kernel, dim3(Q), dim3(EX_THREADS), 0, stream, a);
   }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Collect path (exact results where the lists cannot certify them: ties / duplicates at the k-th score, k > 16).
+
+__global__ void assign_slots_kernel(const int32_t *cert, int Q, int slots, int32_t *col_slot, int32_t *counter) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= Q) return;
+  int slot = -1;
+  if (cert[q] == 0) {
+    slot = atomicAdd(counter, 1);
+    if (slot >= slots) slot = -1;  // pool exhausted: the float64 brute force serves this query
+  }
+  col_slot[q] = slot;
+}
+hipError_t launch_assign_slots(const int32_t *cert, int Q, int slots, int32_t *col_slot, int32_t *counter, hipStream_t st) {
+  hipLaunchKernelGGL(assign_slots_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, cert, Q, slots, col_slot, counter);
+  return hipGetLastError();
+}
+
+// bitonic sort, descending, of n2 (power of two) 64-bit keys in LDS by one workgroup
+__device__ __forceinline__ void lds_sort_desc_u64(unsigned long long *key, int n2, int tid, int nthr) {
+  for (int size = 2; size <= n2; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int i = tid; i < (n2 >> 1); i += nthr) {
+        const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long x = key[lo], y = key[hi];
+        if ((x < y) == desc) {
+          key[lo] = y;
+          key[hi] = x;
+        }
+      }
+    }
+  __syncthreads();
+}
+
+// k > 16: threshold from the k-th best fp32 candidate.  One workgroup per query; NC <= RS_MAXNC candidates.
+__global__ __launch_bounds__(256) void kth_bound_kernel(const float *q, const float *part_scores, const int32_t *part_ids, int Q,
+                                                        int S, int NC, int k, float eps, float *col_thr, int32_t *col_slot) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long kb_key[];  // [n2]
+  __shared__ double s_qn[4];
+  const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int n2 = 1;
+  while (n2 < NC) n2 <<= 1;
+  double v = 0.0;
+  for (int d = tid; d < S; d += 256) v += (double)q[(size_t)qi * S + d] * q[(size_t)qi * S + d];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if (lane == 0) s_qn[w] = v;
+  for (int c = tid; c < n2; c += 256) {
+    unsigned long long key = 0ull;  // empty slots sort last
+    if (c < NC && part_ids[(size_t)qi * NC + c] >= 0) {
+      unsigned u = __float_as_uint(part_scores[(size_t)qi * NC + c]);
+      u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+      key = ((unsigned long long)u << 32) | 1ull;
+    }
+    kb_key[c] = key;
+  }
+  lds_sort_desc_u64(kb_key, n2, tid, 256);
+  if (tid == 0) {
+    float thr = -__builtin_inff();
+    if (k <= n2 && kb_key[k - 1] != 0ull) {
+      unsigned u = (unsigned)(kb_key[k - 1] >> 32);
+      u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+      const float eps_q = eps * (float)sqrt(s_qn[0] + s_qn[1] + s_qn[2] + s_qn[3]);
+      // k rows score (fp32) >= kth, so the exact k-th best is >= kth - eps and every exact top-k row has fp32 score
+      // >= kth - 2 eps
+      thr = __double2float_rd((double)__uint_as_float(u) - 2.0 * (double)eps_q);
+    }
+    col_thr[qi] = thr;
+    col_slot[qi] = qi;
+  }
+}
+hipError_t launch_kth_bound(const float *q, const float *part_scores, const int32_t *part_ids, int Q, int S, int NC, int k,
+                            float eps, float *col_thr, int32_t *col_slot, hipStream_t st) {
+  if (NC > RS_MAXNC) return hipErrorInvalidValue;
+  int n2 = 1;
+  while (n2 < NC) n2 <<= 1;
+  hipLaunchKernelGGL(kth_bound_kernel, dim3(Q), dim3(256), (size_t)n2 * sizeof(unsigned long long), st, q, part_scores, part_ids,
+                     Q, S, NC, k, eps, col_thr, col_slot);
+  return hipGetLastError();
+}
+
+// One workgroup per collected query: float64 scores of its rows (the reference's arithmetic, wave_exact_dot as in the
+// re-scoring pass: bit-identical values), sorted (score descending, then lower row id), first k out.
+__global__ __launch_bounds__(256) void select_topk_kernel(SelectArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sel_smem[];
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int slot = a.col_slot[q];
+  if (slot < 0) return;
+  const int n = a.col_cnt[slot];
+  if (n > a.col_cap || n < a.k) return;  // overflow (or an inconsistent threshold): left to the float64 brute force
+  int n2 = 1;
+  while (n2 < n) n2 <<= 1;
+  // sort key: float64 score mapped to an order-preserving u64 is not enough (ties need the row id): sort indices by
+  // (score, id) with a 64-bit score key in one array and the row in a second one that moves along
+  unsigned long long *skey = sel_smem;                       // [n2] order-preserving score bits
+  int *srow = reinterpret_cast<int *>(sel_smem + n2);        // [n2]
+  const int32_t *rows = a.col_buf + (size_t)slot * a.col_cap;
+  const float *qrow = a.q + (size_t)q * a.S;
+  const int KG = (a.S + 7) / 8;
+  for (int i = w; i < n2; i += 4) {
+    if (i < n) {
+      const int row = rows[i];
+      const double ex = wave_exact_dot(qrow, a.idx32, a.idx64, row, a.S, KG, lane);
+      if (lane == 0) {
+        unsigned long long u = (unsigned long long)__double_as_longlong(ex);
+        u = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+        skey[i] = u;
+        srow[i] = row;
+      }
+    } else if (lane == 0) {
+      skey[i] = 0ull;  // below every real score (-inf maps to 0x000f...: real keys are > 0)
+      srow[i] = 0x7FFFFFFF;
+    }
+  }
+  // bitonic sort on (key descending, row ascending)
+  for (int size = 2; size <= n2; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int i = tid; i < (n2 >> 1); i += 256) {
+        const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long x = skey[lo], y = skey[hi];
+        const int rx = srow[lo], ry = srow[hi];
+        const bool x_after_y = (x < y) || (x == y && rx > ry);  // x ranks after y
+        if (x_after_y == desc) {
+          skey[lo] = y;
+          skey[hi] = x;
+          srow[lo] = ry;
+          srow[hi] = rx;
+        }
+      }
+    }
+  __syncthreads();
+  for (int j = tid; j < a.k; j += 256) {
+    unsigned long long u = skey[j];
+    u = (u >> 63) ? (u & 0x7FFFFFFFFFFFFFFFull) : ~u;
+    a.out_scores[(size_t)q * a.k + j] = __longlong_as_double((long long)u);
+    a.out_ids[(size_t)q * a.k + j] = a.id_base + srow[j];
+  }
+  if (tid == 0) {
+    a.cert[q] = 1;
+    if (a.served) atomicAdd(a.served, 1ull);
+  }
+}
+hipError_t launch_select_topk(const SelectArgs &a, hipStream_t st) {
+  if (a.col_cap > SSE_COLLECT_CAP) return hipErrorInvalidValue;
+  const size_t lds = (size_t)a.col_cap * (sizeof(unsigned long long) + sizeof(int));
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(select_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(select_topk_kernel, dim3(a.Q), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 

@@ -97,6 +97,7 @@ struct sse_handle {
   // scratch
   DevBuf s_ids, s_out, s_q, s_qp, s_ps, s_pi, s_cert, s_os, s_oi, s_tmp, s_tmp2, s_feat, s_zero, s_map;
   DevBuf s_qp32, s_fb_cnt;  // fp32 second chance of the bf16 candidate pass: fp32 query fragments, counter
+  DevBuf s_pb, s_cthr, s_cslot, s_ccnt, s_cbuf;  // per-split bounds; collect path: thresholds, slots, counters, row buffers
   const int32_t *cur_row_map = nullptr;  // set by sse_encode around its launch
   // training
   float lr = 0.9f;
@@ -389,24 +390,10 @@ int index_from_dev_rows(sse_handle *h, const float *rows_dev, int64_t N, int S, 
   return 0;
 }
 
-int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s, int64_t *out_i, hipStream_t st) {
-  if (!h->idxp) return fail(h, "no index uploaded");
-  if (Q < 0) return fail(h, "bad Q");
-  if (Q == 0) return 0;
-  if (k < 1 || k > h->idx_N) return fail(h, "k=%d must be in [1, N=%lld]", k, (long long)h->idx_N);
-  if (k > 16) {
-    // beyond the fused kernel's list size: exact float64 paging (correct for any k <= N)
-    HIPCHECK(h, launch_exact_topk(q, h->idxp, h->idx64, nullptr, out_s, out_i, h->idx_base, h->idx_N, Q, h->idx_S, k, st));
-    return 0;
-  }
-  const int S = h->idx_S, KG = (S + 7) / 8;
-  const int QT = (Q + 31) / 32;
-  const int NQ = (Q <= 32) ? 1 : 4;  // <= 32 queries (demo / web): single query tile, HBM-bound sweep
-  const int QB = (QT + NQ - 1) / NQ;
-  const int64_t NT = (h->idx_N + 31) / 32;
-  // splits of the index range: enough workgroups to fill the 256 CUs (2 waves of them when the
-  // sweep is long), at least 16 n-tiles (2 per wave) per split.  Up to 8 splits keep the 16
-  // per-wave lists; more splits merge them inside the workgroup so the candidate set stays small.
+// splits of the index range for a candidate / collect sweep (see score_dev_locked)
+static int choose_nsplit(int NQ, int QB, int64_t NT) {
+  // enough workgroups to fill the 256 CUs (2 waves of them when the sweep is long), at least 16 n-tiles (2 per
+  // wave) per split
   int nsplit = 1;
   const int max_split = (NQ == 1) ? 256 : 128;
   while (nsplit < max_split && QB * nsplit < 512 && NT / (nsplit * 2) >= 16) nsplit *= 2;
@@ -433,10 +420,116 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
     }
     nsplit = best;
   }
-  // the 16 per-wave lists of a workgroup are always merged in-kernel (a few tens of microseconds per
-  // workgroup): the re-scoring pass then ranks 16 candidates per split instead of 256
-  const int merge = 1;
-  const int NC = nsplit * score_slots_per_split(merge) * 16;
+  return nsplit;
+}
+
+// diagnostic counters on the device: [0] queries whose bf16-candidate result missed its certificate, [1] queries served
+// by the collect path, [2] queries that fell through to the float64 brute force
+static int ensure_counters(sse_handle *h, hipStream_t st) {
+  if (reserve(h, h->s_fb_cnt, 4 * sizeof(unsigned long long))) return 1;
+  if (!h->fb_cnt_init) {
+    HIPCHECK(h, hipMemsetAsync(h->s_fb_cnt.p, 0, 4 * sizeof(unsigned long long), st));
+    h->fb_cnt_init = true;
+  }
+  return 0;
+}
+
+// collect-path scratch: thresholds, slots, counters (+1: the slot allocator), row buffers
+static int reserve_collect(sse_handle *h, int Q, int slots) {
+  if (reserve(h, h->s_cthr, (size_t)Q * sizeof(float))) return 1;
+  if (reserve(h, h->s_cslot, (size_t)Q * sizeof(int32_t))) return 1;
+  if (reserve(h, h->s_ccnt, (size_t)(slots + 1) * sizeof(int32_t))) return 1;
+  if (reserve(h, h->s_cbuf, (size_t)slots * SSE_COLLECT_CAP * sizeof(int32_t))) return 1;
+  return 0;
+}
+
+// k > 16 (sse_demo.py:128-134 and webserver.py take a user-chosen nbest): candidate sweep with enough per-split
+// lists that the k-th best candidate is a tight lower bound of the k-th best row, then a collect sweep of every row
+// that can still be in the exact top-k and a float64 sort of those -- two grid-wide sweeps instead of the
+// one-workgroup-per-query float64 brute force (which stays as the fallback: k > SSE_MAX_SELECT_K, or more than
+// SSE_COLLECT_CAP rows within the bound of the k-th score).
+static int score_select_locked(sse_handle *h, const float *q, int Q, int k, double *out_s, int64_t *out_i, hipStream_t st) {
+  const int S = h->idx_S, KG = (S + 7) / 8;
+  const int64_t NT = (h->idx_N + 31) / 32;
+  const int POOL = 2048;
+  const float eps32 = (float)(2.0 * (S + 2) * 5.97e-8 * h->idx_norm_max);
+  if (ensure_counters(h, st)) return 1;
+  unsigned long long *counters = (unsigned long long *)h->s_fb_cnt.p;
+  for (int q0 = 0; q0 < Q; q0 += POOL) {
+    const int Qc = std::min(POOL, Q - q0);
+    const float *qc = q + (size_t)q0 * S;
+    const int QT = (Qc + 31) / 32;
+    const int NQ = (Qc <= 32) ? 1 : 4;
+    const int QB = (QT + NQ - 1) / NQ;
+    int nsplit = choose_nsplit(NQ, QB, NT);
+    // at least 4k candidates (k-th candidate close to the k-th row), at most RS_MAXNC = 4096, >= 2 tiles per split
+    const int max_split = (NQ == 1) ? 256 : 128;
+    while (nsplit < max_split && nsplit * 16 < 4 * k && NT / (nsplit * 2) >= 2) nsplit *= 2;
+    const int NC = nsplit * 16;
+    if (reserve(h, h->s_qp, (size_t)QB * NQ * KG * 256 * sizeof(float))) return 1;
+    if (reserve(h, h->s_ps, (size_t)Qc * NC * sizeof(float))) return 1;
+    if (reserve(h, h->s_pi, (size_t)Qc * NC * sizeof(int32_t))) return 1;
+    if (reserve(h, h->s_pb, (size_t)Qc * nsplit * sizeof(float))) return 1;
+    if (reserve(h, h->s_cert, (size_t)Qc * sizeof(int32_t))) return 1;
+    if (reserve_collect(h, Qc, Qc)) return 1;
+    HIPCHECK(h, launch_pack_rows(qc, Qc, S, (float *)h->s_qp.p, st));
+    ScoreArgs a;
+    a.idxp = h->idxp;
+    a.qp = (const float *)h->s_qp.p;
+    a.part_scores = (float *)h->s_ps.p;
+    a.part_ids = (int32_t *)h->s_pi.p;
+    a.part_bnd = (float *)h->s_pb.p;
+    a.N = h->idx_N;
+    a.Q = Qc;
+    a.KG = KG;
+    a.NT = (int)NT;
+    a.QT = QT;
+    a.NSPLIT = nsplit;
+    a.KC = 16;
+    a.NQ = NQ;
+    HIPCHECK(h, launch_score_topk(a, st));
+    HIPCHECK(h, launch_kth_bound(qc, a.part_scores, a.part_ids, Qc, S, NC, k, eps32, (float *)h->s_cthr.p,
+                                 (int32_t *)h->s_cslot.p, st));
+    HIPCHECK(h, hipMemsetAsync(h->s_ccnt.p, 0, (size_t)(Qc + 1) * sizeof(int32_t), st));
+    HIPCHECK(h, hipMemsetAsync(h->s_cert.p, 0, (size_t)Qc * sizeof(int32_t), st));
+    ScoreArgs c = a;
+    c.COLLECT = 1;
+    c.col_thr = (const float *)h->s_cthr.p;
+    c.col_slot = (const int32_t *)h->s_cslot.p;
+    c.col_cnt = (int32_t *)h->s_ccnt.p;
+    c.col_buf = (int32_t *)h->s_cbuf.p;
+    c.col_cap = SSE_COLLECT_CAP;
+    HIPCHECK(h, launch_score_topk(c, st));
+    SelectArgs sel{qc, h->idxp, h->idx64, c.col_slot, c.col_cnt, c.col_buf, SSE_COLLECT_CAP,
+                   out_s + (size_t)q0 * k, out_i + (size_t)q0 * k, (int32_t *)h->s_cert.p, h->idx_base, Qc, S, k, counters + 1};
+    HIPCHECK(h, launch_select_topk(sel, st));
+    // whatever overflowed its buffer: float64 brute force (pages of 16)
+    HIPCHECK(h, launch_exact_topk(qc, h->idxp, h->idx64, (const int32_t *)h->s_cert.p, out_s + (size_t)q0 * k,
+                                  out_i + (size_t)q0 * k, h->idx_base, h->idx_N, Qc, S, k, st, counters + 2));
+  }
+  return 0;
+}
+
+int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s, int64_t *out_i, hipStream_t st) {
+  if (!h->idxp) return fail(h, "no index uploaded");
+  if (Q < 0) return fail(h, "bad Q");
+  if (Q == 0) return 0;
+  if (k < 1 || k > h->idx_N) return fail(h, "k=%d must be in [1, N=%lld]", k, (long long)h->idx_N);
+  if (k > SSE_MAX_SELECT_K) {
+    // beyond the collect path's buffers: exact float64 paging (correct for any k <= N, one workgroup per query)
+    HIPCHECK(h, launch_exact_topk(q, h->idxp, h->idx64, nullptr, out_s, out_i, h->idx_base, h->idx_N, Q, h->idx_S, k, st));
+    return 0;
+  }
+  if (k > 16) return score_select_locked(h, q, Q, k, out_s, out_i, st);
+  const int S = h->idx_S, KG = (S + 7) / 8;
+  const int QT = (Q + 31) / 32;
+  const int NQ = (Q <= 32) ? 1 : 4;  // <= 32 queries (demo / web): single query tile, HBM-bound sweep
+  const int QB = (QT + NQ - 1) / NQ;
+  const int64_t NT = (h->idx_N + 31) / 32;
+  // the 16 lane lists of a workgroup are always merged in-kernel (a few tens of microseconds per workgroup): the
+  // re-scoring pass ranks 16 candidates per split
+  const int nsplit = choose_nsplit(NQ, QB, NT);
+  const int NC = nsplit * 16;
   // bf16 candidate pass (option score_bf16): 16x the matrix rate for the 128-query-block variant, half the index
   // bytes for the HBM-bound few-queries sweep
   // (small indexes stay on the fp32 pass: nothing to win, and no bf16 copy / second-chance launches to pay for)
@@ -454,10 +547,15 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
     HIPCHECK(h, launch_frag32_to_bf16(h->idxp, NT, KG, h->idxp16, st));
     h->idxp16_valid = true;
   }
+  const int POOL = std::min(Q, 1024);  // collect-buffer slots for uncertified queries (the rest: float64 brute force)
+  if (ensure_counters(h, st)) return 1;
+  unsigned long long *counters = (unsigned long long *)h->s_fb_cnt.p;
   if (reserve(h, h->s_qp, (size_t)QB * NQ * KG * 256 * sizeof(float))) return 1;
   if (reserve(h, h->s_ps, (size_t)Q * NC * sizeof(float))) return 1;
   if (reserve(h, h->s_pi, (size_t)Q * NC * sizeof(int32_t))) return 1;
+  if (reserve(h, h->s_pb, (size_t)Q * nsplit * sizeof(float))) return 1;
   if (reserve(h, h->s_cert, (size_t)Q * sizeof(int32_t))) return 1;
+  if (reserve_collect(h, Q, POOL)) return 1;
   if (bf) HIPCHECK(h, launch_pack_rows_bf16(q, Q, S, h->s_qp.p, st));
   else HIPCHECK(h, launch_pack_rows(q, Q, S, (float *)h->s_qp.p, st));
   ScoreArgs a;
@@ -466,6 +564,7 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   a.qp = (const float *)h->s_qp.p;
   a.part_scores = (float *)h->s_ps.p;
   a.part_ids = (int32_t *)h->s_pi.p;
+  a.part_bnd = (float *)h->s_pb.p;
   a.N = h->idx_N;
   a.Q = Q;
   a.KG = bf ? KG16 : KG;
@@ -474,7 +573,6 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   a.NSPLIT = nsplit;
   a.KC = 16;
   a.NQ = NQ;
-  a.MERGE = merge;
   HIPCHECK(h, launch_score_topk(a, st));
   RescoreArgs r;
   r.q = q;
@@ -482,6 +580,7 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   r.idx64 = h->idx64;
   r.part_scores = a.part_scores;
   r.part_ids = a.part_ids;
+  r.part_bnd = a.part_bnd;
   r.out_scores = out_s;
   r.out_ids = out_i;
   r.cert = (int32_t *)h->s_cert.p;
@@ -492,36 +591,60 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   r.NC = NC;
   r.k = k;
   // |fp32 fma-chain dot - exact| <= S * 2^-24 * |q||t| (+ the f32 rounding of f64 rows); use 2x margin
-  r.eps = (float)(2.0 * (S + 2) * 5.97e-8 * h->idx_norm_max);
+  const float eps32 = (float)(2.0 * (S + 2) * 5.97e-8 * h->idx_norm_max);
+  r.eps = eps32;
+  r.eps32 = eps32;
+  r.col_thr = (float *)h->s_cthr.p;
   // bf16 operands: |q^.t^ - q.t| <= ((1+u)^2 - 1) sum|q_i t_i| <= (2^-8 + 2^-18) |q||t|, u = 2^-9 (round to nearest)
   if (bf) r.eps += (float)(1.02 * (1.0 / 256.0 + 1.0 / 262144.0) * h->idx_norm_max);
   HIPCHECK(h, launch_rescore(r, st));
+  const float *qp32 = (const float *)h->s_qp.p;  // fp32 query fragments for the collect sweep
   if (bf) {
     // Second chance, entirely on the device (the call stays asynchronous): queries whose bf16-candidate result missed
     // its certificate (top scores packed closer than the bf16 bound) are swept again with fp32 candidates -- the same
     // kernels, where a workgroup whose whole query block is certified returns at once and a certified query is left
-    // alone -- before anything falls through to the float64 brute force.
+    // alone -- before anything falls through to the collect path.
     if (reserve(h, h->s_qp32, (size_t)QB * NQ * KG * 256 * sizeof(float))) return 1;
-    if (reserve(h, h->s_fb_cnt, sizeof(unsigned long long))) return 1;
-    if (h->s_fb_cnt.cap && !h->fb_cnt_init) {
-      HIPCHECK(h, hipMemsetAsync(h->s_fb_cnt.p, 0, sizeof(unsigned long long), st));
-      h->fb_cnt_init = true;
-    }
-    HIPCHECK(h, launch_count_uncert(r.cert, Q, (unsigned long long *)h->s_fb_cnt.p, st));
+    HIPCHECK(h, launch_count_uncert(r.cert, Q, counters, st));
     HIPCHECK(h, launch_pack_rows(q, Q, S, (float *)h->s_qp32.p, st));
+    qp32 = (const float *)h->s_qp32.p;
     ScoreArgs a2 = a;
     a2.BF = 0;
     a2.idxp = h->idxp;
-    a2.qp = (const float *)h->s_qp32.p;
+    a2.qp = qp32;
     a2.KG = KG;
     a2.skip_cert = r.cert;
     HIPCHECK(h, launch_score_topk(a2, st));
     RescoreArgs r2 = r;
-    r2.eps = (float)(2.0 * (S + 2) * 5.97e-8 * h->idx_norm_max);
+    r2.eps = eps32;
     r2.skip = r.cert;
     HIPCHECK(h, launch_rescore(r2, st));
   }
-  HIPCHECK(h, launch_exact_topk(q, h->idxp, h->idx64, r.cert, out_s, out_i, h->idx_base, h->idx_N, Q, S, k, st));
+  // What is still uncertified has its k-th score tied with (or within the fp32 bound of) rows outside the candidate
+  // lists -- e.g. an index holding many exact duplicates of a query's best rows.  Collect path: every row whose fp32
+  // score reaches (exact k-th of the candidates) - bound is gathered by a grid-wide sweep and sorted in float64:
+  // provably the exact top-k, at the cost of one more fp32 sweep for the query blocks concerned.  Launched
+  // unconditionally (no host sync); with everything certified all workgroups return at once.
+  HIPCHECK(h, hipMemsetAsync(h->s_ccnt.p, 0, (size_t)(POOL + 1) * sizeof(int32_t), st));
+  HIPCHECK(h, launch_assign_slots(r.cert, Q, POOL, (int32_t *)h->s_cslot.p, (int32_t *)h->s_ccnt.p + POOL, st));
+  ScoreArgs c = a;
+  c.BF = 0;
+  c.idxp = h->idxp;
+  c.qp = qp32;
+  c.KG = KG;
+  c.skip_cert = nullptr;
+  c.COLLECT = 1;
+  c.col_thr = (const float *)h->s_cthr.p;
+  c.col_slot = (const int32_t *)h->s_cslot.p;
+  c.col_cnt = (int32_t *)h->s_ccnt.p;
+  c.col_buf = (int32_t *)h->s_cbuf.p;
+  c.col_cap = SSE_COLLECT_CAP;
+  HIPCHECK(h, launch_score_topk(c, st));
+  SelectArgs sel{q, h->idxp, h->idx64, c.col_slot, c.col_cnt, c.col_buf, SSE_COLLECT_CAP, out_s, out_i, r.cert, h->idx_base, Q, S, k,
+                 counters + 1};
+  HIPCHECK(h, launch_select_topk(sel, st));
+  // last resort (more than SSE_COLLECT_CAP rows within the bound of the k-th score, or no buffer slot left)
+  HIPCHECK(h, launch_exact_topk(q, h->idxp, h->idx64, r.cert, out_s, out_i, h->idx_base, h->idx_N, Q, S, k, st, counters + 2));
   return 0;
 }
 
@@ -741,14 +864,16 @@ int sse_encode(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int3
 int sse_get_counter(sse_handle *h, const char *name, int64_t *value) {
   if (!h || !name || !value) return 1;
   std::lock_guard<std::mutex> lk(h->mu);
-  if (strcmp(name, "score_bf16_second_chance_queries") == 0) {
-    unsigned long long v = 0;
+  static const char *const names[3] = {"score_bf16_second_chance_queries", "score_collect_queries", "score_bruteforce_queries"};
+  for (int i = 0; i < 3; ++i) {
+    if (strcmp(name, names[i]) != 0) continue;
+    unsigned long long v[4] = {0, 0, 0, 0};
     if (h->s_fb_cnt.p && h->fb_cnt_init) {
       HIPCHECK(h, hipSetDevice(h->cfg.device));
       HIPCHECK(h, hipDeviceSynchronize());
-      HIPCHECK(h, hipMemcpy(&v, h->s_fb_cnt.p, sizeof v, hipMemcpyDeviceToHost));
+      HIPCHECK(h, hipMemcpy(v, h->s_fb_cnt.p, sizeof v, hipMemcpyDeviceToHost));
     }
-    *value = (int64_t)v;
+    *value = (int64_t)v[i];
     return 0;
   }
   return fail(h, "unknown counter '%s'", name);

@@ -65,22 +65,31 @@ hipError_t launch_lstm_fwd(const LstmFwdArgs &a, int Hp, hipStream_t stream);
 struct ScoreArgs {
   const float *idxp;     // packed index  [NT][KG][256]  (frag32, rows = targets)
   const float *qp;       // packed queries [QT][KG][256] (frag32, rows = queries)
-  float *part_scores;    // [Q][NSPLIT][KC] per-split candidate scores (f32)
+  float *part_scores;    // [Q][NSPLIT][KC] per-split candidate scores (f32), sorted descending
   int32_t *part_ids;     // [Q][NSPLIT][KC] row numbers local to this index (or -1)
+  float *part_bnd;       // [Q][NSPLIT] every row of the split outside its KC candidates scores <= this
   int64_t N;             // index rows
   int32_t Q, KG, NT, QT, NSPLIT, KC;
   int32_t NQ = 4;     // query tiles (of 32) per workgroup: 4 (128-query blocks) or 1 (Q <= 32)
-  int32_t MERGE = 0;  // 1: one merged list per (query, split); 0: 16 lists (waves x lane halves)
   int32_t thr_off = 0;  // set by the launcher: LDS offset (floats) of the shared per-query thresholds
   const int32_t *skip_cert = nullptr;  // second-chance pass: a workgroup whose whole query block is already certified returns
   int32_t BF = 0;       // 1: idxp / qp are bf16 fragment copies, KG counts 16-k groups (candidate pass on bf16 MFMA)
+  // collect pass (COLLECT = 1, fp32 only): rows with score >= col_thr[query] are appended to buffer col_slot[query]
+  int32_t COLLECT = 0;
+  const float *col_thr = nullptr;     // [Q]
+  const int32_t *col_slot = nullptr;  // [Q] buffer slot, < 0: query not collected
+  int32_t *col_cnt = nullptr;         // [slots] rows appended (may exceed col_cap: overflow)
+  int32_t *col_buf = nullptr;         // [slots][col_cap] local row numbers
+  int32_t col_cap = 0;
 };
 hipError_t launch_score_topk(const ScoreArgs &a, hipStream_t stream);
 // rows [R][C] fp32 -> bf16 fragment blocks [ceil(R/32)][ceil(C/16)][1 KiB]; fp32 frag32 index -> the same
 hipError_t launch_pack_rows_bf16(const float *rows, int64_t R, int C, void *out, hipStream_t stream);
 hipError_t launch_count_uncert(const int32_t *cert, int Q, unsigned long long *count, hipStream_t st);
 hipError_t launch_frag32_to_bf16(const float *idxp, int64_t NT, int KG, void *out, hipStream_t stream);
-int score_slots_per_split(int merge);  // candidate lists per query and index split
+
+#define SSE_COLLECT_CAP 4096   // rows one query can collect (exact path); more -> float64 brute force
+#define SSE_MAX_SELECT_K 1024  // largest k the collect path serves
 
 struct RescoreArgs {
   const float *q;          // [Q][S] f32 row-major queries
@@ -88,15 +97,43 @@ struct RescoreArgs {
   const double *idx64;     // [N][S] f64 rows or nullptr
   const float *part_scores;
   const int32_t *part_ids;
+  const float *part_bnd;   // [Q][NSPLIT]
   double *out_scores;      // [Q][k]
   int64_t *out_ids;        // [Q][k]
   int32_t *cert;           // [Q] 1 = the f32 candidate set provably contains the exact top-k
   int64_t id_base, N;
   int32_t Q, S, NC, k;     // NC = NSPLIT*KC candidates per query
-  float eps;               // bound on |f32 score - exact score|
+  float eps;               // bound on |candidate score - exact score| / |q|
   const int32_t *skip = nullptr;  // second-chance pass: queries with skip[q] != 0 are already final
+  // optional: collect threshold of every processed query, +inf when certified, else (exact k-th of the
+  // candidates) - eps32 * |q| rounded down: no exact top-k row has a smaller fp32 score
+  float *col_thr = nullptr;
+  float eps32 = 0.0f;      // fp32 bound used for col_thr (eps may be the wider bf16 one)
 };
 hipError_t launch_rescore(const RescoreArgs &a, hipStream_t stream);
+
+// uncertified queries (cert[q] == 0) get collect-buffer slots 0, 1, ... (col_slot[q]; -1 when certified or the pool
+// of `slots` is exhausted); *counter must be zero on entry
+hipError_t launch_assign_slots(const int32_t *cert, int Q, int slots, int32_t *col_slot, int32_t *counter, hipStream_t st);
+// k > 16: col_thr[q] = (k-th best fp32 candidate score) - 2 * eps * |q| rounded down (-inf with fewer than k
+// candidates); col_slot[q] = q
+hipError_t launch_kth_bound(const float *q, const float *part_scores, const int32_t *part_ids, int Q, int S, int NC, int k,
+                            float eps, float *col_thr, int32_t *col_slot, hipStream_t st);
+struct SelectArgs {
+  const float *q;
+  const float *idx32;
+  const double *idx64;
+  const int32_t *col_slot, *col_cnt, *col_buf;
+  int32_t col_cap;
+  double *out_scores;  // [Q][k]
+  int64_t *out_ids;
+  int32_t *cert;       // set to 1 for queries served here; left alone on overflow / fewer than k rows
+  int64_t id_base;
+  int32_t Q, S, k;
+  unsigned long long *served = nullptr;  // diagnostic counter (device), +1 per query served here
+};
+// float64 re-score + sort of the collected rows, first k out (score descending, then lower row id)
+hipError_t launch_select_topk(const SelectArgs &a, hipStream_t st);
 
 hipError_t launch_merge_topk(const double *in_s, const int64_t *in_i, int P, int Q, int k, double *out_s,
                              int64_t *out_i, hipStream_t stream);
@@ -117,7 +154,7 @@ hipError_t launch_row_norm2_max(const float *x, int64_t rows, int cols, float *o
 hipError_t launch_fill(float *p, int64_t n, float v, hipStream_t stream);
 hipError_t launch_exact_topk(const float *q, const float *idxp, const double *idx64, const int32_t *cert,
                              double *out_scores, int64_t *out_ids, int64_t id_base, int64_t N, int Q, int S,
-                             int k, hipStream_t stream);
+                             int k, hipStream_t stream, unsigned long long *served = nullptr);
 
 // ------------------------------ CNN encoder --------------------------------
 // bf16-storage variant (cnn_fwd_bf16.hip): embeddings / filters as bf16, fp32 accumulation, fp32 tail

@@ -270,3 +270,15 @@ def test_bf16_round_is_round_to_nearest_even():
     assert np.all((r.view(np.uint32) & 0xFFFF) == 0) and np.all(np.abs(r - x) <= np.abs(x) * 2.0 ** -8)
     torch_r = torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
     assert np.array_equal(r, torch_r)
+
+
+def test_topk_fast_equals_topk_including_ties():
+    rng = np.random.RandomState(3)
+    s = rng.standard_normal((40, 500))
+    s[:, 100:130] = s[:, 7:8]                                   # 31 exact ties with column 7 in every row
+    s[3, :] = 1.0                                               # a row of nothing but ties: falls back to topk()
+    for k in (1, 10, 16):
+        a, b = O.topk(s, k), O.topk_fast(s, k)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+    small = rng.standard_normal((5, 20))
+    assert np.array_equal(O.topk(small, 10)[1], O.topk_fast(small, 10)[1])
