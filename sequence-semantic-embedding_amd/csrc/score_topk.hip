@@ -14,6 +14,8 @@
 //      and CERTIFIED: if a row outside the candidate set could still reach the
 //      exact top-k (fp32 bound), the query is flagged and
 //   3. exact_topk_kernel recomputes flagged queries by float64 brute force.
+#include <cstdlib>
+
 #include "sse_kernels.h"
 
 #define SC_THREADS 512
@@ -97,6 +99,22 @@ __device__ __forceinline__ void merge8_to16(const float (&as)[8], const int (&ai
       }
 }
 
+// deferred insertion: all lanes insert their parked entries (pend[p * 64], p < cnt) of one query tile, oldest first
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int KL>
+__device__ __forceinline__ void drain_parked(float (&ls)[KL], int (&li)[KL], int &cnt, const f32x2 *pend) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const bool has = cnt > p;
+    if (__ballot(has) != 0ull) {
+      asm volatile("");
+      const f32x2 e = pend[p * 64];
+      list_insert<KL>(ls, li, e[0], __float_as_int(e[1]), has);
+    }
+  }
+  cnt = 0;
+}
+
 // 8 waves per workgroup = 2 per SIMD: there is no barrier in the sweep, so the waves drift
 // apart and one wave's top-k epilogue (VALU) overlaps its partner's MFMA stream.
 // Wave tile: 1 index tile (32 rows, M) x NQ query tiles (N): NQ accumulators + NQ private lists.
@@ -114,6 +132,12 @@ __device__ __forceinline__ void merge8_to16(const float (&as)[8], const int (&ai
 // Insertion: one ballot per accumulator register against the threshold; a register some lane beats it with is inserted
 //   with selects (lanes that do not take keep their list) -- ~50 instructions per hit instead of an
 //   extract-max / find-index / insert-16 round.
+// Deferred insertion (DEFER = the bf16 variants, whose query block leaves LDS room): a hit is almost always ONE lane's,
+//   yet a select-based insertion makes all 64 lanes execute ~75 instructions.  Instead the lane parks (score, row) in
+//   its own 4-entry LDS slot row (one exec-masked ds_write_b64, ~12 instructions per hit) and keeps only its best
+//   score current (that is what the shared threshold is made of); the parked entries are inserted 64 lanes in
+//   parallel when some lane's row is full (about once per 100 wave tiles) and before the final merge.  Parked
+//   entries enter the lists in row order, exactly as they would have; bounds and candidates are unchanged.
 // The accumulators start from the MFMA's zero C operand (first k-group), not from 16 moves per query tile.
 // BF: the candidate pass runs on v_mfma_f32_32x32x16_bf16 -- index and queries are bf16 copies in the same 1-KiB
 // block / 16-byte-per-lane fragment scheme (a block now holds 32 rows x 16 k, a.KG counts 16-k groups), ONE MFMA per
@@ -126,12 +150,14 @@ __device__ __forceinline__ void merge8_to16(const float (&as)[8], const int (&ai
 // exact top-k (select_topk_kernel re-scores and sorts it in float64).
 typedef short bf16x8_t __attribute__((ext_vector_type(8)));
 #define SC_KL 8
+#define SC_PEND 4  // parked entries per (wave, query tile, lane)
 struct TagZ { static constexpr bool value = true; };   // "accumulators start from zero" / "accumulate" tags of mma()
 struct TagA { static constexpr bool value = false; };
 template <int NQ, bool BF, bool COLLECT, bool RINGED>
 __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // query block [NQ][KG][256]; later merge scratch
   constexpr int KC = SC_KC, KL = SC_KL;
+  constexpr bool DEFER = BF && !COLLECT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform (SGPR): tile numbers and load offsets derive from it
   const int KG = a.KG;
@@ -198,18 +224,28 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
 
   // Shared per-query insertion threshold (LDS, order-preserving int encoding of the float): a lower bound of the
   // workgroup's 16th best score -- the SMALLEST of the 16 lane lists' best entries (16 distinct rows score at least
-  // that).  Every list keeps its current best in mx_s[query][list] (monotone, plain stores); wave 0 folds the minimum
+  // that).  Every list keeps its current best in mx_s[q-tile][list][query] (monotone, plain stores); wave 0 folds the minimum
   // into thr_s every few tiles.  Racy reads only see older, smaller -- still valid -- values.  Rows below it can never
   // reach the merged top-16, so every lane may use it as its threshold: the 16 lists of a query share their progress.
   int *thr_s = reinterpret_cast<int *>(smem + (size_t)a.thr_off);
   auto enc = [](float f) -> int { const int i = __float_as_int(f); return i >= 0 ? i : (i ^ 0x7FFFFFFF); };
   auto dec = [](int i) -> float { return __int_as_float(i >= 0 ? i : (i ^ 0x7FFFFFFF)); };
-  float *mx_s = reinterpret_cast<float *>(thr_s + NQ * 32);  // [NQ*32][16]
+  float *mx_s = reinterpret_cast<float *>(thr_s + NQ * 32);  // [NQ][16 lists][32 queries]: lanes of a store / of the fold
+                                                               // hit 32 different banks ([query][list] was a 16-way conflict)
   if constexpr (!COLLECT) {
     for (int i = tid; i < NQ * 32; i += SC_THREADS) thr_s[i] = enc(NEG_INF);
     for (int i = tid; i < NQ * 32 * 16; i += SC_THREADS) mx_s[i] = NEG_INF;
   }
   __syncthreads();
+  // DEFER: parked hits [wave][q-tile][entry][lane] (score, row), this lane's fill count and best score per query tile
+  f32x2 *pend_s = reinterpret_cast<f32x2 *>(mx_s + NQ * 32 * 16) + (size_t)w * NQ * SC_PEND * 64 + lane;
+  int pcnt[NQ];
+  float lbest[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    pcnt[q] = 0;
+    lbest[q] = NEG_INF;
+  }
 
   const int tps = (a.NT + a.NSPLIT - 1) / a.NSPLIT;  // n-tiles per split
   const int t0 = split * tps, t1 = min(a.NT, t0 + tps);
@@ -367,14 +403,20 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
       if (w == 0 && (((tile - t0) / WSTEP) & 3) == 3 && lane < 32) {
 #pragma nounroll
         for (int q = 0; q < NQ; ++q) {  // rolled on purpose: runs once per 4 tiles, must not cost registers
-          const float *mp = mx_s + (q * 32 + lane) * 16;
+          const float *mp = mx_s + q * 16 * 32 + lane;
           float f = mp[0];
 #pragma nounroll
-          for (int j = 1; j < 16; ++j) f = fminf(f, mp[j]);
+          for (int j = 1; j < 16; ++j) f = fminf(f, mp[j * 32]);
           if (f > NEG_INF) atomicMax(&thr_s[q * 32 + lane], enc(f));
         }
       }
       const int rbase = nrow0 + 4 * (lane >> 5);  // row of accumulator register r: rbase + (r & 3) + 8 * (r >> 2)
+      // the NQ shared thresholds up front: one LDS round trip per wave tile instead of one exposed in front of every
+      // query tile's compare
+      int thr_i[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) thr_i[q] = thr_s[q * 32 + (lane & 31)];
+      if (a.dbg & 1) continue;  // measurement aid: k-loop only (results are garbage)
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         if (tail) {
@@ -390,25 +432,72 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
         float m = NEG_INF;
 #pragma unroll
         for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[q][r]);
-        float thr = fmaxf(ls[q][KL - 1], dec(thr_s[q * 32 + (lane & 31)]));
+        float thr = fmaxf(ls[q][KL - 1], dec(thr_i[q]));
         if (__any(m > thr)) {
           // rare (about two hits per wave tile): per register one ballot; a register some lane takes is inserted
           // with selects.  Registers ascend with the row number, '>' keeps the earlier row on equal scores.
+          if constexpr (DEFER) {
+            // takers of this lane (upper bound: the threshold only rises); if they do not fit its row, everybody
+            // inserts what is parked first; more takers than a whole row (start of a sweep, rows sorted by score) are
+            // inserted directly
+            int nt = 0;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const bool take = acc[q][r] > thr;
-            if (__ballot(take) != 0ull) {
-              asm volatile("");  // keep it a branch (see above)
-              list_insert<KL>(ls[q], li[q], acc[q][r], rbase + (r & 3) + 8 * (r >> 2), take);
+            for (int r = 0; r < 16; ++r) nt += (acc[q][r] > thr) ? 1 : 0;
+            bool direct = false;
+            if (__ballot(pcnt[q] + nt > SC_PEND) != 0ull) {
+              asm volatile("");
+              drain_parked<KL>(ls[q], li[q], pcnt[q], pend_s + q * SC_PEND * 64);
               thr = fmaxf(thr, ls[q][KL - 1]);
+              direct = __ballot(nt > SC_PEND) != 0ull;
+            }
+            if (direct) {
+              asm volatile("");
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const bool take = acc[q][r] > thr;
+                if (__ballot(take) != 0ull) {
+                  asm volatile("");
+                  list_insert<KL>(ls[q], li[q], acc[q][r], rbase + (r & 3) + 8 * (r >> 2), take);
+                  thr = fmaxf(thr, ls[q][KL - 1]);
+                  lbest[q] = fmaxf(lbest[q], ls[q][0]);
+                }
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const bool take = acc[q][r] > thr;
+                if (__ballot(take) != 0ull) {
+                  asm volatile("");  // keep it a branch (see above)
+                  if (take) {
+                    pend_s[(q * SC_PEND + pcnt[q]) * 64] = f32x2{acc[q][r], __int_as_float(rbase + (r & 3) + 8 * (r >> 2))};
+                    pcnt[q] += 1;
+                    lbest[q] = fmaxf(lbest[q], acc[q][r]);
+                  }
+                }
+              }
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const bool take = acc[q][r] > thr;
+              if (__ballot(take) != 0ull) {
+                asm volatile("");  // keep it a branch (see above)
+                list_insert<KL>(ls[q], li[q], acc[q][r], rbase + (r & 3) + 8 * (r >> 2), take);
+                thr = fmaxf(thr, ls[q][KL - 1]);
+              }
             }
           }
-          mx_s[(q * 32 + (lane & 31)) * 16 + w * 2 + (lane >> 5)] = ls[q][0];  // publish this list's best
+          // publish this list's best
+          mx_s[(q * 16 + w * 2 + (lane >> 5)) * 32 + (lane & 31)] = DEFER ? lbest[q] : ls[q][0];
         }
       }
     }
   }
   if constexpr (COLLECT) return;
+  if constexpr (DEFER) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) drain_parked<KL>(ls[q], li[q], pcnt[q], pend_s + q * SC_PEND * 64);
+  }
 
   constexpr int WAVES = SC_THREADS / 64;
   // (1) the two lane halves hold lists of the same query over different rows: merge into a 16-list in lanes 0-31;
@@ -490,6 +579,7 @@ static hipError_t launch_score_ringed(const ScoreArgs &a_in, hipStream_t stream)
   ScoreArgs a = a_in;
   a.thr_off = (int32_t)(lds / sizeof(float));  // shared thresholds live behind the query block / merge scratch
   lds += (size_t)NQ * 32 * sizeof(int) + (size_t)NQ * 32 * 16 * sizeof(float);  // thresholds + per-list best entries
+  if (BF && !COLLECT) lds += (size_t)(SC_THREADS / 64) * NQ * SC_PEND * 64 * 8;  // parked hits (deferred insertion)
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const int QB = (a.QT + NQ - 1) / NQ;
   int grid;
@@ -596,7 +686,12 @@ hipError_t launch_frag32_to_bf16(const float *idxp, int64_t NT, int KG, void *ou
   return hipGetLastError();
 }
 
-hipError_t launch_score_topk(const ScoreArgs &a, hipStream_t stream) {
+hipError_t launch_score_topk(const ScoreArgs &a_in, hipStream_t stream) {
+  ScoreArgs a = a_in;
+  {
+    static const int dbg = getenv("SSE_SCORE_DBG") ? atoi(getenv("SSE_SCORE_DBG")) : 0;
+    a.dbg = dbg;
+  }
   if (a.KC != SC_KC) return hipErrorInvalidValue;
   if (a.NSPLIT > 8 && (a.NSPLIT & 7)) return hipErrorInvalidValue;
   if (a.NSPLIT < 8 && (8 % a.NSPLIT)) return hipErrorInvalidValue;

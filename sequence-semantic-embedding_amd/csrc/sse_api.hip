@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cstring>
 #include <mutex>
@@ -574,6 +575,7 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   a.KC = 16;
   a.NQ = NQ;
   HIPCHECK(h, launch_score_topk(a, st));
+  if (getenv("SSE_SCORE_DBG")) return 0;  // measurement aid: the candidate sweep alone (outputs are not produced)
   RescoreArgs r;
   r.q = q;
   r.idx32 = h->idxp;

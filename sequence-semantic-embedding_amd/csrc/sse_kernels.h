@@ -81,6 +81,7 @@ struct ScoreArgs {
   int32_t *col_cnt = nullptr;         // [slots] rows appended (may exceed col_cap: overflow)
   int32_t *col_buf = nullptr;         // [slots][col_cap] local row numbers
   int32_t col_cap = 0;
+  int32_t dbg = 0;  // measurement aids (env SSE_SCORE_DBG): bit 0 = skip the top-k epilogue of the sweep
 };
 hipError_t launch_score_topk(const ScoreArgs &a, hipStream_t stream);
 // rows [R][C] fp32 -> bf16 fragment blocks [ceil(R/32)][ceil(C/16)][1 KiB]; fp32 frag32 index -> the same
