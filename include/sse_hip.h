@@ -126,6 +126,12 @@ int sse_score_topk(sse_handle *h, const float *q_host, int32_t Q, int32_t k, dou
 int sse_score_topk_dev(sse_handle *h, const float *q_dev, int32_t Q, int32_t k, double *out_scores_dev,
                        int64_t *out_ids_dev, void *stream);
 
+/* encode + score in one call, the encodings never leaving the device: session.run([src_seq_embedding | norm_...])
+ * followed by np.dot + getSortedResults[:k] as sse_demo.py:121-129, webserver.py:144-151 (and the three other routes)
+ * and sse_evaluator.py:107-111 do per query / batch.  enc_out_host (may be NULL) also receives the [B,S] encodings. */
+int sse_encode_score_topk(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int32_t T, int32_t normalize,
+                          int32_t k, double *out_scores, int64_t *out_ids, float *enc_out_host);
+
 /* k-way merge of P per-shard top-k lists per query (after the RCCL all-gather
  * of SURVEY 8e): in_* are [P,Q,k] (shard-major), out_* [Q,k]; same order rule. */
 int sse_merge_topk_dev(sse_handle *h, const double *in_scores_dev, const int64_t *in_ids_dev, int32_t P,

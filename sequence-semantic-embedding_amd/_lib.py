@@ -45,6 +45,7 @@ SYMBOLS = {
     "sse_index_set_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int64, _P]),
     "sse_score_topk": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     "sse_score_topk_dev": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "sse_encode_score_topk": (C.c_int, [_P, C.c_int, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "sse_merge_topk_dev": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "sse_train_step": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sse_train_grad_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
@@ -105,6 +106,7 @@ class Handle(object):
     def __init__(self, cfg):
         self.lib = load_library()
         self._h = C.c_void_p()
+        self.index_gen = 0          # bumped by every index upload: lets holders of "their" index notice a replacement
         rc = self.lib.sse_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
             raise SSEError(self.lib.sse_last_error(None).decode())
@@ -178,9 +180,11 @@ class Handle(object):
         else:
             rows = np.ascontiguousarray(rows, dtype=np.float32)
             self.check(self.lib.sse_index_upload(self._h, _ptr(rows), N, S, id_base))
+        self.index_gen += 1
 
     def index_set_dev(self, rows_ptr, N, S, id_base=0, stream=0):
         self.check(self.lib.sse_index_set_dev(self._h, rows_ptr, N, S, id_base, stream))
+        self.index_gen += 1
 
     def score_topk(self, queries, k):
         q = np.ascontiguousarray(queries, dtype=np.float32)
@@ -191,6 +195,20 @@ class Handle(object):
         ids = np.empty((Q, k), np.int64)
         self.check(self.lib.sse_score_topk(self._h, _ptr(q), Q, k, _ptr(scores), _ptr(ids)))
         return scores, ids
+
+    def encode_score_topk(self, side, ids, normalize, k, want_encodings=False):
+        """encode + cosine top-k with the encodings staying on the device (sse_demo.py:121-129,
+        sse_evaluator.py:107-111); returns (scores [B,k] f64, ids [B,k] i64[, encodings [B,S] f32])."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        if ids.ndim != 2:
+            raise ValueError("ids must be [B,T]")
+        B, T = ids.shape
+        scores = np.empty((B, k), np.float64)
+        rows = np.empty((B, k), np.int64)
+        enc = np.empty((B, self.cfg.encoding_size), np.float32) if want_encodings else None
+        self.check(self.lib.sse_encode_score_topk(self._h, side, _ptr(ids), B, T, 1 if normalize else 0, int(k),
+                                                  _ptr(scores), _ptr(rows), _ptr(enc) if want_encodings else None))
+        return (scores, rows, enc) if want_encodings else (scores, rows)
 
     def score_topk_dev(self, q_ptr, Q, k, scores_ptr, ids_ptr, stream=0):
         self.check(self.lib.sse_score_topk_dev(self._h, q_ptr, Q, k, scores_ptr, ids_ptr, stream))

@@ -821,13 +821,8 @@ int sse_encode_dev(sse_handle *h, int side, const int32_t *ids_dev, int32_t B, i
   return encode_dev_locked(h, side, ids_dev, B, T, normalize, out_dev, (hipStream_t)stream);
 }
 
-int sse_encode(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int32_t T, int32_t normalize,
-               float *out_host) {
-  if (!h) return 1;
-  std::lock_guard<std::mutex> lk(h->mu);
-  HIPCHECK(h, hipSetDevice(h->cfg.device));
-  if (B == 0) return 0;
-  if (B < 0 || T < 1 || !ids_host || !out_host) return fail(h, "bad arguments to sse_encode");
+// host ids -> encodings [B][S] in h->s_out (device); the handle mutex is held by the caller
+static int encode_host_ids_locked(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int32_t T, int32_t normalize) {
   const size_t S = h->cfg.encoding_size;
   if (reserve(h, h->s_ids, (size_t)B * T * sizeof(int32_t))) return 1;
   if (reserve(h, h->s_out, (size_t)B * S * sizeof(float))) return 1;
@@ -858,8 +853,40 @@ int sse_encode(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int3
   const int rc = encode_dev_locked(h, side, (const int32_t *)h->s_ids.p, B, T, normalize, (float *)h->s_out.p, st);
   h->cur_row_map = nullptr;
   if (rc) return 1;
-  if (check_err_flag(h, st)) return 1;
-  HIPCHECK(h, hipMemcpy(out_host, h->s_out.p, (size_t)B * S * sizeof(float), hipMemcpyDeviceToHost));
+  return check_err_flag(h, st);
+}
+
+int sse_encode(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int32_t T, int32_t normalize,
+               float *out_host) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  if (B == 0) return 0;
+  if (B < 0 || T < 1 || !ids_host || !out_host) return fail(h, "bad arguments to sse_encode");
+  if (encode_host_ids_locked(h, side, ids_host, B, T, normalize)) return 1;
+  HIPCHECK(h, hipMemcpy(out_host, h->s_out.p, (size_t)B * h->cfg.encoding_size * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int sse_encode_score_topk(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int32_t T, int32_t normalize,
+                          int32_t k, double *out_scores, int64_t *out_ids, float *enc_out_host) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  if (B == 0) return 0;
+  if (B < 0 || T < 1 || !ids_host || !out_scores || !out_ids) return fail(h, "bad arguments to sse_encode_score_topk");
+  if (!h->idxp) return fail(h, "no index uploaded");
+  if (h->cfg.encoding_size != h->idx_S)
+    return fail(h, "index dimension %d != encoding_size %d", h->idx_S, h->cfg.encoding_size);
+  if (encode_host_ids_locked(h, side, ids_host, B, T, normalize)) return 1;
+  if (reserve(h, h->s_os, (size_t)B * k * sizeof(double))) return 1;
+  if (reserve(h, h->s_oi, (size_t)B * k * sizeof(int64_t))) return 1;
+  // the encodings never leave the device between the encoder and the scorer
+  if (score_dev_locked(h, (const float *)h->s_out.p, B, k, (double *)h->s_os.p, (int64_t *)h->s_oi.p, nullptr)) return 1;
+  HIPCHECK(h, hipMemcpy(out_scores, h->s_os.p, (size_t)B * k * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHECK(h, hipMemcpy(out_ids, h->s_oi.p, (size_t)B * k * sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (enc_out_host)
+    HIPCHECK(h, hipMemcpy(enc_out_host, h->s_out.p, (size_t)B * h->cfg.encoding_size * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -1,6 +1,9 @@
 """`sse_demo` command (reference `sse_demo.py:59-146`): read a query per line from
 stdin, encode it with the SOURCE encoder -- un-normalised, as the reference
-does at :123 -- score it against the index on the GPU and print the top-N."""
+does at :123 -- score it against the index on the GPU and print the top-N.
+The line is lower-cased and tokenised WITH its trailing newline, exactly as
+the reference does (`encoder.encode(tf.compat.as_str(sentence).lower())`,
+:113): the same checkpoint, index and keystrokes give the same token ids."""
 import os
 import sys
 
@@ -8,7 +11,7 @@ import numpy as np
 
 from . import flags, sse_data, sse_text
 from .sse_evaluator import load_index_file
-from .sse_model import Session, SSEModel, get_checkpoint_state
+from .sse_model import SSEModel, get_checkpoint_state
 
 FLAGS = flags.FlagSet("sse_demo", [
     ("device", str, "0", "GPU ordinal."),
@@ -35,19 +38,24 @@ def demo(f, nbest, stdin=sys.stdin, out=sys.stdout):
         raise FileNotFoundError("Error!!!Could not load any model from specified folder: %s" % f.model_dir)
     print("Reading model parameters from %s" % ckpt, file=out)
     model.saver.restore(None, ckpt)
-    sess = Session(model)
     model.handle.index_upload(targetEncodings)
+    index_gen = model.handle.index_gen
     max_seq_length = int(cfg["max_seq_length"])
     nbest = min(nbest, len(targetIDs))
     out.write("\n\nPlease type some keywords to get related task results.\nType 'exit' to quit demo.\n > ")
     out.flush()
     sentence = stdin.readline()
     while sentence and sentence.strip().lower() != "exit":
-        tokens = sse_text.pad_tokens(encoder.encode(sentence.strip("\n").lower()), max_seq_length)
+        source_tokens = encoder.encode(sentence.lower())
+        if len(source_tokens) > max_seq_length - 2:
+            print("Input sentence too long, max allowed is %d. Try to increase limit!!!!" % max_seq_length, file=out)
+        tokens = sse_text.pad_tokens(source_tokens, max_seq_length)
         model.set_forward_only(True)
-        enc = np.vstack(sess.run([model.src_seq_embedding],
-                                 feed_dict=model.get_source_encoding_feed_dict(np.array([tokens]))))
-        scores, idx = model.handle.score_topk(enc, nbest)
+        if model.handle.index_gen != index_gen:
+            model.handle.index_upload(targetEncodings)
+            index_gen = model.handle.index_gen
+        # sess.run([model.src_seq_embedding]) + np.dot + getSortedResults[:nbest] (:121-129), encoding kept on the device
+        scores, idx = model.handle.encode_score_topk(0, np.array([tokens], np.int32), False, nbest)
         print("Top %s Prediction results are:\n" % nbest, file=out)
         for r in range(nbest):
             tid = targetIDs[idx[0][r]]

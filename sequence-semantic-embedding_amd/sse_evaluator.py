@@ -57,15 +57,21 @@ class Evaluator(object):
         self.targetIDs, _, self.targetEncodings, self.idLabelMap = load_index_file(tgtIndexFile)
         self.eval_Labels = [[self.idLabelMap[t] for t in entry[1]] for entry in eval_corpus]
         model.handle.index_upload(self.targetEncodings)         # float64 rows, resident on the GPU
+        self._index_gen = model.handle.index_gen
 
     def ranked(self, k=10, batch=600):
         """Top-k row indices per eval source, in batches of 600 (sse_evaluator.py:104-111)."""
         k = min(k, len(self.targetIDs))
+        h = self.model.handle
+        if h.index_gen != self._index_gen:      # predict()/similarity or another Evaluator replaced the handle's index
+            h.index_upload(self.targetEncodings)
+            self._index_gen = h.index_gen
         out = []
         for b in range(int(math.ceil(len(self.srcSeq_batch) / float(batch)))):
-            feed = self.model.get_source_encoding_feed_dict(self.srcSeq_batch[b * batch:(b + 1) * batch])
-            enc = np.vstack(self.session.run([self.model.norm_src_seq_embedding], feed_dict=feed))
-            _, idx = self.model.handle.score_topk(enc, k)
+            ids = np.array(self.srcSeq_batch[b * batch:(b + 1) * batch], dtype=np.int32)   # the feed dict's array
+            # session.run([norm_src_seq_embedding]) + np.dot + getSortedResults in one call: the encodings go from
+            # the encoder to the scorer on the device
+            _, idx = h.encode_score_topk(0, ids, True, k)
             out.append(idx)
         return out
 

@@ -27,8 +27,11 @@ def createIndexFile(model, encoder, rawfile, max_seq_len, encodeIndexFile, sessi
     print("Start indexing whole target space entries with current model ...")
     if model.network_mode in ("source_only_cnn", "source-encoder-only"):
         # no target sequence encoder: norm_tgt_seq_embedding IS the [N,S] variable (sse_model.py:214,233,283);
-        # row r belongs to the r-th well-formed line of the target file (or row_of(id) when the caller knows better)
+        # a target id owns the row of its FIRST occurrence among the well-formed lines -- the order in which
+        # training numbers the ids (Data.target_row: de-duplicated dict order of fullSetTargetIds); a duplicate id
+        # in the file must not shift every later row by one.  row_of(id) overrides when the caller knows better.
         n_rows = int(model.targetSpaceSize)
+        first_row = {}
         table = np.vstack(session.run([model.norm_tgt_seq_embedding],
                                       feed_dict=model.get_target_encoding_feed_dict(np.zeros((n_rows, max_seq_len), np.int32))))
         with codecs.open(encodeIndexFile, "w", "utf-8") as out:
@@ -39,8 +42,10 @@ def createIndexFile(model, encoder, rawfile, max_seq_len, encodeIndexFile, sessi
                 if len(info) != 2:
                     print("Missing field with error line in raw target file: %s " % line)
                     continue
-                row = row_of(info[1]) if row_of else r
-                r += 1
+                if info[1] not in first_row:
+                    first_row[info[1]] = r
+                    r += 1
+                row = row_of(info[1]) if row_of else first_row[info[1]]
                 if row >= n_rows:
                     raise ValueError("target file has more entries than the model's target matrix (%d rows)" % n_rows)
                 out.write(info[1] + "\t" + info[0] + "\t" + index_io.format_rows(table[row:row + 1])[0] + "\n")

@@ -68,12 +68,30 @@ class Saver(object):
         return path
 
     def restore(self, session, path):
-        z = np.load(path if path.endswith(".npz") else path + ".npz")
-        self.model.set_variables({k: z[k] for k in z.files if k not in ("learning_rate", "global_step")})
-        if "learning_rate" in z.files:
-            self.model.handle.learning_rate = float(z["learning_rate"])
-        if "global_step" in z.files:
-            self.model.handle.global_step = int(z["global_step"])
+        """`path`: checkpoint prefix as tf.train.get_checkpoint_state reports it.  A `.npz` written by save() is
+        read directly; a TensorFlow V2 checkpoint of the reference (`<prefix>.index` + `.data-*`, same variable
+        names) is read by tf_checkpoint.read_bundle -- no TensorFlow needed."""
+        from . import tf_checkpoint
+        npz = path if path.endswith(".npz") else path + ".npz"
+        if os.path.exists(npz):
+            z = np.load(npz)
+            arrays = {k: z[k] for k in z.files}
+        elif tf_checkpoint.is_tf_checkpoint(path):
+            arrays = tf_checkpoint.to_npz_arrays(tf_checkpoint.read_bundle(path))
+        else:
+            raise FileNotFoundError("no checkpoint at %s (.npz, or TensorFlow .index/.data-*)" % path)
+        known = set(self.model.variable_names())
+        weights = {k: v for k, v in arrays.items() if k not in ("learning_rate", "global_step")}
+        missing = sorted(known - set(weights))
+        if missing:
+            raise KeyError("checkpoint %s lacks variables %s (network_mode / sizes differ from modelConfig.param?)"
+                           % (path, missing[:4]))
+        self.model.set_variables({k: v for k, v in weights.items()
+                                  if (k[:-len("/Adagrad")] if k.endswith("/Adagrad") else k) in known})
+        if "learning_rate" in arrays:
+            self.model.handle.learning_rate = float(arrays["learning_rate"])
+        if "global_step" in arrays:
+            self.model.handle.global_step = int(arrays["global_step"])
 
 
 def get_checkpoint_state(model_dir):
@@ -85,8 +103,12 @@ def get_checkpoint_state(model_dir):
         if line.startswith("model_checkpoint_path:"):
             name = line.split(":", 1)[1].strip().strip('"')
             full = name if os.path.isabs(name) else os.path.join(model_dir, name)
-            if os.path.exists(full + ".npz"):
-                return full
+            if os.path.exists(full + ".npz") or os.path.exists(full + ".index"):
+                return full                    # ours (.npz) or a TensorFlow V2 checkpoint of the reference (.index)
+            # a `checkpoint` file that names something unreadable must not look like "no checkpoint": sse_train would
+            # silently start from fresh weights and write next to the real model
+            raise FileNotFoundError("%s names checkpoint %r but neither %s.npz nor %s.index exists"
+                                    % (p, name, full, full))
     return None
 
 

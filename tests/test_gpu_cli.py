@@ -86,11 +86,46 @@ def test_train_index_eval_demo_cli(tmp_path):
     sse_demo.demo(f, 5, stdin=io.StringIO(query + "\nexit\n"), out=out)
     text = out.getvalue()
     assert "Top 5 Prediction results are:" in text and text.count("top") >= 5
-    q_ids = np.array([sse_amd.sse_text.pad_tokens(data.encoder.encode(query.lower()), 24)], np.int32)
+    # (the reference tokenises the line WITH its trailing newline, sse_demo.py:113)
+    q_ids = np.array([sse_amd.sse_text.pad_tokens(data.encoder.encode((query + "\n").lower()), 24)], np.int32)
     raw_enc = model.encode_source(q_ids, normalize=False)      # same inputs as the demo: only the ranking is compared
     assert np.abs(raw_enc - O.encode(p, ocfg, "src", q_ids, normalize=False)).max() < 1e-4 * max(1.0, np.abs(raw_enc).max())
     wsc, wids = O.topk(O.scores_f64(raw_enc, enc), 5)
     assert ("top1:  %s , %f" % (ids[wids[0][0]], wsc[0][0])) in text
+
+    # serving shell (webserver.py:124-286): /api/classify ranks the NORMALISED encoding, /api/search the raw one;
+    # concurrent requests through the micro-batcher give each caller the single-request answer
+    import json
+    import threading
+    from sse_amd import sse_serving
+    app = sse_serving.create_app(model_dir=mdir)
+
+    def get(path, qs):
+        out = {}
+        body = b"".join(app({"PATH_INFO": path, "QUERY_STRING": qs}, lambda st, hd: out.update(status=st)))
+        assert out["status"].startswith("200"), (out, body)
+        return json.loads(body)
+
+    from urllib.parse import quote_plus
+    w_ids = np.array([sse_amd.sse_text.pad_tokens(data.encoder.encode(query.lower()), 24)], np.int32)
+    d = get("/api/classify", "keywords=" + quote_plus(query))
+    nsc, nids = O.topk(O.scores_f64(model.encode_source(w_ids, normalize=True), enc), 8)
+    assert [r["targetCategoryId"] for r in d["ClassificationResults"]] == [ids[j] for j in nids[0]]
+    assert np.allclose([r["confidenceScore"] for r in d["ClassificationResults"]], nsc[0], atol=1e-12)
+    d = get("/api/search", "query=%s&nbest=4" % quote_plus(query))
+    rsc, rids = O.topk(O.scores_f64(model.encode_source(w_ids, normalize=False), enc), 4)
+    assert [r["ListingId"] for r in d["SearchRankingResults"]] == [ids[j] for j in rids[0]]
+    assert np.allclose([r["rankingScore"] for r in d["SearchRankingResults"]], rsc[0], atol=1e-12)
+    queries = [l.split("\t")[0] for l in open(os.path.join(mdir, "EvalPairs"), encoding="utf-8").readlines()[:16]]
+    single = [get("/api/qna", "question=" + quote_plus(q)) for q in queries]
+    multi = [None] * len(queries)
+    th = [threading.Thread(target=lambda i=i: multi.__setitem__(i, get("/api/qna", "question=" + quote_plus(queries[i]))))
+          for i in range(len(queries))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60)
+    assert multi == single
 
 
 def test_cnn_mode_train_index_eval_cli(tmp_path):
