@@ -298,11 +298,16 @@ def main():
         ttgt[:, -1] = 1
         tz = np.tile(np.array([1.0, 0.0], np.float32), Bt // 2)
         trainer = sse_amd.DataParallelTrainer(h, device=dev, always_reduce=force_dist)
-        tl = trainer.train_step(tsrc, ttgt, tz, rows_global=Bt * world)
+        # the (synthetic) corpora are resident on the device, as in sse_train: a step ships 2 x Bt row numbers
+        h.corpus_upload(0, tsrc[0::2])
+        h.corpus_upload(1, ttgt)
+        src_rows = np.repeat(np.arange(Bt // 2, dtype=np.int32), 2)          # data.py:95-115: pos,neg share a source
+        tgt_rows = np.arange(Bt, dtype=np.int32)
+        tl = trainer.train_step(src_rows, tgt_rows, tz, rows_global=Bt * world, by_rows=True)
         barrier()
         ts = time.perf_counter()
         for _ in range(args.train_iters):
-            tl = trainer.train_step(tsrc, ttgt, tz, rows_global=Bt * world)
+            tl = trainer.train_step(src_rows, tgt_rows, tz, rows_global=Bt * world, by_rows=True)
         barrier()
         tdt = (time.perf_counter() - ts) / args.train_iters
         if use_dist:
@@ -313,7 +318,7 @@ def main():
                     "collective": ("rccl all_reduce of one flat %.1f MB gradient buffer" % (trainer.arena.numel() * 4 / 1e6))
                     if world > 1 else "none (1 rank)",
                     "algorithmic_tflops_per_gpu": 3.0 * 2 * Bt * FLOP_PER_SEQ / tdt / 1e12,
-                    "loss_last": tl[0], "input": "host int32 ids each step (H2D inside the timed region)"}
+                    "loss_last": tl[0], "input": "corpus resident on the device; 2 x %d int32 row numbers H2D per step" % Bt}
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")

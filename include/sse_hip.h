@@ -20,7 +20,11 @@
  *     encodings row-major float32 [B,S];
  *   - a handle may be used from several threads for encode/score (calls are
  *     serialised internally, like tf.Session.run in webserver.py:108);
- *     sse_train_step is exclusive.
+ *     sse_train_step is exclusive;
+ *   - the internal mutex serialises the HOST side only: the *_dev entry points enqueue on the stream they are given
+ *     and share the handle's packed-weight and scratch buffers, so ONE handle must be driven from ONE stream (or the
+ *     caller orders its streams with events); create one handle per stream for concurrent device-side use.  The
+ *     host-buffer entry points use the null stream and synchronise before returning.
  */
 #ifndef SSE_HIP_H
 #define SSE_HIP_H
@@ -168,6 +172,16 @@ int sse_train_set_grad_arena(sse_handle *h, float *arena_dev, int64_t count);
 int sse_train_grads(sse_handle *h, const int32_t *src_ids_host, const int32_t *tgt_ids_host,
                     const float *labels_host, int32_t B, int32_t T, int64_t rows_global);
 int sse_train_apply(sse_handle *h, float *loss, float *train_acc);
+/* Batches by row number: the padded source / target corpora (the token-id matrices Data builds
+ * from TrainPairs / targetIDs, data.py:95-115) are uploaded once with sse_corpus_upload (side 0 = source corpus
+ * [N,T], side 1 = target corpus) and a step ships 2*B row numbers instead of 2*B*T token ids; the batch's id matrix
+ * is gathered on the device and the step is otherwise sse_train_step / sse_train_grads.  In the modes whose target
+ * side is already a row of the free target matrix, tgt_rows keeps that meaning and no target corpus is needed. */
+int sse_corpus_upload(sse_handle *h, int side, const int32_t *ids_host, int64_t N, int32_t T);
+int sse_train_step_rows(sse_handle *h, const int32_t *src_rows_host, const int32_t *tgt_rows_host,
+                        const float *labels_host, int32_t B, float *loss, float *train_acc);
+int sse_train_grads_rows(sse_handle *h, const int32_t *src_rows_host, const int32_t *tgt_rows_host,
+                         const float *labels_host, int32_t B, int64_t rows_global);
 /* model.learning_rate.eval(), model.global_step.eval(), learning_rate_decay_op
  * (sse_train.py:181,200; sse_model.py:122-125) */
 int sse_get_learning_rate(sse_handle *h, float *lr);

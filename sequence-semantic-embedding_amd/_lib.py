@@ -52,6 +52,9 @@ SYMBOLS = {
     "sse_train_set_grad_arena": (C.c_int, [_P, _P, C.c_int64]),
     "sse_train_grads": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int64]),
     "sse_train_apply": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "sse_corpus_upload": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int32]),
+    "sse_train_step_rows": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "sse_train_grads_rows": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int64]),
     "sse_get_learning_rate": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "sse_set_learning_rate": (C.c_int, [_P, C.c_float]),
     "sse_decay_learning_rate": (C.c_int, [_P]),
@@ -243,6 +246,31 @@ class Handle(object):
         self.check(self.lib.sse_train_step(self._h, _ptr(s), _ptr(t), _ptr(z), s.shape[0], s.shape[1],
                                            C.byref(loss), C.byref(acc)))
         return float(loss.value), float(acc.value)
+
+    # ---- batches by row number: corpora resident on the device
+    def corpus_upload(self, side, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        if ids.ndim != 2:
+            raise ValueError("corpus must be [N,T]")
+        self.check(self.lib.sse_corpus_upload(self._h, int(side), _ptr(ids), ids.shape[0], ids.shape[1]))
+
+    def _rows_batch(self, src_rows, tgt_rows, labels):
+        s = np.ascontiguousarray(src_rows, dtype=np.int32).reshape(-1)
+        t = np.ascontiguousarray(tgt_rows, dtype=np.int32).reshape(-1)
+        z = np.ascontiguousarray(labels, dtype=np.float32).reshape(-1)
+        if not (s.shape == t.shape == z.shape):
+            raise ValueError("src_rows, tgt_rows, labels must all be [B]")
+        return s, t, z
+
+    def train_step_rows(self, src_rows, tgt_rows, labels):
+        s, t, z = self._rows_batch(src_rows, tgt_rows, labels)
+        loss, acc = C.c_float(), C.c_float()
+        self.check(self.lib.sse_train_step_rows(self._h, _ptr(s), _ptr(t), _ptr(z), s.shape[0], C.byref(loss), C.byref(acc)))
+        return float(loss.value), float(acc.value)
+
+    def train_grads_rows(self, src_rows, tgt_rows, labels, rows_global):
+        s, t, z = self._rows_batch(src_rows, tgt_rows, labels)
+        self.check(self.lib.sse_train_grads_rows(self._h, _ptr(s), _ptr(t), _ptr(z), s.shape[0], int(rows_global)))
 
     # ---- data-parallel split of the train step: grads -> all-reduce(arena) -> apply
     def train_grad_count(self):

@@ -63,6 +63,11 @@ struct TrainState {
   // ranks of a data-parallel job (one flat all-reduce)
   float *arena = nullptr;
   bool arena_external = false, grads_ready = false;
+  // corpus resident on the device (sse_corpus_upload): the *_rows train entry points ship row numbers, not token ids
+  DevBuf corpus[2], rows[2];
+  int64_t corpus_N[2] = {0, 0};
+  int32_t corpus_T[2] = {0, 0};
+  bool rows_mode = false;  // set by the *_rows entry points around train_grads_locked
 };
 
 }  // namespace
@@ -357,6 +362,7 @@ int check_err_flag(sse_handle *h, hipStream_t st) {
   if (flag) {
     HIPCHECK(h, hipMemsetAsync(h->err_flag, 0, sizeof(int32_t), st));
     if (flag & 1) return fail(h, "token id out of range [0, %d) (tf.gather would raise; sse_model.py:163-164)", h->cfg.vocab_size);
+    if (flag & 2) return fail(h, "corpus row out of range in a train step by rows");
     return fail(h, "device error flag 0x%x", flag);
   }
   return 0;
@@ -1074,6 +1080,23 @@ static int ensure_arena(sse_handle *h) {
   return 0;
 }
 
+// token ids of one side of the batch into ts.ids[side] ([B][T] on the device): copied from the host, or -- rows mode --
+// gathered on the device from the resident corpus by B row numbers (B ints cross PCIe instead of B*T)
+static int stage_ids(sse_handle *h, TrainState &ts, int side, const int32_t *host, int B, int T, hipStream_t st) {
+  if (reserve(h, ts.ids[side], (size_t)B * T * sizeof(int32_t))) return 1;
+  if (!ts.rows_mode) {
+    HIPCHECK(h, hipMemcpyAsync(ts.ids[side].p, host, (size_t)B * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    return 0;
+  }
+  if (!ts.corpus[side].p || ts.corpus_T[side] != T)
+    return fail(h, "train step by rows: no %s corpus with T = %d on the device (sse_corpus_upload)", side ? "target" : "source", T);
+  if (reserve(h, ts.rows[side], (size_t)B * sizeof(int32_t))) return 1;
+  HIPCHECK(h, hipMemcpyAsync(ts.rows[side].p, host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  HIPCHECK(h, launch_gather_id_rows((const int32_t *)ts.corpus[side].p, (const int32_t *)ts.rows[side].p, B, T,
+                                    ts.corpus_N[side], (int32_t *)ts.ids[side].p, h->err_flag, st));
+  return 0;
+}
+
 // source_only_cnn (BUILDER-DEFINED, see cnn_bwd.hip): row b pairs source sequence b with row tgt_rows[b]
 // of the free target matrix; same loss kernel, CNN forward with arg-max tape, gather/scatter backward.
 static int cnn_train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const int32_t *tgt_rows_host,
@@ -1093,10 +1116,9 @@ static int cnn_train_grads_locked(sse_handle *h, const int32_t *src_ids_host, co
   const float inv_rows = 1.0f / (float)rows_global;
   Variable &emb = h->vars[0], &table = h->vars[h->tgt_table], &M = h->vars[h->cnn_M];
 
-  if (reserve(h, ts.ids[0], (size_t)B * T * sizeof(int32_t))) return 1;
   if (reserve(h, ts.ids[1], (size_t)B * sizeof(int32_t))) return 1;
   if (reserve(h, ts.labels, (size_t)B * sizeof(float))) return 1;
-  HIPCHECK(h, hipMemcpyAsync(ts.ids[0].p, src_ids_host, (size_t)B * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  if (stage_ids(h, ts, 0, src_ids_host, B, T, st)) return 1;
   HIPCHECK(h, hipMemcpyAsync(ts.ids[1].p, tgt_rows_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st));
   HIPCHECK(h, hipMemcpyAsync(ts.labels.p, labels_host, (size_t)B * sizeof(float), hipMemcpyHostToDevice, st));
   for (int s = 0; s < 2; ++s) {
@@ -1205,9 +1227,12 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   // ---- inputs
   const int32_t *ids_host[2] = {src_ids_host, tgt_ids_host};
   for (int s = 0; s < 2; ++s) {
-    const size_t n_ids = (s == 1 && table_tgt) ? (size_t)B : (size_t)B * T;
-    if (reserve(h, ts.ids[s], n_ids * sizeof(int32_t))) return 1;
-    HIPCHECK(h, hipMemcpyAsync(ts.ids[s].p, ids_host[s], n_ids * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (s == 1 && table_tgt) {  // rows of the free target matrix
+      if (reserve(h, ts.ids[s], (size_t)B * sizeof(int32_t))) return 1;
+      HIPCHECK(h, hipMemcpyAsync(ts.ids[s].p, ids_host[s], (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    } else if (stage_ids(h, ts, s, ids_host[s], B, T, st)) {
+      return 1;
+    }
   }
   if (reserve(h, ts.labels, (size_t)B * sizeof(float))) return 1;
   HIPCHECK(h, hipMemcpyAsync(ts.labels.p, labels_host, (size_t)B * sizeof(float), hipMemcpyHostToDevice, st));
@@ -1357,6 +1382,39 @@ int sse_train_grads(sse_handle *h, const int32_t *src_ids_host, const int32_t *t
   std::lock_guard<std::mutex> lk(h->mu);
   HIPCHECK(h, hipSetDevice(h->cfg.device));
   return train_grads_locked(h, src_ids_host, tgt_ids_host, labels_host, B, T, rows_global);
+}
+
+int sse_corpus_upload(sse_handle *h, int side, const int32_t *ids_host, int64_t N, int32_t T) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  if ((side != 0 && side != 1) || !ids_host || N < 1 || T < 1 || N > 2147483000) return fail(h, "bad arguments to sse_corpus_upload");
+  if (!h->train) h->train = new TrainState();
+  TrainState &ts = *h->train;
+  HIPCHECK(h, hipDeviceSynchronize());
+  if (reserve(h, ts.corpus[side], (size_t)N * T * sizeof(int32_t))) return 1;
+  HIPCHECK(h, hipMemcpy(ts.corpus[side].p, ids_host, (size_t)N * T * sizeof(int32_t), hipMemcpyHostToDevice));
+  ts.corpus_N[side] = N;
+  ts.corpus_T[side] = T;
+  return 0;
+}
+
+int sse_train_grads_rows(sse_handle *h, const int32_t *src_rows_host, const int32_t *tgt_rows_host, const float *labels_host,
+                         int32_t B, int64_t rows_global) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  if (!h->train || !h->train->corpus[0].p) return fail(h, "train step by rows: no source corpus on the device (sse_corpus_upload)");
+  h->train->rows_mode = true;
+  const int rc = train_grads_locked(h, src_rows_host, tgt_rows_host, labels_host, B, h->train->corpus_T[0], rows_global);
+  h->train->rows_mode = false;
+  return rc;
+}
+
+int sse_train_step_rows(sse_handle *h, const int32_t *src_rows_host, const int32_t *tgt_rows_host, const float *labels_host,
+                        int32_t B, float *loss, float *train_acc) {
+  if (sse_train_grads_rows(h, src_rows_host, tgt_rows_host, labels_host, B, B)) return 1;
+  return sse_train_apply(h, loss, train_acc);
 }
 
 int sse_train_apply(sse_handle *h, float *loss, float *train_acc) {

@@ -759,3 +759,24 @@ hipError_t launch_adagrad(float *w, float *accum, const float *grad, const float
   hipLaunchKernelGGL(adagrad_kernel, dim3(gridn(n)), dim3(256), 0, st, w, accum, grad, scal, lr, n);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------
+// batch token ids from the device-resident corpus: one wave per batch row
+__global__ void gather_id_rows_kernel(const int32_t *__restrict__ corpus, const int32_t *__restrict__ rows, int B, int T,
+                                      int64_t N, int32_t *__restrict__ out, int32_t *err) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  int64_t r = rows[b];
+  if (r < 0 || r >= N) {
+    if (lane == 0) atomicOr(err, 2);
+    r = 0;
+  }
+  for (int t = lane; t < T; t += 64) out[(size_t)b * T + t] = corpus[(size_t)r * T + t];
+}
+
+hipError_t launch_gather_id_rows(const int32_t *corpus, const int32_t *rows, int B, int T, int64_t N, int32_t *out,
+                                 int32_t *err, hipStream_t st) {
+  hipLaunchKernelGGL(gather_id_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, st, corpus, rows, B, T, N, out, err);
+  return hipGetLastError();
+}

@@ -37,13 +37,17 @@ class DataParallelTrainer(object):
         dist.all_reduce(t, group=self.group)
         return int(t.item())
 
-    def train_step(self, src_ids, tgt_ids, labels, rows_global=None):
+    def train_step(self, src_ids, tgt_ids, labels, rows_global=None, by_rows=False):
         """One step on this rank's rows; returns the GLOBAL (loss, train_acc), evaluated before the update.
-        Pass rows_global when it is known (equal batches: world * len(labels)) to save the tiny extra all-reduce."""
+        Pass rows_global when it is known (equal batches: world * len(labels)) to save the tiny extra all-reduce.
+        by_rows: src_ids / tgt_ids are row numbers into the corpora uploaded with engine.corpus_upload."""
         import torch.distributed as dist
         if rows_global is None:
             rows_global = self.global_rows(len(labels))
-        self.engine.train_grads(src_ids, tgt_ids, labels, rows_global)
+        if by_rows:
+            self.engine.train_grads_rows(src_ids, tgt_ids, labels, rows_global)
+        else:
+            self.engine.train_grads(src_ids, tgt_ids, labels, rows_global)
         if self.world > 1 or self.always_reduce:
             dist.all_reduce(self.arena, group=self.group)          # ONE collective per step (sum)
         return self.engine.train_apply()

@@ -174,6 +174,58 @@ class Data(object):
         labels = np.tile(np.array([1.0, 0.0], np.float32), stop - start)
         return src, tgt, labels
 
+    def corpus_matrices(self):
+        """(source corpus [n_pos, T], target corpus [N, T] in fullSetTargetIds order) int32: what sse_corpus_upload
+        keeps resident on the device."""
+        return self._corpus_arrays()
+
+    def _positives_csr(self):
+        if getattr(self, "_csr", None) is None:
+            cnt = np.array([len(v) for _, v in self.rawTrainPosCorpus], np.int64)
+            off = np.concatenate([[0], np.cumsum(cnt)])
+            flat = np.array([self.target_row(t) for _, v in self.rawTrainPosCorpus for t in v], np.int64)
+            width = int(cnt.max())
+            pad = np.full((len(cnt), width), -1, np.int64)
+            for i, (_, v) in enumerate(self.rawTrainPosCorpus):
+                pad[i, :len(v)] = [self.target_row(t) for t in v]
+            self._csr = (cnt, off, flat, pad)
+        return self._csr
+
+    def get_train_batch_rows(self, batch_size, vectorized=False):
+        """The batch of get_train_batch as ROW NUMBERS: (source-corpus rows [2b], target rows [2b], labels [2b]),
+        pos/neg interleaved, each source row twice (data.py:95-115).  vectorized=False draws exactly the random
+        numbers of get_train_batch in the same order (same seed -> same batch).  vectorized=True samples the whole
+        window with array operations -- the same distribution (positive uniform among the verified targets, negative
+        uniform among the targets that are not positives of the source, by rejection) from a different stream; the
+        reference itself draws from the unseeded global numpy.random, so no stream is part of its contract."""
+        n = len(self.rawTrainPosCorpus)
+        start = self.rng.randint(0, n - batch_size) + batch_size     # data.py:97 (window may be cut at the end)
+        stop = min(n, start + batch_size)
+        b = stop - start
+        rows = np.empty(2 * b, np.int64)
+        if vectorized:
+            cnt, off, flat, pad = self._positives_csr()
+            idx = np.arange(start, stop)
+            rows[0::2] = flat[off[idx] + (self.rng.random_sample(b) * cnt[idx]).astype(np.int64)]
+            neg = self.rng.randint(0, self.rawnegSetLen, size=b)
+            bad = (pad[idx] == neg[:, None]).any(axis=1)
+            while bad.any():
+                neg[bad] = self.rng.randint(0, self.rawnegSetLen, size=int(bad.sum()))
+                bad = (pad[idx] == neg[:, None]).any(axis=1)
+            rows[1::2] = neg
+        else:
+            for i in range(start, stop):
+                verified = self.rawTrainPosCorpus[i][1]
+                pos = verified[self.rng.randint(0, len(verified))]
+                positives = set(verified)
+                neg = self.fullSetTargetIds[self.rng.randint(0, self.rawnegSetLen)]
+                while neg in positives:
+                    neg = self.fullSetTargetIds[self.rng.randint(0, self.rawnegSetLen)]
+                rows[2 * (i - start)] = self.target_row(pos)
+                rows[2 * (i - start) + 1] = self.target_row(neg)
+        src_rows = np.repeat(np.arange(start, stop, dtype=np.int32), 2)
+        return src_rows, rows.astype(np.int32), np.tile(np.array([1.0, 0.0], np.float32), b)
+
     def get_train_batch(self, batch_size, target_rows=False):
         """data.py:95-115.  target_rows=True (source_only_cnn): the target side of each pair is the row of the
         target id in the free target matrix instead of its token sequence."""

@@ -35,6 +35,7 @@ FLAGS = flags.FlagSet("sse_train", [
     ("steps_per_checkpoint", int, 200, "How many training steps to do per checkpoint."),
     ("seed", int, -1, "seed for batch sampling and initialisation (-1: unseeded, like the reference)"),
     ("max_steps", int, 0, "stop after this many steps (0: no limit; for smoke runs)"),
+    ("device_corpus", int, 1, "1: the padded corpora are uploaded once and a step ships row numbers; 0: token-id feed dicts"),
 ])
 
 
@@ -84,6 +85,12 @@ def train(f):
     model = create_model(f, None, data.rawnegSetLen, data.vocab_size, False)
     sess = Session(model)
     summary_op = model.add_summaries()
+    table_tgt = f.network_mode in ("source_only_cnn", "source-encoder-only")
+    if f.device_corpus:
+        src_corpus, tgt_corpus = data.corpus_matrices()
+        model.handle.corpus_upload(0, src_corpus)
+        if not table_tgt:
+            model.handle.corpus_upload(1, tgt_corpus)
     step_time, loss, train_acc = 0.0, 0.0, 0.0
     current_step, previous_accuracies, stop = 0, [], False
     checkpoint_path = os.path.join(f.model_dir, "SSE-LSTM.ckpt")
@@ -91,10 +98,15 @@ def train(f):
         epoc_start = time.time()
         for _ in range(int(epoc_steps)):
             start = time.time()
-            src, tgt, labels = data.get_train_batch_arrays(f.batch_size, target_rows=(f.network_mode in ("source_only_cnn", "source-encoder-only")))
             model.set_forward_only(False)
-            d = model.get_train_feed_dict(src, tgt, labels)
-            _, _, step_loss, step_train_acc = sess.run([model.train, summary_op, model.loss, model.train_acc], feed_dict=d)
+            if f.device_corpus:
+                # the padded corpora live on the device: a step ships 2*batch row numbers, not token-id matrices
+                src_rows, tgt_rows, labels = data.get_train_batch_rows(f.batch_size, vectorized=f.seed < 0)
+                step_loss, step_train_acc = model.handle.train_step_rows(src_rows, tgt_rows, labels)
+            else:
+                src, tgt, labels = data.get_train_batch_arrays(f.batch_size, target_rows=table_tgt)
+                d = model.get_train_feed_dict(src, tgt, labels)
+                _, _, step_loss, step_train_acc = sess.run([model.train, summary_op, model.loss, model.train_acc], feed_dict=d)
             step_time += (time.time() - start) / f.steps_per_checkpoint
             loss += step_loss / f.steps_per_checkpoint
             train_acc += step_train_acc / f.steps_per_checkpoint

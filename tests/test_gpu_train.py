@@ -239,3 +239,33 @@ def test_source_encoder_only_train_step_matches_oracle(V, E, H, S, T, B, N):
     bad[0] = N
     with pytest.raises(sse_amd.SSEError):
         m.train_step(src, bad, z)
+
+
+@pytest.mark.parametrize("mode", ["dual-encoder", "source_only_cnn"])
+def test_train_step_by_rows_equals_train_step_by_ids(mode):
+    """sse_corpus_upload + sse_train_step_rows (batches as row numbers, ids gathered on the device) give bit-identical
+    weights to sse_train_step on the gathered id matrices; a row outside the corpus is an error."""
+    import sse_amd
+    V, T, N = 150, 16, 23
+    params = model_params(mode, V, 24, 64, 64, 32, T, N=N, lr=0.5)
+    rng = np.random.RandomState(3)
+    src_corpus = random_ids(rng, 40, T, V, 0.5)
+    tgt_corpus = random_ids(rng, N, T, V, 0.5)
+    table = mode == "source_only_cnn"
+    ma, p = make_pair(params, seed=2)
+    mb, _ = make_pair(params, seed=2)
+    mb.handle.corpus_upload(0, src_corpus)
+    if not table:
+        mb.handle.corpus_upload(1, tgt_corpus)
+    for step in range(3):
+        sr = np.repeat(rng.randint(0, 40, size=6), 2).astype(np.int32)
+        tr = rng.randint(0, N, size=12).astype(np.int32)
+        z = np.tile(np.array([1.0, 0.0], np.float32), 6)
+        la = ma.train_step(src_corpus[sr], tr if table else tgt_corpus[tr], z)
+        lb = mb.handle.train_step_rows(sr, tr, z)
+        assert la == lb
+    ga, gb = ma.get_variables(with_slots=True), mb.get_variables(with_slots=True)
+    for k in ga:
+        assert np.array_equal(ga[k], gb[k]), k
+    with pytest.raises(sse_amd.SSEError):
+        mb.handle.train_step_rows(np.array([0, 40], np.int32), np.array([0, 1], np.int32), np.array([1, 0], np.float32))
