@@ -88,6 +88,10 @@ int sse_encode_dev(sse_handle *h, int side, const int32_t *ids_dev, int32_t B, i
  * every 64-row tile exactly -- the LSTM state after p leading PAD (id 0) steps is
  * sequence-independent (sse_index.py:79-85 left-pads; sse_model.py:240-242 runs all T steps),
  * so it is precomputed per p with the same kernel; results are bit-identical to pad_skip = 0.
+ * "lstm_small_rows" (default 1024): LSTM encodes of at most this many rows (a demo / web query, an evaluator batch of
+ * 600, the tail batch of an index build) run on the few-sequences kernel -- one workgroup per 4 rows, gate GEMV on the
+ * vector ALUs streaming the kernel matrix from L2 instead of ~38 us per step for a 32-row matrix tile; the same fp32
+ * fma chains in the same order as the matrix kernel: results are bit-identical (tests/test_gpu_encode.py).  0 disables.
  * "score_bf16" (default 1): the candidate pass of sse_score_topk* reads bf16 copies of the index and the queries on
  * the bf16 matrix pipe; the float64 re-scoring pass, its error bound widened to the bf16 rounding, still returns
  * exactly the reference's ids and scores (bit-identical to score_bf16 = 0), ~5x faster; +50 % index memory.  Queries

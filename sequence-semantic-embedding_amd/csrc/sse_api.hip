@@ -31,11 +31,17 @@ struct Encoder {
   int kernel = -1, bias = -1, proj = -1;  // variable indices
   int H = 0, Hp = 0, UB = 0, KGx = 0, KGh = 0, Ep = 0;
   float *Wp = nullptr, *Mp = nullptr;
+  float *Waug = nullptr;      // few-sequences kernel: kernel rows in its k space incl. the bias row
+  bool waug_valid = false;
   int shares_lstm_with = -1;  // shared-encoder: target reuses the source LSTM packing
   // pad-prefix table: state after p leading PAD steps, p = 0..pad_T ([pad_T+1][Hp] each)
   float *pad_h = nullptr, *pad_c = nullptr;
   int pad_T = 0;
   bool pad_valid = false;
+  // the same table for the few-sequences kernel (lstm_small.hip), produced by that kernel ([pad_T_small+1][H])
+  float *pad_h_small = nullptr, *pad_c_small = nullptr;
+  int pad_T_small = 0;
+  bool pad_valid_small = false;
 };
 
 struct DevBuf {  // grow-only device scratch; freed with its owner (handle / TrainState)
@@ -80,6 +86,7 @@ struct sse_handle {
   Encoder enc[2];
   bool packed_dirty = true;
   bool pad_skip = true;      // option "pad_skip": exact left-pad prefix skip in inference encodes
+  int lstm_small_rows = 1024; // option "lstm_small_rows": batches up to this many rows take the few-sequences LSTM kernel
   bool score_bf16 = true;    // option "score_bf16" (default on): candidate pass on the bf16 matrix pipe; results stay exact
   void *idxp16 = nullptr;    // bf16 fragment copy of the index (built on demand)
   size_t idxp16_cap = 0;
@@ -207,6 +214,8 @@ int ensure_packed(sse_handle *h, hipStream_t st) {
     Encoder &e = h->enc[s];
     if (e.H <= 0 || e.kernel < 0) continue;
     e.pad_valid = false;
+    e.pad_valid_small = false;
+    e.waug_valid = false;
     const int KG = e.KGx + e.KGh;
     if (e.shares_lstm_with < 0) {
       if (!e.Wp) HIPCHECK(h, hipMalloc((void **)&e.Wp, (size_t)(e.Hp / 32) * KG * 4 * 256 * sizeof(float)));
@@ -297,6 +306,65 @@ int ensure_pad_table(sse_handle *h, int side, int T, hipStream_t st) {
   return 0;
 }
 
+int ensure_waug(sse_handle *h, int side, hipStream_t st) {
+  Encoder &e = h->enc[side];
+  Encoder &own = e.shares_lstm_with >= 0 ? h->enc[e.shares_lstm_with] : e;
+  if (own.waug_valid) return 0;
+  const int E = h->cfg.embedding_size;
+  if (!own.Waug) HIPCHECK(h, hipMalloc((void **)&own.Waug, lstm_small_waug_floats(E, own.H) * sizeof(float)));
+  HIPCHECK(h, launch_pack_lstm_small(h->vars[own.kernel].dev, h->vars[own.bias].dev, E, own.H, own.Waug, st));
+  own.waug_valid = true;
+  return 0;
+}
+
+void fill_small_args(sse_handle *h, Encoder &e, LstmSmallArgs &a) {
+  const sse_config &c = h->cfg;
+  Encoder &own = e.shares_lstm_with >= 0 ? h->enc[e.shares_lstm_with] : e;
+  a.emb = h->vars[0].dev;
+  a.Waug = own.Waug;
+  a.M = h->vars[e.proj].dev;
+  a.err = h->err_flag;
+  a.V = c.vocab_size;
+  a.E = c.embedding_size;
+  a.H = e.H;
+  a.S = c.encoding_size;
+  a.pad_stride = e.H;
+}
+
+// pad-prefix table of the few-sequences kernel: one all-PAD row through THAT kernel (its own arithmetic, bit for bit)
+int ensure_pad_table_small(sse_handle *h, int side, int T, hipStream_t st) {
+  Encoder &e = h->enc[side];
+  Encoder &own = e.shares_lstm_with >= 0 ? h->enc[e.shares_lstm_with] : e;
+  if (own.pad_valid_small && own.pad_T_small >= T) return 0;
+  const int Tt = T > h->cfg.max_seq_length ? T : h->cfg.max_seq_length;
+  if (own.pad_T_small < Tt || !own.pad_h_small) {
+    if (own.pad_h_small) HIPCHECK(h, hipFree(own.pad_h_small));
+    if (own.pad_c_small) HIPCHECK(h, hipFree(own.pad_c_small));
+    own.pad_h_small = own.pad_c_small = nullptr;
+    HIPCHECK(h, hipMalloc((void **)&own.pad_h_small, (size_t)(Tt + 1) * own.H * sizeof(float)));
+    HIPCHECK(h, hipMalloc((void **)&own.pad_c_small, (size_t)(Tt + 1) * own.H * sizeof(float)));
+    own.pad_T_small = Tt;
+  }
+  HIPCHECK(h, hipMemsetAsync(own.pad_h_small, 0, (size_t)(Tt + 1) * own.H * sizeof(float), st));
+  HIPCHECK(h, hipMemsetAsync(own.pad_c_small, 0, (size_t)(Tt + 1) * own.H * sizeof(float), st));
+  if (reserve(h, h->s_zero, (size_t)Tt * sizeof(int32_t) + (size_t)h->cfg.encoding_size * sizeof(float))) return 1;
+  HIPCHECK(h, hipMemsetAsync(h->s_zero.p, 0, (size_t)Tt * sizeof(int32_t), st));
+  if (ensure_waug(h, side, st)) return 1;
+  LstmSmallArgs a;
+  // the LSTM of `own` with any projection of that cell size (the table only records h, c)
+  fill_small_args(h, own, a);
+  a.ids = (const int32_t *)h->s_zero.p;
+  a.out = (float *)((char *)h->s_zero.p + (size_t)Tt * sizeof(int32_t));
+  a.B = 1;
+  a.T = Tt;
+  a.normalize = 0;
+  a.rec_h = own.pad_h_small;
+  a.rec_c = own.pad_c_small;
+  HIPCHECK(h, launch_lstm_small(a, st));
+  own.pad_valid_small = true;
+  return 0;
+}
+
 int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T, int normalize, float *out,
                       hipStream_t st) {
   const sse_config &c = h->cfg;
@@ -338,6 +406,25 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
   Encoder &e = h->enc[side];
   if (e.kernel < 0) return fail(h, "network mode has no %s sequence encoder (sse_model.py:231-233)", side ? "target" : "source");
   if (ensure_packed(h, st)) return 1;
+  if (B <= h->lstm_small_rows && !h->cur_row_map && lstm_small_lds_bytes(c.embedding_size, e.H, c.encoding_size) <= 160 * 1024) {
+    // a handful of sequences (demo / web query, last batch of an index build): GEMV on the vector ALUs, see lstm_small.hip
+    if (ensure_waug(h, side, st)) return 1;
+    LstmSmallArgs sa;
+    fill_small_args(h, e, sa);
+    sa.ids = ids;
+    sa.out = out;
+    sa.B = B;
+    sa.T = T;
+    sa.normalize = normalize ? 1 : 0;
+    if (h->pad_skip && T > 1) {
+      if (ensure_pad_table_small(h, side, T, st)) return 1;
+      Encoder &own = e.shares_lstm_with >= 0 ? h->enc[e.shares_lstm_with] : e;
+      sa.pad_h = own.pad_h_small;
+      sa.pad_c = own.pad_c_small;
+    }
+    HIPCHECK(h, launch_lstm_small(sa, st));
+    return 0;
+  }
   LstmFwdArgs a;
   fill_fwd_args(h, e, a);
   a.ids = ids;
@@ -748,6 +835,9 @@ void sse_destroy(sse_handle *h) {
       if (e.Wp) hipFree(e.Wp);
       if (e.pad_h) (void)hipFree(e.pad_h);
       if (e.pad_c) (void)hipFree(e.pad_c);
+      if (e.Waug) (void)hipFree(e.Waug);
+      if (e.pad_h_small) (void)hipFree(e.pad_h_small);
+      if (e.pad_c_small) (void)hipFree(e.pad_c_small);
     }
     if (e.Mp) hipFree(e.Mp);
   }
@@ -837,7 +927,7 @@ static int encode_host_ids_locked(sse_handle *h, int side, const int32_t *ids_ho
   // 64-row tile can skip its whole common PAD prefix; results are scattered back in caller order.
   const bool lstm_side = h->cfg.network_mode != SSE_MODE_SOURCE_ONLY_CNN && !(side == SSE_SIDE_TARGET && h->tgt_table >= 0);
   const int32_t *row_map_dev = nullptr;
-  if (h->pad_skip && lstm_side && B > 64) {
+  if (h->pad_skip && lstm_side && B > 64 && B > h->lstm_small_rows) {
     // counting sort of the row numbers by leading-PAD count, longest prefix first
     std::vector<int32_t> lead(B), start(T + 2, 0), order(B);
     for (int b = 0; b < B; ++b) {
@@ -933,6 +1023,11 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value) {
   }
   if (strcmp(name, "pad_skip") == 0) {
     h->pad_skip = value != 0;
+    return 0;
+  }
+  if (strcmp(name, "lstm_small_rows") == 0) {
+    if (value < 0) return fail(h, "lstm_small_rows must be >= 0");
+    h->lstm_small_rows = value;
     return 0;
   }
   return fail(h, "unknown option '%s'", name);

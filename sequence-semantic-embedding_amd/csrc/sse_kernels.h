@@ -61,6 +61,24 @@ bool lstm_fwd_x_double(int KGx, int KGh, int RT);
 int lstm_fwd_rows_per_wg(int Hp, int B);
 hipError_t launch_lstm_fwd(const LstmFwdArgs &a, int Hp, hipStream_t stream);
 
+// few-sequences LSTM forward (lstm_small.hip): one workgroup per 4 sequences, vector-ALU GEMV on the master variables
+struct LstmSmallArgs {
+  const int32_t *ids;    // [B][T]
+  const float *emb;      // word_embedding [V][E] (master variable)
+  const float *Waug;     // [KA][4H] kernel rows in the kernel's k space incl. the bias row (launch_pack_lstm_small)
+  const float *M;        // projection [H][S] (master variable)
+  float *out;            // [B][S]
+  int32_t *err;
+  int32_t B, T, V, E, H, S, normalize;
+  const float *pad_h = nullptr, *pad_c = nullptr;  // [T+1][pad_stride] state after p leading PAD steps (this kernel's own)
+  float *rec_h = nullptr, *rec_c = nullptr;        // table build: states of sequence 0 after every step
+  int32_t pad_stride = 0;
+};
+size_t lstm_small_lds_bytes(int E, int H, int S);
+size_t lstm_small_waug_floats(int E, int H);
+hipError_t launch_pack_lstm_small(const float *K, const float *b, int E, int H, float *out, hipStream_t stream);
+hipError_t launch_lstm_small(const LstmSmallArgs &a, hipStream_t stream);
+
 // ------------------------------ scoring ------------------------------------
 struct ScoreArgs {
   const float *idxp;     // packed index  [NT][KG][256]  (frag32, rows = targets)

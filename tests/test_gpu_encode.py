@@ -24,10 +24,12 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("small_rows", [1024, 0])         # few-sequences kernel for B <= 1024 (default) / matrix kernel only
 @pytest.mark.parametrize("mode,V,E,Hs,Ht,S,T,B", CASES)
-def test_encode_matches_oracle(mode, V, E, Hs, Ht, S, T, B):
+def test_encode_matches_oracle(mode, V, E, Hs, Ht, S, T, B, small_rows):
     params = model_params(mode, V, E, Hs, Ht, S, T)
     m, p = make_pair(params, seed=1)
+    m.handle.set_option("lstm_small_rows", small_rows)
     rng = np.random.RandomState(3)
     ids = random_ids(rng, B, T, V, pad_frac=0.7)
     sides = ("src", "tgt") if mode != "source-encoder-only" else ("src",)
@@ -102,8 +104,17 @@ def test_large_batch_property_rows_independent():
     big = m.encode_source(ids)
     assert np.allclose(np.linalg.norm(big, axis=1), 1.0, atol=1e-5)
     pick = rng.choice(len(ids), 96, replace=False)
+    m.handle.set_option("lstm_small_rows", 0)        # matrix kernel for the small batch too
     small = m.encode_source(ids[pick])
     assert np.array_equal(small, big[pick])          # bit-identical: no cross-row coupling
+    # the few-sequences kernel (same fma chains in the same order on the vector ALUs) agrees to the last bits
+    m.handle.set_option("lstm_small_rows", 1024)
+    few = m.encode_source(ids[pick])
+    print("few-sequences kernel vs matrix kernel: max |d| = %.3g, bit-identical rows: %d / %d"
+          % (np.abs(few - small).max(), int(np.all(few == small, axis=1).sum()), len(pick)))
+    assert np.array_equal(few, small)
+    one = np.concatenate([m.encode_source(ids[pick[i:i + 1]]) for i in range(8)])
+    assert np.array_equal(one, few[:8])              # and is itself independent of the batch it runs in
     want = O.encode(p, params, "src", ids[pick[:16]])
     assert np.abs(small[:16] - want).max() <= TOL
 

@@ -243,8 +243,10 @@ def test_source_encoder_only_train_step_matches_oracle(V, E, H, S, T, B, N):
 
 @pytest.mark.parametrize("mode", ["dual-encoder", "source_only_cnn"])
 def test_train_step_by_rows_equals_train_step_by_ids(mode):
-    """sse_corpus_upload + sse_train_step_rows (batches as row numbers, ids gathered on the device) give bit-identical
-    weights to sse_train_step on the gathered id matrices; a row outside the corpus is an error."""
+    """sse_corpus_upload + sse_train_step_rows (batches as row numbers, ids gathered on the device) == sse_train_step on
+    the gathered id matrices: the first loss bit for bit, afterwards to the run-to-run noise of the step itself (the
+    embedding gradient is accumulated with float atomics, so two runs of the SAME step differ in the last bits);
+    a row outside the corpus is an error."""
     import sse_amd
     V, T, N = 150, 16, 23
     params = model_params(mode, V, 24, 64, 64, 32, T, N=N, lr=0.5)
@@ -263,9 +265,9 @@ def test_train_step_by_rows_equals_train_step_by_ids(mode):
         z = np.tile(np.array([1.0, 0.0], np.float32), 6)
         la = ma.train_step(src_corpus[sr], tr if table else tgt_corpus[tr], z)
         lb = mb.handle.train_step_rows(sr, tr, z)
-        assert la == lb
+        assert la == lb if step == 0 else la == pytest.approx(lb, rel=1e-5)
     ga, gb = ma.get_variables(with_slots=True), mb.get_variables(with_slots=True)
     for k in ga:
-        assert np.array_equal(ga[k], gb[k]), k
+        assert np.abs(ga[k] - gb[k]).max() < 1e-5, k
     with pytest.raises(sse_amd.SSEError):
         mb.handle.train_step_rows(np.array([0, 40], np.int32), np.array([0, 1], np.int32), np.array([1, 0], np.float32))

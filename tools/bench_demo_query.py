@@ -56,3 +56,49 @@ for Q in (1, 32):
     dt = (time.perf_counter() - t0) / 5
     print("Q=%d bf16 candidates: %.3f ms/pass, %.2f TB/s of bf16 index streamed, %.3g scores/s, identical to fp32 candidates: %s"
           % (Q, dt * 1e3, N * S * 2 / dt / 1e12, Q * N / dt, same))
+
+# ---- end to end, one query: token ids in -> top-10 out (sse_demo.py:112-134), encoder + scorer in one call
+import numpy as np  # noqa: E402
+V, E, H, T = 32000, 50, 256, 32
+params = dict(forward_only=True, network_mode="dual-encoder", predict_nbest=10, max_seq_length=T, vocab_size=V,
+              embedding_size=E, encoding_size=S, src_cell_size=H, tgt_cell_size=H, learning_rate=0.9,
+              learning_rate_decay_factor=0.99, targetSpaceSize=571)
+m = sse_amd.SSEModel(params)
+m.init_variables(seed=0)
+hh = m.handle
+rng = np.random.RandomState(0)
+dense = rng.randint(2, V, size=(1, T)).astype(np.int32)
+dense[:, -1] = 1
+short = np.zeros((1, T), np.int32)
+short[0, -9:] = dense[0, -9:]                               # 8 tokens + EOS, left-padded as sse_demo.py:116-119 does
+for n_idx in (571, N):
+    t = torch.nn.functional.normalize(torch.randn((n_idx, S), device=dev), dim=1)
+    hh.index_set_dev(t.data_ptr(), n_idx, S)
+    del t
+    for name, ids in (("dense T=32", dense), ("8 tokens", short)):
+        for small in (1024, 0):
+            hh.set_option("lstm_small_rows", small)
+            hh.encode_score_topk(0, ids, False, 10)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                hh.encode_score_topk(0, ids, False, 10)
+            dt = (time.perf_counter() - t0) / 20
+            t1 = time.perf_counter()
+            for _ in range(20):
+                hh.encode(0, ids, False)
+            de = (time.perf_counter() - t1) / 20
+            print("Q=1 end to end (%s, N=%d, %s LSTM kernel): %.3f ms per query (encode alone %.3f ms, host buffers both ways)"
+                  % (name, n_idx, "few-sequences" if small else "matrix", dt * 1e3, de * 1e3))
+# batch-size sweep of the encoder alone, both kernels
+for B in (1, 4, 32, 128, 256, 512, 1024):
+    ids = rng.randint(2, V, size=(B, T)).astype(np.int32)
+    ids[:, -1] = 1
+    line = "encode B=%d dense T=32:" % B
+    for small in (4096, 0):
+        hh.set_option("lstm_small_rows", small)
+        hh.encode(0, ids, True)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            hh.encode(0, ids, True)
+        line += "  %s %.3f ms" % ("few-seq" if small else "matrix", (time.perf_counter() - t0) / 10 * 1e3)
+    print(line)
