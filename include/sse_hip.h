@@ -144,6 +144,11 @@ int sse_encode_score_topk(sse_handle *h, int side, const int32_t *ids_host, int3
  * of SURVEY 8e): in_* are [P,Q,k] (shard-major), out_* [Q,k]; same order rule. */
 int sse_merge_topk_dev(sse_handle *h, const double *in_scores_dev, const int64_t *in_ids_dev, int32_t P,
                        int32_t Q, int32_t k, double *out_scores_dev, int64_t *out_ids_dev, void *stream);
+/* The same merge on lists that sit `shard_stride` elements apart per shard (list (p, q, j) at p * shard_stride + q * k
+ * + j): lets ONE all-gather carry scores and ids together ([P][2][Q][k] 64-bit words, shard_stride = 2*Q*k). */
+int sse_merge_topk_strided_dev(sse_handle *h, const double *in_scores_dev, const int64_t *in_ids_dev,
+                               int64_t shard_stride, int32_t P, int32_t Q, int32_t k, double *out_scores_dev,
+                               int64_t *out_ids_dev, void *stream);
 
 /* session.run([model.train, model.loss, model.train_acc], feed) --
  * sse_train.py:170-172; loss/acc are evaluated before the update.  labels

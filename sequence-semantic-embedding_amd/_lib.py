@@ -47,6 +47,7 @@ SYMBOLS = {
     "sse_score_topk_dev": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "sse_encode_score_topk": (C.c_int, [_P, C.c_int, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "sse_merge_topk_dev": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "sse_merge_topk_strided_dev": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "sse_train_step": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sse_train_grad_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "sse_train_set_grad_arena": (C.c_int, [_P, _P, C.c_int64]),
@@ -215,6 +216,9 @@ class Handle(object):
 
     def score_topk_dev(self, q_ptr, Q, k, scores_ptr, ids_ptr, stream=0):
         self.check(self.lib.sse_score_topk_dev(self._h, q_ptr, Q, k, scores_ptr, ids_ptr, stream))
+
+    def merge_topk_strided_dev(self, in_s, in_i, shard_stride, P, Q, k, out_s, out_i, stream=0):
+        self.check(self.lib.sse_merge_topk_strided_dev(self._h, in_s, in_i, int(shard_stride), P, Q, k, out_s, out_i, stream))
 
     def merge_topk_dev(self, in_s, in_i, P, Q, k, out_s, out_i, stream=0):
         self.check(self.lib.sse_merge_topk_dev(self._h, in_s, in_i, P, Q, k, out_s, out_i, stream))

@@ -1232,7 +1232,7 @@ hipError_t launch_select_topk(const SelectArgs &a, hipStream_t st) {
 
 // ---------------------------------------------------------------------------
 // k-way merge of P sorted lists per query: in [P][Q][k] -> out [Q][k].
-__global__ void merge_topk_kernel(const double *in_s, const int64_t *in_i, int P, int Q, int k, double *out_s,
+__global__ void merge_topk_kernel(const double *in_s, const int64_t *in_i, int64_t stride, int P, int Q, int k, double *out_s,
                                   int64_t *out_i) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= Q) return;
@@ -1240,14 +1240,14 @@ __global__ void merge_topk_kernel(const double *in_s, const int64_t *in_i, int P
   // sorted, so count with a scan over the other lists (P*k is small)
   for (int p = 0; p < P; ++p)
     for (int j = 0; j < k; ++j) {
-      const double s = in_s[((size_t)p * Q + q) * k + j];
-      const int64_t id = in_i[((size_t)p * Q + q) * k + j];
+      const double s = in_s[(size_t)p * stride + (size_t)q * k + j];
+      const int64_t id = in_i[(size_t)p * stride + (size_t)q * k + j];
       int rank = j;
       for (int p2 = 0; p2 < P && rank < k; ++p2) {
         if (p2 == p) continue;
         for (int j2 = 0; j2 < k; ++j2) {
-          const double s2 = in_s[((size_t)p2 * Q + q) * k + j2];
-          const int64_t id2 = in_i[((size_t)p2 * Q + q) * k + j2];
+          const double s2 = in_s[(size_t)p2 * stride + (size_t)q * k + j2];
+          const int64_t id2 = in_i[(size_t)p2 * stride + (size_t)q * k + j2];
           if (before(s2, id2, s, id)) ++rank; else break;
         }
       }
@@ -1258,9 +1258,9 @@ __global__ void merge_topk_kernel(const double *in_s, const int64_t *in_i, int P
     }
 }
 
-hipError_t launch_merge_topk(const double *in_s, const int64_t *in_i, int P, int Q, int k, double *out_s,
+hipError_t launch_merge_topk(const double *in_s, const int64_t *in_i, int64_t stride, int P, int Q, int k, double *out_s,
                              int64_t *out_i, hipStream_t stream) {
-  hipLaunchKernelGGL(merge_topk_kernel, dim3((Q + 127) / 128), dim3(128), 0, stream, in_s, in_i, P, Q, k, out_s,
+  hipLaunchKernelGGL(merge_topk_kernel, dim3((Q + 127) / 128), dim3(128), 0, stream, in_s, in_i, stride, P, Q, k, out_s,
                      out_i);
   return hipGetLastError();
 }

@@ -1108,15 +1108,20 @@ int sse_score_topk(sse_handle *h, const float *q_host, int32_t Q, int32_t k, dou
   return 0;
 }
 
-int sse_merge_topk_dev(sse_handle *h, const double *in_scores_dev, const int64_t *in_ids_dev, int32_t P, int32_t Q,
-                       int32_t k, double *out_scores_dev, int64_t *out_ids_dev, void *stream) {
+int sse_merge_topk_strided_dev(sse_handle *h, const double *in_scores_dev, const int64_t *in_ids_dev, int64_t shard_stride,
+                               int32_t P, int32_t Q, int32_t k, double *out_scores_dev, int64_t *out_ids_dev, void *stream) {
   if (!h) return 1;
   std::lock_guard<std::mutex> lk(h->mu);
   HIPCHECK(h, hipSetDevice(h->cfg.device));
-  if (P < 1 || Q < 0 || k < 1) return fail(h, "bad arguments to sse_merge_topk_dev");
+  if (P < 1 || Q < 0 || k < 1 || shard_stride < (int64_t)Q * k) return fail(h, "bad arguments to sse_merge_topk_dev");
   if (Q == 0) return 0;
-  HIPCHECK(h, launch_merge_topk(in_scores_dev, in_ids_dev, P, Q, k, out_scores_dev, out_ids_dev, (hipStream_t)stream));
+  HIPCHECK(h, launch_merge_topk(in_scores_dev, in_ids_dev, shard_stride, P, Q, k, out_scores_dev, out_ids_dev, (hipStream_t)stream));
   return 0;
+}
+
+int sse_merge_topk_dev(sse_handle *h, const double *in_scores_dev, const int64_t *in_ids_dev, int32_t P, int32_t Q,
+                       int32_t k, double *out_scores_dev, int64_t *out_ids_dev, void *stream) {
+  return sse_merge_topk_strided_dev(h, in_scores_dev, in_ids_dev, (int64_t)Q * k, P, Q, k, out_scores_dev, out_ids_dev, stream);
 }
 
 static int64_t grad_arena_count(sse_handle *h) {

@@ -154,7 +154,8 @@ struct SelectArgs {
 // float64 re-score + sort of the collected rows, first k out (score descending, then lower row id)
 hipError_t launch_select_topk(const SelectArgs &a, hipStream_t st);
 
-hipError_t launch_merge_topk(const double *in_s, const int64_t *in_i, int P, int Q, int k, double *out_s,
+// in_s / in_i: list (p, q, j) at p * stride + q * k + j (stride = Q*k for plain [P][Q][k] arrays)
+hipError_t launch_merge_topk(const double *in_s, const int64_t *in_i, int64_t stride, int P, int Q, int k, double *out_s,
                              int64_t *out_i, hipStream_t stream);
 
 // ------------------------------ packing / misc -----------------------------

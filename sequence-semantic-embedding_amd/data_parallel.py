@@ -41,7 +41,12 @@ class DataParallelTrainer(object):
         """One step on this rank's rows; returns the GLOBAL (loss, train_acc), evaluated before the update.
         Pass rows_global when it is known (equal batches: world * len(labels)) to save the tiny extra all-reduce.
         by_rows: src_ids / tgt_ids are row numbers into the corpora uploaded with engine.corpus_upload."""
+        import torch
         import torch.distributed as dist
+        if self.arena.is_cuda and torch.cuda.current_stream(self.arena.device) != torch.cuda.default_stream(self.arena.device):
+            # the train step runs on the library's own streams forked from / joined to the null stream, and
+            # torch.distributed orders the all-reduce against torch's CURRENT stream: they must be the same one
+            raise RuntimeError("DataParallelTrainer.train_step must be called with the default CUDA stream current")
         if rows_global is None:
             rows_global = self.global_rows(len(labels))
         if by_rows:

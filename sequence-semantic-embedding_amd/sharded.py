@@ -1,9 +1,14 @@
 """Row-sharded target index over the GPUs of one node (BASELINE
 configs[3]): rank g holds rows [g*N/P, (g+1)*N/P), queries are replicated, every
-rank computes its shard's top-k with GLOBAL row ids, one all-gather (RCCL over
-xGMI when the process group is `nccl`) exchanges the [Q,k] (float64 score,
-int64 id) lists -- 16*Q*k bytes per rank -- and a k-way merge with the same
-order rule (score desc, row id asc) yields exactly the unsharded result.
+rank computes its shard's top-k with GLOBAL row ids, ONE all-gather per query
+block (RCCL over xGMI when the process group is `nccl`) exchanges the [Q,k]
+(float64 score, int64 id) lists packed in one buffer -- 16*Q*k bytes per rank; the
+exact float64 scores must travel: a rank cannot re-score candidates of rows it
+does not hold -- and a k-way merge with the same order rule (score desc, row id
+asc) yields exactly the unsharded result.  Queries go in blocks: the gather of
+block i runs on RCCL's stream while block i+1 sweeps the shard.  Every library
+call is enqueued on torch's CURRENT stream (passed explicitly), which is also
+the stream torch.distributed orders its collectives against.
 
 The reference has no distributed code at all; this is the one real exchange
 step of the hot path.  torch / torch.distributed are plumbing only.
@@ -58,19 +63,39 @@ class ShardedIndex(object):
             raise ValueError("shard of rank %d must have %d rows, got %d" % (self.rank, self.end - self.start, rows.shape[0]))
         self.handle.index_set_dev(rows.data_ptr(), rows.shape[0], rows.shape[1], id_base=self.start)
 
-    def score_topk(self, queries, k):
+    def score_topk(self, queries, k, block=8192):
         """queries: CUDA float32 [Q,S] (identical on every rank).  Returns the global
         top-k (scores float64 [Q,k], row ids int64 [Q,k]) on every rank."""
         import torch
+        import torch.distributed as dist
         Q = queries.shape[0]
-        ls = torch.empty((Q, k), dtype=torch.float64, device=queries.device)
-        li = torch.empty((Q, k), dtype=torch.int64, device=queries.device)
-        self.handle.score_topk_dev(queries.data_ptr(), Q, k, ls.data_ptr(), li.data_ptr())
+        dev = queries.device
+        stream = torch.cuda.current_stream(dev).cuda_stream if queries.is_cuda else 0
+        out = torch.empty((2, Q, k), dtype=torch.int64, device=dev)        # [0] = float64 score bits, [1] = row ids
+        fs, fi = out[0].view(torch.float64), out[1]
         if self.world == 1 and not self.always_gather:
-            return ls, li
-        gs, gi = all_gather_topk(ls, li, self.group, force=self.always_gather)
-        fs, fi = torch.empty_like(ls), torch.empty_like(li)
-        self.handle.merge_topk_dev(gs.data_ptr(), gi.data_ptr(), self.world, Q, k, fs.data_ptr(), fi.data_ptr())
+            self.handle.score_topk_dev(queries.data_ptr(), Q, k, fs.data_ptr(), fi.data_ptr(), stream)
+            return fs, fi
+        world = dist.get_world_size(self.group)
+        pending = None                                                     # (work, gathered, q0, n) of the previous block
+        for q0 in list(range(0, Q, block)) + [None]:
+            if q0 is not None:
+                n = min(block, Q - q0)
+                loc = torch.empty((2, n, k), dtype=torch.int64, device=dev)
+                self.handle.score_topk_dev(queries[q0:q0 + n].data_ptr(), n, k, loc[0].data_ptr(), loc[1].data_ptr(), stream)
+                g = torch.empty((world * 2, n, k), dtype=torch.int64, device=dev)   # concatenation along dim 0 (gloo and nccl)
+                # one collective for scores and ids; async: RCCL's stream waits for the sweep just enqueued, the host
+                # goes on to enqueue the next block's sweep
+                work = dist.all_gather_into_tensor(g, loc, group=self.group, async_op=True)
+                nxt = (work, g, loc, q0, n)
+            else:
+                nxt = None
+            if pending is not None:
+                work, g, _loc, p0, pn = pending
+                work.wait()                                               # current stream waits for the gather
+                self.handle.merge_topk_strided_dev(g.data_ptr(), g[1].data_ptr(), 2 * pn * k, world, pn, k,
+                                                   fs[p0:p0 + pn].data_ptr(), fi[p0:p0 + pn].data_ptr(), stream)
+            pending = nxt
         return fs, fi
 
 

@@ -71,6 +71,69 @@ def test_two_rank_sharded_topk_equals_unsharded(tmp_path):
         assert np.array_equal(z["s"], wsc)
 
 
+class _CpuShardHandle(object):
+    """Stands in for the HIP handle on CPU tensors (raw pointers in, oracle arithmetic): lets the product's
+    ShardedIndex.score_topk -- packed single all-gather, query blocks, strided merge -- run under gloo."""
+
+    def __init__(self, S):
+        self.S = S
+
+    @staticmethod
+    def _view(ptr, shape, dtype):
+        import ctypes
+        n = int(np.prod(shape))
+        buf = (ctypes.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def index_set_dev(self, ptr, n, S, id_base=0, stream=0):
+        self.rows, self.base = self._view(ptr, (n, S), np.float32).astype(np.float64), id_base
+
+    def score_topk_dev(self, q_ptr, Q, k, s_ptr, i_ptr, stream=0):
+        from oracle import sse_oracle as O
+        sc, ids = O.topk(O.scores_f64(self._view(q_ptr, (Q, self.S), np.float32), self.rows), k)
+        self._view(s_ptr, (Q, k), np.float64)[:] = sc
+        self._view(i_ptr, (Q, k), np.int64)[:] = ids + self.base
+
+    def merge_topk_strided_dev(self, s_ptr, i_ptr, stride, P, Q, k, os_ptr, oi_ptr, stream=0):
+        s = self._view(s_ptr, (P * stride,), np.float64)
+        i = self._view(i_ptr - 0, (P * stride,), np.int64)
+        ms = np.stack([s[p * stride:p * stride + Q * k].reshape(Q, k) for p in range(P)], 1).reshape(Q, -1)
+        mi = np.stack([i[p * stride:p * stride + Q * k].reshape(Q, k) for p in range(P)], 1).reshape(Q, -1)
+        order = np.lexsort((mi, -ms), axis=1)[:, :k]
+        self._view(os_ptr, (Q, k), np.float64)[:] = np.take_along_axis(ms, order, 1)
+        self._view(oi_ptr, (Q, k), np.int64)[:] = np.take_along_axis(mi, order, 1)
+
+
+def _sharded_worker(rank, world, port, q_np, t_np, k, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["SSE_NO_TORCH"] = "1"
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sse_amd
+    sh = sse_amd.ShardedIndex(_CpuShardHandle(t_np.shape[1]), rank, world, t_np.shape[0])
+    rows = torch.from_numpy(t_np[sh.start:sh.end].copy())
+    sh.set_local_rows(rows)
+    s, i = sh.score_topk(torch.from_numpy(q_np.copy()), k, block=16)      # 37 queries -> 3 blocks, gathers overlapped
+    np.savez(os.path.join(out_dir, "sh%d.npz" % rank), s=s.numpy(), i=i.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_index_class_blocks_and_packed_gather(tmp_path):
+    from oracle import sse_oracle as O
+    rng = np.random.RandomState(1)
+    Q, N, S, k, world = 37, 403, 16, 10, 2
+    q = rng.standard_normal((Q, S)).astype(np.float32)
+    t = rng.standard_normal((N, S)).astype(np.float32)
+    t[300] = t[5]
+    port = _free_port()
+    mp.spawn(_sharded_worker, args=(world, port, q, t, k, str(tmp_path)), nprocs=world, join=True)
+    wsc, wids = O.topk(O.scores_f64(q, t.astype(np.float64)), k)
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "sh%d.npz" % r))
+        assert np.array_equal(z["i"], wids) and np.abs(z["s"] - wsc).max() < 1e-12   # (BLAS blocks a row slice differently)
+
+
 # --------------------------------------------------------------------------
 # data-parallel train step (sequence-semantic-embedding_amd/data_parallel.py): the product's exchange logic with
 # the numpy oracle as the gradient engine (on the GPU the engine is the HIP handle:
