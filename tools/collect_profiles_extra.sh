@@ -1,0 +1,31 @@
+#!/bin/bash
+# rocprofv3 evidence for the kernels the default bench line does not exercise at size: the
+# few-queries (NQ = 1) HBM-bound sweep and the Q = 1 latency path, the HBM-bound helpers (row l2-normalise, index
+# re-layout), the text-CNN encoders, the isolated training kernels.  Run on the GPU box from the repo root:
+#   tools/collect_profiles_extra.sh <tag>
+# then on the build box:  python tools/summarize_extra.py <tag>   (writes profiles/<tag>_*.txt|csv)
+set -u
+tag=${1:-extra}
+root=$(pwd)
+out=$root/gpurun_out/$tag
+mkdir -p "$out"
+export TMPDIR=/tmp
+run() {  # name, command...
+  name=$1; shift
+  ( cd "$root" && "$@" > "$out/$name.txt" 2>&1 )
+  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${name}_stats" -o p -- "$@" > "$out/${name}_stats.log" 2>&1 )
+}
+pmc() {  # name, counters, command...
+  name=$1; ctr=$2; shift 2
+  ( cd /tmp && rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$out/${name}_pmc_$(echo $ctr | tr ' ' '_' | cut -c1-24)" -o p -- "$@" > /dev/null 2>&1 )
+}
+run demo python "$root/tools/bench_demo_query.py" 10000000
+pmc demo FETCH_SIZE python "$root/tools/bench_demo_query.py" 10000000
+run hbm python "$root/tools/bench_hbm_kernels.py"
+pmc hbm FETCH_SIZE python "$root/tools/bench_hbm_kernels.py"
+pmc hbm WRITE_SIZE python "$root/tools/bench_hbm_kernels.py"
+run cnn python "$root/tools/bench_cnn.py"
+SSE_TRAIN_SERIAL=1 run train python "$root/tools/bench_train.py" 8192
+run train_default python "$root/tools/bench_train_default.py"
+find "$out" -name "*.csv" -size +20M -delete
+ls "$out"
