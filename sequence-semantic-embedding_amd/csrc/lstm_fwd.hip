@@ -144,8 +144,21 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   // <2,1,1>: wave w -> unit block w>>1, row tile w&1.  Waves are placed on SIMD w%4, so the live unit blocks of a
   // small cell (H <= 64: blocks 0,1 -> waves 0..3) land on four different SIMDs and the padding-only blocks, which
   // are not computed at all in inference, leave no SIMD with two busy waves.
-  const int ub0 = (RT == 2 && MT == 1) ? (w >> 1) : w;
-  const int mt0 = (RT == 2 && MT == 1) ? (w & 1) : 0;
+  // Three live unit blocks (64 < H <= 96 -- the reference's default cell size, every makefile recipe): 3 blocks x 2
+  // row tiles = 6 wave jobs on 8 waves leave two SIMDs with two jobs and two with one.  Instead waves 0..3 take
+  // blocks 0,1 whole and block 2 is split BY PASS: wave 4 / 6 compute the i,j pass of row tile 0 / 1 and hand
+  // sigmoid(i)*tanh(j) over through the (already used) parking slots in LDS, wave 5 / 7 compute the f,o pass, own the
+  // cell state and finish the step: 12 pass-units, 3 per SIMD (waves w and w+4 share one).
+  const bool split3 = !TRAIN && RT == 2 && MT == 1 && a.H > 64 && a.H <= 96;
+  int ub0 = (RT == 2 && MT == 1) ? (w >> 1) : w;
+  int mt0 = (RT == 2 && MT == 1) ? (w & 1) : 0;
+  bool do_a = true, do_b = true;
+  if (split3 && w >= 4) {
+    ub0 = 2;
+    mt0 = (w - 4) >> 1;
+    do_a = ((w & 1) == 0);
+    do_b = !do_a;
+  }
   const int KGx = a.KGx, KGh = a.KGh, KG = KGx + KGh, T = a.T;
   const int KGhe = (a.KGhe > 0 && a.KGhe < KGh) ? a.KGhe : KGh;
   // LDS.  LIN (x double-buffered, fits 160 KiB): A tiles [2 bufs][RT][KG][256], the x part of
@@ -161,6 +174,8 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   };
   float *red = smem + (size_t)(LIN ? 2 * RT * KG : RT * KGx + 2 * RT * KGh) * 256;  // [ROWS][NWR] (>= 8 floats)
   const int b0 = blockIdx.x * ROWS;
+  volatile int *pass_flag = reinterpret_cast<volatile int *>(red + 16);  // split3: [row tile] = steps whose i,j pass is parked
+  if (tid < 2) pass_flag[tid] = 0;
 
   // --- x gather assignment: TPR threads per sequence row, 8 floats (one k-group) each.  Consecutive lanes take
   // consecutive ROWS of the same k-group, so a 16-byte x_store of 8 adjacent lanes covers 128 contiguous bytes
@@ -339,9 +354,10 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
           g[m][1][r] = 0.0f;
         }
       }
-      gemm_pass<MT, LIN, SWAP>(wr, wvoff, wsoff, xa, ha, KGx, kend, g);
+      if (do_a) gemm_pass<MT, LIN, SWAP>(wr, wvoff, wsoff, xa, ha, KGx, kend, g);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
+        if (!do_a) break;
         if constexpr (SWAP) {
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) {
@@ -363,6 +379,10 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
           }
         }
       }
+      if (do_a && !do_b) {  // split3: publish the parked products of this step (LDS operations of a wave complete in order)
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        if (lane == 0) pass_flag[mt0] = t + 1;
+      }
       if (u == 0 && XD && have_next) {
         // x_{t+1}: its buffer was last read in step t-1, so it can be written as soon as the
         // prefetch has landed (frees the staging registers before pass B)
@@ -380,9 +400,13 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
           g[m][0][r] = 0.0f;
           g[m][1][r] = 0.0f;
         }
-      gemm_pass<MT, LIN, SWAP>(wr, wvoff, wsoff + 2048, xa, ha, KGx, kend, g);
+      if (do_b) gemm_pass<MT, LIN, SWAP>(wr, wvoff, wsoff + 2048, xa, ha, KGx, kend, g);
+      if (do_b && !do_a) {  // split3: the i,j pass of this (block, row tile) comes from the partner wave
+        while (pass_flag[mt0] < t + 1) __builtin_amdgcn_s_sleep(2);
+      }
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
+        if (!do_b) break;
         if constexpr (SWAP) {
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) {
