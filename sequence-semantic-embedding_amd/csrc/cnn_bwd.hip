@@ -37,7 +37,15 @@ struct CnnBwdArgs {
   float *d_emb;         // [V][E] dense embedding gradient (zeroed by the caller)
   float *sq_part;       // [B]
   int32_t B, T, E, NCH;
+  int32_t bf16;         // option cnn_bf16: the forward ran on bf16-rounded embeddings / filters; the backward
+                        // differentiates THAT function (dW from the rounded windows, dX from the rounded filters)
 };
+
+__device__ __forceinline__ float bf16_rne(float f) {  // nearest bfloat16 (ties to even), as fp32 -- cnn_fwd_bf16.hip
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return __uint_as_float(u & 0xFFFF0000u);
+}
 
 template <int FS, int NF>
 __device__ void dw_body(const CnnBwdArgs &a, float *xs) {
@@ -55,7 +63,10 @@ __device__ void dw_body(const CnnBwdArgs &a, float *xs) {
   int buf = 0;
   for (int b = b_begin; b < b_end; ++b, buf ^= 1) {
     float *xb = xs + buf * T * E;
-    for (int i = tid; i < T * E; i += 256) xb[i] = a.emb[(size_t)a.ids[(size_t)b * T + i / E] * E + i % E];
+    for (int i = tid; i < T * E; i += 256) {
+      const float x = a.emb[(size_t)a.ids[(size_t)b * T + i / E] * E + i % E];
+      xb[i] = a.bf16 ? bf16_rne(x) : x;
+    }
     __syncthreads();
     float g = a.dfeat[(size_t)b * 576 + fo];
     if (!(a.feat[(size_t)b * 576 + fo] > 0.0f)) g = 0.0f;
@@ -171,10 +182,10 @@ __global__ __launch_bounds__(256) void cnn_dx_kernel(CnnBwdArgs a) {
   if (tid == 0) a.sq_part[b] = red[0];
 }
 
-// Wt[f][k] = W[k][f]
-__global__ void transpose_kernel(const float *W, int K, int NF, float *Wt) {
+// Wt[f][k] = W[k][f]  (rounded to bf16 when the forward used the rounded filters)
+__global__ void transpose_kernel(const float *W, int K, int NF, int bf16, float *Wt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < K * NF) Wt[(size_t)(i % NF) * K + i / NF] = W[i];
+  if (i < K * NF) Wt[(size_t)(i % NF) * K + i / NF] = bf16 ? bf16_rne(W[i]) : W[i];
 }
 
 // out[b][:] = table[rows[b]][:] (b < B), 0 for the padding rows; one wave per row
@@ -230,7 +241,7 @@ hipError_t launch_rows_scatter(const float *d, const int32_t *rows, int B, int S
 hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfeat, const float *feat, const int32_t *pos,
                           const float *const W[4], float *const dW[4], float *const db[4], float *dw_part,
                           float *db_part, float *wt_scratch /* [E*1728] */, float *d_emb, float *sq_part, int B, int T,
-                          int E, hipStream_t st) {
+                          int E, int bf16, hipStream_t st) {
   static const int fs[4] = {2, 3, 4, 5}, nf[4] = {256, 128, 128, 64}, foff[4] = {0, 256, 384, 512};
   CnnBwdArgs a;
   a.ids = ids;
@@ -245,12 +256,13 @@ hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfe
   a.T = T;
   a.E = E;
   a.NCH = cnn_bwd_chunks(B);
+  a.bf16 = bf16;
   size_t off = 0, toff = 0;
   for (int i = 0; i < 4; ++i) {
     const int n = fs[i] * E * nf[i];
     a.W[i] = W[i];
     a.Wt[i] = wt_scratch + toff;
-    hipLaunchKernelGGL(transpose_kernel, dim3((n + 255) / 256), dim3(256), 0, st, W[i], fs[i] * E, nf[i], wt_scratch + toff);
+    hipLaunchKernelGGL(transpose_kernel, dim3((n + 255) / 256), dim3(256), 0, st, W[i], fs[i] * E, nf[i], bf16, wt_scratch + toff);
     toff += n;
     a.dw_part[i] = dw_part + off;
     off += (size_t)a.NCH * n;

@@ -21,6 +21,8 @@ struct CnnBf16Args {
   const unsigned short *Wc;  // per width: tiles of [32 filters][16 k] bf16 in fragment order, widths concatenated
   const float *bias;         // [576]
   float *featp;              // frag32(rows = b, red = feature): [ceil(B/32)][72][256]
+  float *feat_rm;            // TRAIN: [B][576] row-major pooled features
+  int32_t *pos;              // TRAIN: [B][576] arg-max positions (first maximum)
   int32_t *err;
   int32_t B, T, V, Ep, wbytes;
 };
@@ -37,14 +39,17 @@ __constant__ int q_nt[4] = {8, 4, 4, 2};
 __constant__ int q_foff[4] = {0, 256, 384, 512};
 }  // namespace
 
-template <int NB>
+// TRAIN: the running maximum is the 64-bit key (value bits << 32 | ~position) of cnn_fwd.hip, so the arg-max tape
+// the backward pass needs comes out of the same atomicMax (equal values keep the first position).
+template <int NB, bool TRAIN>
 __global__ __launch_bounds__(CB_THREADS) void conv_pool_bf16_kernel(CnnBf16Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned short xs[];  // [NB][T][Ep] bf16 + 5*Ep pad | feat | counter
   const int tid = threadIdx.x, lane = tid & 63;
   const int T = a.T, Ep = a.Ep, E8 = Ep / 8;
   const int b0 = blockIdx.x * NB;
   int *feat = reinterpret_cast<int *>(xs + (size_t)NB * T * Ep + 5 * Ep);  // running max as int bits (values >= 0)
-  int *s_next = feat + NB * 576;
+  unsigned long long *featk = reinterpret_cast<unsigned long long *>(feat);  // TRAIN: 64-bit keys (8-byte aligned: see cnn_bf16_lds_nb)
+  int *s_next = feat + NB * 576 * (TRAIN ? 2 : 1);
 
   for (int i = tid; i < NB * T * E8; i += CB_THREADS) {  // 16 bytes = 8 bf16 per thread-step
     const int q = i % E8, tok = i / E8;
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_pool_bf16_kernel(CnnBf16Args 
     reinterpret_cast<f32x4 *>(xs)[i] = *reinterpret_cast<const f32x4 *>(a.emb + (size_t)id * Ep + q * 8);
   }
   for (int i = tid; i < 5 * Ep; i += CB_THREADS) xs[(size_t)NB * T * Ep + i] = 0;
-  for (int i = tid; i < NB * 576; i += CB_THREADS) feat[i] = 0;
+  for (int i = tid; i < NB * 576 * (TRAIN ? 2 : 1); i += CB_THREADS) feat[i] = 0;
   if (tid == 0) *s_next = 0;
   __syncthreads();
 
@@ -124,22 +129,46 @@ __global__ __launch_bounds__(CB_THREADS) void conv_pool_bf16_kernel(CnnBf16Args 
     // bias + ReLU + max over this tile's valid positions (row = position, column = filter)
 #pragma unroll
     for (int s = 0; s < CB_SG; ++s) {
-      float m = 0.0f;
+      if constexpr (TRAIN) {
+        unsigned long long key = 0;  // below every valid position's key
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int p = pt * 32 + mfma_row(r, lane);
-        const float v = fmaxf(acc[s][r] + bias, 0.0f);
-        m = fmaxf(m, (p < P) ? v : 0.0f);
+        for (int r = 0; r < 16; ++r) {
+          const int p = pt * 32 + mfma_row(r, lane);
+          const float v = fmaxf(acc[s][r] + bias, 0.0f);
+          const unsigned long long kv = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(~p);
+          if (p < P && kv > key) key = kv;
+        }
+        const unsigned long long other = __shfl_xor(key, 32);
+        if (other > key) key = other;
+        if (lane < 32) atomicMax(&featk[(sg * CB_SG + s) * 576 + q_foff[wi] + tile * 32 + lane], key);
+      } else {
+        float m = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int p = pt * 32 + mfma_row(r, lane);
+          const float v = fmaxf(acc[s][r] + bias, 0.0f);
+          m = fmaxf(m, (p < P) ? v : 0.0f);
+        }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        if (lane < 32) atomicMax(&feat[(sg * CB_SG + s) * 576 + q_foff[wi] + tile * 32 + lane], __float_as_int(m));
       }
-      m = fmaxf(m, __shfl_xor(m, 32));
-      if (lane < 32) atomicMax(&feat[(sg * CB_SG + s) * 576 + q_foff[wi] + tile * 32 + lane], __float_as_int(m));
     }
   }
   __syncthreads();
   for (int i = tid; i < NB * 576; i += CB_THREADS) {
     const int j = i % 576, b = b0 + i / 576;
-    if (b < a.B)
-      a.featp[((size_t)(b >> 5) * 72 + (j >> 3)) * 256 + ((((j >> 2) & 1) * 32 + (b & 31)) << 2) + (j & 3)] = __int_as_float(feat[i]);
+    if (b < a.B) {
+      float v;
+      if constexpr (TRAIN) {
+        const unsigned long long key = featk[i];
+        v = __uint_as_float((unsigned)(key >> 32));
+        a.feat_rm[(size_t)b * 576 + j] = v;
+        a.pos[(size_t)b * 576 + j] = (int32_t)(~(unsigned)key);
+      } else {
+        v = __int_as_float(feat[i]);
+      }
+      a.featp[((size_t)(b >> 5) * 72 + (j >> 3)) * 256 + ((((j >> 2) & 1) * 32 + (b & 31)) << 2) + (j & 3)] = v;
+    }
   }
 }
 
@@ -175,11 +204,13 @@ size_t cnn_bf16_packed_weight_elems(int Ep) {
   return n;
 }
 
-static size_t cnn_bf16_lds_nb(int T, int Ep, int nb) {
-  return (size_t)(nb * T * Ep + 5 * Ep) * sizeof(unsigned short) + (size_t)nb * 576 * sizeof(int) + 16;
+static size_t cnn_bf16_lds_nb(int T, int Ep, int nb, int train) {  // Ep % 8 == 0: the feat region starts 8-byte aligned
+  return (size_t)(nb * T * Ep + 5 * Ep) * sizeof(unsigned short) + (size_t)nb * 576 * sizeof(int) * (train ? 2 : 1) + 16;
 }
 
-size_t cnn_bf16_lds_bytes(int T, int Ep) { return cnn_bf16_lds_nb(T, Ep, cnn_bf16_lds_nb(T, Ep, 8) <= 160 * 1024 ? 8 : 4); }
+size_t cnn_bf16_lds_bytes(int T, int Ep, int train) {
+  return cnn_bf16_lds_nb(T, Ep, cnn_bf16_lds_nb(T, Ep, 8, train) <= 160 * 1024 ? 8 : 4, train);
+}
 
 hipError_t launch_cnn_bf16_pack(const float *emb, int64_t V, int E, int Ep, unsigned short *emb_bf16, const float *const W[4],
                                 unsigned short *Wc, hipStream_t stream) {
@@ -197,22 +228,25 @@ hipError_t launch_cnn_bf16_pack(const float *emb, int64_t V, int E, int Ep, unsi
   return hipGetLastError();
 }
 
-// conv + pool in bf16 storage; the projection tail is the fp32 proj_norm_kernel of cnn_fwd.hip (launch_cnn_proj)
-hipError_t launch_cnn_fwd_bf16(const int32_t *ids, const unsigned short *emb_bf16, const unsigned short *Wc, const float *bias,
-                               float *featp, int32_t *err, int B, int T, int V, int Ep, hipStream_t stream) {
-  const int nb = cnn_bf16_lds_nb(T, Ep, 8) <= 160 * 1024 ? 8 : 4;
-  const size_t lds = cnn_bf16_lds_nb(T, Ep, nb);
-  CnnBf16Args a{ids, emb_bf16, Wc, bias, featp, err, B, T, V, Ep, (int32_t)(cnn_bf16_packed_weight_elems(Ep) * sizeof(unsigned short))};
-  const dim3 grid((B + nb - 1) / nb), block(CB_THREADS);
-  hipError_t e;
-  if (nb == 8) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pool_bf16_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(conv_pool_bf16_kernel<8>, grid, block, lds, stream, a);
-  } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pool_bf16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(conv_pool_bf16_kernel<4>, grid, block, lds, stream, a);
-  }
+// conv + pool in bf16 storage; the projection tail is the fp32 proj_norm_kernel of cnn_fwd.hip (launch_cnn_proj).
+// feat_rm / pos non-null: training forward (row-major features + arg-max tape as launch_cnn_fwd's).
+template <int NB, bool TRAIN>
+static hipError_t launch_conv_pool_bf16(const CnnBf16Args &a, size_t lds, hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pool_bf16_kernel<NB, TRAIN>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((conv_pool_bf16_kernel<NB, TRAIN>), dim3((a.B + NB - 1) / NB), dim3(CB_THREADS), lds, stream, a);
   return hipGetLastError();
+}
+
+hipError_t launch_cnn_fwd_bf16(const int32_t *ids, const unsigned short *emb_bf16, const unsigned short *Wc, const float *bias,
+                               float *featp, int32_t *err, int B, int T, int V, int Ep, float *feat_rm, int32_t *pos,
+                               hipStream_t stream) {
+  const int train = (feat_rm != nullptr);
+  const int nb = cnn_bf16_lds_nb(T, Ep, 8, train) <= 160 * 1024 ? 8 : 4;
+  const size_t lds = cnn_bf16_lds_nb(T, Ep, nb, train);
+  CnnBf16Args a{ids, emb_bf16, Wc, bias, featp, feat_rm, pos, err, B, T, V, Ep,
+                (int32_t)(cnn_bf16_packed_weight_elems(Ep) * sizeof(unsigned short))};
+  if (train) return nb == 8 ? launch_conv_pool_bf16<8, true>(a, lds, stream) : launch_conv_pool_bf16<4, true>(a, lds, stream);
+  return nb == 8 ? launch_conv_pool_bf16<8, false>(a, lds, stream) : launch_conv_pool_bf16<4, false>(a, lds, stream);
 }

@@ -392,10 +392,10 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
     if (reserve(h, h->s_feat, (size_t)((B + 31) / 32) * 72 * 256 * sizeof(float))) return 1;
     if (h->cnn_bf16) {
       const int Ep8 = round_up(c.embedding_size, 8);
-      if (cnn_bf16_lds_bytes(T, Ep8) > 160 * 1024)
+      if (cnn_bf16_lds_bytes(T, Ep8, 0) > 160 * 1024)
         return fail(h, "source_only_cnn (bf16): T*E = %d*%d does not fit the LDS tile of the gfx950 kernel", T, c.embedding_size);
       HIPCHECK(h, launch_cnn_fwd_bf16(ids, h->emb_bf16, h->cnn_Wc16, h->cnn_bias, (float *)h->s_feat.p, h->err_flag, B, T,
-                                      c.vocab_size, Ep8, st));
+                                      c.vocab_size, Ep8, nullptr, nullptr, st));
       HIPCHECK(h, launch_cnn_proj((const float *)h->s_feat.p, h->cnn_Mp, out, B, c.encoding_size, normalize ? 1 : 0, st));
       return 0;
     }
@@ -1208,7 +1208,8 @@ static int cnn_train_grads_locked(sse_handle *h, const int32_t *src_ids_host, co
   const int Bp = round_up(B, 64);
   if (T < 5) return fail(h, "source_only_cnn needs max_seq_length >= 5 (widest filter)");
   if (E > 64) return fail(h, "train step: embedding_size %d > 64 not supported yet", E);
-  if (cnn_lds_bytes(T, Ep, 1) > 160 * 1024)
+  const int Ep8 = round_up(E, 8);
+  if ((h->cnn_bf16 ? cnn_bf16_lds_bytes(T, Ep8, 1) : cnn_lds_bytes(T, Ep, 1)) > 160 * 1024)
     return fail(h, "source_only_cnn training: T*E = %d*%d does not fit the LDS tile of the gfx950 kernel", T, E);
   if (ensure_arena(h)) return 1;
   if (ensure_packed(h, st)) return 1;
@@ -1239,9 +1240,18 @@ static int cnn_train_grads_locked(sse_handle *h, const int32_t *src_ids_host, co
 
   // ---- forward with the arg-max tape; target rows looked up from the free matrix
   HIPCHECK(h, hipMemsetAsync(ts.feat_rm.p, 0, (size_t)Bp * 576 * sizeof(float), st));  // padding rows feed the dM GEMM
-  HIPCHECK(h, launch_cnn_fwd((const int32_t *)ts.ids[0].p, h->emb_pad, h->cnn_Wc, h->cnn_bias, h->cnn_Mp,
-                             (float *)h->s_feat.p, (float *)ts.raw[0].p, h->err_flag, B, T, V, Ep, S, 0,
-                             (float *)ts.feat_rm.p, (int32_t *)ts.pos.p, st));
+  if (h->cnn_bf16) {
+    // option cnn_bf16 (BASELINE configs[4]): convolution on the bf16 matrix pipe over bf16-rounded embeddings and
+    // filters (fp32 masters, copies refreshed by ensure_packed after every update), fp32 accumulation; bias, ReLU,
+    // pooling, projection, loss and the optimizer in fp32
+    HIPCHECK(h, launch_cnn_fwd_bf16((const int32_t *)ts.ids[0].p, h->emb_bf16, h->cnn_Wc16, h->cnn_bias, (float *)h->s_feat.p,
+                                    h->err_flag, B, T, V, Ep8, (float *)ts.feat_rm.p, (int32_t *)ts.pos.p, st));
+    HIPCHECK(h, launch_cnn_proj((const float *)h->s_feat.p, h->cnn_Mp, (float *)ts.raw[0].p, B, S, 0, st));
+  } else {
+    HIPCHECK(h, launch_cnn_fwd((const int32_t *)ts.ids[0].p, h->emb_pad, h->cnn_Wc, h->cnn_bias, h->cnn_Mp,
+                               (float *)h->s_feat.p, (float *)ts.raw[0].p, h->err_flag, B, T, V, Ep, S, 0,
+                               (float *)ts.feat_rm.p, (int32_t *)ts.pos.p, st));
+  }
   HIPCHECK(h, launch_rows_gather(table.dev, (const int32_t *)ts.ids[1].p, B, Bp, table.rows, S, (float *)ts.raw[1].p,
                                  h->err_flag, st));
   if (check_err_flag(h, st)) return 1;
@@ -1264,7 +1274,7 @@ static int cnn_train_grads_locked(sse_handle *h, const int32_t *src_ids_host, co
   float *sq = (float *)ts.sq_part.p;
   HIPCHECK(h, launch_cnn_bwd((const int32_t *)ts.ids[0].p, emb.dev, (const float *)ts.dfeat.p, (const float *)ts.feat_rm.p,
                              (const int32_t *)ts.pos.p, W, dW, db, (float *)ts.dw_part.p, (float *)ts.dbias_part.p,
-                             (float *)ts.wt.p, emb.grad, sq, B, T, E, st));
+                             (float *)ts.wt.p, emb.grad, sq, B, T, E, h->cnn_bf16 ? 1 : 0, st));
   HIPCHECK(h, launch_rows_scatter((const float *)ts.draw[1].p, (const int32_t *)ts.ids[1].p, B, S, table.grad, sq + B, st));
   // tail[0]: both lookups are IndexedSlices -> raw slice norms
   HIPCHECK(h, launch_sum(sq, 2 * B, (float)B, tail, st));

@@ -179,11 +179,12 @@ hipError_t launch_exact_topk(const float *q, const float *idxp, const double *id
 // ------------------------------ CNN encoder --------------------------------
 // bf16-storage variant (cnn_fwd_bf16.hip): embeddings / filters as bf16, fp32 accumulation, fp32 tail
 size_t cnn_bf16_packed_weight_elems(int Ep);
-size_t cnn_bf16_lds_bytes(int T, int Ep);
+size_t cnn_bf16_lds_bytes(int T, int Ep, int train);
 hipError_t launch_cnn_bf16_pack(const float *emb, int64_t V, int E, int Ep, unsigned short *emb_bf16, const float *const W[4],
                                 unsigned short *Wc, hipStream_t stream);
 hipError_t launch_cnn_fwd_bf16(const int32_t *ids, const unsigned short *emb_bf16, const unsigned short *Wc, const float *bias,
-                               float *featp, int32_t *err, int B, int T, int V, int Ep, hipStream_t stream);
+                               float *featp, int32_t *err, int B, int T, int V, int Ep, float *feat_rm, int32_t *pos,
+                               hipStream_t stream);
 hipError_t launch_cnn_proj(const float *featp, const float *Mp, float *out, int B, int S, int normalize, hipStream_t stream);
 size_t cnn_lds_bytes(int T, int Ep, int train);
 size_t cnn_packed_weight_floats(int Ep);

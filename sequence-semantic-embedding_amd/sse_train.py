@@ -36,6 +36,7 @@ FLAGS = flags.FlagSet("sse_train", [
     ("seed", int, -1, "seed for batch sampling and initialisation (-1: unseeded, like the reference)"),
     ("max_steps", int, 0, "stop after this many steps (0: no limit; for smoke runs)"),
     ("device_corpus", int, 1, "1: the padded corpora are uploaded once and a step ships row numbers; 0: token-id feed dicts"),
+    ("cnn_bf16", int, 0, "source_only_cnn: 1 = mixed precision (convolution on bf16-rounded embeddings / filters, float32 masters)"),
 ])
 
 
@@ -48,6 +49,8 @@ def create_model(f, session, targetSpaceSize, vocabsize, forward_only):
               "targetSpaceSize": targetSpaceSize, "forward_only": forward_only}
     sse_data.save_model_configs(f.model_dir, params)
     model = SSEModel(params, device=int(f.device))
+    if getattr(f, "cnn_bf16", 0):
+        model.handle.set_option("cnn_bf16", 1)                     # fails loudly outside source_only_cnn
     ckpt = get_checkpoint_state(f.model_dir)
     if ckpt:
         logging.info("Reading model parameters from %s" % ckpt)

@@ -142,6 +142,38 @@ def test_cnn_bf16_storage_variant_matches_bf16_oracle(V, E, S, T, B):
     assert np.array_equal(m.encode_source(ids), exact)               # back to the exact fp32 path
 
 
+@pytest.mark.parametrize("V,E,S,T,B,N", [(300, 50, 512, 64, 48, 571), (90, 24, 64, 20, 10, 17), (200, 50, 64, 80, 26, 33)])
+def test_cnn_bf16_train_step_matches_bf16_oracle(V, E, S, T, B, N):
+    """BASELINE configs[4] ("bf16 ... train"): with option cnn_bf16 the training forward runs the convolution on the
+    bf16 matrix pipe over bf16-rounded embeddings / filters (fp32 masters and accumulation), the backward routes
+    through the rounded operands (oracle._cnn_gradients(bf16=True)); three steps, so the refreshed bf16 copies of
+    the UPDATED masters are what steps 2 and 3 read."""
+    params = model_params("source_only_cnn", V, E, 96, 96, S, T, N=N, lr=0.9)
+    cfg16 = dict(params, cnn_bf16=True)
+    m, p = make_pair(params, seed=6)
+    m.handle.set_option("cnn_bf16", 1)
+    st = O.new_optimizer_state(p)
+    src, rows, z = _cnn_batch(np.random.RandomState(3), B, T, V, N)
+    p32 = {k: v.copy() for k, v in p.items()}
+    loss32 = float(O.train_step(p32, O.new_optimizer_state(p32), params, src, rows, z, 0.9)[0])
+    for step in range(3):
+        want_loss, want_acc = O.train_step(p, st, cfg16, src, rows, z, 0.9)
+        loss, acc = m.train_step(src, rows, z)
+        assert loss == pytest.approx(float(want_loss), rel=2e-5, abs=2e-6), step
+        assert acc == pytest.approx(float(want_acc), abs=1e-6), step
+        if step == 0:
+            assert loss != pytest.approx(loss32, rel=1e-7)          # genuinely the bf16 function
+    got = m.get_variables(with_slots=True)
+    for name, w in p.items():
+        assert np.abs(got[name].reshape(w.shape) - w).max() < 1e-3, name
+        assert np.abs(got[name + "/Adagrad"].reshape(w.shape) - st[name]).max() < 1e-3, name + "/Adagrad"
+    # masters stay float32: the updated filters are not bf16-representable
+    w = got["source_only_cnn/conv-maxpool-3/W"]
+    assert not np.array_equal(O.bf16_round(w), w)
+    ids = random_ids(np.random.RandomState(1), 5, T, V, 0.3)
+    assert np.abs(m.encode_source(ids) - O.encode(p, params, "src", ids, cnn_bf16=True)).max() < 2e-3
+
+
 def test_cnn_bf16_option_is_rejected_outside_cnn_mode():
     import sse_amd
     m, _ = make_pair(model_params("dual-encoder", 50, 8, 16, 16, 8, 5), seed=0)

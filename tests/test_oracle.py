@@ -108,6 +108,40 @@ def test_gradients_finite_difference(mode):
         O.FORGET_BIAS, O.L2_EPS, O.LOGIT_SCALE = old(1.0), old(1e-12), old(64.0)
 
 
+def test_cnn_bf16_gradients_are_the_fp32_gradients_at_the_rounded_weights():
+    """cfg["cnn_bf16"] (mixed-precision CNN training, BASELINE configs[4]): forward on bf16-rounded embeddings and
+    filters, straight-through backward.  By construction that is the float32 gradient evaluated at the rounded
+    weights -- checked bit for bit, together with the update touching the float32 MASTER weights."""
+    cfg = _cfg(mode="source_only_cnn", V=40, E=6, H=6, S=8)
+    cfg["targetSpaceSize"] = 7
+    p = O.init_params(cfg, seed=5)
+    rng = np.random.RandomState(1)
+    B, T = 8, 9
+    src = rng.randint(0, 40, size=(B, T)).astype(np.int32)
+    src[0, :5] = 0
+    rows = rng.randint(0, 7, size=B).astype(np.int32)
+    z = np.array([1, 0] * 4, np.float32)
+    rounded = {k: (O.bf16_round(v) if (k == "word_embedding" or k.endswith("/W")) else v.copy()) for k, v in p.items()}
+    assert any(not np.array_equal(rounded[k], p[k]) for k in p)
+    l16, a16, g16 = O.gradients(p, dict(cfg, cnn_bf16=True), src, rows, z)
+    l32, a32, g32 = O.gradients(rounded, cfg, src, rows, z)
+    assert l16 == l32 and a16 == a32 and set(g16) == set(g32)
+    for name in g16:
+        a, b = g16[name], g32[name]
+        if isinstance(a, tuple):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), name
+        else:
+            assert np.array_equal(a, b), name
+    # and it is a different function from the float32 one
+    assert O.gradients(p, cfg, src, rows, z)[0] != l16
+    # the optimizer updates the float32 masters, not the rounded copies
+    st = O.new_optimizer_state(p)
+    q = {k: v.copy() for k, v in p.items()}
+    O.train_step(q, st, dict(cfg, cnn_bf16=True), src, rows, z, 0.5)
+    w = "source_only_cnn/conv-maxpool-3/W"
+    assert not np.array_equal(q[w], p[w]) and not np.array_equal(O.bf16_round(q[w]), q[w])
+
+
 def test_cnn_gradients_finite_difference():
     """Builder-defined CNN pair loss (oracle._cnn_gradients): analytic gradients vs central differences, float64.
     All-PAD windows make exact max-pool ties; FD is taken at points where the arg-max is stable."""

@@ -48,16 +48,19 @@ import time  # noqa: E402
 import numpy as np  # noqa: E402
 
 rng = np.random.RandomState(0)
-for Bt in (1024, 8192):
-    src = np.repeat(rng.randint(2, V, size=(Bt // 2, T)).astype(np.int32), 2, axis=0)
-    rows = rng.randint(0, 571, size=Bt).astype(np.int32)
-    z = np.tile(np.array([1.0, 0.0], np.float32), Bt // 2)
-    for _ in range(2):
-        m.train_step(src, rows, z)
-    n = 10
-    t0 = time.perf_counter()
-    for _ in range(n):
-        loss, acc = m.train_step(src, rows, z)
-    dt = (time.perf_counter() - t0) / n
-    print("CNN train step B_rows=%d: %.3f ms/step  %.0f pair-rows/s  (forward share %.2f ms at the encode rate above), loss %.4f"
-          % (Bt, dt * 1e3, Bt / dt, Bt * ms / B, loss))
+for bf16 in (0, 1):
+    h.set_option("cnn_bf16", bf16)
+    for Bt in (1024, 8192):
+        src = np.repeat(rng.randint(2, V, size=(Bt // 2, T)).astype(np.int32), 2, axis=0)
+        rows = rng.randint(0, 571, size=Bt).astype(np.int32)
+        z = np.tile(np.array([1.0, 0.0], np.float32), Bt // 2)
+        for _ in range(2):
+            m.train_step(src, rows, z)
+        n = 10
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss, acc = m.train_step(src, rows, z)
+        dt = (time.perf_counter() - t0) / n
+        print("CNN train step%s B_rows=%d: %.3f ms/step  %.0f pair-rows/s  (forward conv share %.2f ms at the encode rate above), loss %.4f"
+              % (" (cnn_bf16: bf16 operands, fp32 masters/accumulate)" if bf16 else "", Bt, dt * 1e3, Bt / dt,
+                 Bt * (ms16 if bf16 else ms) / B, loss))
