@@ -132,7 +132,7 @@ __device__ __forceinline__ void gemm_pass(__amdgpu_buffer_rsrc_t wr, int voff, i
 //   <1,1,1>  Hp = 256, 32 rows: wave w owns unit block w      (half the per-step latency: used
 //            when the batch cannot fill the chip with 64-row tiles)
 //   <1,1,2>  Hp = 512, 32 rows: wave w owns unit blocks w and w+8
-template <int RT, int MT, int UBW, bool TRAIN, bool LIN>
+template <int RT, int MT, int UBW, bool TRAIN, bool LIN, bool SPL = false>
 __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int ROWS = RT * 32;                 // sequences per workgroup
@@ -149,6 +149,10 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   // blocks 0,1 whole and block 2 is split BY PASS: wave 4 / 6 compute the i,j pass of row tile 0 / 1 and hand
   // sigmoid(i)*tanh(j) over through the (already used) parking slots in LDS, wave 5 / 7 compute the f,o pass, own the
   // cell state and finish the step: 12 pass-units, 3 per SIMD (waves w and w+4 share one).
+  // SPL (<1,1,1> with Hp = 128: ONE 32-row tile per workgroup, half the per-step latency of the 64-row mapping --
+  // for batches that cannot fill the chip, e.g. the reference's default training shape of 128 pair rows): 4 unit
+  // blocks on 8 waves, every block split by pass in the same way: wave ub computes its i,j pass, wave ub + 4 its f,o
+  // pass and owns the cell state.
   const bool split3 = !TRAIN && RT == 2 && MT == 1 && a.H > 64 && a.H <= 96;
   int ub0 = (RT == 2 && MT == 1) ? (w >> 1) : w;
   int mt0 = (RT == 2 && MT == 1) ? (w & 1) : 0;
@@ -159,6 +163,13 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
     do_a = ((w & 1) == 0);
     do_b = !do_a;
   }
+  if constexpr (SPL) {
+    static_assert(RT == 1 && MT == 1 && UBW == 1, "pass-split mapping is defined for one 32-row tile");
+    ub0 = w & 3;
+    do_a = w < 4;
+    do_b = !do_a;
+  }
+  const int fidx = SPL ? ub0 : mt0;  // hand-over flag of this wave's (unit block | row tile)
   const int KGx = a.KGx, KGh = a.KGh, KG = KGx + KGh, T = a.T;
   const int KGhe = (a.KGhe > 0 && a.KGhe < KGh) ? a.KGhe : KGh;
   // LDS.  LIN (x double-buffered, fits 160 KiB): A tiles [2 bufs][RT][KG][256], the x part of
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   float *red = smem + (size_t)(LIN ? 2 * RT * KG : RT * KGx + 2 * RT * KGh) * 256;  // [ROWS][NWR] (>= 8 floats)
   const int b0 = blockIdx.x * ROWS;
   volatile int *pass_flag = reinterpret_cast<volatile int *>(red + 16);  // split3: [row tile] = steps whose i,j pass is parked
-  if (tid < 2) pass_flag[tid] = 0;
+  if (tid < 4) pass_flag[tid] = 0;
 
   // --- x gather assignment: TPR threads per sequence row, 8 floats (one k-group) each.  Consecutive lanes take
   // consecutive ROWS of the same k-group, so a 16-byte x_store of 8 adjacent lanes covers 128 contiguous bytes
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       }
       if (do_a && !do_b) {  // split3: publish the parked products of this step (LDS operations of a wave complete in order)
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-        if (lane == 0) pass_flag[mt0] = t + 1;
+        if (lane == 0) pass_flag[fidx] = t + 1;
       }
       if (u == 0 && XD && have_next) {
         // x_{t+1}: its buffer was last read in step t-1, so it can be written as soon as the
@@ -402,7 +413,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
         }
       if (do_b) gemm_pass<MT, LIN, SWAP>(wr, wvoff, wsoff + 2048, xa, ha, KGx, kend, g);
       if (do_b && !do_a) {  // split3: the i,j pass of this (block, row tile) comes from the partner wave
-        while (pass_flag[mt0] < t + 1) __builtin_amdgcn_s_sleep(2);
+        while (pass_flag[fidx] < t + 1) __builtin_amdgcn_s_sleep(2);
       }
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -554,37 +565,40 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   }
 }
 
-template <int RT, int MT, int UBW, bool TRAIN, bool LIN>
+template <int RT, int MT, int UBW, bool TRAIN, bool LIN, bool SPL>
 static hipError_t launch_one(const LstmFwdArgs &a, size_t lds, hipStream_t stream) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_kernel<RT, MT, UBW, TRAIN, LIN>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_kernel<RT, MT, UBW, TRAIN, LIN, SPL>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const dim3 grid(a.NT32 > 0 ? a.NT32 / RT : (a.B + RT * 32 - 1) / (RT * 32)), block(LSTM_THREADS);
-  hipLaunchKernelGGL((lstm_fwd_kernel<RT, MT, UBW, TRAIN, LIN>), grid, block, lds, stream, a);
+  hipLaunchKernelGGL((lstm_fwd_kernel<RT, MT, UBW, TRAIN, LIN, SPL>), grid, block, lds, stream, a);
   return hipGetLastError();
 }
 
-template <int RT, int MT, int UBW>
+template <int RT, int MT, int UBW, bool SPL = false>
 static hipError_t launch_cfg(const LstmFwdArgs &a_in, hipStream_t stream) {
   LstmFwdArgs a = a_in;
   a.xdouble = lstm_fwd_x_double(a.KGx, a.KGh, RT) ? 1 : 0;
   const size_t lds = lstm_fwd_lds_bytes(a.KGx, a.KGh, RT);
   const bool train = a.tape_g != nullptr;
-  if (a.xdouble) return train ? launch_one<RT, MT, UBW, true, true>(a, lds, stream) : launch_one<RT, MT, UBW, false, true>(a, lds, stream);
-  return train ? launch_one<RT, MT, UBW, true, false>(a, lds, stream) : launch_one<RT, MT, UBW, false, false>(a, lds, stream);
+  if (a.xdouble)
+    return train ? launch_one<RT, MT, UBW, true, true, SPL>(a, lds, stream) : launch_one<RT, MT, UBW, false, true, SPL>(a, lds, stream);
+  return train ? launch_one<RT, MT, UBW, true, false, SPL>(a, lds, stream) : launch_one<RT, MT, UBW, false, false, SPL>(a, lds, stream);
 }
 
 // rows per workgroup the launcher will use for (Hp, B): 64, or 32 when 64-row tiles cannot fill
 // the 256 CUs (half the per-step latency, all tiles still resident) and for Hp = 512
-int lstm_fwd_rows_per_wg(int Hp, int B) {
+int lstm_fwd_rows_per_wg(int Hp, int B, int tiles_elsewhere) {
   if (Hp == 512) return 32;
-  if (Hp == 256 && (B + 31) / 32 <= 256) return 32;
+  if ((Hp == 256 || Hp == 128) && (B + 31) / 32 + tiles_elsewhere <= 256) return 32;
   return 64;
 }
 
 hipError_t launch_lstm_fwd(const LstmFwdArgs &a, int Hp, hipStream_t stream) {
-  const int rows = lstm_fwd_rows_per_wg(Hp, a.B);
-  if (Hp == 128) return launch_cfg<2, 1, 1>(a, stream);
+  int rows = lstm_fwd_rows_per_wg(Hp, a.B, a.tiles_elsewhere);
+  if (Hp <= 256 && (a.force_rows == 32 || a.force_rows == 64)) rows = a.force_rows;
+  if (rows == 64 && a.NT32 > 0 && (a.NT32 & 1)) return hipErrorInvalidValue;  // tapes are laid out per 32-row tile
+  if (Hp == 128) return rows == 32 ? launch_cfg<1, 1, 1, true>(a, stream) : launch_cfg<2, 1, 1>(a, stream);
   if (Hp == 256) return rows == 32 ? launch_cfg<1, 1, 1>(a, stream) : launch_cfg<2, 2, 1>(a, stream);
   if (Hp == 512) return launch_cfg<1, 1, 2>(a, stream);
   return hipErrorInvalidValue;

@@ -74,6 +74,12 @@ struct TrainState {
   int64_t corpus_N[2] = {0, 0};
   int32_t corpus_T[2] = {0, 0};
   bool rows_mode = false;  // set by the *_rows entry points around train_grads_locked
+  // paired batches (data.py:95-115: every source row appears twice, once with its positive and once with a negative
+  // target): internal row order = [rows 0,2,4,.. | rows 1,3,5,..], the source encoder runs on the first half only
+  DevBuf ids_raw[2], perm;
+  int perm_B = 0;
+  std::vector<int32_t> h_perm, h_rows[2], h_tgt;
+  std::vector<float> h_labels;
 };
 
 }  // namespace
@@ -94,6 +100,8 @@ struct sse_handle {
   bool fb_cnt_init = false;
   bool cnn_bf16 = false;     // option "cnn_bf16": source_only_cnn inference with bf16 storage / fp32 accumulation
   unsigned short *emb_bf16 = nullptr, *cnn_Wc16 = nullptr;
+  int lstm_train_rows = 0;   // option "lstm_train_rows": 0 = automatic, 32 / 64 = rows per workgroup of the training forward (Hp = 256)
+  bool train_pair_dedup = true; // option "train_pair_dedup": run the source encoder once per (pos, neg) pair of rows that share it
   bool train_serial = false; // option "train_serial": both encoders on one stream (profiling: isolated kernel times)
   float *emb_pad = nullptr;  // [V][Ep]
   // source_only_cnn
@@ -1017,6 +1025,15 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value) {
     h->packed_dirty = true;  // (re)build the bf16 copies with the next encode
     return 0;
   }
+  if (strcmp(name, "lstm_train_rows") == 0) {
+    if (value != 0 && value != 32 && value != 64) return fail(h, "lstm_train_rows must be 0, 32 or 64");
+    h->lstm_train_rows = (int)value;
+    return 0;
+  }
+  if (strcmp(name, "train_pair_dedup") == 0) {
+    h->train_pair_dedup = value != 0;
+    return 0;
+  }
   if (strcmp(name, "train_serial") == 0) {
     h->train_serial = value != 0;
     return 0;
@@ -1182,15 +1199,30 @@ static int ensure_arena(sse_handle *h) {
 
 // token ids of one side of the batch into ts.ids[side] ([B][T] on the device): copied from the host, or -- rows mode --
 // gathered on the device from the resident corpus by B row numbers (B ints cross PCIe instead of B*T)
-static int stage_ids(sse_handle *h, TrainState &ts, int side, const int32_t *host, int B, int T, hipStream_t st) {
+// perm (host, [B], or nullptr): internal row r holds the caller's row perm[r].
+static int stage_ids(sse_handle *h, TrainState &ts, int side, const int32_t *host, int B, int T, const int32_t *perm,
+                     hipStream_t st) {
   if (reserve(h, ts.ids[side], (size_t)B * T * sizeof(int32_t))) return 1;
   if (!ts.rows_mode) {
-    HIPCHECK(h, hipMemcpyAsync(ts.ids[side].p, host, (size_t)B * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (!perm) {
+      HIPCHECK(h, hipMemcpyAsync(ts.ids[side].p, host, (size_t)B * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+      return 0;
+    }
+    // the batch as handed over is the "corpus", the permutation the row numbers (ts.perm is uploaded by the caller)
+    if (reserve(h, ts.ids_raw[side], (size_t)B * T * sizeof(int32_t))) return 1;
+    HIPCHECK(h, hipMemcpyAsync(ts.ids_raw[side].p, host, (size_t)B * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHECK(h, launch_gather_id_rows((const int32_t *)ts.ids_raw[side].p, (const int32_t *)ts.perm.p, B, T, B,
+                                      (int32_t *)ts.ids[side].p, h->err_flag, st));
     return 0;
   }
   if (!ts.corpus[side].p || ts.corpus_T[side] != T)
     return fail(h, "train step by rows: no %s corpus with T = %d on the device (sse_corpus_upload)", side ? "target" : "source", T);
   if (reserve(h, ts.rows[side], (size_t)B * sizeof(int32_t))) return 1;
+  if (perm) {
+    ts.h_rows[side].resize(B);
+    for (int r = 0; r < B; ++r) ts.h_rows[side][r] = host[perm[r]];
+    host = ts.h_rows[side].data();
+  }
   HIPCHECK(h, hipMemcpyAsync(ts.rows[side].p, host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st));
   HIPCHECK(h, launch_gather_id_rows((const int32_t *)ts.corpus[side].p, (const int32_t *)ts.rows[side].p, B, T,
                                     ts.corpus_N[side], (int32_t *)ts.ids[side].p, h->err_flag, st));
@@ -1219,7 +1251,7 @@ static int cnn_train_grads_locked(sse_handle *h, const int32_t *src_ids_host, co
 
   if (reserve(h, ts.ids[1], (size_t)B * sizeof(int32_t))) return 1;
   if (reserve(h, ts.labels, (size_t)B * sizeof(float))) return 1;
-  if (stage_ids(h, ts, 0, src_ids_host, B, T, st)) return 1;
+  if (stage_ids(h, ts, 0, src_ids_host, B, T, nullptr, st)) return 1;
   HIPCHECK(h, hipMemcpyAsync(ts.ids[1].p, tgt_rows_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st));
   HIPCHECK(h, hipMemcpyAsync(ts.labels.p, labels_host, (size_t)B * sizeof(float), hipMemcpyHostToDevice, st));
   for (int s = 0; s < 2; ++s) {
@@ -1335,17 +1367,57 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     if (h->enc[s].Hp > 256) return fail(h, "train step: LSTM cell size %d > 256 not supported yet (inference only)", h->enc[s].H);
 
   // ---- inputs
+  // Paired batch (data.py:95-115 builds every batch this way: source row 2i and 2i+1 are the same sequence, once with
+  // its positive and once with a sampled negative target): the rows are taken in the order [0,2,4,.. | 1,3,5,..], the
+  // source encoder runs on the first half only, and its tapes serve both halves of the backward pass.  The backward
+  // itself stays per row: clip_by_global_norm sees the two rows' embedding slices separately (sse_model.py:359-362).
+  bool paired = h->train_pair_dedup && B % 128 == 0;  // both halves whole 64-row tiles
+  if (paired) {
+    if (ts.rows_mode) {
+      for (int i = 0; i < B && paired; i += 2) paired = src_ids_host[i] == src_ids_host[i + 1];
+    } else {
+      for (int i = 0; i < B && paired; i += 2)
+        paired = memcmp(src_ids_host + (size_t)i * T, src_ids_host + (size_t)(i + 1) * T, (size_t)T * sizeof(int32_t)) == 0;
+    }
+  }
+  const int32_t *perm = nullptr;
+  if (paired) {
+    if ((int)ts.h_perm.size() != B) {
+      ts.h_perm.resize(B);
+      for (int r = 0; r < B / 2; ++r) {
+        ts.h_perm[r] = 2 * r;
+        ts.h_perm[B / 2 + r] = 2 * r + 1;
+      }
+      ts.perm_B = 0;
+    }
+    perm = ts.h_perm.data();
+    if (ts.perm_B != B) {
+      if (reserve(h, ts.perm, (size_t)B * sizeof(int32_t))) return 1;
+      HIPCHECK(h, hipMemcpyAsync(ts.perm.p, perm, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+      ts.perm_B = B;
+    }
+    ts.h_labels.resize(B);
+    for (int r = 0; r < B; ++r) ts.h_labels[r] = labels_host[perm[r]];
+    labels_host = ts.h_labels.data();
+  }
   const int32_t *ids_host[2] = {src_ids_host, tgt_ids_host};
   for (int s = 0; s < 2; ++s) {
     if (s == 1 && table_tgt) {  // rows of the free target matrix
       if (reserve(h, ts.ids[s], (size_t)B * sizeof(int32_t))) return 1;
-      HIPCHECK(h, hipMemcpyAsync(ts.ids[s].p, ids_host[s], (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    } else if (stage_ids(h, ts, s, ids_host[s], B, T, st)) {
+      const int32_t *src = ids_host[s];
+      if (perm) {
+        ts.h_tgt.resize(B);
+        for (int r = 0; r < B; ++r) ts.h_tgt[r] = src[perm[r]];
+        src = ts.h_tgt.data();
+      }
+      HIPCHECK(h, hipMemcpyAsync(ts.ids[s].p, src, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    } else if (stage_ids(h, ts, s, ids_host[s], B, T, perm, st)) {
       return 1;
     }
   }
   if (reserve(h, ts.labels, (size_t)B * sizeof(float))) return 1;
   HIPCHECK(h, hipMemcpyAsync(ts.labels.p, labels_host, (size_t)B * sizeof(float), hipMemcpyHostToDevice, st));
+  const int NT_half = NT32 / 2;  // paired: 32-row tiles of one half (B % 128 == 0: Bp = B, NT_half even)
 
   // ---- forward with tapes (un-normalised encodings; the loss kernel normalises); the two
   // encoders are independent: fork onto two side streams, join before the loss
@@ -1364,8 +1436,10 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     const int KT = 2 + e.Hp / 32;
     if (reserve(h, ts.raw[s], (size_t)Bp * S * sizeof(float))) return 1;
     if (reserve(h, ts.draw[s], (size_t)Bp * S * sizeof(float))) return 1;
-    if (reserve(h, ts.tape_g[s], (size_t)T * NT32 * 4 * e.UB * 5 * 1024 * sizeof(float))) return 1;
-    if (reserve(h, ts.tape_a[s], (size_t)T * NT32 * 4 * KT * 256 * sizeof(float))) return 1;
+    const bool half = paired && s == 0;  // the source encoder of a paired batch: first half of the rows only
+    const int NTf = half ? NT_half : NT32, Bf = half ? B / 2 : B;
+    if (reserve(h, ts.tape_g[s], (size_t)T * NTf * 4 * e.UB * 5 * 1024 * sizeof(float))) return 1;
+    if (reserve(h, ts.tape_a[s], (size_t)T * NTf * 4 * KT * 256 * sizeof(float))) return 1;
     if (reserve(h, ts.h_last[s], (size_t)Bp * e.Hp * sizeof(float))) return 1;
     LstmFwdArgs a;
     a.ids = (const int32_t *)ts.ids[s].p;
@@ -1374,7 +1448,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
       a.Mp = e.Mp;
     a.out = (float *)ts.raw[s].p;
     a.err = h->err_flag;
-    a.B = B;
+    a.B = Bf;
     a.T = T;
     a.V = V;
     a.Ep = e.Ep;
@@ -1384,11 +1458,19 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     a.S = S;
     a.NTS = (S + 31) / 32;
     a.normalize = 0;
-    a.NT32 = NT32;
+    a.NT32 = NTf;
+    a.tiles_elsewhere = (nside == 2 && !h->train_serial) ? ((paired && s == 1) ? NT_half : NT32) : 0;  // the other encoder's forward runs beside this one
+    a.force_rows = h->lstm_train_rows;
     a.tape_g = (float *)ts.tape_g[s].p;
     a.tape_a = (float *)ts.tape_a[s].p;
     a.h_last = (float *)ts.h_last[s].p;
     HIPCHECK(h, launch_lstm_fwd(a, e.Hp, fs));
+    if (half) {  // rows B/2 .. B-1 are the same sequences: the loss and the projection backward read them per row
+      HIPCHECK(h, hipMemcpyAsync((float *)ts.raw[s].p + (size_t)Bf * S, ts.raw[s].p, (size_t)Bf * S * sizeof(float),
+                                 hipMemcpyDeviceToDevice, fs));
+      HIPCHECK(h, hipMemcpyAsync((float *)ts.h_last[s].p + (size_t)Bf * e.Hp, ts.h_last[s].p, (size_t)Bf * e.Hp * sizeof(float),
+                                 hipMemcpyDeviceToDevice, fs));
+    }
     HIPCHECK(h, hipEventRecord(ts.ev_join[s], fs));
     HIPCHECK(h, hipStreamWaitEvent(st, ts.ev_join[s], 0));
   }
@@ -1415,8 +1497,10 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   HIPCHECK(h, hipEventRecord(ts.ev_fork, st));  // loss + zeroed embedding gradient are ready
   for (int s = 0; s < nside; ++s) {
     Encoder &e = h->enc[s];
+    const bool half = paired && s == 0;
     const int Hp = e.Hp, KGn = Hp / 2, NTn = Hp / 8, KT = 2 + Hp / 32, RG = T * NT32 * 4;
-    const int SL = dk_slices(RG);
+    const int RGa = half ? RG / 2 : RG;  // r-groups of tape_a: the dK GEMM adds the two halves' dG fragments
+    const int SL = dk_slices(RGa);
     // dual-encoder: the two backward chains are independent -> side streams; shared-encoder: the
     // target side accumulates onto the source side's kernel/bias gradient -> one stream, in order
     hipStream_t bs = (shared || h->train_serial) ? ts.side[0] : ts.side[s];
@@ -1430,10 +1514,11 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     HIPCHECK(h, launch_proj_bwd((const float *)ts.h_last[s].p, (const float *)ts.draw[s].p, h->vars[e.proj].dev, Bp, e.H, Hp,
                                 S, h->vars[e.proj].grad, (float *)ts.dh_last[s].p, (float *)ts.dm_part[s].p, bs));
     HIPCHECK(h, launch_lstm_bwd((const float *)ts.tape_g[s].p, (const float *)ts.dh_last[s].p, ts.KhT[s],
-                                (float *)ts.dg_a[s].p, (float *)ts.dg_b[s].p, (float *)ts.db_part[s].p, T, NT32, Hp, e.H, bs));
+                                (float *)ts.dg_a[s].p, (float *)ts.dg_b[s].p, (float *)ts.db_part[s].p, T, NT32,
+                                half ? NT_half : NT32, Hp, e.H, bs));
     const int accumulate = (shared && s == 1) ? 1 : 0;
-    HIPCHECK(h, launch_dk((const float *)ts.tape_a[s].p, (const float *)ts.dg_b[s].p, (float *)ts.dk_part[s].p, RG, KT, NTn, SL,
-                          E, e.H, Hp, accumulate, h->vars[e.kernel].grad, bs));
+    HIPCHECK(h, launch_dk((const float *)ts.tape_a[s].p, (const float *)ts.dg_b[s].p, (float *)ts.dk_part[s].p, RGa, KT, NTn, SL,
+                          E, e.H, Hp, accumulate, h->vars[e.kernel].grad, half ? NT_half * 4 : 0, bs));
     HIPCHECK(h, launch_db_reduce((const float *)ts.db_part[s].p, NT32, e.H, Hp, accumulate, h->vars[e.bias].grad, bs));
     HIPCHECK(h, launch_dx((const float *)ts.dg_a[s].p, ts.KxT[s], (const int32_t *)ts.ids[s].p, emb.grad,
                           (float *)ts.sq_part.p + (size_t)s * T * NT32, T, NT32, KGn, B, E, V, e.H, bs));

@@ -43,6 +43,9 @@ struct LstmFwdArgs {
   int32_t KGhe = 0;     // k-groups of h that can be non-zero = ceil(H/8) (0: all KGh); units >= H stay exactly 0
   int32_t NT32 = 0;     // training: number of 32-row tiles the tapes are laid out for (0: from the grid)
   int32_t xdouble = 1;  // set by launch_lstm_fwd from lstm_fwd_x_double()
+  int32_t tiles_elsewhere = 0;  // 32-row tiles of launches that run CONCURRENTLY on other streams (the other encoder of a
+                                // train step): the 32- vs 64-row tile choice looks at the chip, not at this launch alone
+  int32_t force_rows = 0;       // 32 / 64: override the tile choice (Hp = 256; measurement aid, option lstm_train_rows)
   // Left-pad prefix skip (exact): the state after p leading PAD (id 0) steps does not depend on
   // the sequence, so a tile starts at t0 = min over its rows of the leading-PAD count with
   // (h, c) = pad_h/pad_c[t0].  pad_* [T+1][Hp] come from rec_* of an all-PAD launch by the same
@@ -58,7 +61,7 @@ struct LstmFwdArgs {
 // Hp = 128 * UB hidden units; 512 threads; dynamic LDS = lstm_fwd_lds_bytes()
 size_t lstm_fwd_lds_bytes(int KGx, int KGh, int RT);
 bool lstm_fwd_x_double(int KGx, int KGh, int RT);
-int lstm_fwd_rows_per_wg(int Hp, int B);
+int lstm_fwd_rows_per_wg(int Hp, int B, int tiles_elsewhere = 0);
 hipError_t launch_lstm_fwd(const LstmFwdArgs &a, int Hp, hipStream_t stream);
 
 // few-sequences LSTM forward (lstm_small.hip): one workgroup per 4 sequences, vector-ALU GEMV on the master variables

@@ -208,6 +208,8 @@ struct LstmBwdArgs {
   float *db_part;       // [NT32][4*Hp] per-tile bias-gradient partials
   int32_t T, NT32, Hp;
   int32_t H;            // real cell size: dG columns of padded units are exactly 0, their k-groups are skipped
+  int32_t NT_tape;      // 32-row tiles the gate tape holds per step: NT32, or NT32/2 when the batch is (pos, neg) pairs
+                        // that share their source sequence -- tiles j and j + NT_tape then read the same tape
 };
 
 template <int UB, int NW>
@@ -227,9 +229,9 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
   // tape reads go through a buffer descriptor: address = SGPR base + SGPR offset + (4*lane), so the 80
   // loads of a refill cost no address VGPRs (per-lane 64-bit pointers spilled this kernel)
   const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(a.tape_g + ((size_t)tile * NW + wn) * UB * 5 * 1024), 0, 0x7fffffff, 0x00020000);
+      const_cast<float *>(a.tape_g + ((size_t)(tile % a.NT_tape) * NW + wn) * UB * 5 * 1024), 0, 0x7fffffff, 0x00020000);
   const int tvo = lane * 4;
-  const int tstep = a.NT32 * NW * UB * 5 * 1024 * 4;  // bytes between consecutive steps (T*tstep < 2^31 checked by the launcher)
+  const int tstep = a.NT_tape * NW * UB * 5 * 1024 * 4;  // bytes between consecutive steps (T*tstep < 2^31 checked by the launcher)
   auto tld = [&](int t, int u, int word) -> float {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(trs, tvo, t * tstep + (u * 5 * 1024 + word) * 4, 0));
   };
@@ -395,6 +397,9 @@ struct DkArgs {
   float *part;          // [SL][KT*32][NTn*32]
   int32_t RG, KT, NTn, SL;
   uint32_t live_k;      // bit i: k'-tile i has non-padding rows (x: 2 tiles of 32 up to E; h: one per 32 units up to H)
+  int32_t pair_rg;      // 0, or r-groups per step of tape_a (= 4 * NT32/2) when the batch is (pos, neg) pairs sharing
+                        // their source: tape_a holds RG r-groups of the shared rows, dg_b 2*RG (per step: the pos tiles,
+                        // then the neg tiles) and A^T dG_pos + A^T dG_neg = A^T (dG_pos + dG_neg): half the MFMAs
 };
 
 // KT fragments of one LDS stage, software-pipelined one fragment ahead of its 4 MFMAs (used twice in the kernel)
@@ -422,7 +427,7 @@ struct DkArgs {
     __builtin_amdgcn_s_setprio(0);                                                                              \
   }
 
-template <int KT>
+template <int KT, bool PAIR>
 __global__ __launch_bounds__(512) void dk_gemm_kernel(DkArgs a) {
   // The KT A fragments of an r-group are the same for all 8 waves: they are fetched ONCE per workgroup
   // (each wave brings 1-2 of the KT 1-KB blocks) into a double-buffered LDS stage, one barrier per r-group;
@@ -443,6 +448,15 @@ __global__ __launch_bounds__(512) void dk_gemm_kernel(DkArgs a) {
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
   const float *pa = a.tape_a + lane * 4;
   const float *pb = a.dg_b + (size_t)nt * 256 + lane * 4;
+  const int pair_rg = a.pair_rg;
+  // dG fragment of r-group rg (an index into tape_a): with pairs, the sum of the two rows' fragments
+  auto gload_b = [&](int rg) -> f32x4 {
+    if constexpr (!PAIR) return *reinterpret_cast<const f32x4 *>(pb + (size_t)rg * a.NTn * 256);
+    const int t = rg / pair_rg, d1 = rg + t * pair_rg;  // (t * 2 * pair_rg + rg % pair_rg)
+    const f32x4 u = *reinterpret_cast<const f32x4 *>(pb + (size_t)d1 * a.NTn * 256);
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(pb + (size_t)(d1 + pair_rg) * a.NTn * 256);
+    return u + v;
+  };
   constexpr bool TWO = KT > 8;  // waves 0 .. KT-9 bring a second block
   const bool second = TWO && (8 + w < KT);
   auto gload_a = [&](int rg, f32x4 &s0, f32x4 &s1) {
@@ -460,12 +474,12 @@ __global__ __launch_bounds__(512) void dk_gemm_kernel(DkArgs a) {
     f32x4 xs0 = {0, 0, 0, 0}, xs1 = {0, 0, 0, 0}, xb, ys0 = {0, 0, 0, 0}, ys1 = {0, 0, 0, 0}, yb, bc;
     auto clampr = [&](int rg) { return rg < rg1 ? rg : rg1 - 1; };
     gload_a(rg0, xs0, xs1);
-    bc = *reinterpret_cast<const f32x4 *>(pb + (size_t)rg0 * a.NTn * 256);
+    bc = gload_b(rg0);
     stash(0, xs0, xs1);
     gload_a(clampr(rg0 + 1), xs0, xs1);
-    xb = *reinterpret_cast<const f32x4 *>(pb + (size_t)clampr(rg0 + 1) * a.NTn * 256);
+    xb = gload_b(clampr(rg0 + 1));
     gload_a(clampr(rg0 + 2), ys0, ys1);
-    yb = *reinterpret_cast<const f32x4 *>(pb + (size_t)clampr(rg0 + 2) * a.NTn * 256);
+    yb = gload_b(clampr(rg0 + 2));
     __syncthreads();
     for (int rg = rg0; rg < rg1; rg += 2) {
       // even step: stage 0 holds r-group rg; set X holds rg+1 (to stage 1), then refetches rg+3
@@ -473,14 +487,14 @@ __global__ __launch_bounds__(512) void dk_gemm_kernel(DkArgs a) {
       if (rg + 1 < rg1) stash(1, xs0, xs1);
       bc = xb;
       gload_a(clampr(rg + 3), xs0, xs1);
-      xb = *reinterpret_cast<const f32x4 *>(pb + (size_t)clampr(rg + 3) * a.NTn * 256);
+      xb = gload_b(clampr(rg + 3));
       __syncthreads();
       // odd step: stage 1 holds rg+1; set Y holds rg+2 (to stage 0), then refetches rg+4
       DK_COMPUTE(1)
       if (rg + 2 < rg1) stash(0, ys0, ys1);
       bc = yb;
       gload_a(clampr(rg + 4), ys0, ys1);
-      yb = *reinterpret_cast<const f32x4 *>(pb + (size_t)clampr(rg + 4) * a.NTn * 256);
+      yb = gload_b(clampr(rg + 4));
       __syncthreads();
     }
   }
@@ -682,8 +696,8 @@ hipError_t launch_proj_bwd(const float *hT, const float *d, const float *M, int 
 }
 
 hipError_t launch_lstm_bwd(const float *tape_g, const float *dh_last, const float *KhT, float *dg_a, float *dg_b,
-                           float *db_part, int T, int NT32, int Hp, int H, hipStream_t st) {
-  LstmBwdArgs a{tape_g, dh_last, KhT, dg_a, dg_b, db_part, T, NT32, Hp, H};
+                           float *db_part, int T, int NT32, int NT_tape, int Hp, int H, hipStream_t st) {
+  LstmBwdArgs a{tape_g, dh_last, KhT, dg_a, dg_b, db_part, T, NT32, Hp, H, NT_tape > 0 ? NT_tape : NT32};
   const size_t lds = (size_t)(Hp / 2) * 256 * sizeof(float);
   if ((size_t)T * NT32 * (Hp / 32) * 5 * 1024 * sizeof(float) >= ((size_t)1 << 31)) return hipErrorInvalidValue;  // 32-bit tape offsets
   hipError_t e;
@@ -709,16 +723,18 @@ int dk_slices(int RG) {
 }
 
 hipError_t launch_dk(const float *tape_a, const float *dg_b, float *part, int RG, int KT, int NTn, int SL, int E, int H,
-                     int Hp, int accumulate, float *dK, hipStream_t st) {
+                     int Hp, int accumulate, float *dK, int pair_rg, hipStream_t st) {
   uint32_t live = 0;
   for (int i = 0; i < KT; ++i) {
     const bool on = (i < 2) ? (i * 32 < E) : ((i - 2) * 32 < H);
     if (on) live |= 1u << i;
   }
-  DkArgs a{tape_a, dg_b, part, RG, KT, NTn, SL, live};
+  DkArgs a{tape_a, dg_b, part, RG, KT, NTn, SL, live, pair_rg};
   const dim3 grid((NTn + 7) / 8, SL);
-  if (KT == 10) hipLaunchKernelGGL(dk_gemm_kernel<10>, grid, dim3(512), 0, st, a);
-  else if (KT == 6) hipLaunchKernelGGL(dk_gemm_kernel<6>, grid, dim3(512), 0, st, a);
+  if (KT == 10 && pair_rg) hipLaunchKernelGGL((dk_gemm_kernel<10, true>), grid, dim3(512), 0, st, a);
+  else if (KT == 10) hipLaunchKernelGGL((dk_gemm_kernel<10, false>), grid, dim3(512), 0, st, a);
+  else if (KT == 6 && pair_rg) hipLaunchKernelGGL((dk_gemm_kernel<6, true>), grid, dim3(512), 0, st, a);
+  else if (KT == 6) hipLaunchKernelGGL((dk_gemm_kernel<6, false>), grid, dim3(512), 0, st, a);
   else return hipErrorInvalidValue;
   hipLaunchKernelGGL(dk_reduce_kernel, dim3(((E + H) * 4 * H + 255) / 256), dim3(256), 0, st, part, SL, KT, NTn, E, H, Hp,
                      accumulate, dK);

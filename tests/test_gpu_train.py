@@ -184,6 +184,39 @@ def test_data_parallel_trainer_world1_and_arena_ownership():
         ma.handle.train_set_grad_arena(tr.arena.data_ptr(), 5)     # wrong size
 
 
+@pytest.mark.parametrize("mode,H", [("dual-encoder", 256), ("shared-encoder", 128), ("source-encoder-only", 96)])
+def test_paired_batch_runs_the_source_encoder_once_per_pair(mode, H):
+    """data.py:95-115 batches: rows 2i and 2i+1 share their source sequence.  With B % 128 == 0 the source forward and
+    the source side of the dK GEMM run on B/2 rows (option train_pair_dedup, default on); same step as the per-row
+    path (option off) up to fp32 summation order, and as the oracle."""
+    V, E, S, T, B, N = 300, 50, 64, 12, 256, 23
+    params = model_params(mode, V, E, H, H, S, T, N=N, lr=0.9)
+    (ma, p), (mb, _) = make_pair(params, seed=11), make_pair(params, seed=11)
+    mb.handle.set_option("train_pair_dedup", 0)
+    st = O.new_optimizer_state(p)
+    rng = np.random.RandomState(5)
+    table = mode == "source-encoder-only"
+    for step in range(2):
+        src = np.repeat(random_ids(rng, B // 2, T, V, 0.4), 2, axis=0)
+        tgt = rng.randint(0, N, size=B).astype(np.int32) if table else random_ids(rng, B, T, V, 0.4)
+        z = np.tile(np.array([1.0, 0.0], np.float32), B // 2)
+        want = O.train_step(p, st, params, src, tgt, z, 0.9)
+        la, lb = ma.train_step(src, tgt, z), mb.train_step(src, tgt, z)
+        assert la[0] == pytest.approx(lb[0], rel=2e-6) and la[1] == pytest.approx(lb[1], abs=1e-6)
+        assert la[0] == pytest.approx(float(want[0]), rel=1e-5, abs=1e-6)
+    va, vb = ma.get_variables(with_slots=True), mb.get_variables(with_slots=True)
+    for name, w in p.items():
+        assert np.abs(va[name] - vb[name]).max() < 2e-5, name
+        assert np.abs(va[name].reshape(w.shape) - w).max() < 2e-4, name
+        assert np.abs(va[name + "/Adagrad"].reshape(w.shape) - st[name]).max() < 2e-4, name
+    # an unpaired batch of the same size takes the per-row path on both handles: identical results
+    src = random_ids(rng, B, T, V, 0.4)
+    tgt = rng.randint(0, N, size=B).astype(np.int32) if table else random_ids(rng, B, T, V, 0.4)
+    z = np.tile(np.array([1.0, 0.0], np.float32), B // 2)
+    la, lb = ma.train_step(src, tgt, z), mb.train_step(src, tgt, z)
+    assert la[0] == pytest.approx(lb[0], rel=1e-4)
+
+
 def test_handles_release_their_device_memory():
     """Create / train / encode / destroy repeatedly: free device memory does not drift (scratch, tapes, arena)."""
     import gc

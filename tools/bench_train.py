@@ -18,9 +18,16 @@ m = sse_amd.SSEModel(params)
 m.init_variables(seed=0)
 if os.environ.get("SSE_TRAIN_SERIAL"):                 # profiling aid: isolated kernel durations
     m.handle.set_option("train_serial", 1)
+if os.environ.get("SSE_TRAIN_ROWS"):                   # 32 / 64 rows per workgroup in the training forward (0: automatic)
+    m.handle.set_option("lstm_train_rows", int(os.environ["SSE_TRAIN_ROWS"]))
+if os.environ.get("SSE_TRAIN_PAIR_DEDUP"):            # 0: run the source encoder on every row of a paired batch
+    m.handle.set_option("train_pair_dedup", int(os.environ["SSE_TRAIN_PAIR_DEDUP"]))
 rng = np.random.RandomState(0)
 for B in [int(x) for x in (sys.argv[1:] or ["128", "1024", "8192"])]:
-    src = rng.randint(2, V, size=(B, T)).astype(np.int32)
+    if os.environ.get("SSE_TRAIN_UNPAIRED"):
+        src = rng.randint(2, V, size=(B, T)).astype(np.int32)
+    else:
+        src = np.repeat(rng.randint(2, V, size=(B // 2, T)).astype(np.int32), 2, axis=0)   # data.py:95-115: pos,neg share a source
     tgt = rng.randint(2, V, size=(B, T)).astype(np.int32)
     z = np.tile(np.array([1.0, 0.0], np.float32), B // 2)
     for _ in range(3):

@@ -17,7 +17,7 @@ params = dict(forward_only=False, network_mode="dual-encoder", predict_nbest=10,
 m = sse_amd.SSEModel(params)
 m.init_variables(seed=0)
 rng = np.random.RandomState(0)
-for B in (128, 8192):
+for B in [int(x) for x in (sys.argv[1:] or ["128", "8192"])]:
     src = np.repeat(rng.randint(2, V, size=(B // 2, T)).astype(np.int32), 2, axis=0)
     tgt = rng.randint(2, V, size=(B, T)).astype(np.int32)
     z = np.tile(np.array([1.0, 0.0], np.float32), B // 2)
