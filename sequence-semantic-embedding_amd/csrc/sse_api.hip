@@ -92,6 +92,9 @@ struct sse_handle {
   Encoder enc[2];
   bool packed_dirty = true;
   bool pad_skip = true;      // option "pad_skip": exact left-pad prefix skip in inference encodes
+  int lstm_persist_rows = 32; // option "lstm_persist_rows": batches up to this many rows (<= 32) take the weights-in-LDS cluster kernel
+  uint32_t persist_epoch = 0; // tag epoch of the cluster kernel's exchange buffers
+  int cu_count = 0;           // compute units of the device (co-residency check of the cluster kernel)
   int lstm_small_rows = 1024; // option "lstm_small_rows": batches up to this many rows take the few-sequences LSTM kernel
   bool score_bf16 = true;    // option "score_bf16" (default on): candidate pass on the bf16 matrix pipe; results stay exact
   void *idxp16 = nullptr;    // bf16 fragment copy of the index (built on demand)
@@ -118,6 +121,7 @@ struct sse_handle {
   // scratch
   DevBuf s_ids, s_out, s_q, s_qp, s_ps, s_pi, s_cert, s_os, s_oi, s_tmp, s_tmp2, s_feat, s_zero, s_map;
   DevBuf s_qp32, s_fb_cnt;  // fp32 second chance of the bf16 candidate pass: fp32 query fragments, counter
+  DevBuf s_persist;  // lstm_persist.hip: h_t / raw-encoding exchange buffers and arrival counters
   DevBuf s_pb, s_cthr, s_cslot, s_ccnt, s_cbuf;  // per-split bounds; collect path: thresholds, slots, counters, row buffers
   const int32_t *cur_row_map = nullptr;  // set by sse_encode around its launch
   // training
@@ -414,7 +418,58 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
   Encoder &e = h->enc[side];
   if (e.kernel < 0) return fail(h, "network mode has no %s sequence encoder (sse_model.py:231-233)", side ? "target" : "source");
   if (ensure_packed(h, st)) return 1;
-  if (B <= h->lstm_small_rows && !h->cur_row_map && lstm_small_lds_bytes(c.embedding_size, e.H, c.encoding_size) <= 160 * 1024) {
+  const bool small_ok = !h->cur_row_map && lstm_small_lds_bytes(c.embedding_size, e.H, c.encoding_size) <= 160 * 1024;
+  if (small_ok && B <= h->lstm_persist_rows && B <= lstm_persist_max_rows() && T <= lstm_persist_max_steps()) {
+    // one to a few queries (sse_demo / webserver): a cluster of workgroups with the weights resident in LDS, see
+    // lstm_persist.hip.  Needs every workgroup of the launch resident at once: at most half the CUs are asked for.
+    const int nwg = lstm_persist_nwg(c.embedding_size, e.H, c.encoding_size);
+    if (h->cu_count == 0) {
+      hipDeviceProp_t prop;
+      HIPCHECK(h, hipGetDeviceProperties(&prop, c.device));
+      h->cu_count = prop.multiProcessorCount;
+    }
+    if (nwg > 0 && 8 * nwg * 2 <= h->cu_count) {
+      if (ensure_waug(h, side, st)) return 1;
+      LstmSmallArgs sa;
+      fill_small_args(h, e, sa);
+      LstmPersistArgs pa;
+      pa.emb = sa.emb;
+      pa.Waug = sa.Waug;
+      pa.M = sa.M;
+      pa.err = sa.err;
+      pa.V = sa.V;
+      pa.E = sa.E;
+      pa.H = sa.H;
+      pa.S = sa.S;
+      pa.pad_stride = sa.pad_stride;
+      pa.ids = ids;
+      pa.out = out;
+      pa.B = B;
+      pa.T = T;
+      pa.map_mode = getenv("SSE_PERSIST_MAP") ? atoi(getenv("SSE_PERSIST_MAP")) : 0;
+      pa.normalize = normalize ? 1 : 0;
+      if (h->pad_skip && T > 1) {
+        if (ensure_pad_table_small(h, side, T, st)) return 1;  // same arithmetic, same table
+        Encoder &own = e.shares_lstm_with >= 0 ? h->enc[e.shares_lstm_with] : e;
+        pa.pad_h = own.pad_h_small;
+        pa.pad_c = own.pad_c_small;
+      }
+      const size_t nhx = lstm_persist_hx_words(e.H), nraw = lstm_persist_raw_words(c.encoding_size);
+      const size_t need = (nhx + nraw) * sizeof(unsigned long long);
+      if (h->persist_epoch == 0 || h->persist_epoch >= (1u << 20) - 1 || need > h->s_persist.cap) {
+        // fresh (or re-sized, or the 20-bit epoch ran out): all tags to "never written"
+        if (reserve(h, h->s_persist, need)) return 1;
+        HIPCHECK(h, hipMemsetAsync(h->s_persist.p, 0, h->s_persist.cap, st));
+        h->persist_epoch = 0;
+      }
+      pa.epoch = ++h->persist_epoch;
+      pa.hx = (unsigned long long *)h->s_persist.p;
+      pa.rawx = pa.hx + nhx;
+      HIPCHECK(h, launch_lstm_persist(pa, st));
+      return 0;
+    }
+  }
+  if (B <= h->lstm_small_rows && small_ok) {
     // a handful of sequences (demo / web query, last batch of an index build): GEMV on the vector ALUs, see lstm_small.hip
     if (ensure_waug(h, side, st)) return 1;
     LstmSmallArgs sa;
@@ -458,6 +513,8 @@ int check_err_flag(sse_handle *h, hipStream_t st) {
     HIPCHECK(h, hipMemsetAsync(h->err_flag, 0, sizeof(int32_t), st));
     if (flag & 1) return fail(h, "token id out of range [0, %d) (tf.gather would raise; sse_model.py:163-164)", h->cfg.vocab_size);
     if (flag & 2) return fail(h, "corpus row out of range in a train step by rows");
+    if (flag & 4) return fail(h, "LSTM cluster kernel: a workgroup of a cluster did not arrive (device oversubscribed?); "
+                                 "set option lstm_persist_rows to 0");
     return fail(h, "device error flag 0x%x", flag);
   }
   return 0;
@@ -1040,6 +1097,11 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value) {
   }
   if (strcmp(name, "pad_skip") == 0) {
     h->pad_skip = value != 0;
+    return 0;
+  }
+  if (strcmp(name, "lstm_persist_rows") == 0) {
+    if (value < 0) return fail(h, "lstm_persist_rows must be >= 0");
+    h->lstm_persist_rows = (int)value;
     return 0;
   }
   if (strcmp(name, "lstm_small_rows") == 0) {

@@ -82,6 +82,31 @@ size_t lstm_small_waug_floats(int E, int H);
 hipError_t launch_pack_lstm_small(const float *K, const float *b, int E, int H, float *out, hipStream_t stream);
 hipError_t launch_lstm_small(const LstmSmallArgs &a, hipStream_t stream);
 
+// a handful of sequences with the recurrent weights resident in LDS (lstm_persist.hip): a cluster of NWG workgroups per
+// 4 sequences, h_t exchanged through global memory every step
+struct LstmPersistArgs {
+  const int32_t *ids;    // [B][T]
+  const float *emb;      // word_embedding [V][E] (master variable)
+  const float *Waug;     // [KA][4H] as for lstm_small.hip
+  const float *M;        // projection [H][S] (master variable)
+  float *out;            // [B][S]
+  int32_t *err;          // bit 0: token id out of range; bit 2: a cluster workgroup never arrived (bounded spin)
+  int32_t B, T, V, E, H, S, normalize;
+  const float *pad_h = nullptr, *pad_c = nullptr;  // the pad-prefix table of lstm_small.hip (same arithmetic)
+  int32_t pad_stride = 0;
+  unsigned long long *hx = nullptr;    // [8][2][4][H] h_t exchange, {value, tag} words (lstm_persist_hx_words)
+  unsigned long long *rawx = nullptr;  // [8][4][S] raw encodings exchange (lstm_persist_raw_words)
+  uint32_t epoch = 0;           // 1 .. 2^20-1, different for every launch on the same exchange buffers
+  int32_t NWG = 0;              // set by the launcher
+  int32_t map_mode = 0;         // 0: cluster = blockIdx % 8 (one XCD per cluster); 1: consecutive blocks (measurement aid)
+};
+int lstm_persist_nwg(int E, int H, int S);   // workgroups per cluster, 0: shape not supported
+int lstm_persist_max_rows();
+int lstm_persist_max_steps();
+size_t lstm_persist_hx_words(int H);
+size_t lstm_persist_raw_words(int S);
+hipError_t launch_lstm_persist(const LstmPersistArgs &a, hipStream_t stream);
+
 // ------------------------------ scoring ------------------------------------
 struct ScoreArgs {
   const float *idxp;     // packed index  [NT][KG][256]  (frag32, rows = targets)

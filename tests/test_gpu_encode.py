@@ -30,6 +30,8 @@ def test_encode_matches_oracle(mode, V, E, Hs, Ht, S, T, B, small_rows):
     params = model_params(mode, V, E, Hs, Ht, S, T)
     m, p = make_pair(params, seed=1)
     m.handle.set_option("lstm_small_rows", small_rows)
+    if small_rows == 0:
+        m.handle.set_option("lstm_persist_rows", 0)       # matrix kernel only
     rng = np.random.RandomState(3)
     ids = random_ids(rng, B, T, V, pad_frac=0.7)
     sides = ("src", "tgt") if mode != "source-encoder-only" else ("src",)
@@ -105,6 +107,7 @@ def test_large_batch_property_rows_independent():
     assert np.allclose(np.linalg.norm(big, axis=1), 1.0, atol=1e-5)
     pick = rng.choice(len(ids), 96, replace=False)
     m.handle.set_option("lstm_small_rows", 0)        # matrix kernel for the small batch too
+    m.handle.set_option("lstm_persist_rows", 0)
     small = m.encode_source(ids[pick])
     assert np.array_equal(small, big[pick])          # bit-identical: no cross-row coupling
     # the few-sequences kernel (same fma chains in the same order on the vector ALUs) agrees to the last bits
@@ -115,8 +118,52 @@ def test_large_batch_property_rows_independent():
     assert np.array_equal(few, small)
     one = np.concatenate([m.encode_source(ids[pick[i:i + 1]]) for i in range(8)])
     assert np.array_equal(one, few[:8])              # and is itself independent of the batch it runs in
+    # the weights-in-LDS cluster kernel (<= 32 rows): the same bits again, alone and in a batch
+    m.handle.set_option("lstm_persist_rows", 32)
+    one = np.concatenate([m.encode_source(ids[pick[i:i + 1]]) for i in range(4)])
+    assert np.array_equal(one, few[:4])
+    assert np.array_equal(m.encode_source(ids[pick[:29]]), few[:29])
     want = O.encode(p, params, "src", ids[pick[:16]])
     assert np.abs(small[:16] - want).max() <= TOL
+
+
+@pytest.mark.parametrize("mode,V,E,Hs,Ht,S,T", [
+    ("dual-encoder", 500, 50, 256, 256, 256, 32),          # configs[1]: 16 workgroups x 16 units
+    ("shared-encoder", 300, 50, 96, 96, 64, 80),           # reference defaults: 6 units per workgroup
+    ("dual-encoder", 200, 50, 512, 300, 128, 12),          # 32 workgroups per cluster; 300 = 19 units each, uneven tail
+    ("dual-encoder", 90, 8, 16, 40, 512, 9),               # tiny cells, widest encoding
+])
+def test_cluster_kernel_equals_the_other_kernels(mode, V, E, Hs, Ht, S, T):
+    """lstm_persist.hip (weights resident in LDS, h_t exchanged between the workgroups of a cluster every step) for
+    1 .. 32 rows: bit-identical to the few-sequences kernel (which the matrix kernel equals), with and without the
+    pad-prefix skip, within the encoder tolerance of the oracle."""
+    params = model_params(mode, V, E, Hs, Ht, S, T)
+    m, p = make_pair(params, seed=8)
+    rng = np.random.RandomState(2)
+    for B in (1, 3, 4, 5, 17, 32):
+        ids = random_ids(rng, B, T, V, pad_frac=0.6)
+        if B == 5:
+            ids[2, :] = 0
+            ids[2, -1] = 1                                 # only EOS
+            ids[4] = rng.randint(2, V, size=T)             # no padding at all
+        for side, enc in (("src", m.encode_source), ("tgt", m.encode_target)):
+            for normalize in (True, False):
+                m.handle.set_option("lstm_persist_rows", 0)
+                ref = enc(ids, normalize=normalize)
+                m.handle.set_option("lstm_persist_rows", 32)
+                got = enc(ids, normalize=normalize)
+                assert np.array_equal(got, ref), (B, side, normalize, np.abs(got - ref).max())
+                m.handle.set_option("pad_skip", 0)
+                assert np.array_equal(enc(ids, normalize=normalize), ref)
+                m.handle.set_option("pad_skip", 1)
+        want = O.encode(p, params, "src", ids)
+        assert np.abs(m.encode_source(ids) - want).max() <= TOL
+    import sse_amd
+    bad = random_ids(rng, 2, T, V)
+    bad[1, -1] = V
+    with pytest.raises(sse_amd.SSEError):
+        m.encode_source(bad)
+    assert np.isfinite(m.encode_source(random_ids(rng, 2, T, V))).all()
 
 
 def test_pad_prefix_skip_is_bit_identical_and_survives_weight_updates():

@@ -76,7 +76,8 @@ for n_idx in (571, N):
     hh.index_set_dev(t.data_ptr(), n_idx, S)
     del t
     for name, ids in (("dense T=32", dense), ("8 tokens", short)):
-        for small in (1024, 0):
+        for kern, persist, small in (("cluster (weights in LDS)", 32, 1024), ("few-sequences", 0, 1024), ("matrix", 0, 0)):
+            hh.set_option("lstm_persist_rows", persist)
             hh.set_option("lstm_small_rows", small)
             hh.encode_score_topk(0, ids, False, 10)
             t0 = time.perf_counter()
@@ -88,17 +89,20 @@ for n_idx in (571, N):
                 hh.encode(0, ids, False)
             de = (time.perf_counter() - t1) / 20
             print("Q=1 end to end (%s, N=%d, %s LSTM kernel): %.3f ms per query (encode alone %.3f ms, host buffers both ways)"
-                  % (name, n_idx, "few-sequences" if small else "matrix", dt * 1e3, de * 1e3))
-# batch-size sweep of the encoder alone, both kernels
+                  % (name, n_idx, kern, dt * 1e3, de * 1e3))
+# batch-size sweep of the encoder alone, the three kernels
 for B in (1, 4, 32, 128, 256, 512, 1024):
     ids = rng.randint(2, V, size=(B, T)).astype(np.int32)
     ids[:, -1] = 1
     line = "encode B=%d dense T=32:" % B
-    for small in (4096, 0):
+    for kern, persist, small in (("cluster", 32, 4096), ("few-seq", 0, 4096), ("matrix", 0, 0)):
+        if kern == "cluster" and B > 32:
+            continue
+        hh.set_option("lstm_persist_rows", persist)
         hh.set_option("lstm_small_rows", small)
         hh.encode(0, ids, True)
         t0 = time.perf_counter()
         for _ in range(10):
             hh.encode(0, ids, True)
-        line += "  %s %.3f ms" % ("few-seq" if small else "matrix", (time.perf_counter() - t0) / 10 * 1e3)
+        line += "  %s %.3f ms" % (kern, (time.perf_counter() - t0) / 10 * 1e3)
     print(line)
