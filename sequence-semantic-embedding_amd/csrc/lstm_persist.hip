@@ -104,22 +104,47 @@ __global__ __launch_bounds__(LP_NT) void lstm_persist_kernel(LstmPersistArgs a) 
 
   // ---- this workgroup's weight columns into LDS, once.  Row (g, u) holds column g*H + u0 + u of Waug with k in the
   // order the fma chain consumes it: within a k-group of 8, position 2e holds k = e and 2e + 1 holds k = 4 + e.
-  // (8 loads in flight per thread: one load -> store round trip per element would cost more than the whole encode)
-  for (int i0 = 0; i0 < 4 * UW * KA; i0 += 8 * LP_NT) {
-    float wv8[8];
+  // (several loads in flight per thread: one load -> store round trip per element would cost more than the whole encode)
+  if ((UW & 3) == 0 && (H & 3) == 0) {
+    // 16-byte loads: 4 consecutive units of one gate at one k
+    const int Q = UW / 4, n4 = 4 * Q * KA;  // float4 pieces: (k, gate, unit quad)
+    for (int i0 = 0; i0 < n4; i0 += 4 * LP_NT) {
+      f32x4 w4[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int i = i0 + j * LP_NT + tid;
-      const int k = i / (4 * UW), r = i - k * (4 * UW);  // consecutive threads: consecutive columns of one k row
-      const int g = r / UW, u = r - g * UW;
-      wv8[j] = (i < 4 * UW * KA && u < nu) ? a.Waug[(size_t)k * N4 + g * H + u0 + u] : 0.0f;
+      for (int j = 0; j < 4; ++j) {
+        const int i = i0 + j * LP_NT + tid;
+        const int k = i / (4 * Q), r = i - k * (4 * Q), g = r / Q, q = r - g * Q;
+        w4[j] = f32x4{0, 0, 0, 0};
+        if (i < n4 && q * 4 < nu) w4[j] = *reinterpret_cast<const f32x4 *>(a.Waug + (size_t)k * N4 + g * H + u0 + q * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = i0 + j * LP_NT + tid;
+        const int k = i / (4 * Q), r = i - k * (4 * Q), g = r / Q, q = r - g * Q;
+        const int kk = k & 7, pos = (k & ~7) + ((kk & 3) << 1) + (kk >> 2);
+        if (i < n4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) Wl[(size_t)(g * UW + q * 4 + e) * KAp + pos] = (q * 4 + e < nu) ? w4[j][e] : 0.0f;
+        }
+      }
     }
+  } else {
+    for (int i0 = 0; i0 < 4 * UW * KA; i0 += 8 * LP_NT) {
+      float wv8[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int i = i0 + j * LP_NT + tid;
-      const int k = i / (4 * UW), r = i - k * (4 * UW);
-      const int kk = k & 7, pos = (k & ~7) + ((kk & 3) << 1) + (kk >> 2);
-      if (i < 4 * UW * KA) Wl[(size_t)r * KAp + pos] = wv8[j];
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + j * LP_NT + tid;
+        const int k = i / (4 * UW), r = i - k * (4 * UW);  // consecutive threads: consecutive columns of one k row
+        const int g = r / UW, u = r - g * UW;
+        wv8[j] = (i < 4 * UW * KA && u < nu) ? a.Waug[(size_t)k * N4 + g * H + u0 + u] : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + j * LP_NT + tid;
+        const int k = i / (4 * UW), r = i - k * (4 * UW);
+        const int kk = k & 7, pos = (k & ~7) + ((kk & 3) << 1) + (kk >> 2);
+        if (i < 4 * UW * KA) Wl[(size_t)r * KAp + pos] = wv8[j];
+      }
     }
   }
   for (int i = tid; i < LP_RB * KAp; i += LP_NT) {
