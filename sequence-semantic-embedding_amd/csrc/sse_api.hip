@@ -76,7 +76,7 @@ struct TrainState {
   bool rows_mode = false;  // set by the *_rows entry points around train_grads_locked
   // paired batches (data.py:95-115: every source row appears twice, once with its positive and once with a negative
   // target): internal row order = [rows 0,2,4,.. | rows 1,3,5,..], the source encoder runs on the first half only
-  DevBuf ids_raw[2], perm;
+  DevBuf ids_raw[2], perm, hot_part[2];
   int perm_B = 0;
   std::vector<int32_t> h_perm, h_rows[2], h_tgt;
   std::vector<float> h_labels;
@@ -1582,8 +1582,10 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     HIPCHECK(h, launch_dk((const float *)ts.tape_a[s].p, (const float *)ts.dg_b[s].p, (float *)ts.dk_part[s].p, RGa, KT, NTn, SL,
                           E, e.H, Hp, accumulate, h->vars[e.kernel].grad, half ? NT_half * 4 : 0, bs));
     HIPCHECK(h, launch_db_reduce((const float *)ts.db_part[s].p, NT32, e.H, Hp, accumulate, h->vars[e.bias].grad, bs));
+    if (reserve(h, ts.hot_part[s], (size_t)T * NT32 * 2 * 64 * sizeof(float))) return 1;
     HIPCHECK(h, launch_dx((const float *)ts.dg_a[s].p, ts.KxT[s], (const int32_t *)ts.ids[s].p, emb.grad,
-                          (float *)ts.sq_part.p + (size_t)s * T * NT32, T, NT32, KGn, B, E, V, e.H, bs));
+                          (float *)ts.sq_part.p + (size_t)s * T * NT32, (float *)ts.hot_part[s].p, T, NT32, KGn, B, E, V,
+                          e.H, bs));
     if (!shared || s == 1) {
       HIPCHECK(h, hipEventRecord(ts.ev_join[s], bs));
       HIPCHECK(h, hipStreamWaitEvent(st, ts.ev_join[s], 0));

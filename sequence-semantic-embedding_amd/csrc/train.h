@@ -15,8 +15,9 @@ int dk_slices(int RG);
 hipError_t launch_dk(const float *tape_a, const float *dg_b, float *part, int RG, int KT, int NTn, int SL, int E, int H,
                      int Hp, int accumulate, float *dK, int pair_rg /* 0: dg_b has RG r-groups */, hipStream_t st);
 hipError_t launch_db_reduce(const float *db_part, int NT32, int H, int Hp, int accumulate, float *db, hipStream_t st);
-hipError_t launch_dx(const float *dg_a, const float *KxT, const int32_t *ids, float *d_emb, float *sq_part, int T,
-                     int NT32, int KGn, int B, int E, int V, int H, hipStream_t st);
+hipError_t launch_dx(const float *dg_a, const float *KxT, const int32_t *ids, float *d_emb, float *sq_part,
+                     float *hot_part /* [T*NT32][2][64] floats */, int T, int NT32, int KGn, int B, int E, int V, int H,
+                     hipStream_t st);
 hipError_t launch_sumsq(const float *g, int64_t n, float *part, int nblocks, hipStream_t st);
 hipError_t launch_sum(const float *part, int n, float tag, float *out /* out[0]=sum, out[3]=tag */, hipStream_t st);
 hipError_t launch_clip_scale(const float *part, int n, float clip, float *scal, hipStream_t st);

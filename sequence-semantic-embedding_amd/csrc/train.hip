@@ -339,7 +339,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
       const float *kb = a.KhT + (size_t)(wn * UB) * KGn * 256 + lane * 4;
       // Kh^T fragments come from L2 (~1-2 k cycles): keep PF k-groups (PF*4*UB MFMAs) of them in flight
       // in a register ring; the dg fragments come from LDS one k-group ahead.  KGn % PF == 0.
-      constexpr int PF = 2;
+      constexpr int PF = (NW == 4) ? 4 : 2;  // Hp = 128 runs one wave per SIMD with registers to spare: a deeper ring
       f32x4 bq[PF][UB], aq[2];
       // reduction index n = gate*Hp + unit: only the k-groups of units < H can be non-zero -> walk
       // 4 gates x KGl live k-groups (logical index i -> physical k-group); 4*KGl is even
@@ -544,6 +544,7 @@ struct DxArgs {
   float *sq_part;      // [T*NT32] partial sums of dx^2
   int32_t T, NT32, KGn, B, E, V;
   int32_t KGl;         // live k-groups per gate = ceil(H/8) (dG columns of padded units are 0)
+  float *hot_part;     // [T*NT32][2][64] this block's sums for the ids 0 (PAD) and 1 (EOS): no atomics for them
 };
 
 __global__ __launch_bounds__(64) void dx_kernel(DxArgs a) {
@@ -583,28 +584,92 @@ __global__ __launch_bounds__(64) void dx_kernel(DxArgs a) {
       rb1[d] = *reinterpret_cast<const f32x4 *>(pb + (size_t)(a.KGn + kn) * 256);
     }
   }
+  // Scatter-add into the dense embedding gradient.  Real batches are left-padded and end in EOS: at most steps most
+  // rows of a tile carry the same id (PAD = 0, EOS = 1), and 8192 rows x 50 columns of float atomics on ONE embedding
+  // row per step serialise in L2 (measured: 0.36 ms with random ids, 0.7 - 2.1 ms with just an EOS column).  So
+  //  * rows of this lane's half that repeat an earlier id are first added onto that row's value (selects, no dynamic
+  //    register indexing): one atomic per distinct id of the half;
+  //  * ids 0 and 1 take no atomics at all: the block's sum for each goes to hot_part[block] and dx_hot_reduce_kernel
+  //    adds the blocks in fixed order.
+  // The squared norm is taken over the un-merged rows (TF: un-deduplicated IndexedSlices).
   float sq = 0.0f;
+  int idr[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int b = tile * 32 + mfma_row(r, lane);
+    int id = -1;
     if (b < a.B) {
-      const int id = a.ids[(size_t)b * a.T + t];
-      if (id >= 0 && id < a.V) {
+      id = a.ids[(size_t)b * a.T + t];
+      if (id < 0 || id >= a.V) id = -1;  // flagged by the forward pass
+    }
+    idr[r] = id;
+    if (id >= 0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int e = j * 32 + (lane & 31);
-          if (e < a.E) {
-            const float v = acc[j][r];
-            sq += v * v;
-            atomicAdd(a.d_emb + (size_t)id * a.E + e, v);
-          }
-        }
+      for (int j = 0; j < 2; ++j)
+        if (j * 32 + (lane & 31) < a.E) sq += acc[j][r] * acc[j][r];
+    }
+  }
+  // leaders: row r is merged into the first earlier row r2 of this half with the same id
+#pragma unroll
+  for (int r = 15; r > 0; --r) {
+    bool merged = false;
+#pragma unroll
+    for (int r2 = 0; r2 < r; ++r2) {
+      const bool hit = !merged && idr[r] >= 0 && idr[r2] == idr[r];
+      acc[0][r2] += hit ? acc[0][r] : 0.0f;
+      acc[1][r2] += hit ? acc[1][r] : 0.0f;
+      merged = merged || hit;
+    }
+    if (merged) idr[r] = -1;
+  }
+#pragma unroll
+  for (int hid = 0; hid < 2; ++hid) {
+    float h0 = 0.0f, h1 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool is = idr[r] == hid;  // at most one leader per half
+      h0 += is ? acc[0][r] : 0.0f;
+      h1 += is ? acc[1][r] : 0.0f;
+      if (is) idr[r] = -1;
+    }
+    h0 += __shfl_xor(h0, 32);
+    h1 += __shfl_xor(h1, 32);
+    if (lane < 32) {
+      float *hp = a.hot_part + ((size_t)blockIdx.x * 2 + hid) * 64;
+      hp[lane] = h0;
+      hp[32 + lane] = h1;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (idr[r] >= 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int e = j * 32 + (lane & 31);
+        if (e < a.E) atomicAdd(a.d_emb + (size_t)idr[r] * a.E + e, acc[j][r]);
       }
     }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
   if (lane == 0) a.sq_part[blockIdx.x] = sq;
+}
+
+// d_emb[hid][e] += sum over blocks of hot_part[block][hid][e], blocks in fixed order (one workgroup per hot id)
+__global__ __launch_bounds__(256) void dx_hot_reduce_kernel(const float *hot_part, int nblocks, int E, int V, float *d_emb) {
+  __shared__ float red[4][64];
+  const int hid = blockIdx.x, e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  float part[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 8 loads in flight per thread
+  for (int b0 = sl; b0 < nblocks; b0 += 32) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int b = b0 + 4 * j;
+      part[j] += (b < nblocks) ? hot_part[((size_t)b * 2 + hid) * 64 + e] : 0.0f;
+    }
+  }
+  red[sl][e] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+  __syncthreads();
+  if (sl == 0 && e < E && hid < V) atomicAdd(d_emb + (size_t)hid * E + e, (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]));
 }
 
 // ---------------------------------------------------------------------------
@@ -746,11 +811,13 @@ hipError_t launch_db_reduce(const float *db_part, int NT32, int H, int Hp, int a
   return hipGetLastError();
 }
 
-hipError_t launch_dx(const float *dg_a, const float *KxT, const int32_t *ids, float *d_emb, float *sq_part, int T,
-                     int NT32, int KGn, int B, int E, int V, int H, hipStream_t st) {
+hipError_t launch_dx(const float *dg_a, const float *KxT, const int32_t *ids, float *d_emb, float *sq_part,
+                     float *hot_part /* [T*NT32][2][64] */, int T, int NT32, int KGn, int B, int E, int V, int H,
+                     hipStream_t st) {
   const int KGg = KGn / 4;
-  DxArgs a{dg_a, KxT, ids, d_emb, sq_part, T, NT32, KGn, B, E, V, (H + 7) / 8 < KGg ? (H + 7) / 8 : KGg};
+  DxArgs a{dg_a, KxT, ids, d_emb, sq_part, T, NT32, KGn, B, E, V, (H + 7) / 8 < KGg ? (H + 7) / 8 : KGg, hot_part};
   hipLaunchKernelGGL(dx_kernel, dim3(T * NT32), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(dx_hot_reduce_kernel, dim3(2), dim3(256), 0, st, hot_part, T * NT32, E, V, d_emb);
   return hipGetLastError();
 }
 

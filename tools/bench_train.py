@@ -29,6 +29,13 @@ for B in [int(x) for x in (sys.argv[1:] or ["128", "1024", "8192"])]:
     else:
         src = np.repeat(rng.randint(2, V, size=(B // 2, T)).astype(np.int32), 2, axis=0)   # data.py:95-115: pos,neg share a source
     tgt = rng.randint(2, V, size=(B, T)).astype(np.int32)
+    if os.environ.get("SSE_TRAIN_REALISTIC"):          # left padding (half the positions on average) and EOS, as data.py pads
+        for arr in (src, tgt):
+            arr[:, -1] = 1
+            lens = rng.randint(2, T, size=arr.shape[0])
+            if arr is src:
+                lens = np.repeat(lens[0::2], 2)[:arr.shape[0]]
+            arr[np.arange(T)[None, :] < (T - lens)[:, None]] = 0
     z = np.tile(np.array([1.0, 0.0], np.float32), B // 2)
     for _ in range(3):
         m.train_step(src, tgt, z)

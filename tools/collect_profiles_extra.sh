@@ -27,5 +27,7 @@ pmc hbm WRITE_SIZE python "$root/tools/bench_hbm_kernels.py"
 run cnn python "$root/tools/bench_cnn.py"
 SSE_TRAIN_SERIAL=1 run train python "$root/tools/bench_train.py" 8192
 run train_default python "$root/tools/bench_train_default.py"
+run query_encode python "$root/tools/bench_query_encode.py"
+run train_concurrent python "$root/tools/bench_train.py" 128 1024 8192
 find "$out" -name "*.csv" -size +20M -delete
 ls "$out"

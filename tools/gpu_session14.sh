@@ -1,0 +1,8 @@
+#!/bin/bash
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+o=$GRAFT_REPO_ROOT/gpurun_out/s14; mkdir -p $o
+timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_fullsize.py tests/test_gpu_cli.py -m gpu -q -x -k "train or cli" > $o/tests.log 2>&1; echo "rc=$?" >> $o/tests.log; tail -6 $o/tests.log
+echo "== random ids"; timeout 300 python tools/bench_train.py 128 1024 8192 2>&1 | grep -v amdgpu.ids
+echo "== realistic ids (left padding + EOS)"; SSE_TRAIN_REALISTIC=1 timeout 300 python tools/bench_train.py 128 1024 8192 2>&1 | grep -v amdgpu.ids
+timeout 300 python tools/bench_train_default.py 2>&1 | grep -v amdgpu.ids
