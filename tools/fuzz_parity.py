@@ -28,16 +28,21 @@ def main(n_cases=40, seed=0, verbose=True):
         Ht = Hs if mode == "shared-encoder" else int(rng.choice([7, 64, 96, 128, 256]))
         S = int(rng.choice([2, 16, 50, 64, 100, 256]))
         T = int(rng.choice([5, 6, 13, 32, 50, 80]))
-        B = int(rng.choice([1, 2, 3, 31, 33, 64, 65, 200]))
+        B = int(rng.choice([1, 2, 3, 5, 31, 33, 64, 65, 128, 200, 256]))
         N = int(rng.choice([1, 5, 33, 571]))
         pad = float(rng.choice([0.0, 0.5, 0.95]))
         params = model_params(mode, V, E, Hs, Ht, S, T, N=N, lr=0.5)
-        tag = "%s V=%d E=%d Hs=%d Ht=%d S=%d T=%d B=%d N=%d pad=%.2f" % (mode, V, E, Hs, Ht, S, T, B, N, pad)
+        bf16 = bool(mode == "source_only_cnn" and rng.rand() < 0.4)     # mixed-precision CNN (option cnn_bf16)
+        paired = bool(rng.rand() < 0.5)                                  # train batch of (pos, neg) pairs sharing the source
+        tag = "%s V=%d E=%d Hs=%d Ht=%d S=%d T=%d B=%d N=%d pad=%.2f%s%s" % (mode, V, E, Hs, Ht, S, T, B, N, pad,
+                                                                              " bf16" if bf16 else "", " paired" if paired else "")
         try:
             m, p = make_pair(params, seed=int(rng.randint(1 << 30)))
+            if bf16:
+                m.handle.set_option("cnn_bf16", 1)
             src = random_ids(rng, B, T, V, pad)
             for normalize in (True, False):
-                want = O.encode(p, params, "src", src, normalize=normalize)
+                want = O.encode(p, params, "src", src, normalize=normalize, cnn_bf16=bf16)
                 got = m.encode_source(src, normalize=normalize)
                 err = float(np.abs(got - want).max() / max(1.0, np.abs(want).max()))
                 worst["enc" if normalize else "raw"] = max(worst["enc" if normalize else "raw"], err)
@@ -70,11 +75,11 @@ def main(n_cases=40, seed=0, verbose=True):
             if Hs <= 256 and Ht <= 256 and B >= 2:
                 Bt = B - B % 2
                 z = np.tile(np.array([1.0, 0.0], np.float32), Bt // 2)
-                tsrc = src[:Bt]
+                tsrc = np.repeat(src[:Bt // 2], 2, axis=0) if paired else src[:Bt]
                 ttgt = (rng.randint(0, N, size=Bt).astype(np.int32) if mode in ("source_only_cnn", "source-encoder-only")
                         else random_ids(rng, Bt, T, V, pad))
                 st = O.new_optimizer_state(p)
-                wl, wa = O.train_step(p, st, params, tsrc, ttgt, z, 0.5)
+                wl, wa = O.train_step(p, st, dict(params, cnn_bf16=bf16), tsrc, ttgt, z, 0.5)
                 m.handle.learning_rate = 0.5
                 gl, ga = m.train_step(tsrc, ttgt, z)
                 assert abs(gl - float(wl)) < 1e-4 * max(1.0, abs(float(wl))), ("loss", gl, wl)
