@@ -1,0 +1,434 @@
+// LSTM sequence encoder forward on the bf16 matrix pipe with SPLIT operands ("bf16x3"), gfx950 -- OPT-IN (option
+// "lstm_x3"): NOT the exact fp32 arithmetic of lstm_fwd.hip, but inside the encoder tolerance by two orders of magnitude.
+//
+// v_mfma_f32_32x32x2_f32 runs at the vector rate (157 TF); v_mfma_f32_32x32x16_bf16 at 16x that.  Every fp32 operand is
+// written as hi + lo with hi = bf16(x), lo = bf16(x - hi) (x = hi + lo to 2^-18 relative), and a product a*b becomes the
+// three bf16 MFMAs  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  accumulated in fp32 -- the dropped a_lo*b_lo term is <= 2^-18 of
+// the product.  3 MFMAs of 32 cycles per 16 k against 8 of 64 cycles: 5.3x less matrix-pipe time for a relative error
+// of ~4e-6 per product (fp32: 6e-8), i.e. encodings within ~1e-5 of the fp32 path (north-star budget 1e-3; SURVEY 7
+// "a bf16-input variant must be parity-qualified against the 1e-3 cosine budget": tests/test_gpu_encode.py).
+//
+// Structure = lstm_fwd.hip's inference configuration <2,2,1>: one 512-thread workgroup per 64 sequences, wave w owns
+// hidden units [32w, 32w+32) for both 32-row tiles, weights are the MFMA's A operand (an accumulator lane owns ONE
+// sequence and 16 units), gates in two passes (i,j then f,o), sigmoid(i)*tanh(j) parked in the lane's own slots of the
+// other h buffer, the bias through a constant-1 embedding column.  What differs:
+//  * operands are bf16 fragments (lane = row & 31, k octet = lane >> 5: 8 consecutive k = 16 bytes), each in a hi and
+//    a lo copy: the kernel matrix is packed once per weight update (pack_lstm_x3_kernel), the embedding table split
+//    once (split_emb_x3_kernel), h_t is split as it is produced;
+//  * the k order of the h part is chosen so that a lane's 16 accumulator registers ARE two whole octets: registers
+//    0..7 of lane (n, half) go to octet (group 2*ub, half), registers 8..15 to (group 2*ub + 1, half) -- h_t leaves the
+//    wave as 16-byte conflict-free stores, no cross-lane exchange; the packed kernel rows follow the same permutation;
+//  * the last step leaves h_T in fp32 (the frag32 layout of lstm_fwd.hip: the same four 16-byte slots per lane), and
+//    the projection + l2-normalise tail is the exact fp32 code of lstm_fwd.hip.
+// Hp = 256 (cell sizes 129..256) only; no left-pad prefix skip (all T steps run).
+#include "sse_kernels.h"
+
+#define X3_THREADS 512
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float x3_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504089f * x)); }
+__device__ __forceinline__ float x3_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008178f * x)); }
+
+__host__ __device__ static inline unsigned short x3_bf16(float f) {  // round to nearest even (finite inputs)
+  unsigned u;
+  __builtin_memcpy(&u, &f, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__host__ __device__ static inline float x3_f32(unsigned short h) {
+  const unsigned u = (unsigned)h << 16;
+  float f;
+  __builtin_memcpy(&f, &u, 4);
+  return f;
+}
+
+// 8 fp32 -> the hi and lo octets (16 bytes each)
+__device__ __forceinline__ void x3_split8(const float (&v)[8], u32x4 &hi, u32x4 &lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned short h0 = x3_bf16(v[2 * i]), h1 = x3_bf16(v[2 * i + 1]);
+    const unsigned short l0 = x3_bf16(v[2 * i] - x3_f32(h0)), l1 = x3_bf16(v[2 * i + 1] - x3_f32(h1));
+    hi[i] = (unsigned)h0 | ((unsigned)h1 << 16);
+    lo[i] = (unsigned)l0 | ((unsigned)l1 << 16);
+  }
+}
+
+// LDS (bytes): x [2 row tiles][KGX][hi|lo][1 KiB] (single-buffered) | h [2 bufs][2 row tiles][KGH = 16][hi|lo][1 KiB] | red
+size_t lstm_x3_lds_bytes(int KGX) { return (size_t)2 * KGX * 2048 + (size_t)2 * 2 * 16 * 2048 + 1024; }
+
+__global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  constexpr int KGH = 16;  // h groups of 16 units (Hp = 256)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // unit block of this wave
+  const int KGX = a.KGX, KG = KGX + KGH, T = a.T;
+  const int KGHe = min(KGH, (a.H + 15) / 16);  // h groups that can be non-zero
+  unsigned char *xbase = smem3;
+  unsigned char *hbase = smem3 + (size_t)2 * KGX * 2048;
+  float *red = reinterpret_cast<float *>(hbase + (size_t)2 * 2 * KGH * 2048);
+  auto xptr = [&](int mt) -> unsigned char * { return xbase + (size_t)mt * KGX * 2048; };
+  auto hptr = [&](int buf, int mt) -> unsigned char * { return hbase + (size_t)(buf * 2 + mt) * KGH * 2048; };
+  const int b0 = blockIdx.x * 64;
+
+  // x gather: thread (row xr, octet xq + 8*i): one 16-byte piece of the hi table and one of the lo table
+  const int xr = tid & 63, xq = tid >> 6;
+  const bool row_ok = (b0 + xr) < a.B;
+  const int32_t *id_row = a.ids + (size_t)(row_ok ? (a.row_map ? a.row_map[b0 + xr] : b0 + xr) : 0) * T;
+  const int EP = KGX * 16;  // columns of the split embedding table per copy
+  auto fetch_id = [&](int t) -> int {
+    int id = row_ok ? id_row[t] : 0;
+    if (id < 0 || id >= a.V) {
+      atomicOr(a.err, 1);
+      id = 0;
+    }
+    return id;
+  };
+  auto x_store = [&](int oc, u32x4 hi, u32x4 lo) {
+    unsigned char *dst = xptr(xr >> 5) + (size_t)(oc >> 1) * 2048 + (size_t)((oc & 1) * 32 + (xr & 31)) * 16;
+    *reinterpret_cast<u32x4 *>(dst) = hi;
+    *reinterpret_cast<u32x4 *>(dst + 1024) = lo;
+  };
+  {
+    const unsigned short *src = a.emb16 + (size_t)fetch_id(0) * 2 * EP;
+    for (int oc = xq; oc < 2 * KGX; oc += 8)
+      x_store(oc, *reinterpret_cast<const u32x4 *>(src + oc * 8), *reinterpret_cast<const u32x4 *>(src + EP + oc * 8));
+  }
+
+  f32x16 c[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[m][r] = 0.0f;
+  __syncthreads();
+
+  // weights: Wx3[unit block][k group][gate][hi|lo][1 KiB] through a buffer descriptor (voffset = 16 * lane)
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned short *>(a.Wx3), 0, 8 * KG * 8192, 0x00020000);
+  const int wvoff = lane * 16;
+  auto wl = [&](int soff) -> bf16x8 { return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff, soff, 0)); };
+
+  for (int t = 0; t < T; ++t) {
+    const bool have_next = (t + 1) < T;
+    u32x4 nhi = {0, 0, 0, 0}, nlo = {0, 0, 0, 0};
+    int nid = 0;
+    if (have_next) {
+      nid = fetch_id(t + 1);
+      if (xq < 2 * KGX) {
+        const unsigned short *src = a.emb16 + (size_t)nid * 2 * EP;
+        nhi = *reinterpret_cast<const u32x4 *>(src + xq * 8);
+        nlo = *reinterpret_cast<const u32x4 *>(src + EP + xq * 8);
+      }
+    }
+    const int cur = t & 1, nxt = (t + 1) & 1;
+    const unsigned char *xa[2], *ha[2];
+    unsigned char *hd[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      xa[m] = xptr(m) + lane * 16;
+      ha[m] = hptr(cur, m) + lane * 16;
+      hd[m] = hptr(nxt, m) + (size_t)w * 4096 + lane * 16;  // this lane's four 16-byte slots: groups 2w, 2w+1, hi | lo
+    }
+    const int kend = (t == 0) ? KGX : KGX + KGHe;  // h_{-1} = 0
+    const int wsoff = w * KG * 8192;
+
+    // one pass = two gates (byte offset g0 * 2048 inside a k group's 8 KiB), both row tiles, k groups [0, kend):
+    // per group 4 weight fragments (L2) + 4 activation fragments (LDS) -> 12 MFMAs; two named operand sets
+    auto a_frag = [&](int m, int kg, int hl) -> bf16x8 {
+      const unsigned char *p = kg < KGX ? xa[m] + (size_t)kg * 2048 : ha[m] + (size_t)(kg - KGX) * 2048;
+      return *reinterpret_cast<const bf16x8 *>(p + hl * 1024);
+    };
+    auto gemm = [&](int g0, f32x16 (&acc)[2][2]) {
+      bf16x8 wp[2][2], wq[2][2], ap[2][2], aq[2][2];  // [gate][hi|lo], [row tile][hi|lo]
+      const int base = wsoff + g0 * 2048;
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) wp[g][hl] = wl(base + g * 2048 + hl * 1024);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) ap[m][hl] = a_frag(m, 0, hl);
+      __builtin_amdgcn_s_setprio(1);
+      int kg = 0;
+      for (; kg + 1 < kend; kg += 2) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int hl = 0; hl < 2; ++hl) wq[g][hl] = wl(base + (kg + 1) * 8192 + g * 2048 + hl * 1024);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int hl = 0; hl < 2; ++hl) aq[m][hl] = a_frag(m, kg + 1, hl);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[g][1], ap[m][0], acc[m][g], 0, 0, 0);  // w_lo * a_hi
+            acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[g][0], ap[m][1], acc[m][g], 0, 0, 0);  // w_hi * a_lo
+            acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[g][0], ap[m][0], acc[m][g], 0, 0, 0);  // w_hi * a_hi
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        const int k2 = (kg + 2 < kend) ? kg + 2 : kg;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int hl = 0; hl < 2; ++hl) wp[g][hl] = wl(base + k2 * 8192 + g * 2048 + hl * 1024);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int hl = 0; hl < 2; ++hl) ap[m][hl] = a_frag(m, k2, hl);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[g][1], aq[m][0], acc[m][g], 0, 0, 0);
+            acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[g][0], aq[m][1], acc[m][g], 0, 0, 0);
+            acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[g][0], aq[m][0], acc[m][g], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (kg < kend) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[g][1], ap[m][0], acc[m][g], 0, 0, 0);
+            acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[g][0], ap[m][1], acc[m][g], 0, 0, 0);
+            acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[g][0], ap[m][0], acc[m][g], 0, 0, 0);
+          }
+      }
+      __builtin_amdgcn_s_setprio(0);
+    };
+
+    f32x16 g[2][2];
+    // ---- pass A: gates i, j -> sigmoid(i) * tanh(j), parked in this lane's slots of the other h buffer
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        g[m][0][r] = 0.0f;
+        g[m][1][r] = 0.0f;
+      }
+    if (w * 32 < a.H) gemm(0, g);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        f32x4 pij;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pij[e] = x3_sigmoid(g[m][0][q4 * 4 + e]) * x3_tanh(g[m][1][q4 * 4 + e]);
+        *reinterpret_cast<f32x4 *>(hd[m] + q4 * 1024) = pij;
+      }
+    // ---- pass B: gates f (+1 in the bias row), o -> c' = c * sigmoid(f) + pij ; h' = tanh(c') * sigmoid(o)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        g[m][0][r] = 0.0f;
+        g[m][1][r] = 0.0f;
+      }
+    if (w * 32 < a.H) gemm(2, g);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float hv[16];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 pij = *reinterpret_cast<const f32x4 *>(hd[m] + q4 * 1024);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = q4 * 4 + e;
+          const float sf = x3_sigmoid(g[m][0][r]);
+          const float so = x3_sigmoid(g[m][1][r]);
+          const float cn = c[m][r] * sf + pij[e];
+          c[m][r] = cn;
+          hv[r] = x3_tanh(cn) * so;
+        }
+      }
+      if (w * 32 >= a.H) {  // a unit block made only of padding keeps h = 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hv[r] = 0.0f;
+      }
+      if (have_next) {
+        // registers 0..7 -> octet (group 2w, this lane's half), 8..15 -> (group 2w + 1, this lane's half); hi | lo
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float v8[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v8[i] = hv[8 * j + i];
+          u32x4 hi, lo;
+          x3_split8(v8, hi, lo);
+          *reinterpret_cast<u32x4 *>(hd[m] + j * 2048) = hi;
+          *reinterpret_cast<u32x4 *>(hd[m] + j * 2048 + 1024) = lo;
+        }
+      } else {
+        // h_T in fp32, frag32 layout of lstm_fwd.hip (k-group 4w + q4 of the row tile: the same four slots)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+          *reinterpret_cast<f32x4 *>(hd[m] + q4 * 1024) = f32x4{hv[q4 * 4], hv[q4 * 4 + 1], hv[q4 * 4 + 2], hv[q4 * 4 + 3]};
+      }
+    }
+    __syncthreads();  // h_t complete; x_t and h_{t-1} no longer needed
+    if (have_next) {
+      if (xq < 2 * KGX) x_store(xq, nhi, nlo);
+      for (int oc = xq + 8; oc < 2 * KGX; oc += 8) {
+        const unsigned short *src = a.emb16 + (size_t)nid * 2 * EP;
+        x_store(oc, *reinterpret_cast<const u32x4 *>(src + oc * 8), *reinterpret_cast<const u32x4 *>(src + EP + oc * 8));
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- projection out = h_T . M (+ optional l2_normalize): the fp32 tail of lstm_fwd.hip, 4 waves per row tile
+  constexpr int NWR = 4, PT = 4, KGh32 = 32;
+  const int wn = w % NWR, wm = w / NWR;
+  const float *hp = reinterpret_cast<const float *>(hptr(T & 1, wm)) + lane * 4;
+  f32x16 pacc[PT];
+  float *ssq = reinterpret_cast<float *>(hptr((T + 1) & 1, 0));  // [64][16]
+  const int KGe = min(KGh32, (a.H + 7) / 8);
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int nt = wn + NWR * i;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pacc[i][r] = 0.0f;
+    if (nt < a.NTS) {
+      const float *mp = a.Mp + (size_t)nt * KGh32 * 256 + lane * 4;
+      f32x4 ax = *reinterpret_cast<const f32x4 *>(hp), bx = *reinterpret_cast<const f32x4 *>(mp), ay, by;
+      int kg = 0;
+      for (; kg + 1 < KGe; kg += 2) {
+        ay = *reinterpret_cast<const f32x4 *>(hp + (kg + 1) * 256);
+        by = *reinterpret_cast<const f32x4 *>(mp + (kg + 1) * 256);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[e], pacc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int k2 = (kg + 2 < KGe) ? kg + 2 : kg;
+        ax = *reinterpret_cast<const f32x4 *>(hp + k2 * 256);
+        bx = *reinterpret_cast<const f32x4 *>(mp + k2 * 256);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[e], by[e], pacc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (kg < KGe) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bx[e], pacc[i], 0, 0, 0);
+      }
+      if (a.normalize) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = pacc[i][r] * pacc[i][r];
+          v += __shfl_xor(v, 1);
+          v += __shfl_xor(v, 2);
+          v += __shfl_xor(v, 4);
+          v += __shfl_xor(v, 8);
+          v += __shfl_xor(v, 16);
+          if ((lane & 31) == 0) ssq[(wm * 32 + mfma_row(r, lane)) * 16 + nt] = v;
+        }
+      }
+    }
+  }
+  float scale[16];
+  if (a.normalize) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float *pr = ssq + (wm * 32 + mfma_row(r, lane)) * 16;
+      float tot = 0.0f;
+      for (int j = 0; j < a.NTS; ++j) tot += pr[j];
+      scale[r] = 1.0f / sqrtf(fmaxf(tot, 1e-12f));
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scale[r] = 1.0f;
+  }
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int nt = wn + NWR * i;
+    const int col = nt * 32 + (lane & 31);
+    if (nt < a.NTS && col < a.S) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = b0 + wm * 32 + mfma_row(r, lane);
+        if (row < a.B) a.out[(size_t)(a.row_map ? a.row_map[row] : row) * a.S + col] = pacc[i][r] * scale[r];
+      }
+    }
+  }
+  (void)red;
+}
+
+// ---- packing --------------------------------------------------------------------------------------------------------
+// Wx3[ub][kg][gate][hi|lo][lane][8]: lane (m = lane & 31 -> unit 32 ub + m, half = lane >> 5), element i -> reduction
+// index k:  x part (kg < KGX): k = 16 kg + 8 half + i (k < E: kernel row k; k = E: bias (+1 for the forget gate));
+// h part: group 2 ub' + j holds, at (half, i), hidden unit 32 ub' + mfma_row(8 j + i, half) -- the accumulator register
+// order, see the file header.
+__global__ void pack_lstm_x3_kernel(const float *__restrict__ K, const float *__restrict__ b, int E, int H, int KGX, int KG,
+                                    int64_t total, unsigned short *__restrict__ out) {
+  const int N4 = 4 * H;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    int64_t rest = idx >> 9;  // ((ub * KG + kg) * 4 + gate)  (hi and lo are written together)
+    const int gate = (int)(rest & 3);
+    rest >>= 2;
+    const int kg = (int)(rest % KG), ub = (int)(rest / KG);
+    const int m = lane & 31, half = lane >> 5, unit = ub * 32 + m;
+    float wv = 0.0f;
+    if (unit < H) {
+      const int col = gate * H + unit;
+      if (kg < KGX) {
+        const int k = kg * 16 + half * 8 + i;
+        if (k < E) wv = K[(size_t)k * N4 + col];
+        else if (k == E) wv = b[col] + (gate == 2 ? 1.0f : 0.0f);
+      } else {
+        const int kgh = kg - KGX, r = 8 * (kgh & 1) + i;
+        const int uk = (kgh >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (uk < H) wv = K[(size_t)(E + uk) * N4 + col];
+      }
+    }
+    const unsigned short hi = x3_bf16(wv), lo = x3_bf16(wv - x3_f32(hi));
+    const int64_t o = (((int64_t)(ub * KG + kg) * 4 + gate) * 2) * 512 + lane * 8 + i;
+    out[o] = hi;
+    out[o + 512] = lo;
+  }
+}
+
+// emb16[id][hi|lo][EP]: columns < E the embedding, column E = 1.0 (carries the bias through the GEMM), rest 0
+__global__ void split_emb_x3_kernel(const float *__restrict__ emb, int64_t V, int E, int EP, unsigned short *__restrict__ out) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < V * EP; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int col = (int)(idx % EP);
+    const int64_t id = idx / EP;
+    const float v = col < E ? emb[id * E + col] : (col == E ? 1.0f : 0.0f);
+    const unsigned short hi = x3_bf16(v), lo = x3_bf16(v - x3_f32(hi));
+    out[id * 2 * EP + col] = hi;
+    out[id * 2 * EP + EP + col] = lo;
+  }
+}
+
+int lstm_x3_kgx(int E) { return (E + 1 + 15) / 16; }
+size_t lstm_x3_weight_elems(int E) { return (size_t)8 * (lstm_x3_kgx(E) + 16) * 4 * 2 * 512; }
+size_t lstm_x3_emb_elems(int64_t V, int E) { return (size_t)V * 2 * lstm_x3_kgx(E) * 16; }
+
+hipError_t launch_pack_lstm_x3(const float *K, const float *b, const float *emb, int64_t V, int E, int H, unsigned short *Wx3,
+                               unsigned short *emb16, hipStream_t stream) {
+  const int KGX = lstm_x3_kgx(E), KG = KGX + 16;
+  const int64_t total = (int64_t)8 * KG * 4 * 512;
+  hipLaunchKernelGGL(pack_lstm_x3_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, K, b, E, H, KGX, KG, total, Wx3);
+  if (emb16) {
+    const int64_t ne = V * KGX * 16;
+    hipLaunchKernelGGL(split_emb_x3_kernel, dim3((int)((ne + 255) / 256 < 8192 ? (ne + 255) / 256 : 8192)), dim3(256), 0, stream,
+                       emb, V, E, KGX * 16, emb16);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_lstm_fwd_x3(const LstmX3Args &a, hipStream_t stream) {
+  if (a.H <= 128 || a.H > 256 || a.B < 1 || a.KGX < 1 || a.KGX > 4) return hipErrorInvalidValue;
+  const size_t lds = lstm_x3_lds_bytes(a.KGX);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(lstm_fwd_x3_kernel, dim3((a.B + 63) / 64), dim3(X3_THREADS), lds, stream, a);
+  return hipGetLastError();
+}

@@ -33,6 +33,8 @@ struct Encoder {
   float *Wp = nullptr, *Mp = nullptr;
   float *Waug = nullptr;      // few-sequences kernel: kernel rows in its k space incl. the bias row
   bool waug_valid = false;
+  unsigned short *Wx3 = nullptr;  // option lstm_x3: hi / lo bf16 fragment copies of the kernel matrix
+  bool x3_valid = false;
   int shares_lstm_with = -1;  // shared-encoder: target reuses the source LSTM packing
   // pad-prefix table: state after p leading PAD steps, p = 0..pad_T ([pad_T+1][Hp] each)
   float *pad_h = nullptr, *pad_c = nullptr;
@@ -92,6 +94,9 @@ struct sse_handle {
   Encoder enc[2];
   bool packed_dirty = true;
   bool pad_skip = true;      // option "pad_skip": exact left-pad prefix skip in inference encodes
+  bool lstm_x3 = false;       // option "lstm_x3": large inference encodes (Hp = 256) on the bf16 matrix pipe with split operands
+  unsigned short *emb16 = nullptr;  // split embedding table of that path
+  bool emb16_valid = false;
   int lstm_persist_rows = 32; // option "lstm_persist_rows": batches up to this many rows (<= 32) take the weights-in-LDS cluster kernel
   uint32_t persist_epoch = 0; // tag epoch of the cluster kernel's exchange buffers
   int cu_count = 0;           // compute units of the device (co-residency check of the cluster kernel)
@@ -219,6 +224,7 @@ int ensure_packed(sse_handle *h, hipStream_t st) {
   if (!h->packed_dirty) return 0;
   const sse_config &c = h->cfg;
   const int Ep = emb_cols(c);
+  h->emb16_valid = false;
   if (!h->emb_pad) HIPCHECK(h, hipMalloc((void **)&h->emb_pad, (size_t)c.vocab_size * Ep * sizeof(float)));
   HIPCHECK(h, launch_pad_rows(h->vars[0].dev, c.vocab_size, c.embedding_size, Ep,
                               c.network_mode == SSE_MODE_SOURCE_ONLY_CNN ? -1 : c.embedding_size, h->emb_pad, st));
@@ -228,6 +234,7 @@ int ensure_packed(sse_handle *h, hipStream_t st) {
     e.pad_valid = false;
     e.pad_valid_small = false;
     e.waug_valid = false;
+    e.x3_valid = false;
     const int KG = e.KGx + e.KGh;
     if (e.shares_lstm_with < 0) {
       if (!e.Wp) HIPCHECK(h, hipMalloc((void **)&e.Wp, (size_t)(e.Hp / 32) * KG * 4 * 256 * sizeof(float)));
@@ -486,6 +493,37 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
       sa.pad_c = own.pad_c_small;
     }
     HIPCHECK(h, launch_lstm_small(sa, st));
+    return 0;
+  }
+  if (h->lstm_x3 && e.Hp == 256 && e.H > 128 && c.embedding_size < 64) {
+    // opt-in: the gate GEMMs on the bf16 matrix pipe with hi + lo split operands (lstm_fwd_x3.hip); ~1e-5 from the fp32 path
+    Encoder &own = e.shares_lstm_with >= 0 ? h->enc[e.shares_lstm_with] : e;
+    const int E = c.embedding_size;
+    if (!own.x3_valid || !h->emb16_valid) {
+      if (!own.Wx3) HIPCHECK(h, hipMalloc((void **)&own.Wx3, lstm_x3_weight_elems(E) * sizeof(unsigned short)));
+      if (!h->emb16) HIPCHECK(h, hipMalloc((void **)&h->emb16, lstm_x3_emb_elems(c.vocab_size, E) * sizeof(unsigned short)));
+      HIPCHECK(h, launch_pack_lstm_x3(h->vars[own.kernel].dev, h->vars[own.bias].dev, h->vars[0].dev, c.vocab_size, E, own.H,
+                                      own.Wx3, h->emb16_valid ? nullptr : h->emb16, st));
+      own.x3_valid = true;
+      h->emb16_valid = true;
+    }
+    LstmX3Args xa;
+    xa.ids = ids;
+    xa.emb16 = h->emb16;
+    xa.Wx3 = own.Wx3;
+    xa.Mp = e.Mp;
+    xa.out = out;
+    xa.err = h->err_flag;
+    xa.B = B;
+    xa.T = T;
+    xa.V = c.vocab_size;
+    xa.KGX = lstm_x3_kgx(E);
+    xa.H = e.H;
+    xa.S = c.encoding_size;
+    xa.NTS = (c.encoding_size + 31) / 32;
+    xa.normalize = normalize ? 1 : 0;
+    xa.row_map = h->cur_row_map;
+    HIPCHECK(h, launch_lstm_fwd_x3(xa, st));
     return 0;
   }
   LstmFwdArgs a;
@@ -901,12 +939,14 @@ void sse_destroy(sse_handle *h) {
       if (e.pad_h) (void)hipFree(e.pad_h);
       if (e.pad_c) (void)hipFree(e.pad_c);
       if (e.Waug) (void)hipFree(e.Waug);
+      if (e.Wx3) (void)hipFree(e.Wx3);
       if (e.pad_h_small) (void)hipFree(e.pad_h_small);
       if (e.pad_c_small) (void)hipFree(e.pad_c_small);
     }
     if (e.Mp) hipFree(e.Mp);
   }
   if (h->emb_pad) hipFree(h->emb_pad);
+  if (h->emb16) (void)hipFree(h->emb16);
   if (h->err_flag) hipFree(h->err_flag);
   if (h->idxp) hipFree(h->idxp);
   if (h->idxp16) (void)hipFree(h->idxp16);
@@ -1097,6 +1137,10 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value) {
   }
   if (strcmp(name, "pad_skip") == 0) {
     h->pad_skip = value != 0;
+    return 0;
+  }
+  if (strcmp(name, "lstm_x3") == 0) {
+    h->lstm_x3 = value != 0;
     return 0;
   }
   if (strcmp(name, "lstm_persist_rows") == 0) {
