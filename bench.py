@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--train-rows", type=int, default=8192, help="train leg: pair rows per GPU per step")
     ap.add_argument("--train-iters", type=int, default=5)
     ap.add_argument("--no-train-leg", action="store_true")
+    ap.add_argument("--no-x3-leg", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -243,6 +244,37 @@ def main():
         got = top_i[:48, 0].cpu().numpy()
         top1_match = float(np.mean(got == wids[:, 0]))
         enc_err = float(np.abs(src_enc[:48].cpu().numpy() - want).max())
+
+    # ---- secondary leg: the SAME step with the opt-in split-bf16 encoder (option lstm_x3: three bf16 MFMAs on hi + lo
+    # operands per product; ~1e-6 from the exact fp32 kernel).  Not the headline: `value` is the exact fp32 path.
+    x3_leg = None
+    if not args.no_x3_leg:
+        h.set_option("lstm_x3", 1)
+        exact_enc = src_enc[:4096].clone()
+        for _ in range(max(1, args.warmup)):
+            step()
+        barrier()
+        t0x = time.perf_counter()
+        for i in range(args.steps):
+            step(i if i < nrec else None)
+        barrier()
+        dtx = time.perf_counter() - t0x
+        h.synchronize()
+        if use_dist:
+            t = torch.tensor([dtx], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtx = float(t.item())
+        x3_ms = sum(h.timer_elapsed_ms(2 * i, 2 * i + 1) for i in range(nrec)) / nrec
+        x3_leg = {"seqs_per_s": world * B * args.steps / dtx, "ms_per_step": dtx / args.steps * 1e3, "encode_kernel_ms": x3_ms,
+                  "arithmetic": "v_mfma_f32_32x32x16_bf16 on hi + lo split fp32 operands (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi), fp32 accumulate",
+                  "algorithmic_tflops_per_gpu": B * FLOP_PER_SEQ / (x3_ms * 1e-3) / 1e12,
+                  "bf16_mfma_tflops_per_gpu": 3 * B * FLOP_PER_SEQ / (x3_ms * 1e-3) / 1e12,
+                  "frac_of_bf16_mfma_peak": 3 * B * FLOP_PER_SEQ / (x3_ms * 1e-3) / 1e12 / 2500.0,
+                  "max_abs_diff_vs_exact_fp32_kernel": float((src_enc[:4096] - exact_enc).abs().max().item())}
+        if rank == 0:
+            x3_leg["max_abs_err_vs_oracle"] = float(np.abs(src_enc[:48].cpu().numpy() - want).max())
+            x3_leg["top1_match_vs_oracle"] = float(np.mean(top_i[:48, 0].cpu().numpy() == wids[:, 0]))
+        h.set_option("lstm_x3", 0)
 
     # ---- secondary leg: ranking-scale sharded scoring with RCCL all-gather of per-shard top-k
     scoring = None
@@ -400,6 +432,8 @@ def main():
         if scoring is not None:
             line["scoring_leg"] = scoring
             line["scoring_leg_fp32_candidates"] = scoring_fp32
+        if x3_leg is not None:
+            line["encode_leg_split_bf16"] = x3_leg
         if latency is not None:
             line["latency_leg"] = latency
         if training is not None:

@@ -20,7 +20,8 @@
 //    wave as 16-byte conflict-free stores, no cross-lane exchange; the packed kernel rows follow the same permutation;
 //  * the last step leaves h_T in fp32 (the frag32 layout of lstm_fwd.hip: the same four 16-byte slots per lane), and
 //    the projection + l2-normalise tail is the exact fp32 code of lstm_fwd.hip.
-// Hp = 256 (cell sizes 129..256) only; no left-pad prefix skip (all T steps run).
+// Hp = 256 (cell sizes 129..256: wave = unit block, both row tiles) and Hp = 128 (cell sizes <= 128: wave = unit block
+// w & 3, row tile w >> 2); no left-pad prefix skip (all T steps run).
 #include "sse_kernels.h"
 
 #define X3_THREADS 512
@@ -55,14 +56,19 @@ __device__ __forceinline__ void x3_split8(const float (&v)[8], u32x4 &hi, u32x4 
   }
 }
 
-// LDS (bytes): x [2 row tiles][KGX][hi|lo][1 KiB] (single-buffered) | h [2 bufs][2 row tiles][KGH = 16][hi|lo][1 KiB] | red
-size_t lstm_x3_lds_bytes(int KGX) { return (size_t)2 * KGX * 2048 + (size_t)2 * 2 * 16 * 2048 + 1024; }
+// LDS (bytes): x [2 row tiles][KGX][hi|lo][1 KiB] (single-buffered) | h [2 bufs][2 row tiles][KGH = Hp/16][hi|lo][1 KiB] | red
+size_t lstm_x3_lds_bytes(int KGX, int Hp) { return (size_t)2 * KGX * 2048 + (size_t)2 * 2 * (Hp / 16) * 2048 + 1024; }
 
+// UBN = unit blocks of 32 hidden units (Hp = 32 * UBN): 8 -> wave = unit block, MT = 2 row tiles; 4 -> MT = 1
+template <int UBN>
 __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-  constexpr int KGH = 16;  // h groups of 16 units (Hp = 256)
+  constexpr int KGH = 2 * UBN;  // h groups of 16 units
+  constexpr int MT = (UBN == 8) ? 2 : 1;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // unit block of this wave
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = (UBN == 8) ? wave : (wave & 3);   // unit block of this wave
+  const int mt0 = (UBN == 8) ? 0 : (wave >> 2);   // its first row tile
   const int KGX = a.KGX, KG = KGX + KGH, T = a.T;
   const int KGHe = min(KGH, (a.H + 15) / 16);  // h groups that can be non-zero
   unsigned char *xbase = smem3;
@@ -96,16 +102,16 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
       x_store(oc, *reinterpret_cast<const u32x4 *>(src + oc * 8), *reinterpret_cast<const u32x4 *>(src + EP + oc * 8));
   }
 
-  f32x16 c[2];
+  f32x16 c[MT];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) c[m][r] = 0.0f;
   __syncthreads();
 
   // weights: Wx3[unit block][k group][gate][hi|lo][1 KiB] through a buffer descriptor (voffset = 16 * lane)
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<unsigned short *>(a.Wx3), 0, 8 * KG * 8192, 0x00020000);
+      const_cast<unsigned short *>(a.Wx3), 0, UBN * KG * 8192, 0x00020000);
   const int wvoff = lane * 16;
   auto wl = [&](int soff) -> bf16x8 { return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff, soff, 0)); };
 
@@ -122,13 +128,13 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
       }
     }
     const int cur = t & 1, nxt = (t + 1) & 1;
-    const unsigned char *xa[2], *ha[2];
-    unsigned char *hd[2];
+    const unsigned char *xa[MT], *ha[MT];
+    unsigned char *hd[MT];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      xa[m] = xptr(m) + lane * 16;
-      ha[m] = hptr(cur, m) + lane * 16;
-      hd[m] = hptr(nxt, m) + (size_t)w * 4096 + lane * 16;  // this lane's four 16-byte slots: groups 2w, 2w+1, hi | lo
+    for (int m = 0; m < MT; ++m) {
+      xa[m] = xptr(mt0 + m) + lane * 16;
+      ha[m] = hptr(cur, mt0 + m) + lane * 16;
+      hd[m] = hptr(nxt, mt0 + m) + (size_t)w * 4096 + lane * 16;  // this lane's four 16-byte slots: groups 2w, 2w+1, hi | lo
     }
     const int kend = (t == 0) ? KGX : KGX + KGHe;  // h_{-1} = 0
     const int wsoff = w * KG * 8192;
@@ -139,15 +145,15 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
       const unsigned char *p = kg < KGX ? xa[m] + (size_t)kg * 2048 : ha[m] + (size_t)(kg - KGX) * 2048;
       return *reinterpret_cast<const bf16x8 *>(p + hl * 1024);
     };
-    auto gemm = [&](int g0, f32x16 (&acc)[2][2]) {
-      bf16x8 wp[2][2], wq[2][2], ap[2][2], aq[2][2];  // [gate][hi|lo], [row tile][hi|lo]
+    auto gemm = [&](int g0, f32x16 (&acc)[MT][2]) {
+      bf16x8 wp[2][2], wq[2][2], ap[MT][2], aq[MT][2];  // [gate][hi|lo], [row tile][hi|lo]
       const int base = wsoff + g0 * 2048;
 #pragma unroll
       for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int hl = 0; hl < 2; ++hl) wp[g][hl] = wl(base + g * 2048 + hl * 1024);
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int hl = 0; hl < 2; ++hl) ap[m][hl] = a_frag(m, 0, hl);
       __builtin_amdgcn_s_setprio(1);
@@ -158,14 +164,14 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
 #pragma unroll
           for (int hl = 0; hl < 2; ++hl) wq[g][hl] = wl(base + (kg + 1) * 8192 + g * 2048 + hl * 1024);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int hl = 0; hl < 2; ++hl) aq[m][hl] = a_frag(m, kg + 1, hl);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
-          for (int m = 0; m < 2; ++m) {
+          for (int m = 0; m < MT; ++m) {
             acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[g][1], ap[m][0], acc[m][g], 0, 0, 0);  // w_lo * a_hi
             acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[g][0], ap[m][1], acc[m][g], 0, 0, 0);  // w_hi * a_lo
             acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[g][0], ap[m][0], acc[m][g], 0, 0, 0);  // w_hi * a_hi
@@ -177,14 +183,14 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
 #pragma unroll
           for (int hl = 0; hl < 2; ++hl) wp[g][hl] = wl(base + k2 * 8192 + g * 2048 + hl * 1024);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int hl = 0; hl < 2; ++hl) ap[m][hl] = a_frag(m, k2, hl);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
-          for (int m = 0; m < 2; ++m) {
+          for (int m = 0; m < MT; ++m) {
             acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[g][1], aq[m][0], acc[m][g], 0, 0, 0);
             acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[g][0], aq[m][1], acc[m][g], 0, 0, 0);
             acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[g][0], aq[m][0], acc[m][g], 0, 0, 0);
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
-          for (int m = 0; m < 2; ++m) {
+          for (int m = 0; m < MT; ++m) {
             acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[g][1], ap[m][0], acc[m][g], 0, 0, 0);
             acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[g][0], ap[m][1], acc[m][g], 0, 0, 0);
             acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[g][0], ap[m][0], acc[m][g], 0, 0, 0);
@@ -204,10 +210,10 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
       __builtin_amdgcn_s_setprio(0);
     };
 
-    f32x16 g[2][2];
+    f32x16 g[MT][2];
     // ---- pass A: gates i, j -> sigmoid(i) * tanh(j), parked in this lane's slots of the other h buffer
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         g[m][0][r] = 0.0f;
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
       }
     if (w * 32 < a.H) gemm(0, g);
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         f32x4 pij;
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
       }
     // ---- pass B: gates f (+1 in the bias row), o -> c' = c * sigmoid(f) + pij ; h' = tanh(c') * sigmoid(o)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         g[m][0][r] = 0.0f;
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
       }
     if (w * 32 < a.H) gemm(2, g);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < MT; ++m) {
       float hv[16];
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
@@ -283,8 +289,8 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
   }
 
   // ---- projection out = h_T . M (+ optional l2_normalize): the fp32 tail of lstm_fwd.hip, 4 waves per row tile
-  constexpr int NWR = 4, PT = 4, KGh32 = 32;
-  const int wn = w % NWR, wm = w / NWR;
+  constexpr int NWR = 4, PT = 4, KGh32 = 4 * UBN;
+  const int wn = wave % NWR, wm = wave / NWR;
   const float *hp = reinterpret_cast<const float *>(hptr(T & 1, wm)) + lane * 4;
   f32x16 pacc[PT];
   float *ssq = reinterpret_cast<float *>(hptr((T + 1) & 1, 0));  // [64][16]
@@ -408,13 +414,13 @@ __global__ void split_emb_x3_kernel(const float *__restrict__ emb, int64_t V, in
 }
 
 int lstm_x3_kgx(int E) { return (E + 1 + 15) / 16; }
-size_t lstm_x3_weight_elems(int E) { return (size_t)8 * (lstm_x3_kgx(E) + 16) * 4 * 2 * 512; }
+size_t lstm_x3_weight_elems(int E, int Hp) { return (size_t)(Hp / 32) * (lstm_x3_kgx(E) + Hp / 16) * 4 * 2 * 512; }
 size_t lstm_x3_emb_elems(int64_t V, int E) { return (size_t)V * 2 * lstm_x3_kgx(E) * 16; }
 
-hipError_t launch_pack_lstm_x3(const float *K, const float *b, const float *emb, int64_t V, int E, int H, unsigned short *Wx3,
-                               unsigned short *emb16, hipStream_t stream) {
-  const int KGX = lstm_x3_kgx(E), KG = KGX + 16;
-  const int64_t total = (int64_t)8 * KG * 4 * 512;
+hipError_t launch_pack_lstm_x3(const float *K, const float *b, const float *emb, int64_t V, int E, int H, int Hp,
+                               unsigned short *Wx3, unsigned short *emb16, hipStream_t stream) {
+  const int KGX = lstm_x3_kgx(E), KG = KGX + Hp / 16;
+  const int64_t total = (int64_t)(Hp / 32) * KG * 4 * 512;
   hipLaunchKernelGGL(pack_lstm_x3_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, K, b, E, H, KGX, KG, total, Wx3);
   if (emb16) {
     const int64_t ne = V * KGX * 16;
@@ -424,11 +430,16 @@ hipError_t launch_pack_lstm_x3(const float *K, const float *b, const float *emb,
   return hipGetLastError();
 }
 
-hipError_t launch_lstm_fwd_x3(const LstmX3Args &a, hipStream_t stream) {
-  if (a.H <= 128 || a.H > 256 || a.B < 1 || a.KGX < 1 || a.KGX > 4) return hipErrorInvalidValue;
-  const size_t lds = lstm_x3_lds_bytes(a.KGX);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+template <int UBN>
+static hipError_t launch_x3(const LstmX3Args &a, hipStream_t stream) {
+  const size_t lds = lstm_x3_lds_bytes(a.KGX, 32 * UBN);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_x3_kernel<UBN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(lstm_fwd_x3_kernel, dim3((a.B + 63) / 64), dim3(X3_THREADS), lds, stream, a);
+  hipLaunchKernelGGL(lstm_fwd_x3_kernel<UBN>, dim3((a.B + 63) / 64), dim3(X3_THREADS), lds, stream, a);
   return hipGetLastError();
+}
+
+hipError_t launch_lstm_fwd_x3(const LstmX3Args &a, hipStream_t stream) {
+  if (a.H < 1 || a.H > 256 || a.B < 1 || a.KGX < 1 || a.KGX > 4) return hipErrorInvalidValue;
+  return a.H > 128 ? launch_x3<8>(a, stream) : launch_x3<4>(a, stream);
 }

@@ -495,15 +495,15 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
     HIPCHECK(h, launch_lstm_small(sa, st));
     return 0;
   }
-  if (h->lstm_x3 && e.Hp == 256 && e.H > 128 && c.embedding_size < 64) {
+  if (h->lstm_x3 && e.Hp <= 256 && c.embedding_size < 64) {
     // opt-in: the gate GEMMs on the bf16 matrix pipe with hi + lo split operands (lstm_fwd_x3.hip); ~1e-5 from the fp32 path
     Encoder &own = e.shares_lstm_with >= 0 ? h->enc[e.shares_lstm_with] : e;
     const int E = c.embedding_size;
     if (!own.x3_valid || !h->emb16_valid) {
-      if (!own.Wx3) HIPCHECK(h, hipMalloc((void **)&own.Wx3, lstm_x3_weight_elems(E) * sizeof(unsigned short)));
+      if (!own.Wx3) HIPCHECK(h, hipMalloc((void **)&own.Wx3, lstm_x3_weight_elems(E, own.Hp) * sizeof(unsigned short)));
       if (!h->emb16) HIPCHECK(h, hipMalloc((void **)&h->emb16, lstm_x3_emb_elems(c.vocab_size, E) * sizeof(unsigned short)));
       HIPCHECK(h, launch_pack_lstm_x3(h->vars[own.kernel].dev, h->vars[own.bias].dev, h->vars[0].dev, c.vocab_size, E, own.H,
-                                      own.Wx3, h->emb16_valid ? nullptr : h->emb16, st));
+                                      own.Hp, own.Wx3, h->emb16_valid ? nullptr : h->emb16, st));
       own.x3_valid = true;
       h->emb16_valid = true;
     }

@@ -82,11 +82,11 @@ size_t lstm_small_waug_floats(int E, int H);
 hipError_t launch_pack_lstm_small(const float *K, const float *b, int E, int H, float *out, hipStream_t stream);
 hipError_t launch_lstm_small(const LstmSmallArgs &a, hipStream_t stream);
 
-// opt-in LSTM forward on the bf16 matrix pipe with split (hi + lo) operands, Hp = 256 (lstm_fwd_x3.hip)
+// opt-in LSTM forward on the bf16 matrix pipe with split (hi + lo) operands, Hp = 128 / 256 (lstm_fwd_x3.hip)
 struct LstmX3Args {
   const int32_t *ids;            // [B][T]
   const unsigned short *emb16;   // [V][hi|lo][KGX*16] bf16 split embedding table, column E = 1.0
-  const unsigned short *Wx3;     // [8][KGX+16][4 gates][hi|lo][512] bf16 fragments (launch_pack_lstm_x3)
+  const unsigned short *Wx3;     // [Hp/32][KGX+Hp/16][4 gates][hi|lo][512] bf16 fragments (launch_pack_lstm_x3)
   const float *Mp;               // packed projection (fp32, as lstm_fwd.hip)
   float *out;                    // [B][S]
   int32_t *err;
@@ -94,10 +94,10 @@ struct LstmX3Args {
   const int32_t *row_map = nullptr;
 };
 int lstm_x3_kgx(int E);
-size_t lstm_x3_weight_elems(int E);
+size_t lstm_x3_weight_elems(int E, int Hp);
 size_t lstm_x3_emb_elems(int64_t V, int E);
 hipError_t launch_pack_lstm_x3(const float *K, const float *b, const float *emb /* master [V][E] */, int64_t V, int E, int H,
-                               unsigned short *Wx3, unsigned short *emb16 /* nullptr: weights only */, hipStream_t stream);
+                               int Hp, unsigned short *Wx3, unsigned short *emb16 /* nullptr: weights only */, hipStream_t stream);
 hipError_t launch_lstm_fwd_x3(const LstmX3Args &a, hipStream_t stream);
 
 // a handful of sequences with the recurrent weights resident in LDS (lstm_persist.hip): a cluster of NWG workgroups per

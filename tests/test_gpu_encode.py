@@ -170,6 +170,8 @@ def test_cluster_kernel_equals_the_other_kernels(mode, V, E, Hs, Ht, S, T):
     ("dual-encoder", 500, 50, 256, 256, 256, 32, 1200, 0.0),      # configs[1] shape
     ("dual-encoder", 300, 50, 200, 160, 64, 80, 1100, 0.7),       # padded cells / units, long left-padded rows
     ("shared-encoder", 120, 8, 256, 256, 100, 2, 1030, 0.3),      # T = 2, narrow embedding (one x group)
+    ("shared-encoder", 300, 50, 96, 96, 64, 80, 1100, 0.6),       # reference defaults: Hp = 128 mapping, 3 live unit blocks
+    ("dual-encoder", 300, 30, 128, 40, 50, 13, 1500, 0.2),        # Hp = 128 full / mostly padding cells
 ])
 def test_split_bf16_matrix_path_stays_within_the_encoder_tolerance(mode, V, E, Hs, Ht, S, T, B, pad):
     """Option lstm_x3 (lstm_fwd_x3.hip): gate GEMMs as three bf16 MFMAs on hi + lo split operands.  Not the fp32

@@ -10,6 +10,8 @@ import sse_amd  # noqa: E402
 
 V, E, H, S, T = 32000, 50, 256, 256, 32
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+if len(sys.argv) > 4:
+    H, S, T = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 params = dict(forward_only=True, network_mode="dual-encoder", predict_nbest=10, max_seq_length=T, vocab_size=V,
               embedding_size=E, encoding_size=S, src_cell_size=H, tgt_cell_size=H, learning_rate=0.9,
               learning_rate_decay_factor=0.99, targetSpaceSize=571)
@@ -32,8 +34,8 @@ for x3 in (0, 1):
     h.timer_record(1)
     ms = h.timer_elapsed_ms(0, 1) / n
     outs.append(out)
-    print("%s: %.3f ms  %.0f seq/s  %.1f TFLOP/s algorithmic%s"
-          % ("lstm_x3 (3 bf16 MFMAs on hi+lo operands)" if x3 else "fp32 MFMA (exact)", ms, B / ms * 1e3, B * flop / ms / 1e9,
+    print("H=%d S=%d T=%d B=%d  %s: %.3f ms  %.0f seq/s  %.1f TFLOP/s algorithmic%s"
+          % (H, S, T, B, "lstm_x3 (3 bf16 MFMAs on hi+lo operands)" if x3 else "fp32 MFMA (exact)", ms, B / ms * 1e3, B * flop / ms / 1e9,
              "  (matrix pipe: %.0f TFLOP/s of bf16 work = %.2f of the 2.5 PF peak)" % (3 * B * flop / ms / 1e9, 3 * B * flop / ms / 1e9 / 2500)
              if x3 else "  (%.3f of the 157.3 TF fp32 peak)" % (B * flop / ms / 1e9 / 157.3)))
 torch.cuda.synchronize()
