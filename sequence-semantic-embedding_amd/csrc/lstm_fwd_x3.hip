@@ -21,7 +21,7 @@
 //  * the last step leaves h_T in fp32 (the frag32 layout of lstm_fwd.hip: the same four 16-byte slots per lane), and
 //    the projection + l2-normalise tail is the exact fp32 code of lstm_fwd.hip.
 // Hp = 256 (cell sizes 129..256: wave = unit block, both row tiles) and Hp = 128 (cell sizes <= 128: wave = unit block
-// w & 3, row tile w >> 2); no left-pad prefix skip (all T steps run).
+// w & 3, row tile w >> 2).  Left-pad prefix skip as in lstm_fwd.hip, from a table this kernel records itself.
 #include "sse_kernels.h"
 
 #define X3_THREADS 512
@@ -96,17 +96,55 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
     *reinterpret_cast<u32x4 *>(dst) = hi;
     *reinterpret_cast<u32x4 *>(dst + 1024) = lo;
   };
+  // left-pad prefix skip: the state after p leading PAD (id 0) steps does not depend on the sequence, so the tile
+  // starts at t0 = min over its rows of the leading-PAD count with (h, c) = pad_h / pad_c[t0] (recorded by an all-PAD
+  // launch of THIS kernel: same arithmetic); rows beyond B count as all-PAD
+  int t0 = 0;
+  if (a.pad_h != nullptr) {
+    int lead = T;
+    if (row_ok) {
+      for (int t = xq; t < T; t += 8)
+        if (id_row[t] != 0) {
+          lead = t;
+          break;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lead = min(lead, __shfl_xor(lead, o));
+    if (lane == 0) red[wave] = __int_as_float(lead);
+    __syncthreads();
+    lead = T;
+    for (int i = 0; i < 8; ++i) lead = min(lead, __float_as_int(red[i]));
+    t0 = min(lead, T - 1);
+    __syncthreads();
+  }
   {
-    const unsigned short *src = a.emb16 + (size_t)fetch_id(0) * 2 * EP;
+    const unsigned short *src = a.emb16 + (size_t)fetch_id(t0) * 2 * EP;
     for (int oc = xq; oc < 2 * KGX; oc += 8)
       x_store(oc, *reinterpret_cast<const u32x4 *>(src + oc * 8), *reinterpret_cast<const u32x4 *>(src + EP + oc * 8));
+  }
+  const int Hp = 32 * UBN;
+  if (t0 > 0) {  // h_{t0-1} = pad_h[t0], the same for every row, split into the operand layout of buffer t0 & 1
+    for (int i = tid; i < 2 * KGH * 64; i += X3_THREADS) {
+      const int sl = i & 63, kgh = (i >> 6) % KGH, mt = i / (64 * KGH);
+      float v8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v8[e] = a.pad_h[(size_t)t0 * Hp + (kgh >> 1) * 32 + mfma_row(8 * (kgh & 1) + e, sl)];
+      u32x4 hi, lo;
+      x3_split8(v8, hi, lo);
+      unsigned char *dst = hptr(t0 & 1, mt) + (size_t)kgh * 2048 + sl * 16;
+      *reinterpret_cast<u32x4 *>(dst) = hi;
+      *reinterpret_cast<u32x4 *>(dst + 1024) = lo;
+    }
   }
 
   f32x16 c[MT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+  for (int r = 0; r < 16; ++r) {
+    const float c0 = (t0 > 0) ? a.pad_c[(size_t)t0 * Hp + w * 32 + mfma_row(r, lane)] : 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) c[m][r] = 0.0f;
+    for (int m = 0; m < MT; ++m) c[m][r] = c0;
+  }
   __syncthreads();
 
   // weights: Wx3[unit block][k group][gate][hi|lo][1 KiB] through a buffer descriptor (voffset = 16 * lane)
@@ -115,7 +153,7 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
   const int wvoff = lane * 16;
   auto wl = [&](int soff) -> bf16x8 { return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, wvoff, soff, 0)); };
 
-  for (int t = 0; t < T; ++t) {
+  for (int t = t0; t < T; ++t) {
     const bool have_next = (t + 1) < T;
     u32x4 nhi = {0, 0, 0, 0}, nlo = {0, 0, 0, 0};
     int nid = 0;
@@ -252,6 +290,11 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
           const float cn = c[m][r] * sf + pij[e];
           c[m][r] = cn;
           hv[r] = x3_tanh(cn) * so;
+          if (a.rec_h != nullptr && blockIdx.x == 0 && mt0 + m == 0 && (lane & 31) == 0) {
+            // sequence 0 of the launch: state after t+1 steps (builds the pad-prefix table)
+            a.rec_h[(size_t)(t + 1) * Hp + w * 32 + mfma_row(r, lane)] = hv[r];
+            a.rec_c[(size_t)(t + 1) * Hp + w * 32 + mfma_row(r, lane)] = cn;
+          }
         }
       }
       if (w * 32 >= a.H) {  // a unit block made only of padding keeps h = 0
@@ -363,7 +406,6 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
       }
     }
   }
-  (void)red;
 }
 
 // ---- packing --------------------------------------------------------------------------------------------------------

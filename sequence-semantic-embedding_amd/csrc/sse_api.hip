@@ -35,6 +35,9 @@ struct Encoder {
   bool waug_valid = false;
   unsigned short *Wx3 = nullptr;  // option lstm_x3: hi / lo bf16 fragment copies of the kernel matrix
   bool x3_valid = false;
+  float *pad_h_x3 = nullptr, *pad_c_x3 = nullptr;  // pad-prefix table of the lstm_x3 path ([pad_T_x3+1][Hp])
+  int pad_T_x3 = 0;
+  bool pad_valid_x3 = false;
   int shares_lstm_with = -1;  // shared-encoder: target reuses the source LSTM packing
   // pad-prefix table: state after p leading PAD steps, p = 0..pad_T ([pad_T+1][Hp] each)
   float *pad_h = nullptr, *pad_c = nullptr;
@@ -235,6 +238,7 @@ int ensure_packed(sse_handle *h, hipStream_t st) {
     e.pad_valid_small = false;
     e.waug_valid = false;
     e.x3_valid = false;
+    e.pad_valid_x3 = false;
     const int KG = e.KGx + e.KGh;
     if (e.shares_lstm_with < 0) {
       if (!e.Wp) HIPCHECK(h, hipMalloc((void **)&e.Wp, (size_t)(e.Hp / 32) * KG * 4 * 256 * sizeof(float)));
@@ -523,6 +527,37 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
     xa.NTS = (c.encoding_size + 31) / 32;
     xa.normalize = normalize ? 1 : 0;
     xa.row_map = h->cur_row_map;
+    if (h->pad_skip && T > 1) {
+      // pad-prefix table of THIS path: one all-PAD row through the same kernel, recorded step by step
+      if (!(own.pad_valid_x3 && own.pad_T_x3 >= T)) {
+        const int Tt = T > c.max_seq_length ? T : c.max_seq_length;
+        if (own.pad_T_x3 < Tt || !own.pad_h_x3) {
+          if (own.pad_h_x3) HIPCHECK(h, hipFree(own.pad_h_x3));
+          if (own.pad_c_x3) HIPCHECK(h, hipFree(own.pad_c_x3));
+          own.pad_h_x3 = own.pad_c_x3 = nullptr;
+          HIPCHECK(h, hipMalloc((void **)&own.pad_h_x3, (size_t)(Tt + 1) * own.Hp * sizeof(float)));
+          HIPCHECK(h, hipMalloc((void **)&own.pad_c_x3, (size_t)(Tt + 1) * own.Hp * sizeof(float)));
+          own.pad_T_x3 = Tt;
+        }
+        HIPCHECK(h, hipMemsetAsync(own.pad_h_x3, 0, (size_t)(Tt + 1) * own.Hp * sizeof(float), st));
+        HIPCHECK(h, hipMemsetAsync(own.pad_c_x3, 0, (size_t)(Tt + 1) * own.Hp * sizeof(float), st));
+        if (reserve(h, h->s_zero, (size_t)Tt * sizeof(int32_t) + (size_t)c.encoding_size * sizeof(float))) return 1;
+        HIPCHECK(h, hipMemsetAsync(h->s_zero.p, 0, (size_t)Tt * sizeof(int32_t), st));
+        LstmX3Args ta = xa;
+        ta.ids = (const int32_t *)h->s_zero.p;
+        ta.out = (float *)((char *)h->s_zero.p + (size_t)Tt * sizeof(int32_t));
+        ta.B = 1;
+        ta.T = Tt;
+        ta.normalize = 0;
+        ta.row_map = nullptr;
+        ta.rec_h = own.pad_h_x3;
+        ta.rec_c = own.pad_c_x3;
+        HIPCHECK(h, launch_lstm_fwd_x3(ta, st));
+        own.pad_valid_x3 = true;
+      }
+      xa.pad_h = own.pad_h_x3;
+      xa.pad_c = own.pad_c_x3;
+    }
     HIPCHECK(h, launch_lstm_fwd_x3(xa, st));
     return 0;
   }
@@ -940,6 +975,8 @@ void sse_destroy(sse_handle *h) {
       if (e.pad_c) (void)hipFree(e.pad_c);
       if (e.Waug) (void)hipFree(e.Waug);
       if (e.Wx3) (void)hipFree(e.Wx3);
+      if (e.pad_h_x3) (void)hipFree(e.pad_h_x3);
+      if (e.pad_c_x3) (void)hipFree(e.pad_c_x3);
       if (e.pad_h_small) (void)hipFree(e.pad_h_small);
       if (e.pad_c_small) (void)hipFree(e.pad_c_small);
     }

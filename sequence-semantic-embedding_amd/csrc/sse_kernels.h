@@ -92,6 +92,8 @@ struct LstmX3Args {
   int32_t *err;
   int32_t B, T, V, KGX, H, S, NTS, normalize;
   const int32_t *row_map = nullptr;
+  const float *pad_h = nullptr, *pad_c = nullptr;  // [T+1][Hp] state after p leading PAD steps (recorded by this kernel)
+  float *rec_h = nullptr, *rec_c = nullptr;        // table build: states of sequence 0 after every step
 };
 int lstm_x3_kgx(int E);
 size_t lstm_x3_weight_elems(int E, int Hp);

@@ -190,6 +190,9 @@ def test_split_bf16_matrix_path_stays_within_the_encoder_tolerance(mode, V, E, H
             want = O.encode(p, params, side, ids[:200], normalize=normalize)
             scale = 1.0 if normalize else max(1.0, float(np.abs(want).max()))
             d_exact, d_oracle = np.abs(got - exact).max() / scale, np.abs(got[:200] - want).max() / scale
+            m.handle.set_option("pad_skip", 0)
+            assert np.array_equal(enc(ids, normalize=normalize), got)     # the left-pad prefix skip is exact on this path too
+            m.handle.set_option("pad_skip", 1)
             print("lstm_x3 %s normalize=%d: |x3 - fp32 kernel| %.2e, |x3 - oracle| %.2e" % (side, normalize, d_exact, d_oracle))
             assert 0 < d_exact < 5e-5 and d_oracle < TOL
             if normalize:

@@ -20,6 +20,9 @@ m.init_variables(seed=0)
 h = m.handle
 dev = torch.device("cuda:0")
 ids = torch.randint(2, V, (B, T), device=dev, dtype=torch.int32)
+if os.environ.get("SSE_X3_PAD"):                     # left padding: lengths uniform in [2, T], rows sorted by length as sse_encode does
+    lens = torch.sort(torch.randint(2, T + 1, (B,), device=dev))[0]
+    ids[torch.arange(T, device=dev)[None, :] < (T - lens)[:, None]] = 0
 flop = T * 8 * H * (E + H) + 2 * H * S
 outs = []
 for x3 in (0, 1):
