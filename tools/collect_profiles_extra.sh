@@ -28,6 +28,9 @@ run cnn python "$root/tools/bench_cnn.py"
 SSE_TRAIN_SERIAL=1 run train python "$root/tools/bench_train.py" 8192
 run train_default python "$root/tools/bench_train_default.py"
 run query_encode python "$root/tools/bench_query_encode.py"
+run x3 python "$root/tools/bench_x3.py"
+pmc x3 "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" python "$root/tools/bench_x3.py"
+run x3_default_shape python "$root/tools/bench_x3.py" 16384 96 64 80
 run train_concurrent python "$root/tools/bench_train.py" 128 1024 8192
 find "$out" -name "*.csv" -size +20M -delete
 ls "$out"
