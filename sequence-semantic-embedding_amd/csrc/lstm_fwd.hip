@@ -299,21 +299,40 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       // r = (t*NT32 + tile32)*32 + b, i.e. AT[(r/8)*KT + k'/32][256].
       const int KT = 2 + KGh / 4;
       const int nk = 64 + KGh * 8;
-      for (int i = tid; i < nk * (ROWS / 4); i += LSTM_THREADS) {
-        const int kp = i % nk, b4 = i / nk;  // b4: rows 4*b4 .. 4*b4+3 of the tile
-        const int mt = b4 >> 3, bl = (b4 & 7) * 4;
-        f32x4 v = {0, 0, 0, 0};
+      auto a_elem = [&](int mt, int kp, int b) -> float {  // element (row b, k' = kp) of row tile mt, 0 beyond the x columns
         if (kp >= 64) {
           const int un = kp - 64;
-          const float *src = hptr(cur, mt) + (size_t)(un >> 3) * 256 + ((((un >> 2) & 1) * 32 + bl) << 2) + (un & 3);
-          v = f32x4{src[0], src[4], src[8], src[12]};
-        } else if (kp < KGx * 8) {
-          const float *src = xptr(cur, mt) + (size_t)(kp >> 3) * 256 + ((((kp >> 2) & 1) * 32 + bl) << 2) + (kp & 3);
-          v = f32x4{src[0], src[4], src[8], src[12]};
+          return hptr(cur, mt)[(size_t)(un >> 3) * 256 + ((((un >> 2) & 1) * 32 + b) << 2) + (un & 3)];
         }
-        const size_t rg = ((size_t)t * NT32 + blockIdx.x * RT + mt) * 4 + (bl >> 3);
-        float *dst = a.tape_a + (rg * KT + (kp >> 5)) * 256 + ((((bl >> 2) & 1) * 32 + (kp & 31)) << 2);
-        *reinterpret_cast<f32x4 *>(dst) = v;
+        if (kp < KGx * 8) return xptr(cur, mt)[(size_t)(kp >> 3) * 256 + ((((kp >> 2) & 1) * 32 + b) << 2) + (kp & 3)];
+        return 0.0f;
+      };
+      if (a.tape_a_split) {
+        // split bf16 operands for the dK GEMM on the bf16 matrix pipe: per 16-row group and k'-tile a hi and a lo frag16
+        // block; lane (k' & 31, half) owns rows 16 j + 8 half .. + 7 of the tile
+        unsigned short *ta = reinterpret_cast<unsigned short *>(a.tape_a);
+        for (int i = tid; i < nk * (ROWS / 8); i += LSTM_THREADS) {
+          const int kp = i % nk, o = i / nk;  // o: rows 8*o .. 8*o+7 of the workgroup
+          const int mt = o >> 2, oc = o & 3;
+          float v8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v8[e] = a_elem(mt, kp, oc * 8 + e);
+          sse_u32x4 hi, lo;
+          sse_split8(v8, hi, lo);
+          const size_t g16 = ((size_t)t * NT32 + blockIdx.x * RT + mt) * 2 + (oc >> 1);
+          unsigned short *dst = ta + ((g16 * KT + (kp >> 5)) * 2) * 512 + ((oc & 1) * 32 + (kp & 31)) * 8;
+          *reinterpret_cast<sse_u32x4 *>(dst) = hi;
+          *reinterpret_cast<sse_u32x4 *>(dst + 512) = lo;
+        }
+      } else {
+        for (int i = tid; i < nk * (ROWS / 4); i += LSTM_THREADS) {
+          const int kp = i % nk, b4 = i / nk;  // b4: rows 4*b4 .. 4*b4+3 of the tile
+          const int mt = b4 >> 3, bl = (b4 & 7) * 4;
+          const f32x4 v = {a_elem(mt, kp, bl), a_elem(mt, kp, bl + 1), a_elem(mt, kp, bl + 2), a_elem(mt, kp, bl + 3)};
+          const size_t rg = ((size_t)t * NT32 + blockIdx.x * RT + mt) * 4 + (bl >> 3);
+          float *dst = a.tape_a + (rg * KT + (kp >> 5)) * 256 + ((((bl >> 2) & 1) * 32 + (kp & 31)) << 2);
+          *reinterpret_cast<f32x4 *>(dst) = v;
+        }
       }
     }
     // h_{-1} = 0: skip the recurrent part of step 0; hidden units >= H are padding whose state stays exactly 0,

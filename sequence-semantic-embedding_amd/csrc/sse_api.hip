@@ -112,6 +112,7 @@ struct sse_handle {
   bool cnn_bf16 = false;     // option "cnn_bf16": source_only_cnn inference with bf16 storage / fp32 accumulation
   unsigned short *emb_bf16 = nullptr, *cnn_Wc16 = nullptr;
   int lstm_train_rows = 0;   // option "lstm_train_rows": 0 = automatic, 32 / 64 = rows per workgroup of the training forward (Hp = 256)
+  bool train_dk_x3 = true;   // option "train_dk_x3": weight-gradient GEMM of the LSTM train step on the bf16 matrix pipe with split operands
   bool train_pair_dedup = true; // option "train_pair_dedup": run the source encoder once per (pos, neg) pair of rows that share it
   bool train_serial = false; // option "train_serial": both encoders on one stream (profiling: isolated kernel times)
   float *emb_pad = nullptr;  // [V][Ep]
@@ -1164,6 +1165,10 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value) {
     h->lstm_train_rows = (int)value;
     return 0;
   }
+  if (strcmp(name, "train_dk_x3") == 0) {
+    h->train_dk_x3 = value != 0;
+    return 0;
+  }
   if (strcmp(name, "train_pair_dedup") == 0) {
     h->train_pair_dedup = value != 0;
     return 0;
@@ -1606,6 +1611,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     a.force_rows = h->lstm_train_rows;
     a.tape_g = (float *)ts.tape_g[s].p;
     a.tape_a = (float *)ts.tape_a[s].p;
+    a.tape_a_split = h->train_dk_x3 ? 1 : 0;
     a.h_last = (float *)ts.h_last[s].p;
     HIPCHECK(h, launch_lstm_fwd(a, e.Hp, fs));
     if (half) {  // rows B/2 .. B-1 are the same sequences: the loss and the projection backward read them per row
@@ -1658,10 +1664,14 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
                                 S, h->vars[e.proj].grad, (float *)ts.dh_last[s].p, (float *)ts.dm_part[s].p, bs));
     HIPCHECK(h, launch_lstm_bwd((const float *)ts.tape_g[s].p, (const float *)ts.dh_last[s].p, ts.KhT[s],
                                 (float *)ts.dg_a[s].p, (float *)ts.dg_b[s].p, (float *)ts.db_part[s].p, T, NT32,
-                                half ? NT_half : NT32, Hp, e.H, bs));
+                                half ? NT_half : NT32, Hp, e.H, h->train_dk_x3 ? 1 : 0, bs));
     const int accumulate = (shared && s == 1) ? 1 : 0;
-    HIPCHECK(h, launch_dk((const float *)ts.tape_a[s].p, (const float *)ts.dg_b[s].p, (float *)ts.dk_part[s].p, RGa, KT, NTn, SL,
-                          E, e.H, Hp, accumulate, h->vars[e.kernel].grad, half ? NT_half * 4 : 0, bs));
+    if (h->train_dk_x3)  // the 8-row r-groups of the fp32 layout pair up into 16-row groups: the same bytes
+      HIPCHECK(h, launch_dk_x3(ts.tape_a[s].p, ts.dg_b[s].p, (float *)ts.dk_part[s].p, RGa / 2, KT, NTn, SL, E, e.H, Hp, accumulate,
+                               h->vars[e.kernel].grad, half ? NT_half * 2 : 0, bs));
+    else
+      HIPCHECK(h, launch_dk((const float *)ts.tape_a[s].p, (const float *)ts.dg_b[s].p, (float *)ts.dk_part[s].p, RGa, KT, NTn, SL,
+                            E, e.H, Hp, accumulate, h->vars[e.kernel].grad, half ? NT_half * 4 : 0, bs));
     HIPCHECK(h, launch_db_reduce((const float *)ts.db_part[s].p, NT32, e.H, Hp, accumulate, h->vars[e.bias].grad, bs));
     if (reserve(h, ts.hot_part[s], (size_t)T * NT32 * 2 * 64 * sizeof(float))) return 1;
     HIPCHECK(h, launch_dx((const float *)ts.dg_a[s].p, ts.KxT[s], (const int32_t *)ts.ids[s].p, emb.grad,

@@ -30,6 +30,36 @@ __device__ static inline int mfma_row(int reg, int lane) { return (reg & 3) + 8 
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// ---------------------------------------------------------------------------
+// Split bf16 operands: an fp32 value x is carried as hi = bf16(x), lo = bf16(x - hi) (x = hi + lo to 2^-18 relative) and a
+// product a*b as the three bf16 MFMAs a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with fp32 accumulation (lstm_fwd_x3.hip, the
+// training dK GEMM).  "frag16" blocks: 32 rows x 16 k bf16 = 1 KiB, lane (row & 31, k octet = lane >> 5) owns 8
+// consecutive k = 16 bytes; a hi block is followed by its lo block.
+// ---------------------------------------------------------------------------
+typedef unsigned int sse_u32x4 __attribute__((ext_vector_type(4)));
+__host__ __device__ static inline unsigned short sse_bf16_rne(float f) {  // round to nearest even (finite inputs)
+  unsigned u;
+  __builtin_memcpy(&u, &f, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__host__ __device__ static inline float sse_bf16_f32(unsigned short h) {
+  const unsigned u = (unsigned)h << 16;
+  float f;
+  __builtin_memcpy(&f, &u, 4);
+  return f;
+}
+// 8 fp32 -> the hi and the lo octet (16 bytes each)
+__device__ static inline void sse_split8(const float (&v)[8], sse_u32x4 &hi, sse_u32x4 &lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned short h0 = sse_bf16_rne(v[2 * i]), h1 = sse_bf16_rne(v[2 * i + 1]);
+    const unsigned short l0 = sse_bf16_rne(v[2 * i] - sse_bf16_f32(h0)), l1 = sse_bf16_rne(v[2 * i + 1] - sse_bf16_f32(h1));
+    hi[i] = (unsigned)h0 | ((unsigned)h1 << 16);
+    lo[i] = (unsigned)l0 | ((unsigned)l1 << 16);
+  }
+}
+
 // ------------------------------ LSTM forward -------------------------------
 struct LstmFwdArgs {
   const int32_t *ids;   // [B][T]
@@ -56,6 +86,7 @@ struct LstmFwdArgs {
   // training only (nullptr for inference): tapes consumed by the backward kernels
   float *tape_g = nullptr;  // [T][NT32][4][UB][5][16][64] gate activations + c, accumulator layout
   float *tape_a = nullptr;  // [(T*NT32*4)][KT][256]  [x_t | h_{t-1}] as frag32(rows = k', red = r)
+  int32_t tape_a_split = 0; // 1: tape_a holds split bf16 frag16 blocks instead: [(T*NT32*2)][KT][hi|lo][512] (same bytes)
   float *h_last = nullptr;  // [Bp][Hp] h_T
 };
 // Hp = 128 * UB hidden units; 512 threads; dynamic LDS = lstm_fwd_lds_bytes()

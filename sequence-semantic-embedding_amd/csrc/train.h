@@ -10,10 +10,13 @@ int proj_bwd_chunks(int Bp);
 hipError_t launch_proj_bwd(const float *hT, const float *d, const float *M, int Bp, int H, int Hp, int S, float *dM,
                            float *dh, float *dm_part /* [proj_bwd_chunks(Bp)][H*S] */, hipStream_t st);
 hipError_t launch_lstm_bwd(const float *tape_g, const float *dh_last, const float *KhT, float *dg_a, float *dg_b,
-                           float *db_part, int T, int NT32, int NT_tape /* 0: NT32 */, int Hp, int H, hipStream_t st);
+                           float *db_part, int T, int NT32, int NT_tape /* 0: NT32 */, int Hp, int H,
+                           int dg_b_split /* 1: split bf16 frag16 blocks for launch_dk_x3 */, hipStream_t st);
 int dk_slices(int RG);
 hipError_t launch_dk(const float *tape_a, const float *dg_b, float *part, int RG, int KT, int NTn, int SL, int E, int H,
                      int Hp, int accumulate, float *dK, int pair_rg /* 0: dg_b has RG r-groups */, hipStream_t st);
+hipError_t launch_dk_x3(const void *tape_a, const void *dg_b, float *part, int G, int KT, int NTn, int SL, int E, int H,
+                        int Hp, int accumulate, float *dK, int pair_g, hipStream_t st);
 hipError_t launch_db_reduce(const float *db_part, int NT32, int H, int Hp, int accumulate, float *db, hipStream_t st);
 hipError_t launch_dx(const float *dg_a, const float *KxT, const int32_t *ids, float *d_emb, float *sq_part,
                      float *hot_part /* [T*NT32][2][64] floats */, int T, int NT32, int KGn, int B, int E, int V, int H,

@@ -208,11 +208,13 @@ struct LstmBwdArgs {
   float *db_part;       // [NT32][4*Hp] per-tile bias-gradient partials
   int32_t T, NT32, Hp;
   int32_t H;            // real cell size: dG columns of padded units are exactly 0, their k-groups are skipped
+  int32_t dg_b_split;   // 1: dg_b is written as split bf16 frag16 blocks [(T*NT32*2)][NTn][hi|lo][512] (same bytes) for the
+                        // dK GEMM on the bf16 matrix pipe (dk_x3_kernel)
   int32_t NT_tape;      // 32-row tiles the gate tape holds per step: NT32, or NT32/2 when the batch is (pos, neg) pairs
                         // that share their source sequence -- tiles j and j + NT_tape then read the same tape
 };
 
-template <int UB, int NW>
+template <int UB, int NW, bool SPLIT>
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float dgs[];  // [KGn][256]: dg tile, frag32(rows = b, red = n)
   constexpr int NTHR = NW * 64;
@@ -313,17 +315,37 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
       const int n4 = KGn * 64, h4 = n4 / 2;
 #pragma unroll 4
       for (int i = grp * h4 + gt; i < (grp + 1) * h4; i += GTHR) ga[i] = ls[i];
-      // (n, 4 consecutive rows) -> one float4 of block (rg, n/32)
-      const size_t rg0 = ((size_t)t * a.NT32 + tile) * 4;
-      const int nb = 4 * Hp * 8, hb = nb / 2;
+      if constexpr (SPLIT) {
+        // (n, 8 consecutive rows) -> one hi and one lo octet of block (16-row group, n/32)
+        unsigned short *gb = reinterpret_cast<unsigned short *>(a.dg_b);
+        const size_t g0 = ((size_t)t * a.NT32 + tile) * 2;
+        const int nb = 4 * Hp * 4, hb = nb / 2;
+#pragma unroll 1
+        for (int i = grp * hb + gt; i < (grp + 1) * hb; i += GTHR) {
+          const int n = i % (4 * Hp), oc = i / (4 * Hp);  // rows 8*oc .. 8*oc+7
+          const float *src = dgs + (size_t)(n >> 3) * 256 + ((((n >> 2) & 1) * 32 + oc * 8) << 2) + (n & 3);
+          float v8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v8[e] = src[4 * e];
+          sse_u32x4 hi, lo;
+          sse_split8(v8, hi, lo);
+          unsigned short *dst = gb + (((g0 + (oc >> 1)) * NTn + (n >> 5)) * 2) * 512 + ((oc & 1) * 32 + (n & 31)) * 8;
+          *reinterpret_cast<sse_u32x4 *>(dst) = hi;
+          *reinterpret_cast<sse_u32x4 *>(dst + 512) = lo;
+        }
+      } else {
+        // (n, 4 consecutive rows) -> one float4 of block (rg, n/32)
+        const size_t rg0 = ((size_t)t * a.NT32 + tile) * 4;
+        const int nb = 4 * Hp * 8, hb = nb / 2;
 #pragma unroll 4
-      for (int i = grp * hb + gt; i < (grp + 1) * hb; i += GTHR) {
-        const int n = i % (4 * Hp), b4 = i / (4 * Hp);  // rows 4*b4 .. 4*b4+3
-        const int bl = b4 * 4;
-        const float *src = dgs + (size_t)(n >> 3) * 256 + ((((n >> 2) & 1) * 32 + bl) << 2) + (n & 3);
-        const f32x4 v = {src[0], src[4], src[8], src[12]};
-        float *dst = a.dg_b + ((rg0 + (bl >> 3)) * NTn + (n >> 5)) * 256 + ((((bl >> 2) & 1) * 32 + (n & 31)) << 2);
-        *reinterpret_cast<f32x4 *>(dst) = v;
+        for (int i = grp * hb + gt; i < (grp + 1) * hb; i += GTHR) {
+          const int n = i % (4 * Hp), b4 = i / (4 * Hp);  // rows 4*b4 .. 4*b4+3
+          const int bl = b4 * 4;
+          const float *src = dgs + (size_t)(n >> 3) * 256 + ((((n >> 2) & 1) * 32 + bl) << 2) + (n & 3);
+          const f32x4 v = {src[0], src[4], src[8], src[12]};
+          float *dst = a.dg_b + ((rg0 + (bl >> 3)) * NTn + (n >> 5)) * 256 + ((((bl >> 2) & 1) * 32 + (n & 31)) << 2);
+          *reinterpret_cast<f32x4 *>(dst) = v;
+        }
       }
     };
     const bool dump_first = wn < NW / 2;
@@ -495,6 +517,132 @@ __global__ __launch_bounds__(512) void dk_gemm_kernel(DkArgs a) {
       bc = yb;
       gload_a(clampr(rg + 4), ys0, ys1);
       yb = gload_b(clampr(rg + 4));
+      __syncthreads();
+    }
+  }
+  if (!live) return;
+  const int ldn = a.NTn * 32;
+  float *out = a.part + (size_t)slice * KT * 32 * ldn;
+#pragma unroll
+  for (int i = 0; i < KT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(size_t)(i * 32 + mfma_row(r, lane)) * ldn + nt * 32 + (lane & 31)] = acc[i][r];
+}
+
+// ---------------------------------------------------------------------------
+// The same dK partials on the bf16 matrix pipe with split operands (see sse_kernels.h): tape_a and dG arrive as hi / lo
+// frag16 blocks (written that way by the forward and BPTT kernels: 16 reduction rows per block, same bytes as fp32), a
+// product costs three v_mfma_f32_32x32x16_bf16 (32 cycles each, 16 r) instead of eight v_mfma_f32_32x32x2_f32 (64 cycles).
+// Relative error of a product ~4e-6: below the fp32 summation-order noise of a 262144-term gradient sum.
+// Same decomposition: workgroup = all KT k'-tiles x 8 n-tiles, wave w owns n-tile w; the 2*KT A blocks of a group are
+// fetched once per workgroup into a double-buffered LDS stage; operands requested two groups ahead.
+// PAIR: A^T dG_pos + A^T dG_neg = A^T (dG_pos + dG_neg): the two rows' dG fragments are rebuilt in fp32, added and split again.
+typedef short dk_bf16x8 __attribute__((ext_vector_type(8)));
+struct DkX3Args {
+  const unsigned short *tape_a;  // [(G)][KT][hi|lo][512]
+  const unsigned short *dg_b;    // [(G or 2G)][NTn][hi|lo][512]
+  float *part;                   // [SL][KT*32][NTn*32]
+  int32_t G, KT, NTn, SL;        // G = 16-row groups of tape_a
+  uint32_t live_k;
+  int32_t pair_g;                // 0, or 16-row groups per step of tape_a (= 2 * NT32/2)
+};
+
+template <int KT, bool PAIR>
+__global__ __launch_bounds__(512) void dk_x3_kernel(DkX3Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned short stage[2][2 * KT][512];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t live_k = a.live_k;
+  const int nt = min(blockIdx.x * 8 + w, a.NTn - 1);
+  const bool live = blockIdx.x * 8 + w < a.NTn;
+  const int slice = blockIdx.y;
+  const int per = (a.G + a.SL - 1) / a.SL;
+  const int g0 = slice * per, g1 = min(a.G, g0 + per);
+  f32x16 acc[KT];
+#pragma unroll
+  for (int i = 0; i < KT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  const unsigned short *pa = a.tape_a + lane * 8;
+  const unsigned short *pb = a.dg_b + (size_t)nt * 1024 + lane * 8;
+  const int pair_g = a.pair_g;
+  constexpr int NBLK = 2 * KT;                   // A blocks per group
+  constexpr int PER_W = (NBLK + 7) / 8;          // blocks a wave brings (<= 3)
+  struct Set {
+    sse_u32x4 s[PER_W];
+    dk_bf16x8 bh, bl;
+  };
+  auto gload = [&](int g, Set &x) {
+#pragma unroll
+    for (int j = 0; j < PER_W; ++j)
+      if (w + 8 * j < NBLK) x.s[j] = *reinterpret_cast<const sse_u32x4 *>(pa + ((size_t)g * NBLK + w + 8 * j) * 512);
+    if constexpr (!PAIR) {
+      const unsigned short *p = pb + (size_t)g * a.NTn * 1024;
+      x.bh = *reinterpret_cast<const dk_bf16x8 *>(p);
+      x.bl = *reinterpret_cast<const dk_bf16x8 *>(p + 512);
+    } else {
+      const int t = g / pair_g, d1 = g + t * pair_g;
+      const unsigned short *p1 = pb + (size_t)d1 * a.NTn * 1024, *p2 = pb + (size_t)(d1 + pair_g) * a.NTn * 1024;
+      const sse_u32x4 h1 = *reinterpret_cast<const sse_u32x4 *>(p1), l1 = *reinterpret_cast<const sse_u32x4 *>(p1 + 512);
+      const sse_u32x4 h2 = *reinterpret_cast<const sse_u32x4 *>(p2), l2 = *reinterpret_cast<const sse_u32x4 *>(p2 + 512);
+      float v8[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v8[2 * e] = (__uint_as_float(h1[e] << 16) + __uint_as_float(l1[e] << 16)) + (__uint_as_float(h2[e] << 16) + __uint_as_float(l2[e] << 16));
+        v8[2 * e + 1] = (__uint_as_float(h1[e] & 0xffff0000u) + __uint_as_float(l1[e] & 0xffff0000u)) +
+                        (__uint_as_float(h2[e] & 0xffff0000u) + __uint_as_float(l2[e] & 0xffff0000u));
+      }
+      sse_u32x4 hi, lo;
+      sse_split8(v8, hi, lo);
+      x.bh = __builtin_bit_cast(dk_bf16x8, hi);
+      x.bl = __builtin_bit_cast(dk_bf16x8, lo);
+    }
+  };
+  auto stash = [&](int buf, const Set &x) {
+#pragma unroll
+    for (int j = 0; j < PER_W; ++j)
+      if (w + 8 * j < NBLK) *reinterpret_cast<sse_u32x4 *>(&stage[buf][w + 8 * j][lane * 8]) = x.s[j];
+  };
+  auto compute = [&](int buf, const dk_bf16x8 &bh, const dk_bf16x8 &bl) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < KT; ++i) {
+      if ((live_k >> i) & 1) {
+        const dk_bf16x8 ah = *reinterpret_cast<const dk_bf16x8 *>(&stage[buf][2 * i][lane * 8]);
+        const dk_bf16x8 al = *reinterpret_cast<const dk_bf16x8 *>(&stage[buf][2 * i + 1][lane * 8]);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  if (g0 < g1) {
+    auto clampg = [&](int g) { return g < g1 ? g : g1 - 1; };
+    Set x, y;
+    dk_bf16x8 bh, bl;
+    gload(g0, x);
+    stash(0, x);
+    bh = x.bh;
+    bl = x.bl;
+    gload(clampg(g0 + 1), x);
+    gload(clampg(g0 + 2), y);
+    __syncthreads();
+    for (int g = g0; g < g1; g += 2) {
+      // even step: stage 0 holds group g; set X holds g+1 (to stage 1), then refetches g+3
+      compute(0, bh, bl);
+      if (g + 1 < g1) stash(1, x);
+      bh = x.bh;
+      bl = x.bl;
+      gload(clampg(g + 3), x);
+      __syncthreads();
+      if (g + 1 >= g1) break;
+      // odd step: stage 1 holds g+1; set Y holds g+2 (to stage 0), then refetches g+4
+      compute(1, bh, bl);
+      if (g + 2 < g1) stash(0, y);
+      bh = y.bh;
+      bl = y.bl;
+      gload(clampg(g + 4), y);
       __syncthreads();
     }
   }
@@ -761,23 +909,19 @@ hipError_t launch_proj_bwd(const float *hT, const float *d, const float *M, int 
 }
 
 hipError_t launch_lstm_bwd(const float *tape_g, const float *dh_last, const float *KhT, float *dg_a, float *dg_b,
-                           float *db_part, int T, int NT32, int NT_tape, int Hp, int H, hipStream_t st) {
-  LstmBwdArgs a{tape_g, dh_last, KhT, dg_a, dg_b, db_part, T, NT32, Hp, H, NT_tape > 0 ? NT_tape : NT32};
+                           float *db_part, int T, int NT32, int NT_tape, int Hp, int H, int dg_b_split, hipStream_t st) {
+  LstmBwdArgs a{tape_g, dh_last, KhT, dg_a, dg_b, db_part, T, NT32, Hp, H, dg_b_split, NT_tape > 0 ? NT_tape : NT32};
   const size_t lds = (size_t)(Hp / 2) * 256 * sizeof(float);
   if ((size_t)T * NT32 * (Hp / 32) * 5 * 1024 * sizeof(float) >= ((size_t)1 << 31)) return hipErrorInvalidValue;  // 32-bit tape offsets
-  hipError_t e;
-  if (Hp == 128) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_bwd_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  auto go = [&](auto kern, int threads) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((lstm_bwd_kernel<1, 4>), dim3(NT32), dim3(256), lds, st, a);
-  } else if (Hp == 256) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_bwd_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((lstm_bwd_kernel<1, 8>), dim3(NT32), dim3(512), lds, st, a);
-  } else {
-    return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3(NT32), dim3(threads), lds, st, a);
+    return hipGetLastError();
+  };
+  if (Hp == 128) return dg_b_split ? go(lstm_bwd_kernel<1, 4, true>, 256) : go(lstm_bwd_kernel<1, 4, false>, 256);
+  if (Hp == 256) return dg_b_split ? go(lstm_bwd_kernel<1, 8, true>, 512) : go(lstm_bwd_kernel<1, 8, false>, 512);
+  return hipErrorInvalidValue;
 }
 
 int dk_slices(int RG) {
@@ -800,6 +944,27 @@ hipError_t launch_dk(const float *tape_a, const float *dg_b, float *part, int RG
   else if (KT == 10) hipLaunchKernelGGL((dk_gemm_kernel<10, false>), grid, dim3(512), 0, st, a);
   else if (KT == 6 && pair_rg) hipLaunchKernelGGL((dk_gemm_kernel<6, true>), grid, dim3(512), 0, st, a);
   else if (KT == 6) hipLaunchKernelGGL((dk_gemm_kernel<6, false>), grid, dim3(512), 0, st, a);
+  else return hipErrorInvalidValue;
+  hipLaunchKernelGGL(dk_reduce_kernel, dim3(((E + H) * 4 * H + 255) / 256), dim3(256), 0, st, part, SL, KT, NTn, E, H, Hp,
+                     accumulate, dK);
+  return hipGetLastError();
+}
+
+// dK on the bf16 matrix pipe: tape_a / dg_b in split frag16 form (tape_a_split / dg_b_split of the producing kernels);
+// G = 16-row groups of tape_a, pair_g as pair_rg of launch_dk in 16-row groups
+hipError_t launch_dk_x3(const void *tape_a, const void *dg_b, float *part, int G, int KT, int NTn, int SL, int E, int H,
+                        int Hp, int accumulate, float *dK, int pair_g, hipStream_t st) {
+  uint32_t live = 0;
+  for (int i = 0; i < KT; ++i) {
+    const bool on = (i < 2) ? (i * 32 < E) : ((i - 2) * 32 < H);
+    if (on) live |= 1u << i;
+  }
+  DkX3Args a{(const unsigned short *)tape_a, (const unsigned short *)dg_b, part, G, KT, NTn, SL, live, pair_g};
+  const dim3 grid((NTn + 7) / 8, SL);
+  if (KT == 10 && pair_g) hipLaunchKernelGGL((dk_x3_kernel<10, true>), grid, dim3(512), 0, st, a);
+  else if (KT == 10) hipLaunchKernelGGL((dk_x3_kernel<10, false>), grid, dim3(512), 0, st, a);
+  else if (KT == 6 && pair_g) hipLaunchKernelGGL((dk_x3_kernel<6, true>), grid, dim3(512), 0, st, a);
+  else if (KT == 6) hipLaunchKernelGGL((dk_x3_kernel<6, false>), grid, dim3(512), 0, st, a);
   else return hipErrorInvalidValue;
   hipLaunchKernelGGL(dk_reduce_kernel, dim3(((E + H) * 4 * H + 255) / 256), dim3(256), 0, st, part, SL, KT, NTn, E, H, Hp,
                      accumulate, dK);

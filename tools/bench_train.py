@@ -22,6 +22,8 @@ if os.environ.get("SSE_TRAIN_ROWS"):                   # 32 / 64 rows per workgr
     m.handle.set_option("lstm_train_rows", int(os.environ["SSE_TRAIN_ROWS"]))
 if os.environ.get("SSE_TRAIN_PAIR_DEDUP"):            # 0: run the source encoder on every row of a paired batch
     m.handle.set_option("train_pair_dedup", int(os.environ["SSE_TRAIN_PAIR_DEDUP"]))
+if os.environ.get("SSE_TRAIN_DK_X3"):                  # 0: fp32 MFMA weight-gradient GEMM
+    m.handle.set_option("train_dk_x3", int(os.environ["SSE_TRAIN_DK_X3"]))
 rng = np.random.RandomState(0)
 for B in [int(x) for x in (sys.argv[1:] or ["128", "1024", "8192"])]:
     if os.environ.get("SSE_TRAIN_UNPAIRED"):
