@@ -115,6 +115,11 @@ class Handle(object):
         if rc != 0:
             raise SSEError(self.lib.sse_last_error(None).decode())
         self.cfg = cfg
+        # SSE_OPTIONS="name=value,name=value": library options (sse_set_option) for any command line without touching it,
+        # e.g. SSE_OPTIONS=lstm_x3=1 python sse_index.py ...; an option the network mode rejects fails loudly
+        for item in filter(None, (x.strip() for x in os.environ.get("SSE_OPTIONS", "").split(","))):
+            name, _, value = item.partition("=")
+            self.set_option(name.strip(), int(value or "1"))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

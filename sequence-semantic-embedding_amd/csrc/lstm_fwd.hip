@@ -32,6 +32,8 @@
 // is re-read lane-privately by the BPTT kernel in that layout.
 // The bias is not added separately: the padded embedding table carries a constant 1.0 in column E
 // and the packed kernel the bias (forget-bias folded in) in k-row E, so it rides in the GEMM.
+#include <cstdlib>
+
 #include "sse_kernels.h"
 
 #define LSTM_THREADS 512
@@ -616,6 +618,10 @@ int lstm_fwd_rows_per_wg(int Hp, int B, int tiles_elsewhere) {
 hipError_t launch_lstm_fwd(const LstmFwdArgs &a, int Hp, hipStream_t stream) {
   int rows = lstm_fwd_rows_per_wg(Hp, a.B, a.tiles_elsewhere);
   if (Hp <= 256 && (a.force_rows == 32 || a.force_rows == 64)) rows = a.force_rows;
+  if (const char *ev = getenv("SSE_FWD_ROWS")) {  // measurement aid
+    const int r = atoi(ev);
+    if (Hp <= 256 && (r == 32 || r == 64)) rows = r;
+  }
   if (rows == 64 && a.NT32 > 0 && (a.NT32 & 1)) return hipErrorInvalidValue;  // tapes are laid out per 32-row tile
   if (Hp == 128) return rows == 32 ? launch_cfg<1, 1, 1, true>(a, stream) : launch_cfg<2, 1, 1>(a, stream);
   if (Hp == 256) return rows == 32 ? launch_cfg<1, 1, 1>(a, stream) : launch_cfg<2, 2, 1>(a, stream);
