@@ -1185,6 +1185,11 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value) {
     h->lstm_x3 = value != 0;
     return 0;
   }
+  if (strcmp(name, "lstm_persist_epoch") == 0) {  // testing aid: move the cluster kernel's 20-bit tag epoch (wrap-around path)
+    if (value < 0 || value >= (1 << 20)) return fail(h, "lstm_persist_epoch must be in [0, 2^20)");
+    h->persist_epoch = (uint32_t)value;
+    return 0;
+  }
   if (strcmp(name, "lstm_persist_rows") == 0) {
     if (value < 0) return fail(h, "lstm_persist_rows must be >= 0");
     h->lstm_persist_rows = (int)value;

@@ -166,6 +166,34 @@ def test_cluster_kernel_equals_the_other_kernels(mode, V, E, Hs, Ht, S, T):
     assert np.isfinite(m.encode_source(random_ids(rng, 2, T, V))).all()
 
 
+def test_cluster_kernel_survives_many_calls_and_shape_changes():
+    """The cluster kernel's exchange buffers are reused across calls with a per-call tag epoch: thousands of calls that
+    alternate sides (different cell sizes -> different exchange layouts), batch sizes and sequence lengths must keep
+    returning exactly the few-sequences kernel's result (a stale tag would read another call's h_t)."""
+    params = model_params("dual-encoder", 400, 50, 256, 96, 64, 24)
+    m, p = make_pair(params, seed=21)
+    rng = np.random.RandomState(6)
+    cases = []
+    for B, T in ((1, 24), (5, 7), (32, 24), (2, 2), (17, 13)):
+        ids = random_ids(rng, B, T, 400, pad_frac=0.4)
+        m.handle.set_option("lstm_persist_rows", 0)
+        ref = (m.encode_source(ids), m.encode_target(ids))
+        cases.append((ids, ref))
+    m.handle.set_option("lstm_persist_rows", 32)
+    for it in range(1500):
+        ids, ref = cases[it % len(cases)]
+        side = it % 2
+        got = (m.encode_source if side == 0 else m.encode_target)(ids)
+        if it % 97 == 0 or it > 1480:
+            assert np.array_equal(got, ref[side]), it
+    assert np.array_equal(m.encode_source(cases[0][0]), cases[0][1][0])
+    # the 20-bit epoch runs out: the buffers are cleared and the epochs restart -- no stale tag can match
+    m.handle.set_option("lstm_persist_epoch", (1 << 20) - 4)
+    for it in range(10):
+        ids, ref = cases[it % len(cases)]
+        assert np.array_equal(m.encode_source(ids), ref[0]), it
+
+
 @pytest.mark.parametrize("mode,V,E,Hs,Ht,S,T,B,pad", [
     ("dual-encoder", 500, 50, 256, 256, 256, 32, 1200, 0.0),      # configs[1] shape
     ("dual-encoder", 300, 50, 200, 160, 64, 80, 1100, 0.7),       # padded cells / units, long left-padded rows
