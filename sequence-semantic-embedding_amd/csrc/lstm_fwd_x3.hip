@@ -22,6 +22,13 @@
 //    the projection + l2-normalise tail is the exact fp32 code of lstm_fwd.hip.
 // Hp = 256 (cell sizes 129..256: wave = unit block, both row tiles) and Hp = 128 (cell sizes <= 128: wave = unit block
 // w & 3, row tile w >> 2).  Left-pad prefix skip as in lstm_fwd.hip, from a table this kernel records itself.
+//
+// TRAIN variant (option "train_fwd_x3": the forward of the LSTM train step): the operand roles of lstm_fwd.hip's training
+// forward -- activations are the A operand, an accumulator lane owns ONE hidden unit and 16 rows -- because the gate tape
+// is re-read lane-privately by the BPTT kernel in that layout.  The h part keeps the natural k order (a second packed copy
+// of the kernel), h_t is scattered into the operand tiles as 2-byte pieces (4-way bank conflicts; the fp32 training
+// forward pays 8-way on 4-byte pieces), the tapes are written as lstm_fwd.hip writes them (tape_a in the split form the
+// dK GEMM on the bf16 pipe reads: the stored hi / lo pieces are copied, not re-split), no pad skip.
 #include "sse_kernels.h"
 
 #define X3_THREADS 512
@@ -60,7 +67,7 @@ __device__ __forceinline__ void x3_split8(const float (&v)[8], u32x4 &hi, u32x4 
 size_t lstm_x3_lds_bytes(int KGX, int Hp) { return (size_t)2 * KGX * 2048 + (size_t)2 * 2 * (Hp / 16) * 2048 + 1024; }
 
 // UBN = unit blocks of 32 hidden units (Hp = 32 * UBN): 8 -> wave = unit block, MT = 2 row tiles; 4 -> MT = 1
-template <int UBN>
+template <int UBN, bool TRAIN>
 __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
   constexpr int KGH = 2 * UBN;  // h groups of 16 units
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
   // starts at t0 = min over its rows of the leading-PAD count with (h, c) = pad_h / pad_c[t0] (recorded by an all-PAD
   // launch of THIS kernel: same arithmetic); rows beyond B count as all-PAD
   int t0 = 0;
-  if (a.pad_h != nullptr) {
+  if (!TRAIN && a.pad_h != nullptr) {
     int lead = T;
     if (row_ok) {
       for (int t = xq; t < T; t += 8)
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
   f32x16 c[MT];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const float c0 = (t0 > 0) ? a.pad_c[(size_t)t0 * Hp + w * 32 + mfma_row(r, lane)] : 0.0f;
+    const float c0 = (!TRAIN && t0 > 0) ? a.pad_c[(size_t)t0 * Hp + w * 32 + mfma_row(r, lane)] : 0.0f;
 #pragma unroll
     for (int m = 0; m < MT; ++m) c[m][r] = c0;
   }
@@ -176,12 +183,50 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
     }
     const int kend = (t == 0) ? KGX : KGX + KGHe;  // h_{-1} = 0
     const int wsoff = w * KG * 8192;
+    const int NT32 = a.NT32;
+    if constexpr (TRAIN) {
+      // A-tape for the dK GEMM on the bf16 pipe: [x_t | h_{t-1}] of both row tiles as split frag16 blocks, lane (k' & 31,
+      // half) owning rows 16 j + 8 half .. + 7: the hi and lo pieces already sit in the operand tiles (lane = row there)
+      const int KT = 2 + Hp / 32, nk = 64 + Hp;
+      unsigned short *ta = reinterpret_cast<unsigned short *>(a.tape_a);
+      for (int i = tid; i < nk * 8; i += X3_THREADS) {
+        const int kp = i % nk, o = i / nk;  // o: rows 8*o .. 8*o+7 of the workgroup's 64
+        const int mt = o >> 2, oc = o & 3;
+        u32x4 hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
+        const bool xpart = kp < 64;
+        const int k = xpart ? kp : kp - 64;
+        if (!xpart || k < KGX * 16) {
+          const unsigned char *src = (xpart ? xptr(mt) : hptr(cur, mt)) + (size_t)(k >> 4) * 2048 +
+                                     (size_t)(((k >> 3) & 1) * 32 + oc * 8) * 16 + (k & 7) * 2;
+          if (xpart || t > 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned h0 = *reinterpret_cast<const unsigned short *>(src + (2 * e) * 16);
+              const unsigned h1 = *reinterpret_cast<const unsigned short *>(src + (2 * e + 1) * 16);
+              const unsigned l0 = *reinterpret_cast<const unsigned short *>(src + 1024 + (2 * e) * 16);
+              const unsigned l1 = *reinterpret_cast<const unsigned short *>(src + 1024 + (2 * e + 1) * 16);
+              hi[e] = h0 | (h1 << 16);
+              lo[e] = l0 | (l1 << 16);
+            }
+          }
+        }
+        const size_t g16 = ((size_t)t * NT32 + blockIdx.x * 2 + mt) * 2 + (oc >> 1);
+        unsigned short *dst = ta + ((g16 * KT + (kp >> 5)) * 2) * 512 + ((oc & 1) * 32 + (kp & 31)) * 8;
+        *reinterpret_cast<u32x4 *>(dst) = hi;
+        *reinterpret_cast<u32x4 *>(dst + 512) = lo;
+      }
+    }
 
     // one pass = two gates (byte offset g0 * 2048 inside a k group's 8 KiB), both row tiles, k groups [0, kend):
     // per group 4 weight fragments (L2) + 4 activation fragments (LDS) -> 12 MFMAs; two named operand sets
     auto a_frag = [&](int m, int kg, int hl) -> bf16x8 {
       const unsigned char *p = kg < KGX ? xa[m] + (size_t)kg * 2048 : ha[m] + (size_t)(kg - KGX) * 2048;
       return *reinterpret_cast<const bf16x8 *>(p + hl * 1024);
+    };
+    // weights are the A operand in inference (accumulator lane = sequence), the B operand in training (lane = unit)
+    auto mm = [](const bf16x8 &wf, const bf16x8 &af, const f32x16 &c3) -> f32x16 {
+      if constexpr (TRAIN) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wf, c3, 0, 0, 0);
+      else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, c3, 0, 0, 0);
     };
     auto gemm = [&](int g0, f32x16 (&acc)[MT][2]) {
       bf16x8 wp[2][2], wq[2][2], ap[MT][2], aq[MT][2];  // [gate][hi|lo], [row tile][hi|lo]
@@ -210,9 +255,9 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
         for (int g = 0; g < 2; ++g)
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[g][1], ap[m][0], acc[m][g], 0, 0, 0);  // w_lo * a_hi
-            acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[g][0], ap[m][1], acc[m][g], 0, 0, 0);  // w_hi * a_lo
-            acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[g][0], ap[m][0], acc[m][g], 0, 0, 0);  // w_hi * a_hi
+            acc[m][g] = mm(wp[g][1], ap[m][0], acc[m][g]);  // w_lo * a_hi
+            acc[m][g] = mm(wp[g][0], ap[m][1], acc[m][g]);  // w_hi * a_lo
+            acc[m][g] = mm(wp[g][0], ap[m][0], acc[m][g]);  // w_hi * a_hi
           }
         __builtin_amdgcn_sched_barrier(0);
         const int k2 = (kg + 2 < kend) ? kg + 2 : kg;
@@ -229,9 +274,9 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
         for (int g = 0; g < 2; ++g)
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[g][1], aq[m][0], acc[m][g], 0, 0, 0);
-            acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[g][0], aq[m][1], acc[m][g], 0, 0, 0);
-            acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[g][0], aq[m][0], acc[m][g], 0, 0, 0);
+            acc[m][g] = mm(wq[g][1], aq[m][0], acc[m][g]);
+            acc[m][g] = mm(wq[g][0], aq[m][1], acc[m][g]);
+            acc[m][g] = mm(wq[g][0], aq[m][0], acc[m][g]);
           }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -240,9 +285,9 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
         for (int g = 0; g < 2; ++g)
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[g][1], ap[m][0], acc[m][g], 0, 0, 0);
-            acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[g][0], ap[m][1], acc[m][g], 0, 0, 0);
-            acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[g][0], ap[m][0], acc[m][g], 0, 0, 0);
+            acc[m][g] = mm(wp[g][1], ap[m][0], acc[m][g]);
+            acc[m][g] = mm(wp[g][0], ap[m][1], acc[m][g]);
+            acc[m][g] = mm(wp[g][0], ap[m][0], acc[m][g]);
           }
       }
       __builtin_amdgcn_s_setprio(0);
@@ -257,15 +302,29 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
         g[m][0][r] = 0.0f;
         g[m][1][r] = 0.0f;
       }
-    if (w * 32 < a.H) gemm(0, g);
+    if (TRAIN || w * 32 < a.H) gemm(0, g);
+    // gate tape (TRAIN), lstm_fwd.hip's layout: [t][tile32][unit block][q = si,tj,sf,so,c][reg][lane]
+    float *tp[MT];
+    if constexpr (TRAIN) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        tp[m] = a.tape_g + (((size_t)t * NT32 + blockIdx.x * 2 + mt0 + m) * UBN + w) * 5 * 1024 + lane;
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         f32x4 pij;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pij[e] = x3_sigmoid(g[m][0][q4 * 4 + e]) * x3_tanh(g[m][1][q4 * 4 + e]);
-        *reinterpret_cast<f32x4 *>(hd[m] + q4 * 1024) = pij;
+        for (int e = 0; e < 4; ++e) {
+          const float si = x3_sigmoid(g[m][0][q4 * 4 + e]), tj = x3_tanh(g[m][1][q4 * 4 + e]);
+          pij[e] = si * tj;
+          if constexpr (TRAIN) {
+            tp[m][(q4 * 4 + e) * 64] = si;
+            tp[m][1024 + (q4 * 4 + e) * 64] = tj;
+          }
+        }
+        *reinterpret_cast<f32x4 *>(hd[m] + q4 * 1024) = pij;  // lane-private round trip: any layout will do
       }
     // ---- pass B: gates f (+1 in the bias row), o -> c' = c * sigmoid(f) + pij ; h' = tanh(c') * sigmoid(o)
 #pragma unroll
@@ -275,7 +334,7 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
         g[m][0][r] = 0.0f;
         g[m][1][r] = 0.0f;
       }
-    if (w * 32 < a.H) gemm(2, g);
+    if (TRAIN || w * 32 < a.H) gemm(2, g);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       float hv[16];
@@ -290,18 +349,41 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
           const float cn = c[m][r] * sf + pij[e];
           c[m][r] = cn;
           hv[r] = x3_tanh(cn) * so;
-          if (a.rec_h != nullptr && blockIdx.x == 0 && mt0 + m == 0 && (lane & 31) == 0) {
+          if constexpr (TRAIN) {
+            tp[m][2048 + r * 64] = sf;
+            tp[m][3072 + r * 64] = so;
+            tp[m][4096 + r * 64] = cn;
+          }
+          if (!TRAIN && a.rec_h != nullptr && blockIdx.x == 0 && mt0 + m == 0 && (lane & 31) == 0) {
             // sequence 0 of the launch: state after t+1 steps (builds the pad-prefix table)
             a.rec_h[(size_t)(t + 1) * Hp + w * 32 + mfma_row(r, lane)] = hv[r];
             a.rec_c[(size_t)(t + 1) * Hp + w * 32 + mfma_row(r, lane)] = cn;
           }
         }
       }
-      if (w * 32 >= a.H) {  // a unit block made only of padding keeps h = 0
+      if (!TRAIN && w * 32 >= a.H) {  // a unit block made only of padding keeps h = 0
 #pragma unroll
         for (int r = 0; r < 16; ++r) hv[r] = 0.0f;
       }
-      if (have_next) {
+      if constexpr (TRAIN) {
+        // lane = unit 32 w + (lane & 31), register r = row mfma_row(r, lane): scatter into the (row-major-in-lanes) tiles
+        const int unit = w * 32 + (lane & 31);
+        unsigned char *tile = hptr(nxt, mt0 + m);
+        if (have_next) {
+          unsigned char *dst = tile + (size_t)(unit >> 4) * 2048 + (size_t)(((unit >> 3) & 1) * 32) * 16 + (unit & 7) * 2;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const unsigned short hi = x3_bf16(hv[r]), lo = x3_bf16(hv[r] - x3_f32(hi));
+            unsigned char *p = dst + mfma_row(r, lane) * 16;
+            *reinterpret_cast<unsigned short *>(p) = hi;
+            *reinterpret_cast<unsigned short *>(p + 1024) = lo;
+          }
+        } else {
+          float *hf = reinterpret_cast<float *>(tile) + (size_t)(unit >> 3) * 256 + ((((unit >> 2) & 1) * 32) << 2) + (unit & 3);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) hf[mfma_row(r, lane) << 2] = hv[r];  // h_T in fp32, frag32 layout
+        }
+      } else if (have_next) {
         // registers 0..7 -> octet (group 2w, this lane's half), 8..15 -> (group 2w + 1, this lane's half); hi | lo
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -328,6 +410,15 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
         x_store(oc, *reinterpret_cast<const u32x4 *>(src + oc * 8), *reinterpret_cast<const u32x4 *>(src + EP + oc * 8));
       }
       __syncthreads();
+    }
+  }
+
+  if constexpr (TRAIN) {
+    // h_T, row-major [Bp][Hp], for dM = h_T^T . d(out)
+    for (int i = tid; i < 64 * Hp; i += X3_THREADS) {
+      const int un = i % Hp, b = i / Hp;
+      a.h_last[(size_t)(b0 + b) * Hp + un] =
+          reinterpret_cast<const float *>(hptr(T & 1, b >> 5))[(size_t)(un >> 3) * 256 + ((((un >> 2) & 1) * 32 + (b & 31)) << 2) + (un & 3)];
     }
   }
 
@@ -414,7 +505,7 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
 // h part: group 2 ub' + j holds, at (half, i), hidden unit 32 ub' + mfma_row(8 j + i, half) -- the accumulator register
 // order, see the file header.
 __global__ void pack_lstm_x3_kernel(const float *__restrict__ K, const float *__restrict__ b, int E, int H, int KGX, int KG,
-                                    int64_t total, unsigned short *__restrict__ out) {
+                                    int natural, int64_t total, unsigned short *__restrict__ out) {
   const int N4 = 4 * H;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int i = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
@@ -432,7 +523,8 @@ __global__ void pack_lstm_x3_kernel(const float *__restrict__ K, const float *__
         else if (k == E) wv = b[col] + (gate == 2 ? 1.0f : 0.0f);
       } else {
         const int kgh = kg - KGX, r = 8 * (kgh & 1) + i;
-        const int uk = (kgh >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int uk = natural ? kgh * 16 + half * 8 + i                        // training forward: unit order
+                               : (kgh >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;  // inference: accumulator register order
         if (uk < H) wv = K[(size_t)(E + uk) * N4 + col];
       }
     }
@@ -460,10 +552,11 @@ size_t lstm_x3_weight_elems(int E, int Hp) { return (size_t)(Hp / 32) * (lstm_x3
 size_t lstm_x3_emb_elems(int64_t V, int E) { return (size_t)V * 2 * lstm_x3_kgx(E) * 16; }
 
 hipError_t launch_pack_lstm_x3(const float *K, const float *b, const float *emb, int64_t V, int E, int H, int Hp,
-                               unsigned short *Wx3, unsigned short *emb16, hipStream_t stream) {
+                               unsigned short *Wx3, unsigned short *emb16, int natural_k, hipStream_t stream) {
   const int KGX = lstm_x3_kgx(E), KG = KGX + Hp / 16;
   const int64_t total = (int64_t)(Hp / 32) * KG * 4 * 512;
-  hipLaunchKernelGGL(pack_lstm_x3_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, K, b, E, H, KGX, KG, total, Wx3);
+  hipLaunchKernelGGL(pack_lstm_x3_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, K, b, E, H, KGX, KG, natural_k,
+                     total, Wx3);
   if (emb16) {
     const int64_t ne = V * KGX * 16;
     hipLaunchKernelGGL(split_emb_x3_kernel, dim3((int)((ne + 255) / 256 < 8192 ? (ne + 255) / 256 : 8192)), dim3(256), 0, stream,
@@ -472,16 +565,22 @@ hipError_t launch_pack_lstm_x3(const float *K, const float *b, const float *emb,
   return hipGetLastError();
 }
 
-template <int UBN>
+template <int UBN, bool TRAIN>
 static hipError_t launch_x3(const LstmX3Args &a, hipStream_t stream) {
   const size_t lds = lstm_x3_lds_bytes(a.KGX, 32 * UBN);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_x3_kernel<UBN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_x3_kernel<UBN, TRAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(lstm_fwd_x3_kernel<UBN>, dim3((a.B + 63) / 64), dim3(X3_THREADS), lds, stream, a);
+  const int blocks = TRAIN ? a.NT32 / 2 : (a.B + 63) / 64;
+  hipLaunchKernelGGL((lstm_fwd_x3_kernel<UBN, TRAIN>), dim3(blocks), dim3(X3_THREADS), lds, stream, a);
   return hipGetLastError();
 }
 
+// a.tape_g != nullptr: the training forward (tapes for NT32 32-row tiles, NT32 even; Wx3 packed with natural_k = 1)
 hipError_t launch_lstm_fwd_x3(const LstmX3Args &a, hipStream_t stream) {
   if (a.H < 1 || a.H > 256 || a.B < 1 || a.KGX < 1 || a.KGX > 4) return hipErrorInvalidValue;
-  return a.H > 128 ? launch_x3<8>(a, stream) : launch_x3<4>(a, stream);
+  if (a.tape_g != nullptr) {
+    if (a.NT32 < 2 || (a.NT32 & 1) || !a.tape_a || !a.h_last) return hipErrorInvalidValue;
+    return a.H > 128 ? launch_x3<8, true>(a, stream) : launch_x3<4, true>(a, stream);
+  }
+  return a.H > 128 ? launch_x3<8, false>(a, stream) : launch_x3<4, false>(a, stream);
 }

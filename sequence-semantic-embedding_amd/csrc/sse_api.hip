@@ -35,6 +35,7 @@ struct Encoder {
   bool waug_valid = false;
   unsigned short *Wx3 = nullptr;  // option lstm_x3: hi / lo bf16 fragment copies of the kernel matrix
   bool x3_valid = false;
+  unsigned short *Wx3t = nullptr;  // option train_fwd_x3: the same copies with the h part in unit order (training forward)
   float *pad_h_x3 = nullptr, *pad_c_x3 = nullptr;  // pad-prefix table of the lstm_x3 path ([pad_T_x3+1][Hp])
   int pad_T_x3 = 0;
   bool pad_valid_x3 = false;
@@ -112,6 +113,7 @@ struct sse_handle {
   bool cnn_bf16 = false;     // option "cnn_bf16": source_only_cnn inference with bf16 storage / fp32 accumulation
   unsigned short *emb_bf16 = nullptr, *cnn_Wc16 = nullptr;
   int lstm_train_rows = 0;   // option "lstm_train_rows": 0 = automatic, 32 / 64 = rows per workgroup of the training forward (Hp = 256)
+  bool train_fwd_x3 = true;  // option "train_fwd_x3": forward of the LSTM train step on the bf16 matrix pipe with split operands
   bool train_dk_x3 = true;   // option "train_dk_x3": weight-gradient GEMM of the LSTM train step on the bf16 matrix pipe with split operands
   bool train_pair_dedup = true; // option "train_pair_dedup": run the source encoder once per (pos, neg) pair of rows that share it
   bool train_serial = false; // option "train_serial": both encoders on one stream (profiling: isolated kernel times)
@@ -500,7 +502,8 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
     HIPCHECK(h, launch_lstm_small(sa, st));
     return 0;
   }
-  if (h->lstm_x3 && e.Hp <= 256 && c.embedding_size < 64) {
+  if (h->lstm_x3 && e.Hp <= 256 && e.H >= 64 && c.embedding_size < 64) {  // (tiny cells: nothing to gain, and their raw
+    // encodings can be small enough for the 2e-6 absolute error to matter after normalisation)
     // opt-in: the gate GEMMs on the bf16 matrix pipe with hi + lo split operands (lstm_fwd_x3.hip); ~1e-5 from the fp32 path
     Encoder &own = e.shares_lstm_with >= 0 ? h->enc[e.shares_lstm_with] : e;
     const int E = c.embedding_size;
@@ -508,7 +511,7 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
       if (!own.Wx3) HIPCHECK(h, hipMalloc((void **)&own.Wx3, lstm_x3_weight_elems(E, own.Hp) * sizeof(unsigned short)));
       if (!h->emb16) HIPCHECK(h, hipMalloc((void **)&h->emb16, lstm_x3_emb_elems(c.vocab_size, E) * sizeof(unsigned short)));
       HIPCHECK(h, launch_pack_lstm_x3(h->vars[own.kernel].dev, h->vars[own.bias].dev, h->vars[0].dev, c.vocab_size, E, own.H,
-                                      own.Hp, own.Wx3, h->emb16_valid ? nullptr : h->emb16, st));
+                                      own.Hp, own.Wx3, h->emb16_valid ? nullptr : h->emb16, 0, st));
       own.x3_valid = true;
       h->emb16_valid = true;
     }
@@ -976,6 +979,7 @@ void sse_destroy(sse_handle *h) {
       if (e.pad_c) (void)hipFree(e.pad_c);
       if (e.Waug) (void)hipFree(e.Waug);
       if (e.Wx3) (void)hipFree(e.Wx3);
+      if (e.Wx3t) (void)hipFree(e.Wx3t);
       if (e.pad_h_x3) (void)hipFree(e.pad_h_x3);
       if (e.pad_c_x3) (void)hipFree(e.pad_c_x3);
       if (e.pad_h_small) (void)hipFree(e.pad_h_small);
@@ -1163,6 +1167,10 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value) {
   if (strcmp(name, "lstm_train_rows") == 0) {
     if (value != 0 && value != 32 && value != 64) return fail(h, "lstm_train_rows must be 0, 32 or 64");
     h->lstm_train_rows = (int)value;
+    return 0;
+  }
+  if (strcmp(name, "train_fwd_x3") == 0) {
+    h->train_fwd_x3 = value != 0;
     return 0;
   }
   if (strcmp(name, "train_dk_x3") == 0) {
@@ -1572,6 +1580,14 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   HIPCHECK(h, hipMemcpyAsync(ts.labels.p, labels_host, (size_t)B * sizeof(float), hipMemcpyHostToDevice, st));
   const int NT_half = NT32 / 2;  // paired: 32-row tiles of one half (B % 128 == 0: Bp = B, NT_half even)
 
+  if (h->train_fwd_x3 && h->train_dk_x3 && E < 64) {  // split embedding table of this step's weights (both encoders read it)
+    if (!h->emb16) HIPCHECK(h, hipMalloc((void **)&h->emb16, lstm_x3_emb_elems(V, E) * sizeof(unsigned short)));
+    Encoder &e0 = h->enc[0];
+    if (!e0.Wx3t) HIPCHECK(h, hipMalloc((void **)&e0.Wx3t, lstm_x3_weight_elems(E, e0.Hp) * sizeof(unsigned short)));
+    HIPCHECK(h, launch_pack_lstm_x3(h->vars[e0.kernel].dev, h->vars[e0.bias].dev, h->vars[0].dev, V, E, e0.H, e0.Hp, e0.Wx3t,
+                                    h->emb16, 1, st));
+    h->emb16_valid = true;  // (ensure_packed above cleared it: the table matches the current weights again)
+  }
   // ---- forward with tapes (un-normalised encodings; the loss kernel normalises); the two
   // encoders are independent: fork onto two side streams, join before the loss
   HIPCHECK(h, hipEventRecord(ts.ev_fork, st));
@@ -1618,7 +1634,40 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     a.tape_a = (float *)ts.tape_a[s].p;
     a.tape_a_split = h->train_dk_x3 ? 1 : 0;
     a.h_last = (float *)ts.h_last[s].p;
-    HIPCHECK(h, launch_lstm_fwd(a, e.Hp, fs));
+    if (h->train_fwd_x3 && h->train_dk_x3 && e.Hp <= 256 && e.H >= 64 && E < 64) {
+      // the gate GEMMs as three bf16 MFMAs on hi + lo split operands (lstm_fwd_x3.hip, TRAIN): same tapes, same outputs
+      Encoder &own = e.shares_lstm_with >= 0 ? h->enc[e.shares_lstm_with] : e;
+      if (e.shares_lstm_with < 0 && s != 0) {  // (side 0 was packed ahead of the fork together with the embedding table)
+        if (!own.Wx3t) HIPCHECK(h, hipMalloc((void **)&own.Wx3t, lstm_x3_weight_elems(E, own.Hp) * sizeof(unsigned short)));
+        if (!h->emb16) HIPCHECK(h, hipMalloc((void **)&h->emb16, lstm_x3_emb_elems(V, E) * sizeof(unsigned short)));
+        // both depend on the weights of this step: repacked on the launch stream (the other side's stream waits for
+        // ev_fork, recorded before; the split embedding table is shared, so it is made on `st` ahead of the fork)
+        HIPCHECK(h, launch_pack_lstm_x3(h->vars[own.kernel].dev, h->vars[own.bias].dev, h->vars[0].dev, V, E, own.H, own.Hp,
+                                        own.Wx3t, nullptr, 1, fs));
+      }
+      LstmX3Args xa;
+      xa.ids = a.ids;
+      xa.emb16 = h->emb16;
+      xa.Wx3 = own.Wx3t;
+      xa.Mp = e.Mp;
+      xa.out = a.out;
+      xa.err = h->err_flag;
+      xa.B = Bf;
+      xa.T = T;
+      xa.V = V;
+      xa.KGX = lstm_x3_kgx(E);
+      xa.H = e.H;
+      xa.S = S;
+      xa.NTS = (S + 31) / 32;
+      xa.normalize = 0;
+      xa.tape_g = a.tape_g;
+      xa.tape_a = a.tape_a;
+      xa.h_last = a.h_last;
+      xa.NT32 = NTf;
+      HIPCHECK(h, launch_lstm_fwd_x3(xa, fs));
+    } else {
+      HIPCHECK(h, launch_lstm_fwd(a, e.Hp, fs));
+    }
     if (half) {  // rows B/2 .. B-1 are the same sequences: the loss and the projection backward read them per row
       HIPCHECK(h, hipMemcpyAsync((float *)ts.raw[s].p + (size_t)Bf * S, ts.raw[s].p, (size_t)Bf * S * sizeof(float),
                                  hipMemcpyDeviceToDevice, fs));

@@ -125,12 +125,16 @@ struct LstmX3Args {
   const int32_t *row_map = nullptr;
   const float *pad_h = nullptr, *pad_c = nullptr;  // [T+1][Hp] state after p leading PAD steps (recorded by this kernel)
   float *rec_h = nullptr, *rec_c = nullptr;        // table build: states of sequence 0 after every step
+  // training forward (tape_g != nullptr): tapes as lstm_fwd.hip's, tape_a in the split frag16 form (tape_a_split = 1)
+  float *tape_g = nullptr, *tape_a = nullptr, *h_last = nullptr;
+  int32_t NT32 = 0;
 };
 int lstm_x3_kgx(int E);
 size_t lstm_x3_weight_elems(int E, int Hp);
 size_t lstm_x3_emb_elems(int64_t V, int E);
 hipError_t launch_pack_lstm_x3(const float *K, const float *b, const float *emb /* master [V][E] */, int64_t V, int E, int H,
-                               int Hp, unsigned short *Wx3, unsigned short *emb16 /* nullptr: weights only */, hipStream_t stream);
+                               int Hp, unsigned short *Wx3, unsigned short *emb16 /* nullptr: weights only */,
+                               int natural_k /* 1: h part in unit order (training forward) */, hipStream_t stream);
 hipError_t launch_lstm_fwd_x3(const LstmX3Args &a, hipStream_t stream);
 
 // a handful of sequences with the recurrent weights resident in LDS (lstm_persist.hip): a cluster of NWG workgroups per

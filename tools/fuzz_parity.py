@@ -68,6 +68,9 @@ def main(n_cases=40, seed=0, verbose=True):
             tie = np.zeros_like(ids, bool)
             tie[:, 1:] |= np.abs(np.diff(wsc, axis=1)) < 1e-12
             tie[:, :-1] |= np.abs(np.diff(wsc, axis=1)) < 1e-12
+            if N > k:                                                 # ... and the k-th may tie with the (k+1)-th, outside the list
+                wsc1, _ = O.topk(O.scores_f64(ns, idx64), k + 1)
+                tie[:, -1] |= np.abs(wsc1[:, k] - wsc1[:, k - 1]) < 1e-12
             if k == N:
                 assert all(sorted(a) == sorted(b) for a, b in zip(ids.tolist(), wids.tolist())), "top-k id sets"
             assert np.array_equal(ids[~tie], wids[~tie]), "top-k ids"
