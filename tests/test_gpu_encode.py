@@ -222,7 +222,10 @@ def test_split_bf16_matrix_path_stays_within_the_encoder_tolerance(mode, V, E, H
             assert np.array_equal(enc(ids, normalize=normalize), got)     # the left-pad prefix skip is exact on this path too
             m.handle.set_option("pad_skip", 1)
             print("lstm_x3 %s normalize=%d: |x3 - fp32 kernel| %.2e, |x3 - oracle| %.2e" % (side, normalize, d_exact, d_oracle))
-            assert 0 < d_exact < 5e-5 and d_oracle < TOL
+            if (Hs if side == "src" else Ht) >= 64:
+                assert 0 < d_exact < 5e-5 and d_oracle < TOL
+            else:                      # cells below 64 units keep the exact fp32 kernel
+                assert d_exact == 0 and d_oracle < TOL
             if normalize:
                 assert np.sum(got.astype(np.float64) * exact, axis=1).min() > 1 - 1e-6    # fp32 norms: 1 +- 2e-7
     # the split copies follow a weight update
