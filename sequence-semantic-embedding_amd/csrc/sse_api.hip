@@ -69,6 +69,7 @@ struct TrainState {
   hipStream_t side[2] = {nullptr, nullptr};  // the two encoders run concurrently (forward and backward)
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   float *KhT[2] = {nullptr, nullptr}, *KxT[2] = {nullptr, nullptr};
+  unsigned short *KhT16[2] = {nullptr, nullptr};  // option train_bwd_x3: Kh^T as split frag16 blocks
   bool packed_dirty = true;
   // gradient arena: [grad of variable 0 | ... | grad of variable n-1 | tail[4]]; tail = {sum of squares of the
   // un-deduplicated embedding-gradient slices, loss, train_acc, rows}, every entry a plain sum over the
@@ -113,6 +114,7 @@ struct sse_handle {
   bool cnn_bf16 = false;     // option "cnn_bf16": source_only_cnn inference with bf16 storage / fp32 accumulation
   unsigned short *emb_bf16 = nullptr, *cnn_Wc16 = nullptr;
   int lstm_train_rows = 0;   // option "lstm_train_rows": 0 = automatic, 32 / 64 = rows per workgroup of the training forward (Hp = 256)
+  bool train_bwd_x3 = true;  // option "train_bwd_x3": recurrent GEMM of BPTT on the bf16 matrix pipe with split operands (needs train_dk_x3)
   bool train_fwd_x3 = true;  // option "train_fwd_x3": forward of the LSTM train step on the bf16 matrix pipe with split operands
   bool train_dk_x3 = true;   // option "train_dk_x3": weight-gradient GEMM of the LSTM train step on the bf16 matrix pipe with split operands
   bool train_pair_dedup = true; // option "train_pair_dedup": run the source encoder once per (pos, neg) pair of rows that share it
@@ -1005,6 +1007,7 @@ void sse_destroy(sse_handle *h) {
       if (t->ev_join[s]) (void)hipEventDestroy(t->ev_join[s]);
       if (t->KhT[s] && (s == 0 || t->KhT[s] != t->KhT[0])) (void)hipFree(t->KhT[s]);
       if (t->KxT[s] && (s == 0 || t->KxT[s] != t->KxT[0])) (void)hipFree(t->KxT[s]);
+      if (t->KhT16[s] && (s == 0 || t->KhT16[s] != t->KhT16[0])) (void)hipFree(t->KhT16[s]);
     }
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
     delete t;
@@ -1167,6 +1170,10 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value) {
   if (strcmp(name, "lstm_train_rows") == 0) {
     if (value != 0 && value != 32 && value != 64) return fail(h, "lstm_train_rows must be 0, 32 or 64");
     h->lstm_train_rows = (int)value;
+    return 0;
+  }
+  if (strcmp(name, "train_bwd_x3") == 0) {
+    h->train_bwd_x3 = value != 0;
     return 0;
   }
   if (strcmp(name, "train_fwd_x3") == 0) {
@@ -1514,8 +1521,11 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
       if (e.shares_lstm_with >= 0) {
         ts.KhT[s] = ts.KhT[e.shares_lstm_with];
         ts.KxT[s] = ts.KxT[e.shares_lstm_with];
+        ts.KhT16[s] = ts.KhT16[e.shares_lstm_with];
         continue;
       }
+      if (!ts.KhT16[s]) HIPCHECK(h, hipMalloc((void **)&ts.KhT16[s], kT16_elems(e.Hp) * sizeof(unsigned short)));
+      HIPCHECK(h, launch_pack_kT16(h->vars[e.kernel].dev, E, e.H, e.Hp, ts.KhT16[s], st));
       if (!ts.KhT[s]) HIPCHECK(h, hipMalloc((void **)&ts.KhT[s], (size_t)(e.Hp / 32) * (e.Hp / 2) * 256 * sizeof(float)));
       if (!ts.KxT[s]) HIPCHECK(h, hipMalloc((void **)&ts.KxT[s], (size_t)2 * (e.Hp / 2) * 256 * sizeof(float)));
       HIPCHECK(h, launch_pack_kT(h->vars[e.kernel].dev, E, e.H, e.Hp / 32, e.H, e.Hp, ts.KhT[s], st));
@@ -1718,7 +1728,8 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
                                 S, h->vars[e.proj].grad, (float *)ts.dh_last[s].p, (float *)ts.dm_part[s].p, bs));
     HIPCHECK(h, launch_lstm_bwd((const float *)ts.tape_g[s].p, (const float *)ts.dh_last[s].p, ts.KhT[s],
                                 (float *)ts.dg_a[s].p, (float *)ts.dg_b[s].p, (float *)ts.db_part[s].p, T, NT32,
-                                half ? NT_half : NT32, Hp, e.H, h->train_dk_x3 ? 1 : 0, bs));
+                                half ? NT_half : NT32, Hp, e.H, h->train_dk_x3 ? 1 : 0,
+                                (h->train_bwd_x3 && h->train_dk_x3 && e.H >= 64) ? ts.KhT16[s] : nullptr, bs));
     const int accumulate = (shared && s == 1) ? 1 : 0;
     if (h->train_dk_x3)  // the 8-row r-groups of the fp32 layout pair up into 16-row groups: the same bytes
       HIPCHECK(h, launch_dk_x3(ts.tape_a[s].p, ts.dg_b[s].p, (float *)ts.dk_part[s].p, RGa / 2, KT, NTn, SL, E, e.H, Hp, accumulate,

@@ -11,7 +11,10 @@ hipError_t launch_proj_bwd(const float *hT, const float *d, const float *M, int 
                            float *dh, float *dm_part /* [proj_bwd_chunks(Bp)][H*S] */, hipStream_t st);
 hipError_t launch_lstm_bwd(const float *tape_g, const float *dh_last, const float *KhT, float *dg_a, float *dg_b,
                            float *db_part, int T, int NT32, int NT_tape /* 0: NT32 */, int Hp, int H,
-                           int dg_b_split /* 1: split bf16 frag16 blocks for launch_dk_x3 */, hipStream_t st);
+                           int dg_b_split /* 1: split bf16 frag16 blocks for launch_dk_x3 */,
+                           const unsigned short *KhT16 /* non-null: split-operand recurrent GEMM (launch_pack_kT16) */, hipStream_t st);
+size_t kT16_elems(int Hp);
+hipError_t launch_pack_kT16(const float *K, int E, int H, int Hp, unsigned short *out, hipStream_t stream);
 int dk_slices(int RG);
 hipError_t launch_dk(const float *tape_a, const float *dg_b, float *part, int RG, int KT, int NTn, int SL, int E, int H,
                      int Hp, int accumulate, float *dK, int pair_rg /* 0: dg_b has RG r-groups */, hipStream_t st);

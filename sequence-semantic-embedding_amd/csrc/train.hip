@@ -208,15 +208,21 @@ struct LstmBwdArgs {
   float *db_part;       // [NT32][4*Hp] per-tile bias-gradient partials
   int32_t T, NT32, Hp;
   int32_t H;            // real cell size: dG columns of padded units are exactly 0, their k-groups are skipped
+  const unsigned short *KhT16;  // X3: Kh^T as split frag16 blocks [Hp/32][4Hp/16][hi|lo][512] (launch_pack_kT16)
   int32_t dg_b_split;   // 1: dg_b is written as split bf16 frag16 blocks [(T*NT32*2)][NTn][hi|lo][512] (same bytes) for the
                         // dK GEMM on the bf16 matrix pipe (dk_x3_kernel)
   int32_t NT_tape;      // 32-row tiles the gate tape holds per step: NT32, or NT32/2 when the batch is (pos, neg) pairs
                         // that share their source sequence -- tiles j and j + NT_tape then read the same tape
 };
 
-template <int UB, int NW, bool SPLIT>
+// X3 (with SPLIT): the dG tile lives in LDS as split bf16 frag16 blocks [4Hp/16][hi|lo][1 KiB] (lane (row, half) owns 8
+// consecutive n; the same bytes), written by 2-byte scatters, and the recurrent GEMM runs as three
+// v_mfma_f32_32x32x16_bf16 per 16 n (see sse_kernels.h) against Kh^T in the same form.
+template <int UB, int NW, bool SPLIT, bool X3>
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
+  static_assert(!X3 || SPLIT, "the split-operand BPTT feeds the split-operand dK GEMM");
   extern __shared__ __attribute__((aligned(16))) float dgs[];  // [KGn][256]: dg tile, frag32(rows = b, red = n)
+  unsigned char *dgb = reinterpret_cast<unsigned char *>(dgs);
   constexpr int NTHR = NW * 64;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform (SGPR): the tape descriptor depends on it
@@ -277,12 +283,25 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
         dbacc[u][2] += g_f;
         dbacc[u][3] += g_o;
         const int b = mfma_row(r, lane);
-        // element (b, n = g*Hp + unit) -> dgs[n/8][((n%8)/4*32 + b)*4 + n%4]; Hp % 8 == 0 so n%8 == unit%8
-        float *dst = dgs + (size_t)(unit >> 3) * 256 + ((((unit >> 2) & 1) * 32 + b) << 2) + (unit & 3);
-        dst[(size_t)(0 * Hp / 8) * 256] = g_i;
-        dst[(size_t)(1 * Hp / 8) * 256] = g_j;
-        dst[(size_t)(2 * Hp / 8) * 256] = g_f;
-        dst[(size_t)(3 * Hp / 8) * 256] = g_o;
+        if constexpr (X3) {
+          // element (b, n = g*Hp + unit) -> group n/16, slot ((n/8)&1)*32 + b, piece n%8; hi block, lo block 1 KiB on
+          unsigned char *dst = dgb + (size_t)(unit >> 4) * 2048 + (size_t)((((unit >> 3) & 1) * 32 + b) * 16) + (unit & 7) * 2;
+          const int GS = (Hp / 16) * 2048;
+          const float gv[4] = {g_i, g_j, g_f, g_o};
+#pragma unroll
+          for (int gi = 0; gi < 4; ++gi) {
+            const unsigned short hi = sse_bf16_rne(gv[gi]), lo = sse_bf16_rne(gv[gi] - sse_bf16_f32(hi));
+            *reinterpret_cast<unsigned short *>(dst + gi * GS) = hi;
+            *reinterpret_cast<unsigned short *>(dst + gi * GS + 1024) = lo;
+          }
+        } else {
+          // element (b, n = g*Hp + unit) -> dgs[n/8][((n%8)/4*32 + b)*4 + n%4]; Hp % 8 == 0 so n%8 == unit%8
+          float *dst = dgs + (size_t)(unit >> 3) * 256 + ((((unit >> 2) & 1) * 32 + b) << 2) + (unit & 3);
+          dst[(size_t)(0 * Hp / 8) * 256] = g_i;
+          dst[(size_t)(1 * Hp / 8) * 256] = g_j;
+          dst[(size_t)(2 * Hp / 8) * 256] = g_f;
+          dst[(size_t)(3 * Hp / 8) * 256] = g_o;
+        }
         if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the interleaving (register pressure)
       }
     }
@@ -310,6 +329,49 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
     auto dump = [&]() {
       constexpr int GTHR = NTHR / 2;
       const int grp = (wn >= NW / 2) ? 1 : 0, gt = tid - grp * GTHR;
+      if constexpr (X3) {
+        // dg_a (fp32 frag32, for the dX kernel) rebuilt from the split tile: slot (group, half, row) = 8 consecutive n =
+        // the two float4 of k-group 2*group + half; then dg_b: the stored hi / lo pieces regrouped by row octets
+        float *gaf = a.dg_a + ((size_t)t * a.NT32 + tile) * KGn * 256;
+        const int ns = (4 * Hp / 16) * 64, hs = ns / 2;
+#pragma unroll 2
+        for (int i = grp * hs + gt; i < (grp + 1) * hs; i += GTHR) {
+          const int g16 = i >> 6, sl = i & 63;
+          const sse_u32x4 hi = *reinterpret_cast<const sse_u32x4 *>(dgb + (size_t)g16 * 2048 + sl * 16);
+          const sse_u32x4 lo = *reinterpret_cast<const sse_u32x4 *>(dgb + (size_t)g16 * 2048 + 1024 + sl * 16);
+          f32x4 v0, v1;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            v0[2 * e] = __uint_as_float(hi[e] << 16) + __uint_as_float(lo[e] << 16);
+            v0[2 * e + 1] = __uint_as_float(hi[e] & 0xffff0000u) + __uint_as_float(lo[e] & 0xffff0000u);
+            v1[2 * e] = __uint_as_float(hi[2 + e] << 16) + __uint_as_float(lo[2 + e] << 16);
+            v1[2 * e + 1] = __uint_as_float(hi[2 + e] & 0xffff0000u) + __uint_as_float(lo[2 + e] & 0xffff0000u);
+          }
+          float *dst = gaf + (size_t)(2 * g16 + (sl >> 5)) * 256 + (sl & 31) * 4;
+          *reinterpret_cast<f32x4 *>(dst) = v0;
+          *reinterpret_cast<f32x4 *>(dst + 128) = v1;
+        }
+        unsigned short *gb = reinterpret_cast<unsigned short *>(a.dg_b);
+        const size_t g0 = ((size_t)t * a.NT32 + tile) * 2;
+        const int nb = 4 * Hp * 4, hb = nb / 2;
+#pragma unroll 1
+        for (int i = grp * hb + gt; i < (grp + 1) * hb; i += GTHR) {
+          const int n = i % (4 * Hp), oc = i / (4 * Hp);  // rows 8*oc .. 8*oc+7
+          const unsigned char *src = dgb + (size_t)(n >> 4) * 2048 + (size_t)((((n >> 3) & 1) * 32 + oc * 8) * 16) + (n & 7) * 2;
+          sse_u32x4 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            hi[e] = (unsigned)*reinterpret_cast<const unsigned short *>(src + (2 * e) * 16) |
+                    ((unsigned)*reinterpret_cast<const unsigned short *>(src + (2 * e + 1) * 16) << 16);
+            lo[e] = (unsigned)*reinterpret_cast<const unsigned short *>(src + 1024 + (2 * e) * 16) |
+                    ((unsigned)*reinterpret_cast<const unsigned short *>(src + 1024 + (2 * e + 1) * 16) << 16);
+          }
+          unsigned short *dst = gb + (((g0 + (oc >> 1)) * NTn + (n >> 5)) * 2) * 512 + ((oc & 1) * 32 + (n & 31)) * 8;
+          *reinterpret_cast<sse_u32x4 *>(dst) = hi;
+          *reinterpret_cast<sse_u32x4 *>(dst + 512) = lo;
+        }
+        return;
+      }
       f32x4 *ga = reinterpret_cast<f32x4 *>(a.dg_a + ((size_t)t * a.NT32 + tile) * KGn * 256);
       const f32x4 *ls = reinterpret_cast<const f32x4 *>(dgs);
       const int n4 = KGn * 64, h4 = n4 / 2;
@@ -352,7 +414,56 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
     if (dump_first) dump();
 
     // ---- recurrent GEMM: dh_{t-1}[b][j] = sum_n dg[b][n] * Kh[j][n]
-    if (t > 0) {
+    if (X3 && t > 0) {
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[u][r] = 0.0f;
+      typedef short bw_bf16x8 __attribute__((ext_vector_type(8)));
+      const unsigned char *la = dgb + lane * 16;
+      const int KG16 = 4 * Hp / 16, KGg = Hp / 16, KGl = min(KGg, (a.H + 15) / 16), NL = 4 * KGl;  // live groups of 16 n
+      const unsigned short *kb = a.KhT16 + (size_t)(wn * UB) * KG16 * 1024 + lane * 8;
+      auto phys = [&](int i) { return (i / KGl) * KGg + i % KGl; };
+      constexpr int PF = 2;
+      bw_bf16x8 bq[PF][UB][2], aq[2][2];
+      auto bld = [&](int u, int g16, int hl) -> bw_bf16x8 {
+        return *reinterpret_cast<const bw_bf16x8 *>(kb + ((size_t)u * KG16 + g16) * 1024 + hl * 512);
+      };
+#pragma unroll
+      for (int p = 0; p < PF; ++p)
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          bq[p][u][0] = bld(u, phys(p), 0);
+          bq[p][u][1] = bld(u, phys(p), 1);
+        }
+      aq[0][0] = *reinterpret_cast<const bw_bf16x8 *>(la);
+      aq[0][1] = *reinterpret_cast<const bw_bf16x8 *>(la + 1024);
+      __builtin_amdgcn_s_setprio(1);
+      for (int kg = 0; kg < NL; kg += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+          const int kn = phys((kg + p + 1 < NL) ? kg + p + 1 : kg + p);
+          aq[(p + 1) & 1][0] = *reinterpret_cast<const bw_bf16x8 *>(la + (size_t)kn * 2048);
+          aq[(p + 1) & 1][1] = *reinterpret_cast<const bw_bf16x8 *>(la + (size_t)kn * 2048 + 1024);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            dh[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[p & 1][1], bq[p][u][0], dh[u], 0, 0, 0);  // dg_lo * K_hi
+            dh[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[p & 1][0], bq[p][u][1], dh[u], 0, 0, 0);  // dg_hi * K_lo
+            dh[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[p & 1][0], bq[p][u][0], dh[u], 0, 0, 0);  // dg_hi * K_hi
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const int kp = phys((kg + p + PF < NL) ? kg + p + PF : kg + p);
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            bq[p][u][0] = bld(u, kp, 0);
+            bq[p][u][1] = bld(u, kp, 1);
+          }
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    if (!X3 && t > 0) {
 #pragma unroll
       for (int u = 0; u < UB; ++u)
 #pragma unroll
@@ -922,8 +1033,9 @@ hipError_t launch_proj_bwd(const float *hT, const float *d, const float *M, int 
 }
 
 hipError_t launch_lstm_bwd(const float *tape_g, const float *dh_last, const float *KhT, float *dg_a, float *dg_b,
-                           float *db_part, int T, int NT32, int NT_tape, int Hp, int H, int dg_b_split, hipStream_t st) {
-  LstmBwdArgs a{tape_g, dh_last, KhT, dg_a, dg_b, db_part, T, NT32, Hp, H, dg_b_split, NT_tape > 0 ? NT_tape : NT32};
+                           float *db_part, int T, int NT32, int NT_tape, int Hp, int H, int dg_b_split,
+                           const unsigned short *KhT16, hipStream_t st) {
+  LstmBwdArgs a{tape_g, dh_last, KhT, dg_a, dg_b, db_part, T, NT32, Hp, H, KhT16, dg_b_split, NT_tape > 0 ? NT_tape : NT32};
   const size_t lds = (size_t)(Hp / 2) * 256 * sizeof(float);
   if ((size_t)T * NT32 * (Hp / 32) * 5 * 1024 * sizeof(float) >= ((size_t)1 << 31)) return hipErrorInvalidValue;  // 32-bit tape offsets
   auto go = [&](auto kern, int threads) -> hipError_t {
@@ -932,9 +1044,42 @@ hipError_t launch_lstm_bwd(const float *tape_g, const float *dh_last, const floa
     hipLaunchKernelGGL(kern, dim3(NT32), dim3(threads), lds, st, a);
     return hipGetLastError();
   };
-  if (Hp == 128) return dg_b_split ? go(lstm_bwd_kernel<1, 4, true>, 256) : go(lstm_bwd_kernel<1, 4, false>, 256);
-  if (Hp == 256) return dg_b_split ? go(lstm_bwd_kernel<1, 8, true>, 512) : go(lstm_bwd_kernel<1, 8, false>, 512);
+  if (KhT16 != nullptr && !dg_b_split) return hipErrorInvalidValue;
+  if (Hp == 128) {
+    if (KhT16) return go(lstm_bwd_kernel<1, 4, true, true>, 256);
+    return dg_b_split ? go(lstm_bwd_kernel<1, 4, true, false>, 256) : go(lstm_bwd_kernel<1, 4, false, false>, 256);
+  }
+  if (Hp == 256) {
+    if (KhT16) return go(lstm_bwd_kernel<1, 8, true, true>, 512);
+    return dg_b_split ? go(lstm_bwd_kernel<1, 8, true, false>, 512) : go(lstm_bwd_kernel<1, 8, false, false>, 512);
+  }
   return hipErrorInvalidValue;
+}
+
+// Kh^T as split frag16 blocks for the split-operand BPTT: out[ub][g16][hi|lo][lane][i], lane (j = 32 ub + (lane & 31),
+// half), reduction index n = 16 g16 + 8 half + i = gate * Hp + unit: K[(E + j)][gate * H + unit]
+__global__ void pack_kT16_kernel(const float *__restrict__ K, int E, int H, int Hp, int64_t total, unsigned short *__restrict__ out) {
+  const int KG16 = 4 * Hp / 16;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    const int64_t blk = idx >> 9;
+    const int g16 = (int)(blk % KG16), ub = (int)(blk / KG16);
+    const int j = ub * 32 + (lane & 31), n = g16 * 16 + (lane >> 5) * 8 + i;
+    const int gate = n / Hp, unit = n % Hp;
+    const float v = (j < H && unit < H) ? K[(size_t)(E + j) * 4 * H + gate * H + unit] : 0.0f;
+    const unsigned short hi = sse_bf16_rne(v), lo = sse_bf16_rne(v - sse_bf16_f32(hi));
+    const int64_t o = (blk * 2) * 512 + lane * 8 + i;
+    out[o] = hi;
+    out[o + 512] = lo;
+  }
+}
+
+size_t kT16_elems(int Hp) { return (size_t)(Hp / 32) * (4 * Hp / 16) * 2 * 512; }
+
+hipError_t launch_pack_kT16(const float *K, int E, int H, int Hp, unsigned short *out, hipStream_t stream) {
+  const int64_t total = (int64_t)(Hp / 32) * (4 * Hp / 16) * 512;
+  hipLaunchKernelGGL(pack_kT16_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, K, E, H, Hp, total, out);
+  return hipGetLastError();
 }
 
 int dk_slices(int RG) {

@@ -26,6 +26,8 @@ if os.environ.get("SSE_TRAIN_DK_X3"):                  # 0: fp32 MFMA weight-gra
     m.handle.set_option("train_dk_x3", int(os.environ["SSE_TRAIN_DK_X3"]))
 if os.environ.get("SSE_TRAIN_FWD_X3"):
     m.handle.set_option("train_fwd_x3", int(os.environ["SSE_TRAIN_FWD_X3"]))
+if os.environ.get("SSE_TRAIN_BWD_X3"):
+    m.handle.set_option("train_bwd_x3", int(os.environ["SSE_TRAIN_BWD_X3"]))
 rng = np.random.RandomState(0)
 for B in [int(x) for x in (sys.argv[1:] or ["128", "1024", "8192"])]:
     if os.environ.get("SSE_TRAIN_UNPAIRED"):
