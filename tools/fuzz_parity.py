@@ -85,7 +85,10 @@ def main(n_cases=40, seed=0, verbose=True):
                 wl, wa = O.train_step(p, st, dict(params, cnn_bf16=bf16), tsrc, ttgt, z, 0.5)
                 m.handle.learning_rate = 0.5
                 gl, ga = m.train_step(tsrc, ttgt, z)
-                assert abs(gl - float(wl)) < 1e-4 * max(1.0, abs(float(wl))), ("loss", gl, wl)
+                # the loss is a mean of softplus(+-64 cos): |d loss| <= 64 |d cos|.  Bound: a cosine error of 5e-5 (1/20 of the
+                # north-star budget of 1e-3) or 1e-4 relative, whichever is larger -- degenerate shapes (S = 2, E = 3: raw
+                # encodings of norm ~0.05) turn the ~2e-6 absolute error of the split-bf16 training forward into ~3e-5 on a cosine
+                assert abs(gl - float(wl)) < max(1e-4 * max(1.0, abs(float(wl))), 64 * 5e-5), ("loss", gl, wl)
                 got = m.get_variables()
                 for name, w in p.items():
                     d = float(np.abs(got[name].reshape(w.shape) - w).max())

@@ -1,6 +1,11 @@
 #!/bin/bash
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_fullsize.py tests/test_gpu_fuzz.py -m gpu -q -k "train or fuzz" 2>&1 | grep -v amdgpu | tail -12
-for x in 1 0; do echo "== train_bwd_x3=$x"; SSE_TRAIN_BWD_X3=$x timeout 300 python tools/bench_train.py 128 1024 8192 2>&1 | grep -v amdgpu.ids; done
-timeout 300 python tools/bench_train_default.py 2>&1 | grep -v amdgpu.ids
+o=$GRAFT_REPO_ROOT/gpurun_out/s21; mkdir -p $o
+timeout 600 python tools/fuzz_parity.py 300 555 2>&1 | grep -v "^ok" | grep -v amdgpu | tail -4
+cd /tmp
+SSE_TRAIN_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d $o/train_stats -o p -- python $GRAFT_REPO_ROOT/tools/bench_train.py 8192 > $o/train_serial.txt 2>&1
+head -12 $(find $o/train_stats -name "*kernel_stats.csv" | head -1) | cut -c1-140
+rocprofv3 --kernel-trace --output-format csv -d $o/tdef -o p -- python $GRAFT_REPO_ROOT/tools/bench_train_default.py 128 > $o/tdef.txt 2>&1
+python $GRAFT_REPO_ROOT/tools/analyze_step_trace.py $(find $o/tdef -name "*kernel_trace.csv" | head -1) | grep -v "    [0-9.]* *[0-9.]* idle *0.0  q0   \(adagrad\|sumsq\|pack\)" | tail -40
+find $o -name "*.csv" -size +20M -delete
