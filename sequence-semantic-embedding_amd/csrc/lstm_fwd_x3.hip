@@ -63,30 +63,40 @@ __device__ __forceinline__ void x3_split8(const float (&v)[8], u32x4 &hi, u32x4 
   }
 }
 
-// LDS (bytes): x [2 row tiles][KGX][hi|lo][1 KiB] (single-buffered) | h [2 bufs][2 row tiles][KGH = Hp/16][hi|lo][1 KiB] | red
-size_t lstm_x3_lds_bytes(int KGX, int Hp) { return (size_t)2 * KGX * 2048 + (size_t)2 * 2 * (Hp / 16) * 2048 + 1024; }
+// LDS (bytes): x [RT row tiles][KGX][hi|lo][1 KiB] (single-buffered) | h [2 bufs][RT row tiles][KGH = Hp/16][hi|lo][1 KiB] | red
+size_t lstm_x3_lds_bytes(int KGX, int Hp, int RT) { return (size_t)RT * KGX * 2048 + (size_t)2 * RT * (Hp / 16) * 2048 + 1024; }
 
-// UBN = unit blocks of 32 hidden units (Hp = 32 * UBN): 8 -> wave = unit block, MT = 2 row tiles; 4 -> MT = 1
-template <int UBN, bool TRAIN>
+// UBN = unit blocks of 32 hidden units (Hp = 32 * UBN): 8 -> wave = unit block, MT = 2 row tiles; 4 -> MT = 1.
+// RT = 32-row tiles per workgroup: 2, or 1 (UBN = 4 only): ONE tile and every unit block split by pass over two waves --
+// wave ub computes the i,j pass and hands sigmoid(i)*tanh(j) over through the parking slots (same lane mapping in both
+// waves), wave ub + 4 the f,o pass and owns the cell state: half the per-step latency on twice the workgroups, for batches
+// that cannot fill the chip (the reference's default training shape: 128 pair rows).
+template <int UBN, bool TRAIN, int RT>
 __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
+  static_assert(RT == 2 || UBN == 4, "the one-tile mapping is defined for 4 unit blocks");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
   constexpr int KGH = 2 * UBN;  // h groups of 16 units
   constexpr int MT = (UBN == 8) ? 2 : 1;
+  constexpr int ROWS = 32 * RT, NXQ = X3_THREADS / ROWS;
+  constexpr bool PSPLIT = (RT == 1);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int w = (UBN == 8) ? wave : (wave & 3);   // unit block of this wave
-  const int mt0 = (UBN == 8) ? 0 : (wave >> 2);   // its first row tile
+  const int mt0 = (UBN == 8 || PSPLIT) ? 0 : (wave >> 2);   // its first row tile
+  const bool do_a = !PSPLIT || wave < 4, do_b = !PSPLIT || wave >= 4;
   const int KGX = a.KGX, KG = KGX + KGH, T = a.T;
   const int KGHe = min(KGH, (a.H + 15) / 16);  // h groups that can be non-zero
   unsigned char *xbase = smem3;
-  unsigned char *hbase = smem3 + (size_t)2 * KGX * 2048;
-  float *red = reinterpret_cast<float *>(hbase + (size_t)2 * 2 * KGH * 2048);
+  unsigned char *hbase = smem3 + (size_t)RT * KGX * 2048;
+  float *red = reinterpret_cast<float *>(hbase + (size_t)2 * RT * KGH * 2048);
+  volatile int *pass_flag = reinterpret_cast<volatile int *>(red + 16);  // PSPLIT: [unit block] = steps whose i,j pass is parked
+  if (tid < 4) pass_flag[tid] = 0;
   auto xptr = [&](int mt) -> unsigned char * { return xbase + (size_t)mt * KGX * 2048; };
-  auto hptr = [&](int buf, int mt) -> unsigned char * { return hbase + (size_t)(buf * 2 + mt) * KGH * 2048; };
-  const int b0 = blockIdx.x * 64;
+  auto hptr = [&](int buf, int mt) -> unsigned char * { return hbase + (size_t)(buf * RT + mt) * KGH * 2048; };
+  const int b0 = blockIdx.x * ROWS;
 
   // x gather: thread (row xr, octet xq + 8*i): one 16-byte piece of the hi table and one of the lo table
-  const int xr = tid & 63, xq = tid >> 6;
+  const int xr = tid % ROWS, xq = tid / ROWS;
   const bool row_ok = (b0 + xr) < a.B;
   const int32_t *id_row = a.ids + (size_t)(row_ok ? (a.row_map ? a.row_map[b0 + xr] : b0 + xr) : 0) * T;
   const int EP = KGX * 16;  // columns of the split embedding table per copy
@@ -110,7 +120,7 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
   if (!TRAIN && a.pad_h != nullptr) {
     int lead = T;
     if (row_ok) {
-      for (int t = xq; t < T; t += 8)
+      for (int t = xq; t < T; t += NXQ)
         if (id_row[t] != 0) {
           lead = t;
           break;
@@ -127,12 +137,12 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
   }
   {
     const unsigned short *src = a.emb16 + (size_t)fetch_id(t0) * 2 * EP;
-    for (int oc = xq; oc < 2 * KGX; oc += 8)
+    for (int oc = xq; oc < 2 * KGX; oc += NXQ)
       x_store(oc, *reinterpret_cast<const u32x4 *>(src + oc * 8), *reinterpret_cast<const u32x4 *>(src + EP + oc * 8));
   }
   const int Hp = 32 * UBN;
   if (t0 > 0) {  // h_{t0-1} = pad_h[t0], the same for every row, split into the operand layout of buffer t0 & 1
-    for (int i = tid; i < 2 * KGH * 64; i += X3_THREADS) {
+    for (int i = tid; i < RT * KGH * 64; i += X3_THREADS) {
       const int sl = i & 63, kgh = (i >> 6) % KGH, mt = i / (64 * KGH);
       float v8[8];
 #pragma unroll
@@ -189,8 +199,8 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
       // half) owning rows 16 j + 8 half .. + 7: the hi and lo pieces already sit in the operand tiles (lane = row there)
       const int KT = 2 + Hp / 32, nk = 64 + Hp;
       unsigned short *ta = reinterpret_cast<unsigned short *>(a.tape_a);
-      for (int i = tid; i < nk * 8; i += X3_THREADS) {
-        const int kp = i % nk, o = i / nk;  // o: rows 8*o .. 8*o+7 of the workgroup's 64
+      for (int i = tid; i < nk * (ROWS / 8); i += X3_THREADS) {
+        const int kp = i % nk, o = i / nk;  // o: rows 8*o .. 8*o+7 of the workgroup's rows
         const int mt = o >> 2, oc = o & 3;
         u32x4 hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
         const bool xpart = kp < 64;
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
             }
           }
         }
-        const size_t g16 = ((size_t)t * NT32 + blockIdx.x * 2 + mt) * 2 + (oc >> 1);
+        const size_t g16 = ((size_t)t * NT32 + blockIdx.x * RT + mt) * 2 + (oc >> 1);
         unsigned short *dst = ta + ((g16 * KT + (kp >> 5)) * 2) * 512 + ((oc & 1) * 32 + (kp & 31)) * 8;
         *reinterpret_cast<u32x4 *>(dst) = hi;
         *reinterpret_cast<u32x4 *>(dst + 512) = lo;
@@ -302,18 +312,19 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
         g[m][0][r] = 0.0f;
         g[m][1][r] = 0.0f;
       }
-    if (TRAIN || w * 32 < a.H) gemm(0, g);
+    if (do_a && (TRAIN || w * 32 < a.H)) gemm(0, g);
     // gate tape (TRAIN), lstm_fwd.hip's layout: [t][tile32][unit block][q = si,tj,sf,so,c][reg][lane]
     float *tp[MT];
     if constexpr (TRAIN) {
 #pragma unroll
       for (int m = 0; m < MT; ++m)
-        tp[m] = a.tape_g + (((size_t)t * NT32 + blockIdx.x * 2 + mt0 + m) * UBN + w) * 5 * 1024 + lane;
+        tp[m] = a.tape_g + (((size_t)t * NT32 + blockIdx.x * RT + mt0 + m) * UBN + w) * 5 * 1024 + lane;
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
+        if (!do_a) break;
         f32x4 pij;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -334,9 +345,17 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
         g[m][0][r] = 0.0f;
         g[m][1][r] = 0.0f;
       }
-    if (TRAIN || w * 32 < a.H) gemm(2, g);
+    if (do_a && !do_b) {  // publish the parked products of this step (LDS operations of a wave complete in order)
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+      if (lane == 0) pass_flag[w] = t + 1;
+    }
+    if (do_b && (TRAIN || w * 32 < a.H)) gemm(2, g);
+    if (do_b && !do_a) {  // the i,j pass of this unit block comes from the partner wave
+      while (pass_flag[w] < t + 1) __builtin_amdgcn_s_sleep(2);
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
+      if (!do_b) break;
       float hv[16];
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
@@ -405,7 +424,7 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
     __syncthreads();  // h_t complete; x_t and h_{t-1} no longer needed
     if (have_next) {
       if (xq < 2 * KGX) x_store(xq, nhi, nlo);
-      for (int oc = xq + 8; oc < 2 * KGX; oc += 8) {
+      for (int oc = xq + NXQ; oc < 2 * KGX; oc += NXQ) {
         const unsigned short *src = a.emb16 + (size_t)nid * 2 * EP;
         x_store(oc, *reinterpret_cast<const u32x4 *>(src + oc * 8), *reinterpret_cast<const u32x4 *>(src + EP + oc * 8));
       }
@@ -415,7 +434,7 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
 
   if constexpr (TRAIN) {
     // h_T, row-major [Bp][Hp], for dM = h_T^T . d(out)
-    for (int i = tid; i < 64 * Hp; i += X3_THREADS) {
+    for (int i = tid; i < ROWS * Hp; i += X3_THREADS) {
       const int un = i % Hp, b = i / Hp;
       a.h_last[(size_t)(b0 + b) * Hp + un] =
           reinterpret_cast<const float *>(hptr(T & 1, b >> 5))[(size_t)(un >> 3) * 256 + ((((un >> 2) & 1) * 32 + (b & 31)) << 2) + (un & 3)];
@@ -423,7 +442,7 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
   }
 
   // ---- projection out = h_T . M (+ optional l2_normalize): the fp32 tail of lstm_fwd.hip, 4 waves per row tile
-  constexpr int NWR = 4, PT = 4, KGh32 = 4 * UBN;
+  constexpr int NWR = 8 / RT, PT = 16 / NWR, KGh32 = 4 * UBN;
   const int wn = wave % NWR, wm = wave / NWR;
   const float *hp = reinterpret_cast<const float *>(hptr(T & 1, wm)) + lane * 4;
   f32x16 pacc[PT];
@@ -565,13 +584,13 @@ hipError_t launch_pack_lstm_x3(const float *K, const float *b, const float *emb,
   return hipGetLastError();
 }
 
-template <int UBN, bool TRAIN>
+template <int UBN, bool TRAIN, int RT>
 static hipError_t launch_x3(const LstmX3Args &a, hipStream_t stream) {
-  const size_t lds = lstm_x3_lds_bytes(a.KGX, 32 * UBN);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_x3_kernel<UBN, TRAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const size_t lds = lstm_x3_lds_bytes(a.KGX, 32 * UBN, RT);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_x3_kernel<UBN, TRAIN, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  const int blocks = TRAIN ? a.NT32 / 2 : (a.B + 63) / 64;
-  hipLaunchKernelGGL((lstm_fwd_x3_kernel<UBN, TRAIN>), dim3(blocks), dim3(X3_THREADS), lds, stream, a);
+  const int blocks = TRAIN ? a.NT32 / RT : (a.B + 32 * RT - 1) / (32 * RT);
+  hipLaunchKernelGGL((lstm_fwd_x3_kernel<UBN, TRAIN, RT>), dim3(blocks), dim3(X3_THREADS), lds, stream, a);
   return hipGetLastError();
 }
 
@@ -580,7 +599,10 @@ hipError_t launch_lstm_fwd_x3(const LstmX3Args &a, hipStream_t stream) {
   if (a.H < 1 || a.H > 256 || a.B < 1 || a.KGX < 1 || a.KGX > 4) return hipErrorInvalidValue;
   if (a.tape_g != nullptr) {
     if (a.NT32 < 2 || (a.NT32 & 1) || !a.tape_a || !a.h_last) return hipErrorInvalidValue;
-    return a.H > 128 ? launch_x3<8, true>(a, stream) : launch_x3<4, true>(a, stream);
+    if (a.H > 128) return launch_x3<8, true, 2>(a, stream);
+    // cells <= 128: one-tile pass-split workgroups while the launch (and the other encoder's, running beside it) cannot
+    // fill the chip with 64-row ones
+    return (a.NT32 + a.tiles_elsewhere <= 256) ? launch_x3<4, true, 1>(a, stream) : launch_x3<4, true, 2>(a, stream);
   }
-  return a.H > 128 ? launch_x3<8, false>(a, stream) : launch_x3<4, false>(a, stream);
+  return a.H > 128 ? launch_x3<8, false, 2>(a, stream) : launch_x3<4, false, 2>(a, stream);
 }

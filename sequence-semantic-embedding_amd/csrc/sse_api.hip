@@ -1674,6 +1674,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
       xa.tape_a = a.tape_a;
       xa.h_last = a.h_last;
       xa.NT32 = NTf;
+      xa.tiles_elsewhere = a.tiles_elsewhere;
       HIPCHECK(h, launch_lstm_fwd_x3(xa, fs));
     } else {
       HIPCHECK(h, launch_lstm_fwd(a, e.Hp, fs));

@@ -128,6 +128,7 @@ struct LstmX3Args {
   // training forward (tape_g != nullptr): tapes as lstm_fwd.hip's, tape_a in the split frag16 form (tape_a_split = 1)
   float *tape_g = nullptr, *tape_a = nullptr, *h_last = nullptr;
   int32_t NT32 = 0;
+  int32_t tiles_elsewhere = 0;  // 32-row tiles of the other encoder's forward running concurrently (tile-size choice)
 };
 int lstm_x3_kgx(int E);
 size_t lstm_x3_weight_elems(int E, int Hp);
