@@ -97,9 +97,21 @@ int sse_encode_dev(sse_handle *h, int side, const int32_t *ids_dev, int32_t B, i
  * exactly the reference's ids and scores (bit-identical to score_bf16 = 0), ~5x faster; +50 % index memory.  Queries
  * whose result misses the certificate (top scores packed closer than the bf16 bound) are swept again with fp32
  * candidates on the device before anything reaches the float64 brute force.  0 = fp32 candidates only.
- * "cnn_bf16" (default 0; source_only_cnn only): the convolution of inference encodes reads embeddings and
- * filters rounded to bf16 (fp32 accumulation, fp32 bias/ReLU/pool/projection) on the bf16 matrix pipe -- the
- * reference has no reduced-precision behaviour; BASELINE configs[4] names bf16.  Training stays fp32.
+ * "lstm_persist_rows" (default 32): encodes of at most this many rows (<= 32) run on a cluster of workgroups that keeps
+ * the LSTM kernel matrix in LDS and exchanges h_t every step (single query 0.13 ms at H = 256, T = 32); bit-identical
+ * to the other kernels; used only when the device has at least 2 x 8 x 16 CUs.  0 disables.
+ * "lstm_x3" (default 0): inference encodes of more than lstm_small_rows rows (cell sizes 64 .. 256, embedding < 64) run
+ * their gate GEMMs as three bf16 MFMAs per product on hi + lo split fp32 operands (x = bf16(x) + bf16(x - bf16(x))):
+ * NOT bit-identical to the fp32 path, ~2e-6 from it on normalised encodings, 2.2 - 2.9x faster.
+ * "train_fwd_x3", "train_bwd_x3", "train_dk_x3" (default 1; LSTM modes, cell sizes 64 .. 256): the forward, the BPTT
+ * recurrence and the weight-gradient GEMM of sse_train_step* on split operands in the same way (~4e-6 relative per
+ * product; loss within ~1e-5 .. 1e-4 relative of the fp32 kernels).  All three 0 = fp32 MFMA throughout.
+ * "train_pair_dedup" (default 1): a train batch whose rows 2i, 2i+1 carry the same source sequence (data.py:95-115 builds
+ * every batch that way) runs the source encoder once per pair.  "lstm_train_rows" (0 | 32 | 64): fp32 training forward
+ * tile rows (measurement aid).
+ * "cnn_bf16" (default 0; source_only_cnn only): the convolution of inference encodes AND of the train step reads
+ * embeddings and filters rounded to bf16 (fp32 masters, fp32 accumulation, fp32 bias/ReLU/pool/projection) on the bf16
+ * matrix pipe -- the reference has no reduced-precision behaviour; BASELINE configs[4] names bf16.
  * "train_serial" (default 0): run both encoders of a train step on one stream (profiling aid:
  * isolated kernel durations; same results). */
 int sse_set_option(sse_handle *h, const char *name, int32_t value);

@@ -220,6 +220,28 @@ def test_paired_batch_runs_the_source_encoder_once_per_pair(mode, H):
     assert la[0] == pytest.approx(lb[0], rel=1e-4)
 
 
+@pytest.mark.parametrize("fwd,bwd,dk", [(0, 0, 0), (1, 0, 1), (0, 1, 1), (0, 0, 1), (1, 1, 1)])
+def test_split_operand_options_are_independent(fwd, bwd, dk):
+    """train_fwd_x3 / train_bwd_x3 / train_dk_x3 select the split-bf16 GEMMs kernel by kernel (the forward and BPTT
+    variants need the split tape / dG formats of train_dk_x3); every combination is the same step to the loss tolerance
+    of its forward and 2e-4 on the updated weights."""
+    params = model_params("dual-encoder", 300, 50, 256, 96, 64, 9, lr=0.9)
+    m, p = make_pair(params, seed=17)
+    for name, v in (("train_fwd_x3", fwd), ("train_bwd_x3", bwd), ("train_dk_x3", dk)):
+        m.handle.set_option(name, v)
+    st = O.new_optimizer_state(p)
+    rng = np.random.RandomState(3)
+    for step in range(2):
+        src, tgt, z = _batch(rng, 128, 9, 300)
+        want = O.train_step(p, st, params, src, tgt, z, 0.9)
+        got = m.train_step(src, tgt, z)
+        assert got[0] == pytest.approx(float(want[0]), rel=LOSS_REL if fwd else LOSS_REL_EXACT, abs=1e-6)
+    v = m.get_variables(with_slots=True)
+    for name, w in p.items():
+        assert np.abs(v[name].reshape(w.shape) - w).max() < 2e-4, name
+        assert np.abs(v[name + "/Adagrad"].reshape(w.shape) - st[name]).max() < 2e-4, name
+
+
 def test_handles_release_their_device_memory():
     """Create / train / encode / destroy repeatedly: free device memory does not drift (scratch, tapes, arena)."""
     import gc
