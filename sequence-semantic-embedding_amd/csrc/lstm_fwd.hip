@@ -127,71 +127,6 @@ __device__ __forceinline__ void gemm_pass(__amdgpu_buffer_rsrc_t wr, int voff, i
   __builtin_amdgcn_s_setprio(0);
 }
 
-// gemm_pass for the f,o pass of the throughput configuration (MT = 2, weights = A operand) with the gate epilogue of
-// the PREVIOUS pass woven in: the k-loop is fully unrolled (at most 20 double steps), and after the MFMAs of double step
-// `it` the caller's hook(it) emits a slice of sigmoid(i)*tanh(j) -- vector-ALU and transcendental work that executes in
-// the shadow of the matrix pipe instead of after the pass, when both waves of a SIMD would do it at the same time with
-// the matrix pipe idle.  Returns the number of double steps executed.
-template <bool LIN, typename Hook>
-__device__ __forceinline__ int gemm_pass_hook(__amdgpu_buffer_rsrc_t wr, int voff, int soff, const float *const (&xa)[2],
-                                              const float *const (&ha)[2], int KGx, int kend, f32x16 (&acc)[2][2], Hook &&hook) {
-  auto a_frag = [&](int m, int kg) -> f32x4 {
-    if constexpr (LIN) return *reinterpret_cast<const f32x4 *>(xa[m] + kg * 256);
-    return *reinterpret_cast<const f32x4 *>(kg < KGx ? xa[m] + kg * 256 : ha[m] + (kg - KGx) * 256);
-  };
-  f32x4 p0 = wload(wr, voff, soff), p1 = wload(wr, voff + 1024, soff);
-  f32x4 q0, q1, a0[2], a1[2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m) a0[m] = a_frag(m, 0);
-  __builtin_amdgcn_s_setprio(1);
-  int done = 0;
-#pragma unroll
-  for (int it = 0; it < 20; ++it) {
-    const int kg = 2 * it;
-    if (kg + 1 >= kend) break;
-    q0 = wload(wr, voff, soff + (kg + 1) * 4096);
-    q1 = wload(wr, voff + 1024, soff + (kg + 1) * 4096);
-#pragma unroll
-    for (int m = 0; m < 2; ++m) a1[m] = a_frag(m, kg + 1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p0[e], a0[m][e], acc[m][0], 0, 0, 0);
-        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p1[e], a0[m][e], acc[m][1], 0, 0, 0);
-      }
-    hook(it);
-    __builtin_amdgcn_sched_barrier(0);
-    const int k2 = (kg + 2 < kend) ? kg + 2 : kg;
-    p0 = wload(wr, voff, soff + k2 * 4096);
-    p1 = wload(wr, voff + 1024, soff + k2 * 4096);
-#pragma unroll
-    for (int m = 0; m < 2; ++m) a0[m] = a_frag(m, k2);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(q0[e], a1[m][e], acc[m][0], 0, 0, 0);
-        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1[e], a1[m][e], acc[m][1], 0, 0, 0);
-      }
-    __builtin_amdgcn_sched_barrier(0);
-    done = it + 1;
-  }
-  if ((kend & 1) && 2 * done < kend) {  // odd k-group count: operands of the last group are already loaded
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p0[e], a0[m][e], acc[m][0], 0, 0, 0);
-        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p1[e], a0[m][e], acc[m][1], 0, 0, 0);
-      }
-  }
-  __builtin_amdgcn_s_setprio(0);
-  return done;
-}
-
 // Kernel configurations (RT = 32-row tiles per workgroup, MT = row tiles per wave, UBW = unit
 // blocks of 32 hidden units a wave processes one after the other); always 8 waves:
 //   <2,2,1>  Hp = 256, 64 rows: wave w owns unit block w for both row tiles      (throughput)
@@ -452,20 +387,9 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
         }
       }
       if (do_a) gemm_pass<MT, LIN, SWAP>(wr, wvoff, wsoff, xa, ha, KGx, kend, g);
-      // HOOK (the throughput configuration): sigmoid(i)*tanh(j) is NOT computed here but woven into the k-loop of the f,o
-      // pass (gemm_pass_hook), from a copy of these accumulators
-      constexpr bool HOOK = !TRAIN && RT == 2 && MT == 2 && UBW == 1 && !SPL;
-      f32x16 gA[MT][2];
-      if constexpr (HOOK) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          gA[m][0] = g[m][0];
-          gA[m][1] = g[m][1];
-        }
-      }
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        if (!do_a || HOOK) break;
+        if (!do_a) break;
         if constexpr (SWAP) {
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) {
@@ -508,24 +432,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
           g[m][0][r] = 0.0f;
           g[m][1][r] = 0.0f;
         }
-      if constexpr (HOOK) {
-        // one (row tile, 4-register group) of the parked product per double step 0, 2, 4, ..: 8 units in all
-        auto park = [&](int unit) {
-          const int m = unit >> 2, q4 = unit & 3;
-          f32x4 pij;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pij[e] = fast_sigmoid(gA[m][0][q4 * 4 + e]) * fast_tanh(gA[m][1][q4 * 4 + e]);
-          *reinterpret_cast<f32x4 *>(hdst[m] + q4 * 256) = pij;
-        };
-        const int done = gemm_pass_hook<LIN>(wr, wvoff, wsoff + 2048, xa, ha, KGx, kend, g, [&](int it) {
-          if ((it & 1) == 0 && it < 16) park(it >> 1);
-        });
-#pragma unroll
-        for (int unit = 0; unit < 8; ++unit)
-          if (2 * unit >= done) park(unit);  // a short k-loop (step 0: x part only) leaves some for here
-      } else if (do_b) {
-        gemm_pass<MT, LIN, SWAP>(wr, wvoff, wsoff + 2048, xa, ha, KGx, kend, g);
-      }
+      if (do_b) gemm_pass<MT, LIN, SWAP>(wr, wvoff, wsoff + 2048, xa, ha, KGx, kend, g);
       if (do_b && !do_a) {  // split3: the i,j pass of this (block, row tile) comes from the partner wave
         while (pass_flag[fidx] < t + 1) __builtin_amdgcn_s_sleep(2);
       }
