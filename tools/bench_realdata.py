@@ -24,11 +24,17 @@ tgt = np.tile(z["tgt_ids"], (reps, 1))          # 34,076 rows ~ the 32,060-targe
 src = np.tile(z["src_ids"], (28, 1))            # 16,800 rows ~ the 16,491 eval queries
 for name, ids, enc in (("targets", tgt, m.encode_target), ("queries", src, m.encode_source)):
     nonpad = float((ids != 0).sum(1).mean())
-    for skip in (0, 1):
-        m.handle.set_option("pad_skip", skip)
-        enc(ids[:256])
-        t0 = time.perf_counter()
-        out = enc(ids)
-        dt = time.perf_counter() - t0
-        print("%s: %d rows x T=50 (mean non-pad %.1f) pad_skip=%d: %.1f ms  %.0f seq/s (host buffers in/out)"
-              % (name, len(ids), nonpad, skip, dt * 1e3, len(ids) / dt))
+    ref = None
+    for x3 in (0, 1):                                       # exact fp32 kernel / opt-in split-bf16 kernel
+        m.handle.set_option("lstm_x3", x3)
+        for skip in (0, 1):
+            m.handle.set_option("pad_skip", skip)
+            enc(ids[:2048])
+            t0 = time.perf_counter()
+            out = enc(ids)
+            dt = time.perf_counter() - t0
+            if ref is None:
+                ref = out
+            print("%s: %d rows x T=50 (mean non-pad %.1f) lstm_x3=%d pad_skip=%d: %.1f ms  %.0f seq/s (host buffers in/out), max |d| vs first %.2e"
+                  % (name, len(ids), nonpad, x3, skip, dt * 1e3, len(ids) / dt, float(np.abs(out - ref).max())))
+    m.handle.set_option("lstm_x3", 0)
