@@ -462,7 +462,6 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
       pa.out = out;
       pa.B = B;
       pa.T = T;
-      pa.map_mode = getenv("SSE_PERSIST_MAP") ? atoi(getenv("SSE_PERSIST_MAP")) : 0;
       pa.normalize = normalize ? 1 : 0;
       if (h->pad_skip && T > 1) {
         if (ensure_pad_table_small(h, side, T, st)) return 1;  // same arithmetic, same table
