@@ -73,12 +73,13 @@ size_t lstm_x3_lds_bytes(int KGX, int Hp, int RT) { return (size_t)RT * KGX * 20
 // that cannot fill the chip (the reference's default training shape: 128 pair rows).
 template <int UBN, bool TRAIN, int RT>
 __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
-  static_assert(RT == 2 || UBN == 4, "the one-tile mapping is defined for 4 unit blocks");
+  // (RT = 1 with UBN = 8: one tile, wave = unit block, no pass split -- for launches that cannot fill the chip with
+  // 64-row workgroups; two such workgroups fit a CU)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
   constexpr int KGH = 2 * UBN;  // h groups of 16 units
-  constexpr int MT = (UBN == 8) ? 2 : 1;
+  constexpr int MT = (UBN == 8 && RT == 2) ? 2 : 1;
   constexpr int ROWS = 32 * RT, NXQ = X3_THREADS / ROWS;
-  constexpr bool PSPLIT = (RT == 1);
+  constexpr bool PSPLIT = (RT == 1 && UBN == 4);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int w = (UBN == 8) ? wave : (wave & 3);   // unit block of this wave
@@ -599,7 +600,9 @@ hipError_t launch_lstm_fwd_x3(const LstmX3Args &a, hipStream_t stream) {
   if (a.H < 1 || a.H > 256 || a.B < 1 || a.KGX < 1 || a.KGX > 4) return hipErrorInvalidValue;
   if (a.tape_g != nullptr) {
     if (a.NT32 < 2 || (a.NT32 & 1) || !a.tape_a || !a.h_last) return hipErrorInvalidValue;
-    if (a.H > 128) return launch_x3<8, true, 2>(a, stream);
+    if (a.H > 128)  // 32-row workgroups while they all fit one per CU (measured: 1024 rows 2.44 -> 2.09 ms; at 8192 rows,
+                    // 384 tiles, the doubled weight traffic loses: 5.43 vs 5.67 ms)
+      return (a.NT32 + a.tiles_elsewhere <= 256) ? launch_x3<8, true, 1>(a, stream) : launch_x3<8, true, 2>(a, stream);
     // cells <= 128: one-tile pass-split workgroups while the launch (and the other encoder's, running beside it) cannot
     // fill the chip with 64-row ones
     return (a.NT32 + a.tiles_elsewhere <= 256) ? launch_x3<4, true, 1>(a, stream) : launch_x3<4, true, 2>(a, stream);
