@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsse_hip.so")
 SOURCES = ["sse_api.hip", "lstm_fwd.hip", "lstm_small.hip", "lstm_persist.hip", "lstm_fwd_x3.hip", "cnn_fwd.hip", "cnn_fwd_bf16.hip", "score_topk.hip", "pack.hip", "train.hip", "cnn_bwd.hip", "index_io.cpp"]
+EXTRA = os.environ.get("SSE_HIPCC_EXTRA", "").split()   # e.g. -DSSE_SCORE_MEASURE for the measurement builds of tools/
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 
 
@@ -34,18 +35,24 @@ def build(force=False, verbose=False):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     hdr_mtime = max(os.path.getmtime(p) for p in _deps())
-    objs, rebuilt = [], False
+    objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_mtime):
             flags = FLAGS if src.endswith(".hip") else [f for f in FLAGS if not f.startswith("--offload-arch")] + ["-pthread"]
-            cmd = [hipcc] + flags + ["-c", s, "-o", o]
+            jobs.append([hipcc] + flags + EXTRA + ["-c", s, "-o", o])
+    if jobs:  # independent translation units: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
-            rebuilt = True
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(run, jobs))
+    rebuilt = bool(jobs)
     if rebuilt or not os.path.exists(LIB):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs
         if verbose:

@@ -416,7 +416,9 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
       int thr_i[NQ];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) thr_i[q] = thr_s[q * 32 + (lane & 31)];
-      if (a.dbg & 1) continue;  // measurement aid: k-loop only (results are garbage)
+#ifdef SSE_SCORE_MEASURE  // measurement builds only (tools/): k-loop without the top-k epilogue, results are garbage
+      if (a.dbg & 1) continue;
+#endif
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         if (tail) {
@@ -571,15 +573,37 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   }
 }
 
-template <int NQ, bool BF, bool COLLECT, bool RINGED>
-static hipError_t launch_score_ringed(const ScoreArgs &a_in, hipStream_t stream) {
-  size_t lds = (size_t)NQ * a_in.KG * 256 * sizeof(float);
+// dynamic LDS of one workgroup: query block (re-used as merge scratch) + shared thresholds + per-list bests (+ parked hits)
+static size_t score_lds_layout(int NQ, int KG, bool BF, bool COLLECT, int32_t *thr_off) {
+  size_t lds = (size_t)NQ * KG * 256 * sizeof(float);
   const size_t merge_lds = (size_t)(SC_THREADS / 128) * NQ * (SC_KC * 2 + 1) * 32 * 4;  // (score, id) planes + bounds
   if (!COLLECT && merge_lds > lds) lds = merge_lds;
-  ScoreArgs a = a_in;
-  a.thr_off = (int32_t)(lds / sizeof(float));  // shared thresholds live behind the query block / merge scratch
+  if (thr_off) *thr_off = (int32_t)(lds / sizeof(float));  // shared thresholds live behind the query block / merge scratch
   lds += (size_t)NQ * 32 * sizeof(int) + (size_t)NQ * 32 * 16 * sizeof(float);  // thresholds + per-list best entries
   if (BF && !COLLECT) lds += (size_t)(SC_THREADS / 64) * NQ * SC_PEND * 64 * 8;  // parked hits (deferred insertion)
+  return lds;
+}
+size_t score_lds_bytes(int NQ, int KG, int BF, int COLLECT) { return score_lds_layout(NQ, KG, BF != 0, COLLECT != 0, nullptr); }
+
+// Query tiles per workgroup for an index of dimension S.  <= 32 queries: one tile (HBM-bound sweep).  Otherwise the
+// largest of 4 / 2 / 1 whose query block fits the 160 KiB of LDS in EVERY variant a call may launch (fp32 candidates,
+// fp32 collect, and -- with_bf16 -- the bf16 candidate pass with its parked-hit rows): 4 up to S = 296, 2 up to S = 616
+// (BASELINE configs[4]: S = 512), 1 up to SSE_MAX_INDEX_DIM.  0: S does not fit at all.
+int score_pick_nq(int Q, int S, int with_bf16) {
+  const int KG = (S + 7) / 8, KG16 = (S + 15) / 16;
+  const size_t cap = 160 * 1024;
+  for (int nq = (Q <= 32) ? 1 : 4; nq >= 1; nq >>= 1) {
+    if (score_lds_bytes(nq, KG, 0, 0) > cap || score_lds_bytes(nq, KG, 0, 1) > cap) continue;
+    if (with_bf16 && score_lds_bytes(nq, KG16, 1, 0) > cap) continue;
+    return nq;
+  }
+  return 0;
+}
+
+template <int NQ, bool BF, bool COLLECT, bool RINGED>
+static hipError_t launch_score_ringed(const ScoreArgs &a_in, hipStream_t stream) {
+  ScoreArgs a = a_in;
+  const size_t lds = score_lds_layout(NQ, a.KG, BF, COLLECT, &a.thr_off);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const int QB = (a.QT + NQ - 1) / NQ;
   int grid;
@@ -688,26 +712,31 @@ hipError_t launch_frag32_to_bf16(const float *idxp, int64_t NT, int KG, void *ou
 
 hipError_t launch_score_topk(const ScoreArgs &a_in, hipStream_t stream) {
   ScoreArgs a = a_in;
+#ifdef SSE_SCORE_MEASURE
   {
     static const int dbg = getenv("SSE_SCORE_DBG") ? atoi(getenv("SSE_SCORE_DBG")) : 0;
     a.dbg = dbg;
   }
+#endif
   if (a.KC != SC_KC) return hipErrorInvalidValue;
   if (a.NSPLIT > 8 && (a.NSPLIT & 7)) return hipErrorInvalidValue;
   if (a.NSPLIT < 8 && (8 % a.NSPLIT)) return hipErrorInvalidValue;
   if (a.COLLECT) {  // collect pass: fp32 scores only (the thresholds are fp32 bounds)
     if (a.BF || !a.col_thr || !a.col_slot || !a.col_cnt || !a.col_buf) return hipErrorInvalidValue;
     if (a.NQ == 1) return launch_score_variant<1, false, true>(a, stream);
+    if (a.NQ == 2) return launch_score_variant<2, false, true>(a, stream);
     if (a.NQ == 4) return launch_score_variant<4, false, true>(a, stream);
     return hipErrorInvalidValue;
   }
   if (!a.part_bnd) return hipErrorInvalidValue;
   if (a.BF) {
     if (a.NQ == 1) return launch_score_variant<1, true, false>(a, stream);
+    if (a.NQ == 2) return launch_score_variant<2, true, false>(a, stream);
     if (a.NQ == 4) return launch_score_variant<4, true, false>(a, stream);
     return hipErrorInvalidValue;
   }
   if (a.NQ == 1) return launch_score_variant<1, false, false>(a, stream);
+  if (a.NQ == 2) return launch_score_variant<2, false, false>(a, stream);
   if (a.NQ == 4) return launch_score_variant<4, false, false>(a, stream);
   return hipErrorInvalidValue;
 }

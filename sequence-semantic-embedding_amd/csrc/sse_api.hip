@@ -600,7 +600,7 @@ int check_err_flag(sse_handle *h, hipStream_t st) {
 
 int index_from_dev_rows(sse_handle *h, const float *rows_dev, int64_t N, int S, int64_t id_base, hipStream_t st) {
   if (N <= 0 || S <= 0) return fail(h, "empty index");
-  if (S > 320) return fail(h, "index dimension %d > 320 not supported by the scoring kernel", S);
+  if (S > SSE_MAX_INDEX_DIM) return fail(h, "index dimension %d > %d not supported by the scoring kernel", S, SSE_MAX_INDEX_DIM);
   if (N > (int64_t)2147483000) return fail(h, "index shard too large for int32 row ids");
   const int KG = (S + 7) / 8;
   const int64_t NT = (N + 31) / 32;
@@ -632,7 +632,7 @@ static int choose_nsplit(int NQ, int QB, int64_t NT) {
   // enough workgroups to fill the 256 CUs (2 waves of them when the sweep is long), at least 16 n-tiles (2 per
   // wave) per split
   int nsplit = 1;
-  const int max_split = (NQ == 1) ? 256 : 128;
+  const int max_split = (NQ == 1) ? 256 : 128;  // 16 candidates per split, at most RS_MAXNC = 4096 per query
   while (nsplit < max_split && QB * nsplit < 512 && NT / (nsplit * 2) >= 16) nsplit *= 2;
   if (nsplit <= 8) {
     nsplit = 1;
@@ -641,7 +641,7 @@ static int choose_nsplit(int NQ, int QB, int64_t NT) {
   // one workgroup per CU is resident (the query block fills LDS): the launch runs in ceil(WGs/256) rounds and the
   // last round may be nearly empty (782 query blocks = 3.05 rounds ran at 76 % of the 64-block rate).  Split
   // further while that evens the rounds out by more than the extra per-split cost (~1 % per doubling).
-  if (NQ == 4) {
+  if (NQ >= 2) {
     auto eff = [&](int ns) {
       const double r = (double)QB * ns / 256.0;
       return r / std::ceil(r);
@@ -696,7 +696,8 @@ static int score_select_locked(sse_handle *h, const float *q, int Q, int k, doub
     const int Qc = std::min(POOL, Q - q0);
     const float *qc = q + (size_t)q0 * S;
     const int QT = (Qc + 31) / 32;
-    const int NQ = (Qc <= 32) ? 1 : 4;
+    const int NQ = score_pick_nq(Qc, S, 0);
+    if (NQ == 0) return fail(h, "index dimension %d does not fit the scoring kernel's LDS query block", S);
     const int QB = (QT + NQ - 1) / NQ;
     int nsplit = choose_nsplit(NQ, QB, NT);
     // at least 4k candidates (k-th candidate close to the k-th row), at most RS_MAXNC = 4096, >= 2 tiles per split
@@ -760,17 +761,20 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   if (k > 16) return score_select_locked(h, q, Q, k, out_s, out_i, st);
   const int S = h->idx_S, KG = (S + 7) / 8;
   const int QT = (Q + 31) / 32;
-  const int NQ = (Q <= 32) ? 1 : 4;  // <= 32 queries (demo / web): single query tile, HBM-bound sweep
+  // bf16 candidate pass (option score_bf16): 16x the matrix rate for the 128-query-block variant, half the index
+  // bytes for the HBM-bound few-queries sweep
+  // (small indexes stay on the fp32 pass: nothing to win, and no bf16 copy / second-chance launches to pay for)
+  const bool bf = h->score_bf16 && h->idx_N >= 8192;
+  // <= 32 queries (demo / web): single query tile, HBM-bound sweep; else 128-query blocks while they fit LDS (index
+  // dimension <= 296), 64-query blocks up to 616 (configs[4]: 512), 32-query blocks beyond
+  const int NQ = score_pick_nq(Q, S, bf ? 1 : 0);
+  if (NQ == 0) return fail(h, "index dimension %d does not fit the scoring kernel's LDS query block", S);
   const int QB = (QT + NQ - 1) / NQ;
   const int64_t NT = (h->idx_N + 31) / 32;
   // the 16 lane lists of a workgroup are always merged in-kernel (a few tens of microseconds per workgroup): the
   // re-scoring pass ranks 16 candidates per split
   const int nsplit = choose_nsplit(NQ, QB, NT);
   const int NC = nsplit * 16;
-  // bf16 candidate pass (option score_bf16): 16x the matrix rate for the 128-query-block variant, half the index
-  // bytes for the HBM-bound few-queries sweep
-  // (small indexes stay on the fp32 pass: nothing to win, and no bf16 copy / second-chance launches to pay for)
-  const bool bf = h->score_bf16 && h->idx_N >= 8192;
   const int KG16 = (S + 15) / 16;
   if (bf && !h->idxp16_valid) {
     const size_t need = (size_t)NT * KG16 * 1024;
@@ -811,7 +815,6 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   a.KC = 16;
   a.NQ = NQ;
   HIPCHECK(h, launch_score_topk(a, st));
-  if (getenv("SSE_SCORE_DBG")) return 0;  // measurement aid: the candidate sweep alone (outputs are not produced)
   RescoreArgs r;
   r.q = q;
   r.idx32 = h->idxp;

@@ -172,7 +172,7 @@ struct ScoreArgs {
   float *part_bnd;       // [Q][NSPLIT] every row of the split outside its KC candidates scores <= this
   int64_t N;             // index rows
   int32_t Q, KG, NT, QT, NSPLIT, KC;
-  int32_t NQ = 4;     // query tiles (of 32) per workgroup: 4 (128-query blocks) or 1 (Q <= 32)
+  int32_t NQ = 4;     // query tiles (of 32) per workgroup: 4 (128-query blocks), 2 (index dimension > 296) or 1 (Q <= 32, dimension > 616)
   int32_t thr_off = 0;  // set by the launcher: LDS offset (floats) of the shared per-query thresholds
   const int32_t *skip_cert = nullptr;  // second-chance pass: a workgroup whose whole query block is already certified returns
   int32_t BF = 0;       // 1: idxp / qp are bf16 fragment copies, KG counts 16-k groups (candidate pass on bf16 MFMA)
@@ -183,9 +183,14 @@ struct ScoreArgs {
   int32_t *col_cnt = nullptr;         // [slots] rows appended (may exceed col_cap: overflow)
   int32_t *col_buf = nullptr;         // [slots][col_cap] local row numbers
   int32_t col_cap = 0;
-  int32_t dbg = 0;  // measurement aids (env SSE_SCORE_DBG): bit 0 = skip the top-k epilogue of the sweep
+  int32_t dbg = 0;  // builds with -DSSE_SCORE_MEASURE only (env SSE_SCORE_DBG): bit 0 = skip the top-k epilogue of the sweep
 };
 hipError_t launch_score_topk(const ScoreArgs &a, hipStream_t stream);
+// query tiles per workgroup (4 / 2 / 1) whose LDS query block fits for index dimension S in every variant of a call
+// (0: none); dynamic LDS of one variant
+#define SSE_MAX_INDEX_DIM 1024
+int score_pick_nq(int Q, int S, int with_bf16);
+size_t score_lds_bytes(int NQ, int KG, int BF, int COLLECT);
 // rows [R][C] fp32 -> bf16 fragment blocks [ceil(R/32)][ceil(C/16)][1 KiB]; fp32 frag32 index -> the same
 hipError_t launch_pack_rows_bf16(const float *rows, int64_t R, int C, void *out, hipStream_t stream);
 hipError_t launch_count_uncert(const int32_t *cert, int Q, unsigned long long *count, hipStream_t st);

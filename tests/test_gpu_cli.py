@@ -160,6 +160,69 @@ def test_cnn_mode_train_index_eval_cli(tmp_path):
     assert "train_binary_acc" in log
 
 
+def test_cnn_configs4_shape_index_eval_demo_serving(tmp_path):
+    """BASELINE configs[4] shape (source_only_cnn, T = 64, S = 512, E = 50, bf16 training) through every consumer of
+    the index: sse_train (+ its index build) -> Evaluator.eval -> sse_demo -> /api/classify.  The 512-wide index
+    runs the scorer with 64-query LDS blocks; rankings are checked against the float64 oracle on the GPU's own
+    encodings, the encodings against the oracle's CNN (sse_model.py:179-214,286; sse_evaluator.py:110-111)."""
+    import json
+    import logging
+    import sse_amd
+    from urllib.parse import quote_plus
+    from sse_amd import sse_data, sse_demo, sse_evaluator, sse_index, sse_serving, sse_train
+    tmp = str(tmp_path)
+    raw = _standin(tmp, n_targets=37, n_train=700, n_eval=650, n_vocab=400, seed=3)
+    mdir = os.path.join(tmp, "models-cnn512")
+    sse_train.main(["--task_type=classification", "--data_dir=" + raw, "--model_dir=" + mdir, "--max_epoc=4",
+                    "--steps_per_checkpoint=20", "--batch_size=32", "--network_mode=source_only_cnn", "--cnn_bf16=1",
+                    "--vocab_size=600", "--max_seq_length=64", "--embedding_size=50", "--encoding_size=512", "--seed=0",
+                    "--max_steps=120", "--learning_rate=0.1"])
+    logging.getLogger("").handlers.clear()
+    cfg = sse_data.load_model_configs(mdir)
+    assert int(cfg["encoding_size"]) == 512 and int(cfg["max_seq_length"]) == 64
+    model = sse_amd.SSEModel(cfg)
+    model.saver.restore(None, sse_amd.get_checkpoint_state(mdir))
+    p = model.get_variables()
+    ocfg = {k: (int(v) if k.endswith("_size") or k in ("max_seq_length", "targetSpaceSize") else v) for k, v in cfg.items()}
+    sse_index.main(["--idx_model_dir=" + mdir])
+    index_path = os.path.join(mdir, "targetEncodingIndex.tsv")
+    ids, sents, enc = O.parse_index_lines(open(index_path, encoding="utf-8").readlines())
+    assert enc.shape == (37, 512)
+    assert np.abs(enc - O.l2_normalize(p["target_embedding/tgt_seq_embedding"])).max() < 1e-6
+    data = sse_data.Data(mdir, raw, 600, 64, log=lambda *a: None)
+    # Evaluator: 650 eval sources = one full 600-batch + a short one (sse_evaluator.py:104-113), index dimension 512
+    ev = sse_evaluator.Evaluator(model, data.rawEvalCorpus, index_path, sse_amd.Session(model))
+    got = ev.eval()
+    src_rows = np.array([e[0] for e in data.rawEvalCorpus], np.int32)
+    gpu_src = model.encode_source(src_rows)
+    assert np.abs(gpu_src - O.encode(p, ocfg, "src", src_rows)).max() < 1e-4
+    labels = [[ids.index(t) for t in e[1]] for e in data.rawEvalCorpus]
+    assert got == pytest.approx(O.evaluator_accuracy(gpu_src, enc, labels), abs=1e-12)
+    assert got[2] > 0.5, got
+    sc, rk = model.handle.score_topk(gpu_src, 10)               # the index the Evaluator uploaded (float64 rows)
+    wsc, wids = O.topk(O.scores_f64(gpu_src, enc), 10)
+    assert np.array_equal(rk, wids) and np.abs(sc - wsc).max() < 1e-12
+    # sse_demo (un-normalised encoding, sse_demo.py:121-129)
+    out = io.StringIO()
+    query = open(os.path.join(mdir, "EvalPairs"), encoding="utf-8").readline().split("\t")[0]
+    sse_demo.demo(sse_demo.FLAGS.parse(["--model_dir=" + mdir]), 5, stdin=io.StringIO(query + "\nexit\n"), out=out)
+    q_ids = np.array([sse_amd.sse_text.pad_tokens(data.encoder.encode((query + "\n").lower()), 64)], np.int32)
+    raw_enc = model.encode_source(q_ids, normalize=False)
+    dsc, dids = O.topk(O.scores_f64(raw_enc, enc), 5)
+    assert ("top1:  %s , %f" % (ids[dids[0][0]], dsc[0][0])) in out.getvalue()
+    # /api/classify (normalised encoding, webserver.py:144-151)
+    app = sse_serving.create_app(model_dir=mdir)
+    st = {}
+    body = b"".join(app({"PATH_INFO": "/api/classify", "QUERY_STRING": "keywords=" + quote_plus(query)},
+                        lambda status, hd: st.update(status=status)))
+    assert st["status"].startswith("200"), (st, body)
+    d = json.loads(body)
+    w_ids = np.array([sse_amd.sse_text.pad_tokens(data.encoder.encode(query.lower()), 64)], np.int32)
+    nsc, nids = O.topk(O.scores_f64(model.encode_source(w_ids, normalize=True), enc), 8)
+    assert [r["targetCategoryId"] for r in d["ClassificationResults"]] == [ids[j] for j in nids[0]]
+    assert np.allclose([r["confidenceScore"] for r in d["ClassificationResults"]], nsc[0], atol=1e-12)
+
+
 def test_crosslingual_real_data_slice_matches_oracle():
     """SURVEY 8d C3 on real token ids: encode 4868 targets (index) and 600 queries with
     the dual-encoder H=S=256 T=50 model, score, rank: cosine |d| <= 1e-4, top-10 ids and

@@ -282,6 +282,29 @@ def test_in_graph_predict_and_similarity():
     assert np.abs(got_sim - sim).max() < 1e-5
 
 
+def test_in_graph_predict_and_similarity_at_encoding_size_512():
+    """The same two fetches at configs[4]'s encoding size (S = 512: the scorer's 64-query LDS blocks), with more
+    than 64 source rows and a target batch larger than one index tile (sse_model.py:286,344-352)."""
+    import sse_amd
+    params = model_params("dual-encoder", 120, 16, 64, 64, 512, 9)
+    m, p = make_pair(params, seed=10)
+    rng = np.random.RandomState(3)
+    src, tgt = random_ids(rng, 70, 9, 120), random_ids(rng, 45, 9, 120)
+    ns, nt = O.encode(p, params, "src", src), O.encode(p, params, "tgt", tgt)
+    gs, gt = m.encode_source(src), m.encode_target(tgt)
+    assert np.abs(gs - ns).max() < 1e-4 and np.abs(gt - nt).max() < 1e-4
+    sess = sse_amd.Session(m)
+    scores, labels = sess.run([m.predicted_tgts_score, m.predicted_labels], feed_dict=m.get_predict_feed_dict(src, tgt))
+    # ranking parity on identical inputs (the GPU's own encodings), values against the oracle's encodings
+    assert np.array_equal(labels, O.topk(O.scores_f64(gs, gt.astype(np.float64)), 10)[1])
+    sim = O.similarity(ns, nt)
+    want_sc = np.take_along_axis(sim, labels, axis=1)
+    want_sc = want_sc / np.linalg.norm(want_sc, axis=1, keepdims=True)
+    assert np.abs(scores - want_sc).max() < 1e-4
+    got_sim = sess.run(m.similarity, feed_dict=m.get_predict_feed_dict(src, tgt))
+    assert got_sim.shape == (70, 45) and np.abs(got_sim - sim).max() < 1e-4
+
+
 def test_concurrent_encode_and_score_from_threads():
     """webserver.py:108 calls sess.run from Flask worker threads on ONE session; the handle serialises
     encode / score calls internally (include/sse_hip.h): results equal the single-threaded ones."""

@@ -313,3 +313,67 @@ def test_bf16_candidates_second_chance_on_densely_packed_scores():
     assert np.array_equal(ids, wids) and np.abs(sc - wsc).max() < 1e-12
     n = h.get_counter("score_bf16_second_chance_queries")
     assert 3 <= n <= 30, n                                   # the crowded queries took it; the ordinary ones did not
+
+
+# --------------------------------------------------------------------------
+# index dimensions beyond one 128-query LDS block: the sweep runs with 64-query blocks (296 < S <= 616; BASELINE
+# configs[4] has S = 512) or 32-query blocks (S <= 1024).  The reference scores any S with one np.dot
+# (sse_evaluator.py:110-111, sse_model.py:286); same exactness bar as everywhere above.
+# --------------------------------------------------------------------------
+
+@pytest.mark.parametrize("Q,N,S,bf", [(600, 571, 512, 0), (600, 571, 512, 1), (300, 9000, 297, 0), (300, 9000, 320, 1),
+                                      (257, 12000, 616, 1), (130, 8500, 617, 1), (70, 9000, 1024, 1), (1, 9000, 1024, 1),
+                                      (33, 40, 700, 0), (7, 150000, 512, 1)])
+def test_wide_index_dimensions_exact(Q, N, S, bf):
+    rng = np.random.RandomState(Q + N + S)
+    q, t = _unit(rng, Q, S), _unit(rng, N, S)
+    t[N - 1] = t[3]                                          # an exact tie, the later copy in the last (partial) tile
+    q[0] = t[3]
+    h = _scorer()
+    h.set_option("score_bf16", bf)
+    h.index_upload(t)
+    k = min(10, N)
+    sc, ids = h.score_topk(q, k)
+    wsc, wids = O.topk(O.scores_f64(q, t.astype(np.float64)), k)
+    assert ids[0, :2].tolist() == [3, N - 1]
+    assert np.array_equal(ids, wids)
+    assert np.abs(sc - wsc).max() < 1e-12
+
+
+@pytest.mark.parametrize("k", [10, 40])
+def test_configs4_dimension_100k_rows_bf16_equals_fp32_candidates(k):
+    """100,000 x 512 index, 2,000 queries (64-query blocks): bf16 and fp32 candidate passes return bit-identical
+    ids / scores; a sample is checked against the float64 oracle; k = 40 takes the collect path at S = 512."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(4)
+    N, S, Q = 100_000, 512, 2000
+    t = torch.nn.functional.normalize(torch.randn((N, S), generator=g, device=dev), dim=1)
+    q = torch.nn.functional.normalize(torch.randn((Q, S), generator=g, device=dev), dim=1)
+    rows = torch.randperm(N, generator=g, device=dev)[:Q]
+    t[rows] = torch.nn.functional.normalize(q + 0.05 * torch.randn((Q, S), generator=g, device=dev), dim=1)
+    h = _scorer()
+    h.index_set_dev(t.data_ptr(), N, S)
+    res = {}
+    for bf in (1, 0):
+        h.set_option("score_bf16", bf)
+        out_s = torch.empty((Q, k), dtype=torch.float64, device=dev)
+        out_i = torch.empty((Q, k), dtype=torch.int64, device=dev)
+        h.score_topk_dev(q.data_ptr(), Q, k, out_s.data_ptr(), out_i.data_ptr())
+        torch.cuda.synchronize()
+        res[bf] = (out_s.cpu().numpy(), out_i.cpu().numpy())
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][0], res[1][0])
+    s, i = res[1]
+    assert np.array_equal(i[:, 0], rows.cpu().numpy())
+    sample = np.random.RandomState(0).choice(Q, 100, replace=False)
+    wsc, wids = O.topk(O.scores_f64(q.cpu().numpy()[sample], t.cpu().numpy().astype(np.float64)), k)
+    assert np.array_equal(i[sample], wids)
+    assert np.abs(s[sample] - wsc).max() < 1e-12
+    assert h.get_counter("score_bruteforce_queries") == 0
+
+
+def test_index_dimension_limit_is_loud():
+    import sse_amd
+    h = _scorer()
+    with pytest.raises(sse_amd.SSEError, match="index dimension"):
+        h.index_upload(np.zeros((4, 1025), np.float32))
