@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libsse_hip.so")
+LIB = os.path.join(HERE, os.environ.get("SSE_LIB_NAME", "libsse_hip.so"))   # SSE_LIB_NAME + SSE_HIPCC_EXTRA: measurement builds
 SOURCES = ["sse_api.hip", "lstm_fwd.hip", "lstm_small.hip", "lstm_persist.hip", "lstm_fwd_x3.hip", "cnn_fwd.hip", "cnn_fwd_bf16.hip", "score_topk.hip", "pack.hip", "train.hip", "cnn_bwd.hip", "index_io.cpp"]
 EXTRA = os.environ.get("SSE_HIPCC_EXTRA", "").split()   # e.g. -DSSE_SCORE_MEASURE for the measurement builds of tools/
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
@@ -32,7 +32,7 @@ def _deps():
 def build(force=False, verbose=False):
     """Compile every HIP source and link libsse_hip.so; returns its path."""
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build", os.environ["SSE_LIB_NAME"] + ".o.d") if os.environ.get("SSE_LIB_NAME") else os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     hdr_mtime = max(os.path.getmtime(p) for p in _deps())
     objs, jobs = [], []

@@ -70,6 +70,7 @@ struct TrainState {
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   float *KhT[2] = {nullptr, nullptr}, *KxT[2] = {nullptr, nullptr};
   unsigned short *KhT16[2] = {nullptr, nullptr};  // option train_bwd_x3: Kh^T as split frag16 blocks
+  unsigned short *KxT16[2] = {nullptr, nullptr};  // ... and Kx^T as 16x16x32 B fragments (dX inside the BPTT kernel)
   bool packed_dirty = true;
   // gradient arena: [grad of variable 0 | ... | grad of variable n-1 | tail[4]]; tail = {sum of squares of the
   // un-deduplicated embedding-gradient slices, loss, train_acc, rows}, every entry a plain sum over the
@@ -1010,6 +1011,7 @@ void sse_destroy(sse_handle *h) {
       if (t->KhT[s] && (s == 0 || t->KhT[s] != t->KhT[0])) (void)hipFree(t->KhT[s]);
       if (t->KxT[s] && (s == 0 || t->KxT[s] != t->KxT[0])) (void)hipFree(t->KxT[s]);
       if (t->KhT16[s] && (s == 0 || t->KhT16[s] != t->KhT16[0])) (void)hipFree(t->KhT16[s]);
+      if (t->KxT16[s] && (s == 0 || t->KxT16[s] != t->KxT16[0])) (void)hipFree(t->KxT16[s]);
     }
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
     delete t;
@@ -1524,10 +1526,13 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
         ts.KhT[s] = ts.KhT[e.shares_lstm_with];
         ts.KxT[s] = ts.KxT[e.shares_lstm_with];
         ts.KhT16[s] = ts.KhT16[e.shares_lstm_with];
+        ts.KxT16[s] = ts.KxT16[e.shares_lstm_with];
         continue;
       }
       if (!ts.KhT16[s]) HIPCHECK(h, hipMalloc((void **)&ts.KhT16[s], kT16_elems(e.Hp) * sizeof(unsigned short)));
       HIPCHECK(h, launch_pack_kT16(h->vars[e.kernel].dev, E, e.H, e.Hp, ts.KhT16[s], st));
+      if (!ts.KxT16[s]) HIPCHECK(h, hipMalloc((void **)&ts.KxT16[s], kxT16_elems(e.Hp) * sizeof(unsigned short)));
+      HIPCHECK(h, launch_pack_kxT16(h->vars[e.kernel].dev, E, e.H, e.Hp, ts.KxT16[s], st));
       if (!ts.KhT[s]) HIPCHECK(h, hipMalloc((void **)&ts.KhT[s], (size_t)(e.Hp / 32) * (e.Hp / 2) * 256 * sizeof(float)));
       if (!ts.KxT[s]) HIPCHECK(h, hipMalloc((void **)&ts.KxT[s], (size_t)2 * (e.Hp / 2) * 256 * sizeof(float)));
       HIPCHECK(h, launch_pack_kT(h->vars[e.kernel].dev, E, e.H, e.Hp / 32, e.H, e.Hp, ts.KhT[s], st));
@@ -1702,13 +1707,21 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   // ---- backward
   Variable &emb = h->vars[0];
   HIPCHECK(h, hipMemsetAsync(emb.grad, 0, emb.count * sizeof(float), st));
-  const int n_sq = table_tgt ? T * NT32 + B : 2 * T * NT32;  // dx partials per side (+ one per target row)
+  // partial sums of dx^2 per side: one per (tile, wave) when dX comes out of the split-operand BPTT kernel, one per
+  // (step, tile) from dx_kernel (+ one per target row in source-encoder-only mode)
+  bool bwd_x3[2] = {false, false};
+  int sq_off[3] = {0, 0, 0};
+  for (int s = 0; s < nside; ++s) {
+    bwd_x3[s] = h->train_bwd_x3 && h->train_dk_x3 && h->enc[s].H >= 64 && h->enc[s].Hp <= 256;
+    sq_off[s + 1] = sq_off[s] + (bwd_x3[s] ? NT32 * (h->enc[s].Hp / 32) : T * NT32);
+  }
+  const int n_sq = sq_off[nside] + (table_tgt ? B : 0);
   if (reserve(h, ts.sq_part, (size_t)n_sq * sizeof(float))) return 1;
   if (table_tgt) {
     Variable &table = h->vars[h->tgt_table];
     HIPCHECK(h, hipMemsetAsync(table.grad, 0, table.count * sizeof(float), st));
     HIPCHECK(h, launch_rows_scatter((const float *)ts.draw[1].p, (const int32_t *)ts.ids[1].p, B, S, table.grad,
-                                    (float *)ts.sq_part.p + (size_t)T * NT32, st));
+                                    (float *)ts.sq_part.p + sq_off[1], st));
   }
   HIPCHECK(h, hipEventRecord(ts.ev_fork, st));  // loss + zeroed embedding gradient are ready
   for (int s = 0; s < nside; ++s) {
@@ -1722,7 +1735,10 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     hipStream_t bs = (shared || h->train_serial) ? ts.side[0] : ts.side[s];
     if (!shared || s == 0) HIPCHECK(h, hipStreamWaitEvent(bs, ts.ev_fork, 0));
     if (reserve(h, ts.dh_last[s], (size_t)Bp * Hp * sizeof(float))) return 1;
-    if (reserve(h, ts.dg_a[s], (size_t)T * NT32 * KGn * 256 * sizeof(float))) return 1;
+    if (!bwd_x3[s] && reserve(h, ts.dg_a[s], (size_t)T * NT32 * KGn * 256 * sizeof(float))) return 1;
+    if (reserve(h, ts.hot_part[s], (size_t)T * NT32 * 2 * 2 * 64 * sizeof(float))) return 1;
+    BwdDxArgs bdx{ts.KxT16[s], (const int32_t *)ts.ids[s].p, emb.grad, (float *)ts.sq_part.p + sq_off[s], (float *)ts.hot_part[s].p,
+                  B, E, V};
     if (reserve(h, ts.dg_b[s], (size_t)RG * NTn * 256 * sizeof(float))) return 1;
     if (reserve(h, ts.db_part[s], (size_t)NT32 * 4 * Hp * sizeof(float))) return 1;
     if (reserve(h, ts.dk_part[s], (size_t)SL * KT * 32 * NTn * 32 * sizeof(float))) return 1;
@@ -1731,8 +1747,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
                                 S, h->vars[e.proj].grad, (float *)ts.dh_last[s].p, (float *)ts.dm_part[s].p, bs));
     HIPCHECK(h, launch_lstm_bwd((const float *)ts.tape_g[s].p, (const float *)ts.dh_last[s].p, ts.KhT[s],
                                 (float *)ts.dg_a[s].p, (float *)ts.dg_b[s].p, (float *)ts.db_part[s].p, T, NT32,
-                                half ? NT_half : NT32, Hp, e.H, h->train_dk_x3 ? 1 : 0,
-                                (h->train_bwd_x3 && h->train_dk_x3 && e.H >= 64) ? ts.KhT16[s] : nullptr, bs));
+                                half ? NT_half : NT32, Hp, e.H, h->train_dk_x3 ? 1 : 0, bwd_x3[s] ? ts.KhT16[s] : nullptr, &bdx, bs));
     const int accumulate = (shared && s == 1) ? 1 : 0;
     if (h->train_dk_x3)  // the 8-row r-groups of the fp32 layout pair up into 16-row groups: the same bytes
       HIPCHECK(h, launch_dk_x3(ts.tape_a[s].p, ts.dg_b[s].p, (float *)ts.dk_part[s].p, RGa / 2, KT, NTn, SL, E, e.H, Hp, accumulate,
@@ -1741,10 +1756,11 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
       HIPCHECK(h, launch_dk((const float *)ts.tape_a[s].p, (const float *)ts.dg_b[s].p, (float *)ts.dk_part[s].p, RGa, KT, NTn, SL,
                             E, e.H, Hp, accumulate, h->vars[e.kernel].grad, half ? NT_half * 4 : 0, bs));
     HIPCHECK(h, launch_db_reduce((const float *)ts.db_part[s].p, NT32, e.H, Hp, accumulate, h->vars[e.bias].grad, bs));
-    if (reserve(h, ts.hot_part[s], (size_t)T * NT32 * 2 * 64 * sizeof(float))) return 1;
-    HIPCHECK(h, launch_dx((const float *)ts.dg_a[s].p, ts.KxT[s], (const int32_t *)ts.ids[s].p, emb.grad,
-                          (float *)ts.sq_part.p + (size_t)s * T * NT32, (float *)ts.hot_part[s].p, T, NT32, KGn, B, E, V,
-                          e.H, bs));
+    if (bwd_x3[s])  // dX left the BPTT kernel already; only the PAD / EOS rows are still to be added
+      HIPCHECK(h, launch_dx_hot_reduce((const float *)ts.hot_part[s].p, T * NT32 * 2, E, V, emb.grad, bs));
+    else
+      HIPCHECK(h, launch_dx((const float *)ts.dg_a[s].p, ts.KxT[s], (const int32_t *)ts.ids[s].p, emb.grad,
+                            (float *)ts.sq_part.p + sq_off[s], (float *)ts.hot_part[s].p, T, NT32, KGn, B, E, V, e.H, bs));
     if (!shared || s == 1) {
       HIPCHECK(h, hipEventRecord(ts.ev_join[s], bs));
       HIPCHECK(h, hipStreamWaitEvent(st, ts.ev_join[s], 0));

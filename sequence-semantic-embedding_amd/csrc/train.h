@@ -9,10 +9,25 @@ hipError_t launch_loss(const float *src_raw, const float *tgt_raw, const float *
 int proj_bwd_chunks(int Bp);
 hipError_t launch_proj_bwd(const float *hT, const float *d, const float *M, int Bp, int H, int Hp, int S, float *dM,
                            float *dh, float *dm_part /* [proj_bwd_chunks(Bp)][H*S] */, hipStream_t st);
+// embedding-gradient part of the split-operand BPTT kernel (KhT16 != nullptr): dX = dG . Kx^T is formed from the dG tile in
+// LDS and scattered into d_emb by the kernel itself -- dg_a is not written and launch_dx is not used; the caller runs
+// launch_dx_hot_reduce(hot_part, T * NT32 * 2, ...) afterwards and sums sq_part[NT32 * (Hp / 32)]
+struct BwdDxArgs {
+  const unsigned short *KxT16;  // launch_pack_kxT16
+  const int32_t *ids;           // [B][T]
+  float *d_emb;                 // [V][E] zero-initialised
+  float *sq_part;               // [NT32 * Hp/32]
+  float *hot_part;              // [T * NT32 * 2][2][64]
+  int32_t B, E, V;
+};
 hipError_t launch_lstm_bwd(const float *tape_g, const float *dh_last, const float *KhT, float *dg_a, float *dg_b,
                            float *db_part, int T, int NT32, int NT_tape /* 0: NT32 */, int Hp, int H,
                            int dg_b_split /* 1: split bf16 frag16 blocks for launch_dk_x3 */,
-                           const unsigned short *KhT16 /* non-null: split-operand recurrent GEMM (launch_pack_kT16) */, hipStream_t st);
+                           const unsigned short *KhT16 /* non-null: split-operand recurrent GEMM (launch_pack_kT16) */,
+                           const BwdDxArgs *dx /* with KhT16 */, hipStream_t st);
+size_t kxT16_elems(int Hp);
+hipError_t launch_pack_kxT16(const float *K, int E, int H, int Hp, unsigned short *out, hipStream_t stream);
+hipError_t launch_dx_hot_reduce(const float *hot_part, int nblocks, int E, int V, float *d_emb, hipStream_t st);
 size_t kT16_elems(int Hp);
 hipError_t launch_pack_kT16(const float *K, int E, int H, int Hp, unsigned short *out, hipStream_t stream);
 int dk_slices(int RG);

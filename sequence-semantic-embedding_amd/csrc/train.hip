@@ -13,6 +13,8 @@
 //           the recurrent GEMM dh = dg . Kh^T and of dX = dg . Kx^T
 //   dg_b    the same values as frag32(rows = n, red = r): B operand of
 //           dK = A^T . dG
+#include <cstdio>
+
 #include "train.h"
 
 #include "sse_kernels.h"
@@ -158,6 +160,45 @@ __global__ void proj_bwd_dm_reduce_kernel(const float *part, int nchunks, int n,
   dM[i] = acc;
 }
 
+// The same partials on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation): the batch is
+// the reduction dimension, so both operands are read as they lie in memory -- lane (column, k half) takes one float of
+// row b + k half, a coalesced 128-byte row segment per half wave -- no LDS.  Workgroup = one 32-unit tile x four 32-column
+// tiles (a wave each; the h fragment is the same for the four waves and comes from L1), grid.z = batch chunks.
+// (The VALU kernel above took 0.11 ms per encoder at 8192 rows, a third of a forward pass on the bf16 pipe.)
+__global__ __launch_bounds__(256) void proj_bwd_dm_mfma_kernel(const float *__restrict__ hT, const float *__restrict__ d, int Bp,
+                                                               int H, int Hp, int S, int chunk, float *__restrict__ part) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int jt = blockIdx.y, st = blockIdx.x * 4 + w;
+  if (st * 32 >= S) return;  // (no barriers in this kernel)
+  const int b0 = blockIdx.z * chunk, b1 = min(Bp, b0 + chunk);
+  const int j = jt * 32 + (lane & 31), sc = st * 32 + (lane & 31), kk = lane >> 5;
+  const bool jok = j < Hp, sok = sc < S;
+  const float *pa = hT + (size_t)(b0 + kk) * Hp + (jok ? j : 0);
+  const float *pb = d + (size_t)(b0 + kk) * S + (sok ? sc : 0);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  constexpr int U = 8;  // 8 row pairs (16 loads) in flight; chunk and Bp are multiples of 16
+  for (int b = b0; b < b1; b += 2 * U) {
+    float av[U], bv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      av[u] = pa[(size_t)(2 * u) * Hp];
+      bv[u] = pb[(size_t)(2 * u) * S];
+    }
+    pa += (size_t)2 * U * Hp;
+    pb += (size_t)2 * U * S;
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(jok ? av[u] : 0.0f, sok ? bv[u] : 0.0f, acc, 0, 0, 0);
+  }
+  float *out = part + (size_t)blockIdx.z * H * S;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int jr = jt * 32 + mfma_row(r, lane);
+    if (jr < H && sok) out[(size_t)jr * S + sc] = acc[r];
+  }
+}
+
 __global__ __launch_bounds__(256) void proj_bwd_dh_kernel(const float *__restrict__ d, const float *__restrict__ M, int Bp,
                                                           int H, int Hp, int S, float *__restrict__ dh) {
   __shared__ float As[PB_K][PB_TILE + 4], Bs[PB_K][PB_TILE + 4];  // [s][b] and [s][j]
@@ -213,7 +254,29 @@ struct LstmBwdArgs {
                         // dK GEMM on the bf16 matrix pipe (dk_x3_kernel)
   int32_t NT_tape;      // 32-row tiles the gate tape holds per step: NT32, or NT32/2 when the batch is (pos, neg) pairs
                         // that share their source sequence -- tiles j and j + NT_tape then read the same tape
+  // X3: dX_t = dG_t . Kx^T is taken from the dG tile while it sits in LDS (no dg_a dump, no dx_kernel) and scattered
+  // into the dense embedding gradient here
+  const unsigned short *KxT16;  // [4 e-tiles of 16][4Hp/32][hi|lo][512]: B fragments of v_mfma_f32_16x16x32_bf16 (launch_pack_kxT16)
+  const int32_t *ids;           // [B][T]
+  float *d_emb;                 // [V][E], zero-initialised
+  float *sq_part;               // [NT32][NW] sum of dx^2 over OCCURRENCES (tf.global_norm sees IndexedSlices.values raw)
+  float *hot_part;              // [T*NT32*2][2][64] per (step, tile, row half) sums for the ids 0 (PAD) and 1 (EOS)
+  int32_t B, E, V;
+  long long *clk;               // -DSSE_BWD_CLOCK builds only: per-wave phase cycle sums of tile 0 ([wave][8])
 };
+
+#ifdef SSE_BWD_CLOCK  // measurement builds (tools/): cycles per phase of the BPTT step, summed over the steps
+#define BWD_CLK_DECL long long ck_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ck_t = clock64();
+#define BWD_CLK(i)                 \
+  {                                \
+    const long long n_ = clock64(); \
+    ck_[i] += n_ - ck_t;           \
+    ck_t = n_;                     \
+  }
+#else
+#define BWD_CLK_DECL
+#define BWD_CLK(i)
+#endif
 
 // X3 (with SPLIT): the dG tile lives in LDS as split bf16 frag16 blocks [4Hp/16][hi|lo][1 KiB] (lane (row, half) owns 8
 // consecutive n; the same bytes), written by 2-byte scatters, and the recurrent GEMM runs as three
@@ -226,7 +289,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
   constexpr int NTHR = NW * 64;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform (SGPR): the tape descriptor depends on it
-  const int tile = blockIdx.x, Hp = a.Hp, KGn = Hp / 2, NTn = Hp / 8, T = a.T;
+  constexpr int Hp = 32 * UB * NW;  // (= a.Hp: the launcher picks the instantiation by it) compile-time, so that the tile
+                                    // offsets below are instruction immediates instead of address registers
+  constexpr int KGn = Hp / 2, NTn = Hp / 8;
+  const int tile = blockIdx.x, T = a.T;
   const int half = lane >> 5;
 
   f32x16 dh[UB], dc[UB];
@@ -259,6 +325,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
     for (int g = 0; g < 4; ++g) dbacc[u][g] = 0.0f;
   }
 
+  float xsq = 0.0f;  // X3: this lane's share of sum(dx^2) over all steps
+  BWD_CLK_DECL
   for (int t = T - 1; t >= 0; --t) {
     // ---- elementwise gate backward, results into the LDS dg tile
 #pragma unroll
@@ -286,7 +354,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
         if constexpr (X3) {
           // element (b, n = g*Hp + unit) -> group n/16, slot ((n/8)&1)*32 + b, piece n%8; hi block, lo block 1 KiB on
           unsigned char *dst = dgb + (size_t)(unit >> 4) * 2048 + (size_t)((((unit >> 3) & 1) * 32 + b) * 16) + (unit & 7) * 2;
-          const int GS = (Hp / 16) * 2048;
+          constexpr int GS = (Hp / 16) * 2048;
           const float gv[4] = {g_i, g_j, g_f, g_o};
 #pragma unroll
           for (int gi = 0; gi < 4; ++gi) {
@@ -306,21 +374,30 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
       }
     }
     // refill the tape registers for step t-1 (c_{t-1} is already here: it was this step's c_prev); the fence
-    // keeps the scheduler from hoisting these loads above the last use of the old values (two live copies spill)
-    __builtin_amdgcn_sched_barrier(0);
-    if (t > 0) {
+    // keeps the scheduler from hoisting these loads above the last use of the old values (two live copies spill).
+    // fp32 kernels: requested here, in flight under the recurrent GEMM.  X3: requested AFTER the recurrent GEMM (in
+    // flight under the dX product, the dump and the wait at the barrier) -- with 80 tape registers pending the GEMM had
+    // 16 registers for its operand ring and the kernel still spilled.
+    auto refill = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      if (t > 0) {
 #pragma unroll
-      for (int u = 0; u < UB; ++u) {
+        for (int u = 0; u < UB; ++u) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+          for (int r = 0; r < 16; ++r) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) tg[u][g][r] = tld(t - 1, u, g * 1024 + r * 64);
-          tcn[u][r] = tcp[u][r];
-          tcp[u][r] = tld(t > 1 ? t - 2 : 0, u, 4096 + r * 64);  // step 0 ignores it (c_{-1} = 0)
+            for (int g = 0; g < 4; ++g) tg[u][g][r] = tld(t - 1, u, g * 1024 + r * 64);
+            tcn[u][r] = tcp[u][r];
+            tcp[u][r] = tld(t > 1 ? t - 2 : 0, u, 4096 + r * 64);  // step 0 ignores it (c_{-1} = 0)
+          }
         }
       }
-    }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    BWD_CLK(0)
+    if constexpr (!X3) refill();
     __syncthreads();
+    BWD_CLK(1)
 
     // ---- dump the tile: linear copy (A-operand layout) and transposed (B-operand layout).  Both the dump
     // and the recurrent GEMM only READ the LDS tile, so the two waves that share a SIMD run them in
@@ -328,29 +405,12 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
     // overlap its partner's MFMA stream.  Each group dumps its half of the tile.
     auto dump = [&]() {
       constexpr int GTHR = NTHR / 2;
-      const int grp = (wn >= NW / 2) ? 1 : 0, gt = tid - grp * GTHR;
+      int td = tid;
+      asm volatile("" : "+v"(td));  // opaque copy: dump addresses are recomputed per step (register pressure)
+      const int grp = (wn >= NW / 2) ? 1 : 0, gt = td - grp * GTHR;
       if constexpr (X3) {
-        // dg_a (fp32 frag32, for the dX kernel) rebuilt from the split tile: slot (group, half, row) = 8 consecutive n =
-        // the two float4 of k-group 2*group + half; then dg_b: the stored hi / lo pieces regrouped by row octets
-        float *gaf = a.dg_a + ((size_t)t * a.NT32 + tile) * KGn * 256;
-        const int ns = (4 * Hp / 16) * 64, hs = ns / 2;
-#pragma unroll 2
-        for (int i = grp * hs + gt; i < (grp + 1) * hs; i += GTHR) {
-          const int g16 = i >> 6, sl = i & 63;
-          const sse_u32x4 hi = *reinterpret_cast<const sse_u32x4 *>(dgb + (size_t)g16 * 2048 + sl * 16);
-          const sse_u32x4 lo = *reinterpret_cast<const sse_u32x4 *>(dgb + (size_t)g16 * 2048 + 1024 + sl * 16);
-          f32x4 v0, v1;
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            v0[2 * e] = __uint_as_float(hi[e] << 16) + __uint_as_float(lo[e] << 16);
-            v0[2 * e + 1] = __uint_as_float(hi[e] & 0xffff0000u) + __uint_as_float(lo[e] & 0xffff0000u);
-            v1[2 * e] = __uint_as_float(hi[2 + e] << 16) + __uint_as_float(lo[2 + e] << 16);
-            v1[2 * e + 1] = __uint_as_float(hi[2 + e] & 0xffff0000u) + __uint_as_float(lo[2 + e] & 0xffff0000u);
-          }
-          float *dst = gaf + (size_t)(2 * g16 + (sl >> 5)) * 256 + (sl & 31) * 4;
-          *reinterpret_cast<f32x4 *>(dst) = v0;
-          *reinterpret_cast<f32x4 *>(dst + 128) = v1;
-        }
+        // dg_b for the dK GEMM: the stored hi / lo pieces regrouped by row octets (dX is computed below from the tile
+        // itself: no A-operand copy leaves the workgroup)
         unsigned short *gb = reinterpret_cast<unsigned short *>(a.dg_b);
         const size_t g0 = ((size_t)t * a.NT32 + tile) * 2;
         const int nb = 4 * Hp * 4, hb = nb / 2;
@@ -412,6 +472,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
     };
     const bool dump_first = wn < NW / 2;
     if (dump_first) dump();
+    BWD_CLK(2)
 
     // ---- recurrent GEMM: dh_{t-1}[b][j] = sum_n dg[b][n] * Kh[j][n]
     if (X3 && t > 0) {
@@ -420,14 +481,18 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dh[u][r] = 0.0f;
       typedef short bw_bf16x8 __attribute__((ext_vector_type(8)));
-      const unsigned char *la = dgb + lane * 16;
+      int lg = lane;
+      asm volatile("" : "+v"(lg));
+      const unsigned char *la = dgb + lg * 16;
       const int KG16 = 4 * Hp / 16, KGg = Hp / 16, KGl = min(KGg, (a.H + 15) / 16), NL = 4 * KGl;  // live groups of 16 n
-      const unsigned short *kb = a.KhT16 + (size_t)(wn * UB) * KG16 * 1024 + lane * 8;
+      // Kh^T fragments through a buffer descriptor (SGPR base + SGPR offset + 16 * lane): no per-lane 64-bit pointers
+      const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<unsigned short *>(a.KhT16) + (size_t)(wn * UB) * KG16 * 1024, 0, UB * KG16 * 2048, 0x00020000);
       auto phys = [&](int i) { return (i / KGl) * KGg + i % KGl; };
-      constexpr int PF = 2;
+      constexpr int PF = 2;  // (4 groups in flight cost 16 more registers than this kernel has)
       bw_bf16x8 bq[PF][UB][2], aq[2][2];
       auto bld = [&](int u, int g16, int hl) -> bw_bf16x8 {
-        return *reinterpret_cast<const bw_bf16x8 *>(kb + ((size_t)u * KG16 + g16) * 1024 + hl * 512);
+        return __builtin_bit_cast(bw_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(krs, lg * 16, ((u * KG16 + g16) * 2 + hl) * 1024, 0));
       };
 #pragma unroll
       for (int p = 0; p < PF; ++p)
@@ -463,13 +528,23 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
       }
       __builtin_amdgcn_s_setprio(0);
     }
+    BWD_CLK(3)
+    if constexpr (X3) refill();
+    BWD_CLK(4)
     if (!X3 && t > 0) {
 #pragma unroll
       for (int u = 0; u < UB; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dh[u][r] = 0.0f;
-      const float *la = dgs + lane * 4;
-      const float *kb = a.KhT + (size_t)(wn * UB) * KGn * 256 + lane * 4;
+      int lg = lane;
+      asm volatile("" : "+v"(lg));  // opaque copy: these addresses are recomputed per step (register pressure)
+      const float *la = dgs + lg * 4;
+      // Kh^T fragments through a buffer descriptor (SGPR base + SGPR offset + 16 * lane): no per-lane 64-bit pointers
+      const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float *>(a.KhT) + (size_t)(wn * UB) * KGn * 256, 0, UB * KGn * 1024, 0x00020000);
+      auto kld = [&](int u, int kg) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, lg * 16, (u * KGn + kg) * 1024, 0));
+      };
       // Kh^T fragments come from L2 (~1-2 k cycles): keep PF k-groups (PF*4*UB MFMAs) of them in flight
       // in a register ring; the dg fragments come from LDS one k-group ahead.  KGn % PF == 0.
       constexpr int PF = (NW == 4) ? 4 : 2;  // Hp = 128 runs one wave per SIMD with registers to spare: a deeper ring
@@ -481,7 +556,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
 #pragma unroll
       for (int p = 0; p < PF; ++p)
 #pragma unroll
-        for (int u = 0; u < UB; ++u) bq[p][u] = *reinterpret_cast<const f32x4 *>(kb + ((size_t)u * KGn + phys(p)) * 256);
+        for (int u = 0; u < UB; ++u) bq[p][u] = kld(u, phys(p));
       aq[0] = *reinterpret_cast<const f32x4 *>(la);
       __builtin_amdgcn_s_setprio(1);
       for (int kg = 0; kg < NL; kg += PF) {
@@ -497,13 +572,108 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
           __builtin_amdgcn_sched_barrier(0);
           const int kp = phys((kg + p + PF < NL) ? kg + p + PF : kg + p);
 #pragma unroll
-          for (int u = 0; u < UB; ++u) bq[p][u] = *reinterpret_cast<const f32x4 *>(kb + ((size_t)u * KGn + kp) * 256);
+          for (int u = 0; u < UB; ++u) bq[p][u] = kld(u, kp);
         }
       }
       __builtin_amdgcn_s_setprio(0);
     }
+    if constexpr (X3) {
+      // ---- dX_t[b][e] = sum_n dG[b][n] * Kx[e][n] on v_mfma_f32_16x16x32_bf16 (three per product, split operands):
+      // 2 row halves x 4 e-tiles of 16 = 8 output tiles, wave = (row half wn & 1, e-tile(s) wn >> 1 (+ NW/2)); the A
+      // fragment of lane (row l & 15, n octet q = l >> 4) is the 16-byte slot (group 2 ks + (q >> 1), half q & 1, row)
+      // of the dG tile, B comes from L2 (KxT16, 256 KiB per encoder)
+      typedef short bx_bf16x8 __attribute__((ext_vector_type(8)));
+      constexpr int NE = 8 / NW;
+      const int rh = wn & 1, et0 = wn >> 1;
+      int lx = lane;
+      asm volatile("" : "+v"(lx));  // opaque copy: the addresses below are recomputed every step, not kept across the phases
+      const int KS = 4 * Hp / 32, KSg = Hp / 32, KSl = min(KSg, (a.H + 31) / 32), NS = 4 * KSl;  // live 32-n steps
+      auto physs = [&](int i) { return (i / KSl) * KSg + i % KSl; };
+      const unsigned char *lax = dgb + (size_t)(lx >> 5) * 2048 + (size_t)(((lx >> 4) & 1) * 32 + rh * 16 + (lx & 15)) * 16;
+      const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.KxT16), 0, 4 * KS * 2048, 0x00020000);
+      // outputs through descriptors as well (the embedding gradient is < 4 GiB: V * E floats)
+      const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc(a.d_emb, 0, a.V * a.E * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(a.hot_part, 0, T * a.NT32 * 2 * 512, 0x00020000);
+      // token ids of the four rows whose dX this lane will hold: requested here, used after the k-loop (buffer loads:
+      // SGPR base + one lane offset + an SGPR per row; rows >= B fall outside the descriptor and read 0, masked below)
+      int xid[4];
+      {
+        const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.ids), 0, a.B * T * 4, 0x00020000);
+        const int b0 = tile * 32 + rh * 16 + 4 * (lx >> 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int id = __builtin_amdgcn_raw_buffer_load_b32(irs, b0 * T * 4, (i * T + t) * 4, 0);
+          xid[i] = (b0 + i < a.B && id >= 0 && id < a.V) ? id : -1;  // out-of-range ids were flagged by the forward pass
+        }
+      }
+      f32x4 xacc[NE];
+#pragma unroll
+      for (int j = 0; j < NE; ++j) xacc[j] = f32x4{0, 0, 0, 0};
+      bool elive[NE];
+#pragma unroll
+      for (int j = 0; j < NE; ++j) elive[j] = (et0 + j * (NW / 2)) * 16 < a.E;
+      // (no software pipeline here: the wave's partner on the SIMD covers the L2 latency of the B fragments, and a
+      // second operand set pushed the kernel into scratch)
+#pragma nounroll
+      for (int i = 0; i < NS; ++i) {
+        const int ks = physs(i);
+        const bx_bf16x8 ah = *reinterpret_cast<const bx_bf16x8 *>(lax + (size_t)ks * 4096);
+        const bx_bf16x8 al = *reinterpret_cast<const bx_bf16x8 *>(lax + (size_t)ks * 4096 + 1024);
+#pragma unroll
+        for (int j = 0; j < NE; ++j)
+          if (elive[j]) {
+            const int so = ((et0 + j * (NW / 2)) * KS + ks) * 2048;
+            const bx_bf16x8 bh = __builtin_bit_cast(bx_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, lx * 16, so, 0));
+            const bx_bf16x8 bl = __builtin_bit_cast(bx_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, lx * 16, so + 1024, 0));
+            xacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, xacc[j], 0, 0, 0);
+            xacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, xacc[j], 0, 0, 0);
+            xacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, xacc[j], 0, 0, 0);
+          }
+      }
+      BWD_CLK(5)
+      // scatter-add into the dense embedding gradient (duplicate ids summed, as TF's sparse Adagrad does); lane holds
+      // rows rh*16 + 4 (l >> 4) + i, column e.  PAD (0) and EOS (1) fill most rows of a left-padded batch: their sums
+      // go to hot_part without atomics and dx_hot_reduce_kernel adds the blocks in fixed order.  sum(dx^2) is taken per
+      // OCCURRENCE (un-deduplicated IndexedSlices, sse_model.py:359-362).
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        if (!elive[j]) continue;
+        const int e = (et0 + j * (NW / 2)) * 16 + (lx & 15);
+        float h0 = 0.0f, h1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = xacc[j][i];
+          const int id = xid[i];
+          if (id >= 0) xsq += v * v;  // (columns >= E multiply zero weights: v = 0)
+          h0 += (id == 0) ? v : 0.0f;
+          h1 += (id == 1) ? v : 0.0f;
+          if (id >= 2 && e < a.E) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, ers, (id * a.E + e) * 4, 0, 0);
+        }
+        h0 += __shfl_xor(h0, 16);
+        h1 += __shfl_xor(h1, 16);
+        h0 += __shfl_xor(h0, 32);
+        h1 += __shfl_xor(h1, 32);
+        if (lx < 16) {
+          const int so = ((t * a.NT32 + tile) * 2 + rh) * 512;  // wave-uniform
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h0), hrs, e * 4, so, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h1), hrs, e * 4, so + 256, 0);
+        }
+      }
+    }
+    BWD_CLK(6)
     if (!dump_first) dump();
+    BWD_CLK(2)
     __syncthreads();
+    BWD_CLK(7)
+  }
+#ifdef SSE_BWD_CLOCK
+  if (a.clk && tile == 0 && lane == 0)
+    for (int i = 0; i < 8; ++i) a.clk[wn * 8 + i] = ck_[i];
+#endif
+  if constexpr (X3) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) xsq += __shfl_xor(xsq, o);
+    if (lane == 0) a.sq_part[tile * NW + wn] = xsq;
   }
 
   // bias-gradient partials of this tile (sum over its 32 rows and all steps)
@@ -1017,14 +1187,18 @@ hipError_t launch_loss(const float *src_raw, const float *tgt_raw, const float *
   return hipGetLastError();
 }
 
-int proj_bwd_chunks(int Bp) { return Bp <= 512 ? 1 : (Bp + 511) / 512 > 32 ? 32 : (Bp + 511) / 512; }
+int proj_bwd_chunks(int Bp) { return Bp <= 256 ? 1 : (Bp + 255) / 256 > 32 ? 32 : (Bp + 255) / 256; }
 
 hipError_t launch_proj_bwd(const float *hT, const float *d, const float *M, int Bp, int H, int Hp, int S, float *dM,
                            float *dh, float *dm_part, hipStream_t st) {
   const int nch = proj_bwd_chunks(Bp);
   const int chunk = ((Bp + nch - 1) / nch + PB_K - 1) / PB_K * PB_K;
-  hipLaunchKernelGGL(proj_bwd_dm_kernel, dim3((S + PB_TILE - 1) / PB_TILE, (H + PB_TILE - 1) / PB_TILE, nch), dim3(256), 0, st,
-                     hT, d, Bp, H, Hp, S, chunk, nch == 1 ? dM : dm_part);
+  if (Bp % 16 == 0)  // (always: rows are padded to whole 64-row tiles)
+    hipLaunchKernelGGL(proj_bwd_dm_mfma_kernel, dim3((S + 127) / 128, (H + 31) / 32, nch), dim3(256), 0, st, hT, d, Bp, H, Hp, S,
+                       chunk, nch == 1 ? dM : dm_part);
+  else
+    hipLaunchKernelGGL(proj_bwd_dm_kernel, dim3((S + PB_TILE - 1) / PB_TILE, (H + PB_TILE - 1) / PB_TILE, nch), dim3(256), 0, st,
+                       hT, d, Bp, H, Hp, S, chunk, nch == 1 ? dM : dm_part);
   if (nch > 1)
     hipLaunchKernelGGL(proj_bwd_dm_reduce_kernel, dim3((H * S + 255) / 256), dim3(256), 0, st, dm_part, nch, H * S, dM);
   hipLaunchKernelGGL(proj_bwd_dh_kernel, dim3((Hp + PB_TILE - 1) / PB_TILE, (Bp + PB_TILE - 1) / PB_TILE), dim3(256), 0, st, d,
@@ -1034,8 +1208,41 @@ hipError_t launch_proj_bwd(const float *hT, const float *d, const float *M, int 
 
 hipError_t launch_lstm_bwd(const float *tape_g, const float *dh_last, const float *KhT, float *dg_a, float *dg_b,
                            float *db_part, int T, int NT32, int NT_tape, int Hp, int H, int dg_b_split,
-                           const unsigned short *KhT16, hipStream_t st) {
-  LstmBwdArgs a{tape_g, dh_last, KhT, dg_a, dg_b, db_part, T, NT32, Hp, H, KhT16, dg_b_split, NT_tape > 0 ? NT_tape : NT32};
+                           const unsigned short *KhT16, const BwdDxArgs *dx, hipStream_t st) {
+  LstmBwdArgs a{tape_g, dh_last, KhT, dg_a, dg_b, db_part, T, NT32, Hp, H, KhT16, dg_b_split, NT_tape > 0 ? NT_tape : NT32,
+                nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr};
+#ifdef SSE_BWD_CLOCK
+  static long long *clk_dev = nullptr;
+  if (!clk_dev) (void)hipMalloc((void **)&clk_dev, 64 * sizeof(long long));
+  (void)hipMemsetAsync(clk_dev, 0, 64 * sizeof(long long), st);
+  a.clk = clk_dev;
+  struct Report {
+    long long *p;
+    hipStream_t st;
+    int T;
+    ~Report() {
+      long long v[64];
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(v, p, sizeof v, hipMemcpyDeviceToHost);
+      static int n = 0;
+      if (n++ % 8 < 2)
+        for (int w = 0; w < 8; w += 7)
+          fprintf(stderr, "[bwd clock] wave %d cycles/step: elementwise %lld | barrier1 %lld | dump %lld | gemm %lld | refill-issue %lld | dX-loop %lld | dX-epilogue %lld | barrier2 %lld\n",
+                  w, v[w * 8 + 0] / T, v[w * 8 + 1] / T, v[w * 8 + 2] / T, v[w * 8 + 3] / T, v[w * 8 + 4] / T, v[w * 8 + 5] / T, v[w * 8 + 6] / T, v[w * 8 + 7] / T);
+    }
+  } report{clk_dev, st, T};
+#endif
+  if (KhT16 != nullptr) {  // split-operand BPTT: dX is part of the kernel
+    if (!dx || !dx->KxT16 || !dx->ids || !dx->d_emb || !dx->sq_part || !dx->hot_part || dx->E > 64) return hipErrorInvalidValue;
+    a.KxT16 = dx->KxT16;
+    a.ids = dx->ids;
+    a.d_emb = dx->d_emb;
+    a.sq_part = dx->sq_part;
+    a.hot_part = dx->hot_part;
+    a.B = dx->B;
+    a.E = dx->E;
+    a.V = dx->V;
+  }
   const size_t lds = (size_t)(Hp / 2) * 256 * sizeof(float);
   if ((size_t)T * NT32 * (Hp / 32) * 5 * 1024 * sizeof(float) >= ((size_t)1 << 31)) return hipErrorInvalidValue;  // 32-bit tape offsets
   auto go = [&](auto kern, int threads) -> hipError_t {
@@ -1072,6 +1279,30 @@ __global__ void pack_kT16_kernel(const float *__restrict__ K, int E, int H, int 
     out[o] = hi;
     out[o + 512] = lo;
   }
+}
+
+// Kx^T as B fragments of v_mfma_f32_16x16x32_bf16 for the dX product inside the split-operand BPTT kernel:
+// out[et][ks][hi|lo][lane][i], lane (e = 16 et + (lane & 15), n octet lane >> 4), n = 32 ks + 8 (lane >> 4) + i = gate * Hp + unit
+__global__ void pack_kxT16_kernel(const float *__restrict__ K, int E, int H, int Hp, int64_t total, unsigned short *__restrict__ out) {
+  const int KS = 4 * Hp / 32;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    const int64_t blk = idx >> 9;
+    const int ks = (int)(blk % KS), et = (int)(blk / KS);
+    const int e = et * 16 + (lane & 15), n = ks * 32 + (lane >> 4) * 8 + i;
+    const int gate = n / Hp, unit = n % Hp;
+    const float v = (e < E && unit < H) ? K[(size_t)e * 4 * H + gate * H + unit] : 0.0f;
+    const unsigned short hi = sse_bf16_rne(v), lo = sse_bf16_rne(v - sse_bf16_f32(hi));
+    const int64_t o = (blk * 2) * 512 + lane * 8 + i;
+    out[o] = hi;
+    out[o + 512] = lo;
+  }
+}
+size_t kxT16_elems(int Hp) { return (size_t)4 * (4 * Hp / 32) * 2 * 512; }
+hipError_t launch_pack_kxT16(const float *K, int E, int H, int Hp, unsigned short *out, hipStream_t stream) {
+  const int64_t total = (int64_t)4 * (4 * Hp / 32) * 512;
+  hipLaunchKernelGGL(pack_kxT16_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, K, E, H, Hp, total, out);
+  return hipGetLastError();
 }
 
 size_t kT16_elems(int Hp) { return (size_t)(Hp / 32) * (4 * Hp / 16) * 2 * 512; }
@@ -1141,6 +1372,11 @@ hipError_t launch_dx(const float *dg_a, const float *KxT, const int32_t *ids, fl
   DxArgs a{dg_a, KxT, ids, d_emb, sq_part, T, NT32, KGn, B, E, V, (H + 7) / 8 < KGg ? (H + 7) / 8 : KGg, hot_part};
   hipLaunchKernelGGL(dx_kernel, dim3(T * NT32), dim3(64), 0, st, a);
   hipLaunchKernelGGL(dx_hot_reduce_kernel, dim3(2, DXH_SLICES), dim3(256), 0, st, hot_part, T * NT32, E, V, d_emb);
+  return hipGetLastError();
+}
+
+hipError_t launch_dx_hot_reduce(const float *hot_part, int nblocks, int E, int V, float *d_emb, hipStream_t st) {
+  hipLaunchKernelGGL(dx_hot_reduce_kernel, dim3(2, DXH_SLICES), dim3(256), 0, st, hot_part, nblocks, E, V, d_emb);
   return hipGetLastError();
 }
 
