@@ -363,12 +363,13 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       const int hoff = SWAP ? (ub * 4) * 256 + lane * 4
                             : (unit >> 3) * 256 + ((((unit >> 2) & 1) * 32) << 2) + (unit & 3);
       const int wsoff = __builtin_amdgcn_readfirstlane(ub) * KG * 4096;
-      // gate tape, accumulator layout: [t][tile32][unit block][q][reg][lane], q = si,tj,sf,so,c
+      // gate tape, accumulator layout: [t][tile32][unit block][q][reg / 4][lane][reg % 4], q = si,tj,sf,so,c: a lane's
+      // registers 4 q4 .. 4 q4 + 3 of a quantity are one 16-byte piece (one store here, one load in the BPTT kernel)
       float *tp[MT];
       if constexpr (TRAIN) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
-          tp[m] = a.tape_g + (((size_t)t * NT32 + blockIdx.x * RT + mt0 + m) * (KGh / 4) + ub) * 5 * 1024 + lane;
+          tp[m] = a.tape_g + (((size_t)t * NT32 + blockIdx.x * RT + mt0 + m) * (KGh / 4) + ub) * 5 * 1024 + lane * 4;
       }
 
       // pass A: gates i, j  ->  pij = sigmoid(i) * tanh(j)      (BasicLSTMCell, TF 1.x)
@@ -400,13 +401,18 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
           }
         } else {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float si = fast_sigmoid(g[m][0][r]);
-            const float tj = fast_tanh(g[m][1][r]);
-            hdst[m][mfma_row(r, lane) << 2] = si * tj;
+          for (int q4 = 0; q4 < 4; ++q4) {
+            f32x4 si4, tj4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = q4 * 4 + e;
+              si4[e] = fast_sigmoid(g[m][0][r]);
+              tj4[e] = fast_tanh(g[m][1][r]);
+              hdst[m][mfma_row(r, lane) << 2] = si4[e] * tj4[e];
+            }
             if constexpr (TRAIN) {
-              tp[m][r * 64] = si;
-              tp[m][1024 + r * 64] = tj;
+              __builtin_nontemporal_store(si4, reinterpret_cast<f32x4 *>(tp[m] + q4 * 256));
+              __builtin_nontemporal_store(tj4, reinterpret_cast<f32x4 *>(tp[m] + 1024 + q4 * 256));
             }
           }
         }
@@ -462,17 +468,25 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
           }
         } else {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float sf = fast_sigmoid(g[m][0][r]);
-            const float so = fast_sigmoid(g[m][1][r]);
-            const float cn = c[u][m][r] * sf + hdst[m][mfma_row(r, lane) << 2];
-            c[u][m][r] = cn;
-            const float hv = fast_tanh(cn) * so;
-            hdst[m][mfma_row(r, lane) << 2] = hv;  // h_t, A-fragment order
+          for (int q4 = 0; q4 < 4; ++q4) {
+            f32x4 sf4, so4, cn4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = q4 * 4 + e;
+              const float sf = fast_sigmoid(g[m][0][r]);
+              const float so = fast_sigmoid(g[m][1][r]);
+              const float cn = c[u][m][r] * sf + hdst[m][mfma_row(r, lane) << 2];
+              c[u][m][r] = cn;
+              const float hv = fast_tanh(cn) * so;
+              hdst[m][mfma_row(r, lane) << 2] = hv;  // h_t, A-fragment order
+              sf4[e] = sf;
+              so4[e] = so;
+              cn4[e] = cn;
+            }
             if constexpr (TRAIN) {
-              tp[m][2048 + r * 64] = sf;
-              tp[m][3072 + r * 64] = so;
-              tp[m][4096 + r * 64] = cn;
+              __builtin_nontemporal_store(sf4, reinterpret_cast<f32x4 *>(tp[m] + 2048 + q4 * 256));
+              __builtin_nontemporal_store(so4, reinterpret_cast<f32x4 *>(tp[m] + 3072 + q4 * 256));
+              __builtin_nontemporal_store(cn4, reinterpret_cast<f32x4 *>(tp[m] + 4096 + q4 * 256));
             }
           }
         }

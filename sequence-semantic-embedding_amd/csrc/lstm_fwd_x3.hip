@@ -55,11 +55,11 @@ __host__ __device__ static inline float x3_f32(unsigned short h) {
 // 8 fp32 -> the hi and lo octets (16 bytes each)
 __device__ __forceinline__ void x3_split8(const float (&v)[8], u32x4 &hi, u32x4 &lo) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const unsigned short h0 = x3_bf16(v[2 * i]), h1 = x3_bf16(v[2 * i + 1]);
-    const unsigned short l0 = x3_bf16(v[2 * i] - x3_f32(h0)), l1 = x3_bf16(v[2 * i + 1] - x3_f32(h1));
-    hi[i] = (unsigned)h0 | ((unsigned)h1 << 16);
-    lo[i] = (unsigned)l0 | ((unsigned)l1 << 16);
+  for (int i = 0; i < 4; ++i) {  // (hardware converter, see sse_kernels.h)
+    unsigned h, l;
+    sse_split2(v[2 * i], v[2 * i + 1], h, l);
+    hi[i] = h;
+    lo[i] = l;
   }
 }
 
@@ -223,8 +223,8 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
         }
         const size_t g16 = ((size_t)t * NT32 + blockIdx.x * RT + mt) * 2 + (oc >> 1);
         unsigned short *dst = ta + ((g16 * KT + (kp >> 5)) * 2) * 512 + ((oc & 1) * 32 + (kp & 31)) * 8;
-        *reinterpret_cast<u32x4 *>(dst) = hi;
-        *reinterpret_cast<u32x4 *>(dst + 512) = lo;
+        __builtin_nontemporal_store(hi, reinterpret_cast<u32x4 *>(dst));  // tapes are streamed: keep the weights in L2
+        __builtin_nontemporal_store(lo, reinterpret_cast<u32x4 *>(dst + 512));
       }
     }
 
@@ -314,27 +314,29 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
         g[m][1][r] = 0.0f;
       }
     if (do_a && (TRAIN || w * 32 < a.H)) gemm(0, g);
-    // gate tape (TRAIN), lstm_fwd.hip's layout: [t][tile32][unit block][q = si,tj,sf,so,c][reg][lane]
+    // gate tape (TRAIN), lstm_fwd.hip's layout: [t][tile32][unit block][q = si,tj,sf,so,c][reg / 4][lane][reg % 4]: a lane's
+    // registers 4 q4 .. 4 q4 + 3 of a quantity are ONE 16-byte store here and one 16-byte load in the BPTT kernel
     float *tp[MT];
     if constexpr (TRAIN) {
 #pragma unroll
       for (int m = 0; m < MT; ++m)
-        tp[m] = a.tape_g + (((size_t)t * NT32 + blockIdx.x * RT + mt0 + m) * UBN + w) * 5 * 1024 + lane;
+        tp[m] = a.tape_g + (((size_t)t * NT32 + blockIdx.x * RT + mt0 + m) * UBN + w) * 5 * 1024 + lane * 4;
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         if (!do_a) break;
-        f32x4 pij;
+        f32x4 pij, si4, tj4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float si = x3_sigmoid(g[m][0][q4 * 4 + e]), tj = x3_tanh(g[m][1][q4 * 4 + e]);
-          pij[e] = si * tj;
-          if constexpr (TRAIN) {
-            tp[m][(q4 * 4 + e) * 64] = si;
-            tp[m][1024 + (q4 * 4 + e) * 64] = tj;
-          }
+          si4[e] = x3_sigmoid(g[m][0][q4 * 4 + e]);
+          tj4[e] = x3_tanh(g[m][1][q4 * 4 + e]);
+          pij[e] = si4[e] * tj4[e];
+        }
+        if constexpr (TRAIN) {
+          __builtin_nontemporal_store(si4, reinterpret_cast<f32x4 *>(tp[m] + q4 * 256));
+          __builtin_nontemporal_store(tj4, reinterpret_cast<f32x4 *>(tp[m] + 1024 + q4 * 256));
         }
         *reinterpret_cast<f32x4 *>(hd[m] + q4 * 1024) = pij;  // lane-private round trip: any layout will do
       }
@@ -361,6 +363,7 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         const f32x4 pij = *reinterpret_cast<const f32x4 *>(hd[m] + q4 * 1024);
+        f32x4 sf4, so4, cn4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = q4 * 4 + e;
@@ -369,16 +372,19 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
           const float cn = c[m][r] * sf + pij[e];
           c[m][r] = cn;
           hv[r] = x3_tanh(cn) * so;
-          if constexpr (TRAIN) {
-            tp[m][2048 + r * 64] = sf;
-            tp[m][3072 + r * 64] = so;
-            tp[m][4096 + r * 64] = cn;
-          }
+          sf4[e] = sf;
+          so4[e] = so;
+          cn4[e] = cn;
           if (!TRAIN && a.rec_h != nullptr && blockIdx.x == 0 && mt0 + m == 0 && (lane & 31) == 0) {
             // sequence 0 of the launch: state after t+1 steps (builds the pad-prefix table)
             a.rec_h[(size_t)(t + 1) * Hp + w * 32 + mfma_row(r, lane)] = hv[r];
             a.rec_c[(size_t)(t + 1) * Hp + w * 32 + mfma_row(r, lane)] = cn;
           }
+        }
+        if constexpr (TRAIN) {
+          __builtin_nontemporal_store(sf4, reinterpret_cast<f32x4 *>(tp[m] + 2048 + q4 * 256));
+          __builtin_nontemporal_store(so4, reinterpret_cast<f32x4 *>(tp[m] + 3072 + q4 * 256));
+          __builtin_nontemporal_store(cn4, reinterpret_cast<f32x4 *>(tp[m] + 4096 + q4 * 256));
         }
       }
       if (!TRAIN && w * 32 >= a.H) {  // a unit block made only of padding keeps h = 0
@@ -392,11 +398,14 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
         if (have_next) {
           unsigned char *dst = tile + (size_t)(unit >> 4) * 2048 + (size_t)(((unit >> 3) & 1) * 32) * 16 + (unit & 7) * 2;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const unsigned short hi = x3_bf16(hv[r]), lo = x3_bf16(hv[r] - x3_f32(hi));
+          for (int r = 0; r < 16; r += 2) {  // rows mfma_row(r), mfma_row(r) + 1: one v_cvt_pk_bf16_f32 pair each for hi and lo
+            unsigned hi, lo;
+            sse_split2(hv[r], hv[r + 1], hi, lo);
             unsigned char *p = dst + mfma_row(r, lane) * 16;
-            *reinterpret_cast<unsigned short *>(p) = hi;
-            *reinterpret_cast<unsigned short *>(p + 1024) = lo;
+            *reinterpret_cast<unsigned short *>(p) = (unsigned short)hi;
+            *reinterpret_cast<unsigned short *>(p + 16) = (unsigned short)(hi >> 16);
+            *reinterpret_cast<unsigned short *>(p + 1024) = (unsigned short)lo;
+            *reinterpret_cast<unsigned short *>(p + 1024 + 16) = (unsigned short)(lo >> 16);
           }
         } else {
           float *hf = reinterpret_cast<float *>(tile) + (size_t)(unit >> 3) * 256 + ((((unit >> 2) & 1) * 32) << 2) + (unit & 3);

@@ -49,14 +49,31 @@ __host__ __device__ static inline float sse_bf16_f32(unsigned short h) {
   __builtin_memcpy(&f, &u, 4);
   return f;
 }
+// two fp32 -> packed hi pair and packed lo pair (element 0 in the low half-word) on the hardware converter
+// (v_cvt_pk_bf16_f32: round to nearest even, the same values as sse_bf16_rne for finite inputs): 5 instructions per pair
+// where the integer restatement takes ~24
+__device__ static inline void sse_split2(float a, float b, unsigned &hi, unsigned &lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __bf16 sse_bf2 __attribute__((ext_vector_type(2)));
+  typedef float sse_f2 __attribute__((ext_vector_type(2)));
+  const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(sse_f2{a, b}, sse_bf2));
+  const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
+  hi = h;
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(sse_f2{ra, rb}, sse_bf2));
+#else  // (host pass of the single-source compile: never called)
+  const unsigned short h0 = sse_bf16_rne(a), h1 = sse_bf16_rne(b);
+  hi = (unsigned)h0 | ((unsigned)h1 << 16);
+  lo = (unsigned)sse_bf16_rne(a - sse_bf16_f32(h0)) | ((unsigned)sse_bf16_rne(b - sse_bf16_f32(h1)) << 16);
+#endif
+}
 // 8 fp32 -> the hi and the lo octet (16 bytes each)
 __device__ static inline void sse_split8(const float (&v)[8], sse_u32x4 &hi, sse_u32x4 &lo) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const unsigned short h0 = sse_bf16_rne(v[2 * i]), h1 = sse_bf16_rne(v[2 * i + 1]);
-    const unsigned short l0 = sse_bf16_rne(v[2 * i] - sse_bf16_f32(h0)), l1 = sse_bf16_rne(v[2 * i + 1] - sse_bf16_f32(h1));
-    hi[i] = (unsigned)h0 | ((unsigned)h1 << 16);
-    lo[i] = (unsigned)l0 | ((unsigned)l1 << 16);
+    unsigned h, l;
+    sse_split2(v[2 * i], v[2 * i + 1], h, l);
+    hi[i] = h;
+    lo[i] = l;
   }
 }
 
@@ -84,7 +101,8 @@ struct LstmFwdArgs {
   const int32_t *row_map = nullptr;  // optional: logical row b reads ids / writes out at row row_map[b]
   float *rec_h = nullptr, *rec_c = nullptr;
   // training only (nullptr for inference): tapes consumed by the backward kernels
-  float *tape_g = nullptr;  // [T][NT32][4][UB][5][16][64] gate activations + c, accumulator layout
+  float *tape_g = nullptr;  // [T][NT32][4][UB][5][4][64][4] gate activations + c, accumulator layout: lane l, register r at word
+                            // (r >> 2) * 256 + 4 l + (r & 3) of its 1024-word block (16-byte pieces per lane)
   float *tape_a = nullptr;  // [(T*NT32*4)][KT][256]  [x_t | h_{t-1}] as frag32(rows = k', red = r)
   int32_t tape_a_split = 0; // 1: tape_a holds split bf16 frag16 blocks instead: [(T*NT32*2)][KT][hi|lo][512] (same bytes)
   float *h_last = nullptr;  // [Bp][Hp] h_T

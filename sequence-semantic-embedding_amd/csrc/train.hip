@@ -265,6 +265,12 @@ struct LstmBwdArgs {
   long long *clk;               // -DSSE_BWD_CLOCK builds only: per-wave phase cycle sums of tile 0 ([wave][8])
 };
 
+#ifndef BWD_ROT  // measurement builds override these (tools/)
+#define BWD_ROT 1
+#endif
+#ifndef BWD_NT   // cache policy of the tape loads: 2 = nt (streamed once; the 1.25 MiB of weights every step re-reads should
+#define BWD_NT 2 // stay in the XCD's 4 MiB L2 instead of being flushed by ~9 MiB of tape / dump traffic per step)
+#endif
 #ifdef SSE_BWD_CLOCK  // measurement builds (tools/): cycles per phase of the BPTT step, summed over the steps
 #define BWD_CLK_DECL long long ck_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ck_t = clock64();
 #define BWD_CLK(i)                 \
@@ -300,26 +306,34 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
   // gate tape of the step about to be processed, held in registers and refilled (for step t-1) while the
   // recurrent GEMM of step t runs: the HBM latency of the tape never sits on the critical path
   float tg[UB][4][16], tcn[UB][16], tcp[UB][16];
-  // tape reads go through a buffer descriptor: address = SGPR base + SGPR offset + (4*lane), so the 80
+  // tape reads go through a buffer descriptor: address = SGPR base + SGPR offset + (16*lane), so the 20
   // loads of a refill cost no address VGPRs (per-lane 64-bit pointers spilled this kernel)
   const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(a.tape_g + ((size_t)(tile % a.NT_tape) * NW + wn) * UB * 5 * 1024), 0, 0x7fffffff, 0x00020000);
-  const int tvo = lane * 4;
+  const int tvo = lane * 16;  // 16-byte pieces: registers 4q .. 4q+3 of a quantity are one buffer_load_dwordx4 (20 per refill)
   const int tstep = a.NT_tape * NW * UB * 5 * 1024 * 4;  // bytes between consecutive steps (T*tstep < 2^31 checked by the launcher)
-  auto tld = [&](int t, int u, int word) -> float {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(trs, tvo, t * tstep + (u * 5 * 1024 + word) * 4, 0));
+  auto tld4 = [&](int t, int u, int qty, int q4) -> f32x4 {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, tvo, t * tstep + (u * 5 * 1024 + qty * 1024 + q4 * 256) * 4, BWD_NT));
   };
 #pragma unroll
   for (int u = 0; u < UB; ++u) {
     const int unit = (wn * UB + u) * 32 + (lane & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      dh[u][r] = a.dh_last[(size_t)(tile * 32 + mfma_row(r, lane)) * Hp + unit];
-      dc[u][r] = 0.0f;
+    for (int q4 = 0; q4 < 4; ++q4) {
+      f32x4 v[6];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) tg[u][g][r] = tld(T - 1, u, g * 1024 + r * 64);
-      tcn[u][r] = tld(T - 1, u, 4096 + r * 64);
-      tcp[u][r] = tld(T > 1 ? T - 2 : 0, u, 4096 + r * 64);  // unused when T == 1
+      for (int g = 0; g < 5; ++g) v[g] = tld4(T - 1, u, g, q4);
+      v[5] = tld4(T > 1 ? T - 2 : 0, u, 4, q4);  // unused when T == 1
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = q4 * 4 + e;
+        dh[u][r] = a.dh_last[(size_t)(tile * 32 + mfma_row(r, lane)) * Hp + unit];
+        dc[u][r] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) tg[u][g][r] = v[g][e];
+        tcn[u][r] = v[4][e];
+        tcp[u][r] = v[5][e];
+      }
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) dbacc[u][g] = 0.0f;
@@ -332,6 +346,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       const int unit = (wn * UB + u) * 32 + (lane & 31);
+      float gq[4][2];  // X3: the even row's values, waiting for the odd row
+      (void)gq;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float si = tg[u][0][r], tj = tg[u][1][r], sf = tg[u][2][r], so = tg[u][3][r];
@@ -352,15 +368,25 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
         dbacc[u][3] += g_o;
         const int b = mfma_row(r, lane);
         if constexpr (X3) {
-          // element (b, n = g*Hp + unit) -> group n/16, slot ((n/8)&1)*32 + b, piece n%8; hi block, lo block 1 KiB on
-          unsigned char *dst = dgb + (size_t)(unit >> 4) * 2048 + (size_t)((((unit >> 3) & 1) * 32 + b) * 16) + (unit & 7) * 2;
-          constexpr int GS = (Hp / 16) * 2048;
-          const float gv[4] = {g_i, g_j, g_f, g_o};
+          // element (b, n = g*Hp + unit) -> group n/16, slot ((n/8)&1)*32 + b, piece n%8; hi block, lo block 1 KiB on.
+          // Registers r, r+1 (rows b, b+1) are split together on the hardware converter (v_cvt_pk_bf16_f32) and leave as
+          // the low / high half-words of the packed results
+          gq[0][r & 1] = g_i;
+          gq[1][r & 1] = g_j;
+          gq[2][r & 1] = g_f;
+          gq[3][r & 1] = g_o;
+          if (r & 1) {
+            unsigned char *dst = dgb + (size_t)(unit >> 4) * 2048 + (size_t)((((unit >> 3) & 1) * 32 + (b - 1)) * 16) + (unit & 7) * 2;
+            constexpr int GS = (Hp / 16) * 2048;
 #pragma unroll
-          for (int gi = 0; gi < 4; ++gi) {
-            const unsigned short hi = sse_bf16_rne(gv[gi]), lo = sse_bf16_rne(gv[gi] - sse_bf16_f32(hi));
-            *reinterpret_cast<unsigned short *>(dst + gi * GS) = hi;
-            *reinterpret_cast<unsigned short *>(dst + gi * GS + 1024) = lo;
+            for (int gi = 0; gi < 4; ++gi) {
+              unsigned hi, lo;
+              sse_split2(gq[gi][0], gq[gi][1], hi, lo);
+              *reinterpret_cast<unsigned short *>(dst + gi * GS) = (unsigned short)hi;
+              *reinterpret_cast<unsigned short *>(dst + gi * GS + 16) = (unsigned short)(hi >> 16);
+              *reinterpret_cast<unsigned short *>(dst + gi * GS + 1024) = (unsigned short)lo;
+              *reinterpret_cast<unsigned short *>(dst + gi * GS + 1024 + 16) = (unsigned short)(lo >> 16);
+            }
           }
         } else {
           // element (b, n = g*Hp + unit) -> dgs[n/8][((n%8)/4*32 + b)*4 + n%4]; Hp % 8 == 0 so n%8 == unit%8
@@ -370,32 +396,40 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
           dst[(size_t)(2 * Hp / 8) * 256] = g_f;
           dst[(size_t)(3 * Hp / 8) * 256] = g_o;
         }
-        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the interleaving (register pressure)
+        if ((r & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // bound the interleaving to a pair of rows (register pressure: 0 B scratch)
       }
     }
     // refill the tape registers for step t-1 (c_{t-1} is already here: it was this step's c_prev); the fence
     // keeps the scheduler from hoisting these loads above the last use of the old values (two live copies spill).
-    // fp32 kernels: requested here, in flight under the recurrent GEMM.  X3: requested AFTER the recurrent GEMM (in
-    // flight under the dX product, the dump and the wait at the barrier) -- with 80 tape registers pending the GEMM had
-    // 16 registers for its operand ring and the kernel still spilled.
+    // Requested AFTER the recurrent GEMM and the dX product (in flight under the dump and the wait at the barrier): with
+    // the tape registers pending the GEMM had 16 registers for its operand ring, spilled, and waited for L2 on every
+    // k-group (clock64: 27 - 35 k cycles per step for 6 k cycles of MFMA); now both loops keep 8 groups of weights in flight.
     auto refill = [&]() {
       __builtin_amdgcn_sched_barrier(0);
-      if (t > 0) {
+      // unconditional (the last step re-reads step 0 for nothing): behind an `if (t > 0)` the old values stay live through
+      // the GEMM for the not-taken path and cost 64 registers
+      const int tp = t > 0 ? t - 1 : 0, tpp = t > 1 ? t - 2 : 0;
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
+      for (int u = 0; u < UB; ++u) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
+        for (int q4 = 0; q4 < 4; ++q4) {
+          f32x4 v[5];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) tg[u][g][r] = tld(t - 1, u, g * 1024 + r * 64);
+          for (int g = 0; g < 4; ++g) v[g] = tld4(tp, u, g, q4);
+          v[4] = tld4(tpp, u, 4, q4);  // step 0 ignores it (c_{-1} = 0)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = q4 * 4 + e;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) tg[u][g][r] = v[g][e];
             tcn[u][r] = tcp[u][r];
-            tcp[u][r] = tld(t > 1 ? t - 2 : 0, u, 4096 + r * 64);  // step 0 ignores it (c_{-1} = 0)
+            tcp[u][r] = v[4][e];
           }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     };
     BWD_CLK(0)
-    if constexpr (!X3) refill();
     __syncthreads();
     BWD_CLK(1)
 
@@ -427,8 +461,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
                     ((unsigned)*reinterpret_cast<const unsigned short *>(src + 1024 + (2 * e + 1) * 16) << 16);
           }
           unsigned short *dst = gb + (((g0 + (oc >> 1)) * NTn + (n >> 5)) * 2) * 512 + ((oc & 1) * 32 + (n & 31)) * 8;
-          *reinterpret_cast<sse_u32x4 *>(dst) = hi;
-          *reinterpret_cast<sse_u32x4 *>(dst + 512) = lo;
+          __builtin_nontemporal_store(hi, reinterpret_cast<sse_u32x4 *>(dst));  // streamed once: do not displace the weights in L2
+          __builtin_nontemporal_store(lo, reinterpret_cast<sse_u32x4 *>(dst + 512));
         }
         return;
       }
@@ -452,8 +486,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
           sse_u32x4 hi, lo;
           sse_split8(v8, hi, lo);
           unsigned short *dst = gb + (((g0 + (oc >> 1)) * NTn + (n >> 5)) * 2) * 512 + ((oc & 1) * 32 + (n & 31)) * 8;
-          *reinterpret_cast<sse_u32x4 *>(dst) = hi;
-          *reinterpret_cast<sse_u32x4 *>(dst + 512) = lo;
+          __builtin_nontemporal_store(hi, reinterpret_cast<sse_u32x4 *>(dst));  // streamed once: do not displace the weights in L2
+          __builtin_nontemporal_store(lo, reinterpret_cast<sse_u32x4 *>(dst + 512));
         }
       } else {
         // (n, 4 consecutive rows) -> one float4 of block (rg, n/32)
@@ -488,28 +522,47 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
       // Kh^T fragments through a buffer descriptor (SGPR base + SGPR offset + 16 * lane): no per-lane 64-bit pointers
       const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<unsigned short *>(a.KhT16) + (size_t)(wn * UB) * KG16 * 1024, 0, UB * KG16 * 2048, 0x00020000);
-      auto phys = [&](int i) { return (i / KGl) * KGg + i % KGl; };
-      constexpr int PF = 2;  // (4 groups in flight cost 16 more registers than this kernel has)
+      // The walk over the 4 x KGl live k-groups starts at a different group per wave and tile and wraps around.  It is
+      // kept as (gate base, group in gate) counters that advance by compare-and-select: `i / KGl` per k-group cost ~60
+      // scalar instructions an iteration and its branches made the compiler drain the operand ring (vmcnt(0)).
+      struct Walk {
+        int l, base;
+      };
+      const int rot = BWD_ROT ? (wn * (NL / NW) + tile * 3) % NL : 0;
+      const Walk w0{rot % KGl, (rot / KGl) * KGg};
+      auto adv = [&](Walk &w) {
+        const int l1 = w.l + 1;
+        const bool wrap = l1 == KGl;
+        const int b1 = w.base + KGg;
+        w.base = wrap ? (b1 == 4 * KGg ? 0 : b1) : w.base;
+        w.l = wrap ? 0 : l1;
+      };
+      constexpr int PF = 4;  // Kh^T groups in flight per wave; NL = 4 * KGl is a multiple of it (no tail)
       bw_bf16x8 bq[PF][UB][2], aq[2][2];
       auto bld = [&](int u, int g16, int hl) -> bw_bf16x8 {
         return __builtin_bit_cast(bw_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(krs, lg * 16, ((u * KG16 + g16) * 2 + hl) * 1024, 0));
       };
+      Walk wb = w0, wa = w0;  // wb: next group to request from L2, wa: next dG fragment to read from LDS
 #pragma unroll
-      for (int p = 0; p < PF; ++p)
+      for (int p = 0; p < PF; ++p) {
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-          bq[p][u][0] = bld(u, phys(p), 0);
-          bq[p][u][1] = bld(u, phys(p), 1);
+          bq[p][u][0] = bld(u, wb.base + wb.l, 0);
+          bq[p][u][1] = bld(u, wb.base + wb.l, 1);
         }
-      aq[0][0] = *reinterpret_cast<const bw_bf16x8 *>(la);
-      aq[0][1] = *reinterpret_cast<const bw_bf16x8 *>(la + 1024);
+        adv(wb);
+      }
+      aq[0][0] = *reinterpret_cast<const bw_bf16x8 *>(la + (size_t)(wa.base + wa.l) * 2048);
+      aq[0][1] = *reinterpret_cast<const bw_bf16x8 *>(la + (size_t)(wa.base + wa.l) * 2048 + 1024);
+      adv(wa);
       __builtin_amdgcn_s_setprio(1);
       for (int kg = 0; kg < NL; kg += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-          const int kn = phys((kg + p + 1 < NL) ? kg + p + 1 : kg + p);
-          aq[(p + 1) & 1][0] = *reinterpret_cast<const bw_bf16x8 *>(la + (size_t)kn * 2048);
-          aq[(p + 1) & 1][1] = *reinterpret_cast<const bw_bf16x8 *>(la + (size_t)kn * 2048 + 1024);
+          // (past the end both walks wrap to the start: valid addresses, values unused)
+          aq[(p + 1) & 1][0] = *reinterpret_cast<const bw_bf16x8 *>(la + (size_t)(wa.base + wa.l) * 2048);
+          aq[(p + 1) & 1][1] = *reinterpret_cast<const bw_bf16x8 *>(la + (size_t)(wa.base + wa.l) * 2048 + 1024);
+          adv(wa);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int u = 0; u < UB; ++u) {
@@ -518,19 +571,16 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
             dh[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[p & 1][0], bq[p][u][0], dh[u], 0, 0, 0);  // dg_hi * K_hi
           }
           __builtin_amdgcn_sched_barrier(0);
-          const int kp = phys((kg + p + PF < NL) ? kg + p + PF : kg + p);
 #pragma unroll
           for (int u = 0; u < UB; ++u) {
-            bq[p][u][0] = bld(u, kp, 0);
-            bq[p][u][1] = bld(u, kp, 1);
+            bq[p][u][0] = bld(u, wb.base + wb.l, 0);
+            bq[p][u][1] = bld(u, wb.base + wb.l, 1);
           }
+          adv(wb);
         }
       }
       __builtin_amdgcn_s_setprio(0);
     }
-    BWD_CLK(3)
-    if constexpr (X3) refill();
-    BWD_CLK(4)
     if (!X3 && t > 0) {
 #pragma unroll
       for (int u = 0; u < UB; ++u)
@@ -545,38 +595,52 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
       auto kld = [&](int u, int kg) -> f32x4 {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, lg * 16, (u * KGn + kg) * 1024, 0));
       };
-      // Kh^T fragments come from L2 (~1-2 k cycles): keep PF k-groups (PF*4*UB MFMAs) of them in flight
-      // in a register ring; the dg fragments come from LDS one k-group ahead.  KGn % PF == 0.
-      constexpr int PF = (NW == 4) ? 4 : 2;  // Hp = 128 runs one wave per SIMD with registers to spare: a deeper ring
+      // Kh^T fragments come from L2: PF k-groups (PF*4*UB MFMAs) of them in flight in a register ring; the dg fragments
+      // come from LDS one k-group ahead.  Reduction index n = gate*Hp + unit: only the k-groups of units < H can be
+      // non-zero -> a division-free walk over 4 gates x KGl live k-groups (NL = 4 * KGl is a multiple of PF), fixed
+      // order: the exact path keeps one summation order for every tile
+      constexpr int PF = 4;  // (the tape registers are refilled after this loop: room for a deeper ring than round 2's 2)
       f32x4 bq[PF][UB], aq[2];
-      // reduction index n = gate*Hp + unit: only the k-groups of units < H can be non-zero -> walk
-      // 4 gates x KGl live k-groups (logical index i -> physical k-group); 4*KGl is even
       const int KGg = Hp / 8, KGl = min(KGg, (a.H + 7) / 8), NL = 4 * KGl;
-      auto phys = [&](int i) { return (i / KGl) * KGg + i % KGl; };
+      struct Walk {
+        int l, base;
+      };
+      auto adv = [&](Walk &w) {
+        const int l1 = w.l + 1;
+        const bool wrap = l1 == KGl;
+        const int b1 = w.base + KGg;
+        w.base = wrap ? (b1 == 4 * KGg ? 0 : b1) : w.base;
+        w.l = wrap ? 0 : l1;
+      };
+      Walk wb{0, 0}, wa{0, 0};
 #pragma unroll
-      for (int p = 0; p < PF; ++p)
+      for (int p = 0; p < PF; ++p) {
 #pragma unroll
-        for (int u = 0; u < UB; ++u) bq[p][u] = kld(u, phys(p));
+        for (int u = 0; u < UB; ++u) bq[p][u] = kld(u, wb.base + wb.l);
+        adv(wb);
+      }
       aq[0] = *reinterpret_cast<const f32x4 *>(la);
+      adv(wa);
       __builtin_amdgcn_s_setprio(1);
       for (int kg = 0; kg < NL; kg += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-          const int kn = phys((kg + p + 1 < NL) ? kg + p + 1 : kg + p);
-          aq[(p + 1) & 1] = *reinterpret_cast<const f32x4 *>(la + kn * 256);
+          aq[(p + 1) & 1] = *reinterpret_cast<const f32x4 *>(la + (wa.base + wa.l) * 256);  // (wraps to group 0 past the end: unused)
+          adv(wa);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int u = 0; u < UB; ++u) dh[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[p & 1][e], bq[p][u][e], dh[u], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          const int kp = phys((kg + p + PF < NL) ? kg + p + PF : kg + p);
 #pragma unroll
-          for (int u = 0; u < UB; ++u) bq[p][u] = kld(u, kp);
+          for (int u = 0; u < UB; ++u) bq[p][u] = kld(u, wb.base + wb.l);
+          adv(wb);
         }
       }
       __builtin_amdgcn_s_setprio(0);
     }
+    BWD_CLK(3)
     if constexpr (X3) {
       // ---- dX_t[b][e] = sum_n dG[b][n] * Kx[e][n] on v_mfma_f32_16x16x32_bf16 (three per product, split operands):
       // 2 row halves x 4 e-tiles of 16 = 8 output tiles, wave = (row half wn & 1, e-tile(s) wn >> 1 (+ NW/2)); the A
@@ -588,7 +652,19 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
       int lx = lane;
       asm volatile("" : "+v"(lx));  // opaque copy: the addresses below are recomputed every step, not kept across the phases
       const int KS = 4 * Hp / 32, KSg = Hp / 32, KSl = min(KSg, (a.H + 31) / 32), NS = 4 * KSl;  // live 32-n steps
-      auto physs = [&](int i) { return (i / KSl) * KSg + i % KSl; };
+      // (staggered, division-free walk over the 4 x KSl live 32-n steps, as in the recurrent GEMM)
+      struct WalkX {
+        int l, base;
+      };
+      const int rots = BWD_ROT ? (wn * (NS / NW) + tile * 3) % NS : 0;
+      const WalkX x0{rots % KSl, (rots / KSl) * KSg};
+      auto advx = [&](WalkX &w) {
+        const int l1 = w.l + 1;
+        const bool wrap = l1 == KSl;
+        const int b1 = w.base + KSg;
+        w.base = wrap ? (b1 == 4 * KSg ? 0 : b1) : w.base;
+        w.l = wrap ? 0 : l1;
+      };
       const unsigned char *lax = dgb + (size_t)(lx >> 5) * 2048 + (size_t)(((lx >> 4) & 1) * 32 + rh * 16 + (lx & 15)) * 16;
       const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.KxT16), 0, 4 * KS * 2048, 0x00020000);
       // outputs through descriptors as well (the embedding gradient is < 4 GiB: V * E floats)
@@ -612,23 +688,48 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
       bool elive[NE];
 #pragma unroll
       for (int j = 0; j < NE; ++j) elive[j] = (et0 + j * (NW / 2)) * 16 < a.E;
-      // (no software pipeline here: the wave's partner on the SIMD covers the L2 latency of the B fragments, and a
-      // second operand set pushed the kernel into scratch)
-#pragma nounroll
-      for (int i = 0; i < NS; ++i) {
-        const int ks = physs(i);
-        const bx_bf16x8 ah = *reinterpret_cast<const bx_bf16x8 *>(lax + (size_t)ks * 4096);
-        const bx_bf16x8 al = *reinterpret_cast<const bx_bf16x8 *>(lax + (size_t)ks * 4096 + 1024);
+      // B fragments: a ring of PFX 32-n steps in flight (L2; one step is 3 MFMAs of 16 cycles: without the ring this loop
+      // waited 25 k cycles per BPTT step, clock64); A fragments (LDS) one step ahead.  NS = 4 * KSl is a multiple of PFX.
+      constexpr int PFX = 4;
+      bx_bf16x8 xb[PFX][NE][2], xa[2][2];
+      auto xbld = [&](int j, int ks, int hl) -> bx_bf16x8 {
+        return __builtin_bit_cast(bx_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, lx * 16, (((et0 + j * (NW / 2)) * KS + ks) * 2 + hl) * 1024, 0));
+      };
+      WalkX xwb = x0, xwa = x0;
 #pragma unroll
-        for (int j = 0; j < NE; ++j)
-          if (elive[j]) {
-            const int so = ((et0 + j * (NW / 2)) * KS + ks) * 2048;
-            const bx_bf16x8 bh = __builtin_bit_cast(bx_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, lx * 16, so, 0));
-            const bx_bf16x8 bl = __builtin_bit_cast(bx_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, lx * 16, so + 1024, 0));
-            xacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, xacc[j], 0, 0, 0);
-            xacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, xacc[j], 0, 0, 0);
-            xacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, xacc[j], 0, 0, 0);
+      for (int p = 0; p < PFX; ++p) {
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+          xb[p][j][0] = xbld(j, xwb.base + xwb.l, 0);
+          xb[p][j][1] = xbld(j, xwb.base + xwb.l, 1);
+        }
+        advx(xwb);
+      }
+      xa[0][0] = *reinterpret_cast<const bx_bf16x8 *>(lax + (size_t)(xwa.base + xwa.l) * 4096);
+      xa[0][1] = *reinterpret_cast<const bx_bf16x8 *>(lax + (size_t)(xwa.base + xwa.l) * 4096 + 1024);
+      advx(xwa);
+      for (int i0 = 0; i0 < NS; i0 += PFX) {
+#pragma unroll
+        for (int p = 0; p < PFX; ++p) {
+          xa[(p + 1) & 1][0] = *reinterpret_cast<const bx_bf16x8 *>(lax + (size_t)(xwa.base + xwa.l) * 4096);
+          xa[(p + 1) & 1][1] = *reinterpret_cast<const bx_bf16x8 *>(lax + (size_t)(xwa.base + xwa.l) * 4096 + 1024);
+          advx(xwa);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < NE; ++j)
+            if (elive[j]) {
+              xacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[p & 1][1], xb[p][j][0], xacc[j], 0, 0, 0);  // dg_lo * K_hi
+              xacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[p & 1][0], xb[p][j][1], xacc[j], 0, 0, 0);  // dg_hi * K_lo
+              xacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[p & 1][0], xb[p][j][0], xacc[j], 0, 0, 0);  // dg_hi * K_hi
+            }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < NE; ++j) {
+            xb[p][j][0] = xbld(j, xwb.base + xwb.l, 0);
+            xb[p][j][1] = xbld(j, xwb.base + xwb.l, 1);
           }
+          advx(xwb);
+        }
       }
       BWD_CLK(5)
       // scatter-add into the dense embedding gradient (duplicate ids summed, as TF's sparse Adagrad does); lane holds
@@ -661,6 +762,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
       }
     }
     BWD_CLK(6)
+    refill();
+    BWD_CLK(4)
     if (!dump_first) dump();
     BWD_CLK(2)
     __syncthreads();
@@ -859,7 +962,7 @@ __global__ __launch_bounds__(512) void dk_x3_kernel(DkX3Args a) {
       if (w + 8 * j < NBLK) x.s[j] = *reinterpret_cast<const sse_u32x4 *>(pa + ((size_t)g * NBLK + w + 8 * j) * 512);
     if constexpr (!PAIR) {
       const unsigned short *p = pb + (size_t)g * a.NTn * 1024;
-      x.bh = *reinterpret_cast<const dk_bf16x8 *>(p);
+      x.bh = *reinterpret_cast<const dk_bf16x8 *>(p);  // (nt loads measured 10 % slower here)
       x.bl = *reinterpret_cast<const dk_bf16x8 *>(p + 512);
     } else {
       const int t = g / pair_g, d1 = g + t * pair_g;
@@ -995,12 +1098,21 @@ __global__ __launch_bounds__(64) void dx_kernel(DxArgs a) {
   // the dG tile streams from HBM: a ring of 4 k-groups of operands in flight (KGn = Hp/2 is a multiple of 4)
   constexpr int RING = 4;
   f32x4 ra[RING], rb0[RING], rb1[RING];
-  // logical index over 4 gates x KGl live k-groups -> physical k-group (padding skipped); NL is a multiple of 4
+  // 4 gates x KGl live k-groups (padding skipped), walked with (gate base, group) counters instead of a division per
+  // k-group; NL is a multiple of 4
   const int KGg = a.KGn / 4, KGl = a.KGl, NL = 4 * KGl;
-  auto phys = [&](int i) { return (i / KGl) * KGg + i % KGl; };
+  int wl_ = 0, wbase = 0;
+  auto adv = [&]() {
+    const int l1 = wl_ + 1;
+    const bool wrap = l1 == KGl;
+    const int b1 = wbase + KGg;
+    wbase = wrap ? (b1 == 4 * KGg ? 0 : b1) : wbase;
+    wl_ = wrap ? 0 : l1;
+  };
 #pragma unroll
   for (int d = 0; d < RING; ++d) {
-    const int k = phys(d < NL ? d : NL - 1);
+    const int k = wbase + wl_;
+    adv();
     ra[d] = *reinterpret_cast<const f32x4 *>(pa + k * 256);
     rb0[d] = *reinterpret_cast<const f32x4 *>(pb + k * 256);
     rb1[d] = *reinterpret_cast<const f32x4 *>(pb + (size_t)(a.KGn + k) * 256);
@@ -1013,7 +1125,8 @@ __global__ __launch_bounds__(64) void dx_kernel(DxArgs a) {
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[d][e], rb0[d][e], acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[d][e], rb1[d][e], acc[1], 0, 0, 0);
       }
-      const int kn = phys((kg0 + d + RING < NL) ? kg0 + d + RING : kg0 + d);  // clamped: harmless reload at the end
+      const int kn = wbase + wl_;  // (wraps to the start past the end: a harmless reload)
+      adv();
       ra[d] = *reinterpret_cast<const f32x4 *>(pa + kn * 256);
       rb0[d] = *reinterpret_cast<const f32x4 *>(pb + kn * 256);
       rb1[d] = *reinterpret_cast<const f32x4 *>(pb + (size_t)(a.KGn + kn) * 256);
