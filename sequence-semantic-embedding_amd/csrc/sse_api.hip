@@ -72,6 +72,7 @@ struct TrainState {
   unsigned short *KhT16[2] = {nullptr, nullptr};  // option train_bwd_x3: Kh^T as split frag16 blocks
   unsigned short *KxT16[2] = {nullptr, nullptr};  // ... and Kx^T as 16x16x32 B fragments (dX inside the BPTT kernel)
   bool packed_dirty = true;
+  bool fp32_dirty = true;  // the fp32 Kh^T / Kx^T fragment copies are stale (rebuilt only by steps that run fp32 BPTT kernels)
   // gradient arena: [grad of variable 0 | ... | grad of variable n-1 | tail[4]]; tail = {sum of squares of the
   // un-deduplicated embedding-gradient slices, loss, train_acc, rows}, every entry a plain sum over the
   // ranks of a data-parallel job (one flat all-reduce)
@@ -82,6 +83,8 @@ struct TrainState {
   int64_t corpus_N[2] = {0, 0};
   int32_t corpus_T[2] = {0, 0};
   bool rows_mode = false;  // set by the *_rows entry points around train_grads_locked
+  bool defer_err = false;  // set by the fused step entry points: the device error flag is read once, with the loss, after the
+                           // whole step has been queued (a flagged step cancels its own update on the device)
   // paired batches (data.py:95-115: every source row appears twice, once with its positive and once with a negative
   // target): internal row order = [rows 0,2,4,.. | rows 1,3,5,..], the source encoder runs on the first half only
   DevBuf ids_raw[2], perm, hot_part[2];
@@ -99,6 +102,7 @@ struct sse_handle {
   std::vector<Variable> vars;
   Encoder enc[2];
   bool packed_dirty = true;
+  bool mp_fresh = false;     // the packed projections match the variables although packed_dirty is set (ensure_proj_packed)
   bool pad_skip = true;      // option "pad_skip": exact left-pad prefix skip in inference encodes
   bool lstm_x3 = false;       // option "lstm_x3": large inference encodes (Hp = 256) on the bf16 matrix pipe with split operands
   unsigned short *emb16 = nullptr;  // split embedding table of that path
@@ -229,6 +233,22 @@ static int emb_cols(const sse_config &c) {
 }
 
 // (re)build the kernel-facing layouts from the master variables
+// the packed projections alone (what a train step whose LSTM kernels all run on split operands reads of these layouts):
+// the embedding pad, the fp32 kernel fragments and the CNN layouts stay stale (packed_dirty) until an encode needs them
+int ensure_proj_packed(sse_handle *h, hipStream_t st) {
+  if (!h->packed_dirty || h->mp_fresh) return 0;
+  const sse_config &c = h->cfg;
+  for (int s = 0; s < 2; ++s) {
+    Encoder &e = h->enc[s];
+    if (e.H <= 0 || e.kernel < 0) continue;
+    const int NTS = (c.encoding_size + 31) / 32;
+    if (!e.Mp) HIPCHECK(h, hipMalloc((void **)&e.Mp, (size_t)NTS * e.KGh * 256 * sizeof(float)));
+    HIPCHECK(h, launch_pack_kn(h->vars[e.proj].dev, e.H, c.encoding_size, e.KGh, e.Mp, st));
+  }
+  h->mp_fresh = true;
+  return 0;
+}
+
 int ensure_packed(sse_handle *h, hipStream_t st) {
   if (!h->packed_dirty) return 0;
   const sse_config &c = h->cfg;
@@ -280,6 +300,7 @@ int ensure_packed(sse_handle *h, hipStream_t st) {
     HIPCHECK(h, launch_pack_kn(h->vars[h->cnn_M].dev, 576, c.encoding_size, 72, h->cnn_Mp, st));
   }
   h->packed_dirty = false;
+  h->mp_fresh = true;
   return 0;
 }
 
@@ -1045,7 +1066,8 @@ int sse_set_variable(sse_handle *h, const char *name, const float *host, int64_t
   HIPCHECK(h, hipMemcpy(slot ? h->vars[i].slot : h->vars[i].dev, host, count * sizeof(float), hipMemcpyHostToDevice));
   if (!slot) {
     h->packed_dirty = true;
-    if (h->train) h->train->packed_dirty = true;
+    h->mp_fresh = false;
+    if (h->train) h->train->packed_dirty = h->train->fp32_dirty = true;
   }
   return 0;
 }
@@ -1169,6 +1191,7 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value) {
     if (h->cfg.network_mode != SSE_MODE_SOURCE_ONLY_CNN) return fail(h, "option cnn_bf16 needs network_mode source_only_cnn");
     h->cnn_bf16 = value != 0;
     h->packed_dirty = true;  // (re)build the bf16 copies with the next encode
+    h->mp_fresh = false;
     return 0;
   }
   if (strcmp(name, "lstm_train_rows") == 0) {
@@ -1458,7 +1481,7 @@ static int cnn_train_grads_locked(sse_handle *h, const int32_t *src_ids_host, co
   }
   HIPCHECK(h, launch_rows_gather(table.dev, (const int32_t *)ts.ids[1].p, B, Bp, table.rows, S, (float *)ts.raw[1].p,
                                  h->err_flag, st));
-  if (check_err_flag(h, st)) return 1;
+  if (check_err_flag(h, st)) return 1;  // (never deferred here: the gather / scatter backward below trusts the ids)
   HIPCHECK(h, launch_loss((const float *)ts.raw[0].p, (const float *)ts.raw[1].p, (const float *)ts.labels.p,
                           (float *)ts.draw[0].p, (float *)ts.draw[1].p, (float *)ts.row_loss.p, (float *)ts.row_acc.p,
                           tail + 1, B, Bp, S, inv_rows, st));
@@ -1517,9 +1540,20 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   float *tail = ts.arena + grad_arena_count(h) - 4;
   const float inv_rows = 1.0f / (float)rows_global;
 
-  if (ensure_packed(h, st)) return 1;
-  // transposed kernel slices for the backward GEMMs
-  if (ts.packed_dirty) {
+  // which kernel families this step runs on split bf16 operands (options train_fwd_x3 / train_bwd_x3 / train_dk_x3)
+  bool fwd_x3[2] = {false, false}, bwd_x3[2] = {false, false};
+  bool all_x3 = true;
+  for (int s = 0; s < nside; ++s) {
+    const Encoder &e = h->enc[s];
+    fwd_x3[s] = h->train_fwd_x3 && h->train_dk_x3 && e.Hp <= 256 && e.H >= 64 && E < 64;
+    bwd_x3[s] = h->train_bwd_x3 && h->train_dk_x3 && e.H >= 64 && e.Hp <= 256;
+    all_x3 = all_x3 && fwd_x3[s] && bwd_x3[s];
+  }
+  // layouts derived from the variables, rebuilt after every update: only the ones this step's kernels read (an all-split
+  // step needs the projections, Kh^T / Kx^T in split form and -- below -- the split kernel matrix and embedding table;
+  // the fp32 fragment copies wait for the next encode or fp32 step: 7 fewer launches on the critical path of a step)
+  if (all_x3 ? ensure_proj_packed(h, st) : ensure_packed(h, st)) return 1;
+  if (ts.packed_dirty || (!all_x3 && ts.fp32_dirty)) {
     for (int s = 0; s < nside; ++s) {
       Encoder &e = h->enc[s];
       if (e.shares_lstm_with >= 0) {
@@ -1529,15 +1563,20 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
         ts.KxT16[s] = ts.KxT16[e.shares_lstm_with];
         continue;
       }
-      if (!ts.KhT16[s]) HIPCHECK(h, hipMalloc((void **)&ts.KhT16[s], kT16_elems(e.Hp) * sizeof(unsigned short)));
-      HIPCHECK(h, launch_pack_kT16(h->vars[e.kernel].dev, E, e.H, e.Hp, ts.KhT16[s], st));
-      if (!ts.KxT16[s]) HIPCHECK(h, hipMalloc((void **)&ts.KxT16[s], kxT16_elems(e.Hp) * sizeof(unsigned short)));
-      HIPCHECK(h, launch_pack_kxT16(h->vars[e.kernel].dev, E, e.H, e.Hp, ts.KxT16[s], st));
-      if (!ts.KhT[s]) HIPCHECK(h, hipMalloc((void **)&ts.KhT[s], (size_t)(e.Hp / 32) * (e.Hp / 2) * 256 * sizeof(float)));
-      if (!ts.KxT[s]) HIPCHECK(h, hipMalloc((void **)&ts.KxT[s], (size_t)2 * (e.Hp / 2) * 256 * sizeof(float)));
-      HIPCHECK(h, launch_pack_kT(h->vars[e.kernel].dev, E, e.H, e.Hp / 32, e.H, e.Hp, ts.KhT[s], st));
-      HIPCHECK(h, launch_pack_kT(h->vars[e.kernel].dev, 0, E, 2, e.H, e.Hp, ts.KxT[s], st));
+      if (ts.packed_dirty) {
+        if (!ts.KhT16[s]) HIPCHECK(h, hipMalloc((void **)&ts.KhT16[s], kT16_elems(e.Hp) * sizeof(unsigned short)));
+        HIPCHECK(h, launch_pack_kT16(h->vars[e.kernel].dev, E, e.H, e.Hp, ts.KhT16[s], st));
+        if (!ts.KxT16[s]) HIPCHECK(h, hipMalloc((void **)&ts.KxT16[s], kxT16_elems(e.Hp) * sizeof(unsigned short)));
+        HIPCHECK(h, launch_pack_kxT16(h->vars[e.kernel].dev, E, e.H, e.Hp, ts.KxT16[s], st));
+      }
+      if (!all_x3) {
+        if (!ts.KhT[s]) HIPCHECK(h, hipMalloc((void **)&ts.KhT[s], (size_t)(e.Hp / 32) * (e.Hp / 2) * 256 * sizeof(float)));
+        if (!ts.KxT[s]) HIPCHECK(h, hipMalloc((void **)&ts.KxT[s], (size_t)2 * (e.Hp / 2) * 256 * sizeof(float)));
+        HIPCHECK(h, launch_pack_kT(h->vars[e.kernel].dev, E, e.H, e.Hp / 32, e.H, e.Hp, ts.KhT[s], st));
+        HIPCHECK(h, launch_pack_kT(h->vars[e.kernel].dev, 0, E, 2, e.H, e.Hp, ts.KxT[s], st));
+      }
     }
+    if (!all_x3) ts.fp32_dirty = false;
     ts.packed_dirty = false;
   }
   if (E > 64) return fail(h, "train step: embedding_size %d > 64 not supported yet", E);
@@ -1651,7 +1690,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     a.tape_a = (float *)ts.tape_a[s].p;
     a.tape_a_split = h->train_dk_x3 ? 1 : 0;
     a.h_last = (float *)ts.h_last[s].p;
-    if (h->train_fwd_x3 && h->train_dk_x3 && e.Hp <= 256 && e.H >= 64 && E < 64) {
+    if (fwd_x3[s]) {
       // the gate GEMMs as three bf16 MFMAs on hi + lo split operands (lstm_fwd_x3.hip, TRAIN): same tapes, same outputs
       Encoder &own = e.shares_lstm_with >= 0 ? h->enc[e.shares_lstm_with] : e;
       if (e.shares_lstm_with < 0 && s != 0) {  // (side 0 was packed ahead of the fork together with the embedding table)
@@ -1695,7 +1734,10 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     HIPCHECK(h, hipEventRecord(ts.ev_join[s], fs));
     HIPCHECK(h, hipStreamWaitEvent(st, ts.ev_join[s], 0));
   }
-  if (check_err_flag(h, st)) return 1;
+  // token ids / corpus rows out of range: the sequence-encoder backward kernels validate every id themselves, so the fused
+  // step reads the flag once at its end (train_apply_locked; a flagged step cancels its own update on the device) instead
+  // of stalling the queue here; the free-target-matrix scatter trusts its rows: checked now
+  if ((!ts.defer_err || table_tgt) && check_err_flag(h, st)) return 1;
 
   // ---- loss, train accuracy, d(raw encodings)
   if (reserve(h, ts.row_loss, (size_t)B * sizeof(float))) return 1;
@@ -1709,12 +1751,8 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   HIPCHECK(h, hipMemsetAsync(emb.grad, 0, emb.count * sizeof(float), st));
   // partial sums of dx^2 per side: one per (tile, wave) when dX comes out of the split-operand BPTT kernel, one per
   // (step, tile) from dx_kernel (+ one per target row in source-encoder-only mode)
-  bool bwd_x3[2] = {false, false};
   int sq_off[3] = {0, 0, 0};
-  for (int s = 0; s < nside; ++s) {
-    bwd_x3[s] = h->train_bwd_x3 && h->train_dk_x3 && h->enc[s].H >= 64 && h->enc[s].Hp <= 256;
-    sq_off[s + 1] = sq_off[s] + (bwd_x3[s] ? NT32 * (h->enc[s].Hp / 32) : T * NT32);
-  }
+  for (int s = 0; s < nside; ++s) sq_off[s + 1] = sq_off[s] + (bwd_x3[s] ? NT32 * (h->enc[s].Hp / 32) : T * NT32);
   const int n_sq = sq_off[nside] + (table_tgt ? B : 0);
   if (reserve(h, ts.sq_part, (size_t)n_sq * sizeof(float))) return 1;
   if (table_tgt) {
@@ -1779,32 +1817,46 @@ static int train_apply_locked(sse_handle *h, float *loss, float *train_acc) {
   TrainState &ts = *h->train;
   hipStream_t st = nullptr;
   const int NORM_BLOCKS = 64;
-  int nparts = 0;
   float *tail = ts.arena + grad_arena_count(h) - 4;
   if (reserve(h, ts.scal, 4 * sizeof(float))) return 1;
-  float *scal = (float *)ts.scal.p;  // [0] global norm [1] clip scale
+  float *scal = (float *)ts.scal.p;  // [0] global norm [1] clip scale [2] update cancelled
   if (reserve(h, ts.norm_part, (size_t)(h->vars.size() * NORM_BLOCKS + 1) * sizeof(float))) return 1;
   float *np_ = (float *)ts.norm_part.p;
-  for (size_t i = 1; i < h->vars.size(); ++i) {
-    if ((int)i == h->tgt_table) continue;  // a lookup table like word_embedding: its raw slices are in tail[0]
+  if (h->vars.size() > SSE_MAX_TENSORS) return fail(h, "too many variables");
+  // dense tensors enter the global norm whole; the lookup tables (word_embedding, tgt_seq_embedding) through the raw
+  // slice norm in tail[0] (tf.clip_by_global_norm over IndexedSlices.values, sse_model.py:359-362)
+  MultiTensor dense, all;
+  dense.n = all.n = 0;
+  for (size_t i = 0; i < h->vars.size(); ++i) {
     Variable &v = h->vars[i];
-    HIPCHECK(h, launch_sumsq(v.grad, v.count, np_ + nparts, NORM_BLOCKS, st));
-    nparts += NORM_BLOCKS;
+    all.w[all.n] = v.dev;
+    all.slot[all.n] = v.slot;
+    all.grad[all.n] = v.grad;
+    all.count[all.n++] = v.count;
+    if (i == 0 || (int)i == h->tgt_table) continue;
+    dense.w[dense.n] = v.dev;
+    dense.slot[dense.n] = v.slot;
+    dense.grad[dense.n] = v.grad;
+    dense.count[dense.n++] = v.count;
   }
-  HIPCHECK(h, hipMemcpyAsync(np_ + nparts, tail, sizeof(float), hipMemcpyDeviceToDevice, st));
-  nparts += 1;
-  HIPCHECK(h, launch_clip_scale(np_, nparts, 5.0f /* max_gradient_norm, sse_model.py:117 */, scal, st));
-
+  HIPCHECK(h, launch_sumsq_multi(dense, np_, NORM_BLOCKS, st));
+  // a token id out of range seen by this step's kernels (deferred check of the fused step) cancels the update on the device
+  HIPCHECK(h, launch_clip_scale_multi(np_, dense.n * NORM_BLOCKS, tail, 5.0f /* max_gradient_norm, sse_model.py:117 */, h->err_flag,
+                                      scal, st));
   // ---- Adagrad (dense for every tensor; rows of word_embedding with zero gradient are unchanged)
-  for (auto &v : h->vars) HIPCHECK(h, launch_adagrad(v.dev, v.slot, v.grad, scal, h->lr, v.count, st));
-  h->global_step += 1;
+  HIPCHECK(h, launch_adagrad_multi(all, scal, h->lr, st));
   h->packed_dirty = true;
-  ts.packed_dirty = true;
+  h->mp_fresh = false;
+  ts.packed_dirty = ts.fp32_dirty = true;
   ts.grads_ready = false;
 
   float out[4];
+  int32_t flag = 0;
   HIPCHECK(h, hipMemcpyAsync(out, tail, sizeof out, hipMemcpyDeviceToHost, st));
+  HIPCHECK(h, hipMemcpyAsync(&flag, h->err_flag, sizeof flag, hipMemcpyDeviceToHost, st));
   HIPCHECK(h, hipStreamSynchronize(st));
+  if (flag) return check_err_flag(h, st);  // (resets the flag; the update was cancelled on the device: variables unchanged)
+  h->global_step += 1;
   if (loss) *loss = out[1];
   if (train_acc) *train_acc = out[2];
   return 0;
@@ -1847,8 +1899,17 @@ int sse_train_grads_rows(sse_handle *h, const int32_t *src_rows_host, const int3
 
 int sse_train_step_rows(sse_handle *h, const int32_t *src_rows_host, const int32_t *tgt_rows_host, const float *labels_host,
                         int32_t B, float *loss, float *train_acc) {
-  if (sse_train_grads_rows(h, src_rows_host, tgt_rows_host, labels_host, B, B)) return 1;
-  return sse_train_apply(h, loss, train_acc);
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  if (!h->train || !h->train->corpus[0].p) return fail(h, "train step by rows: no source corpus on the device (sse_corpus_upload)");
+  h->train->rows_mode = true;
+  h->train->defer_err = true;
+  const int rc = train_grads_locked(h, src_rows_host, tgt_rows_host, labels_host, B, h->train->corpus_T[0], B);
+  h->train->rows_mode = false;
+  h->train->defer_err = false;
+  if (rc) return 1;
+  return train_apply_locked(h, loss, train_acc);
 }
 
 int sse_train_apply(sse_handle *h, float *loss, float *train_acc) {
@@ -1863,7 +1924,11 @@ int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tg
   if (!h || !loss || !train_acc) return 1;
   std::lock_guard<std::mutex> lk(h->mu);
   HIPCHECK(h, hipSetDevice(h->cfg.device));
-  if (train_grads_locked(h, src_ids_host, tgt_ids_host, labels_host, B, T, B)) return 1;
+  if (!h->train) h->train = new TrainState();
+  h->train->defer_err = true;  // one host sync per step: the error flag is read with the loss
+  const int rc = train_grads_locked(h, src_ids_host, tgt_ids_host, labels_host, B, T, B);
+  h->train->defer_err = false;
+  if (rc) return 1;
   return train_apply_locked(h, loss, train_acc);
 }
 

@@ -39,6 +39,19 @@ hipError_t launch_db_reduce(const float *db_part, int NT32, int H, int Hp, int a
 hipError_t launch_dx(const float *dg_a, const float *KxT, const int32_t *ids, float *d_emb, float *sq_part,
                      float *hot_part /* [T*NT32][2][64] floats */, int T, int NT32, int KGn, int B, int E, int V, int H,
                      hipStream_t st);
+// every tensor of the model in one launch (blockIdx.y = tensor)
+#define SSE_MAX_TENSORS 16
+struct MultiTensor {
+  float *w[SSE_MAX_TENSORS], *slot[SSE_MAX_TENSORS];
+  const float *grad[SSE_MAX_TENSORS];
+  int64_t count[SSE_MAX_TENSORS];
+  int32_t n;
+};
+hipError_t launch_sumsq_multi(const MultiTensor &mt, float *part /* [mt.n][nblocks] */, int nblocks, hipStream_t st);
+// scal[0] = sqrt(sum(part[0..n)) + *extra), scal[1] = clip * min(1/norm, 1/clip); *err != 0 cancels the update (scal[1] = 0, scal[2] = 1)
+hipError_t launch_clip_scale_multi(const float *part, int n, const float *extra, float clip, const int32_t *err, float *scal,
+                                   hipStream_t st);
+hipError_t launch_adagrad_multi(const MultiTensor &mt, const float *scal, float lr, hipStream_t st);
 hipError_t launch_sumsq(const float *g, int64_t n, float *part, int nblocks, hipStream_t st);
 hipError_t launch_sum(const float *part, int n, float tag, float *out /* out[0]=sum, out[3]=tag */, hipStream_t st);
 hipError_t launch_clip_scale(const float *part, int n, float clip, float *scal, hipStream_t st);

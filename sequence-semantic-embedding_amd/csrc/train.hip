@@ -1288,8 +1288,80 @@ __global__ void adagrad_kernel(float *w, float *accum, const float *grad, const 
   }
 }
 
+// All tensors of the model in ONE launch each (a train step used to end in 6 sumsq + 7 adagrad launches of ~5 us):
+// blockIdx.y selects the tensor.
+__global__ void sumsq_multi_kernel(MultiTensor mt, float *part /*[n][gridDim.x]*/) {
+  __shared__ float sh[256];
+  const float *g = mt.grad[blockIdx.y];
+  const int64_t n = mt.count[blockIdx.y];
+  float acc = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += g[i] * g[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = sh[0];
+}
+
+// scal[0] = global norm over part[0..n) plus *extra (the raw embedding-slice norm), scal[1] = clip scale; a pending
+// device error (err != 0: token id out of range seen by this step's kernels) turns the update into a no-op: scal[1] = 0
+// and scal[2] = 1 (adagrad_multi_kernel returns), so the host may check the flag AFTER queueing the whole step
+__global__ void clip_scale_multi_kernel(const float *part, int n, const float *extra, float clip, const int32_t *err, float *scal) {
+  __shared__ double sh[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += (double)part[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float gn = (float)sqrt(sh[0] + (double)*extra);
+    const bool bad = err != nullptr && *err != 0;
+    scal[0] = gn;
+    scal[1] = bad ? 0.0f : ((gn > 0.0f) ? clip * fminf(1.0f / gn, 1.0f / clip) : 1.0f);
+    scal[2] = bad ? 1.0f : 0.0f;
+  }
+}
+
+__global__ void adagrad_multi_kernel(MultiTensor mt, const float *scal, float lr) {
+  if (scal[2] != 0.0f) return;  // step cancelled (see clip_scale_multi_kernel)
+  float *w = mt.w[blockIdx.y], *accum = mt.slot[blockIdx.y];
+  const float *grad = mt.grad[blockIdx.y];
+  const int64_t n = mt.count[blockIdx.y];
+  const float sc = scal[1];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float g = grad[i] * sc;
+    const float ac = accum[i] + g * g;
+    accum[i] = ac;
+    w[i] -= lr * g / sqrtf(ac);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host-side launchers
+hipError_t launch_sumsq_multi(const MultiTensor &mt, float *part, int nblocks, hipStream_t st) {
+  if (mt.n == 0) return hipSuccess;
+  hipLaunchKernelGGL(sumsq_multi_kernel, dim3(nblocks, mt.n), dim3(256), 0, st, mt, part);
+  return hipGetLastError();
+}
+hipError_t launch_clip_scale_multi(const float *part, int n, const float *extra, float clip, const int32_t *err, float *scal,
+                                   hipStream_t st) {
+  hipLaunchKernelGGL(clip_scale_multi_kernel, dim3(1), dim3(256), 0, st, part, n, extra, clip, err, scal);
+  return hipGetLastError();
+}
+hipError_t launch_adagrad_multi(const MultiTensor &mt, const float *scal, float lr, hipStream_t st) {
+  if (mt.n == 0) return hipSuccess;
+  int64_t mx = 0;
+  for (int i = 0; i < mt.n; ++i) mx = mt.count[i] > mx ? mt.count[i] : mx;
+  const int bx = (int)((mx + 255) / 256 < 1024 ? (mx + 255) / 256 : 1024);
+  hipLaunchKernelGGL(adagrad_multi_kernel, dim3(bx, mt.n), dim3(256), 0, st, mt, scal, lr);
+  return hipGetLastError();
+}
+
 static inline int gridn(int64_t n, int cap = 4096) { return (int)((n + 255) / 256 < cap ? (n + 255) / 256 : cap); }
 
 hipError_t launch_loss(const float *src_raw, const float *tgt_raw, const float *labels, float *d_src, float *d_tgt,
