@@ -24,7 +24,8 @@
  *   - the internal mutex serialises the HOST side only: the *_dev entry points enqueue on the stream they are given
  *     and share the handle's packed-weight and scratch buffers, so ONE handle must be driven from ONE stream (or the
  *     caller orders its streams with events); create one handle per stream for concurrent device-side use.  The
- *     host-buffer entry points use the null stream and synchronise before returning.
+ *     host-buffer entry points use the null stream and synchronise before returning; the train step runs on the
+ *     stream set with sse_set_stream (default: the null stream).
  */
 #ifndef SSE_HIP_H
 #define SSE_HIP_H
@@ -99,7 +100,10 @@ int sse_encode_dev(sse_handle *h, int side, const int32_t *ids_dev, int32_t B, i
  * candidates on the device before anything reaches the float64 brute force.  0 = fp32 candidates only.
  * "lstm_persist_rows" (default 32): encodes of at most this many rows (<= 32) run on a cluster of workgroups that keeps
  * the LSTM kernel matrix in LDS and exchanges h_t every step (single query 0.13 ms at H = 256, T = 32); bit-identical
- * to the other kernels; used only when the device has at least 2 x 8 x 16 CUs.  0 disables.
+ * to the other kernels; used only when the device has at least 2 x 8 x 16 CUs.  0 disables.  The cluster's workgroups
+ * must be resident together: when one does not arrive within a bounded spin (device busy with other work) the
+ * host-buffer entry points re-run the batch on the few-sequences kernel (counter "lstm_persist_fallbacks");
+ * sse_encode_dev reports the condition through sse_synchronize.
  * "lstm_x3" (default 0): inference encodes of more than lstm_small_rows rows (cell sizes 64 .. 256, embedding < 64) run
  * their gate GEMMs as three bf16 MFMAs per product on hi + lo split fp32 operands (x = bf16(x) + bf16(x - bf16(x))):
  * NOT bit-identical to the fp32 path, ~2e-6 from it on normalised encodings, 2.2 - 2.9x faster.
@@ -119,7 +123,8 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value);
  * its certificate and were re-run with fp32 candidates.  "score_collect_queries": queries served by the collect path
  * (k > 16, or a k-th score tied with rows outside the candidate lists: one more grid-wide sweep gathers every row that
  * can be in the exact top-k).  "score_bruteforce_queries": queries that fell through to the one-workgroup-per-query
- * float64 sweep (k > 1024, or more than 4096 rows within the fp32 bound of the k-th score). */
+ * float64 sweep (k > 1024, or more than 4096 rows within the fp32 bound of the k-th score).
+ * "lstm_persist_fallbacks": host-buffer encodes re-run on the few-sequences kernel (see option lstm_persist_rows). */
 int sse_get_counter(sse_handle *h, const char *name, int64_t *value);
 
 /* tf.nn.l2_normalize(x, dim=-1) on device rows (sse_model.py:282-283). */
@@ -188,6 +193,13 @@ int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tg
  * the buffer (e.g. a torch tensor handed to torch.distributed.all_reduce);
  * NULL returns to a library-owned one.  sse_train_step == grads(rows_global =
  * B) + apply. */
+/* The stream the train-step entry points (sse_train_step[_rows], sse_train_grads[_rows], sse_train_apply) enqueue on;
+ * NULL (the default) is the null stream.  The two encoders of a step run on internal side streams forked from and joined
+ * to this stream, so a caller that orders other work against it (torch.distributed orders a collective against torch's
+ * current stream: data_parallel.py hands that stream over) needs no further synchronisation.  The call waits for the
+ * previously set stream to drain.  The other entry points take their stream per call (*_dev) or use the null stream and
+ * synchronise before returning (host buffers). */
+int sse_set_stream(sse_handle *h, void *stream);
 int sse_train_grad_count(sse_handle *h, int64_t *count);
 int sse_train_set_grad_arena(sse_handle *h, float *arena_dev, int64_t count);
 int sse_train_grads(sse_handle *h, const int32_t *src_ids_host, const int32_t *tgt_ids_host,
@@ -236,6 +248,10 @@ int64_t sse_format_rows_stride(int32_t S);
 int sse_format_rows_f32(const float *rows, int64_t n_rows, int32_t S, char *out, int64_t *lengths);
 int sse_parse_rows_f64(const char *text, const int64_t *offsets, int64_t n_rows, int32_t S, double *out,
                        int64_t *bad_row);
+/* CRC-32C (Castagnoli) of n bytes, host only: the checksum TensorFlow V2 checkpoints carry per table block and per
+ * tensor (saver.restore of a reference-trained model directory, sse_train.py:110-113: tf_checkpoint.py verifies them).
+ * seed = 0 for a fresh sum, or the value returned for the preceding bytes. */
+uint32_t sse_crc32c(const void *data, int64_t n, uint32_t seed);
 
 #ifdef __cplusplus
 }

@@ -49,6 +49,7 @@ SYMBOLS = {
     "sse_merge_topk_dev": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "sse_merge_topk_strided_dev": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "sse_train_step": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "sse_set_stream": (C.c_int, [_P, _P]),
     "sse_train_grad_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "sse_train_set_grad_arena": (C.c_int, [_P, _P, C.c_int64]),
     "sse_train_grads": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int64]),
@@ -67,6 +68,7 @@ SYMBOLS = {
     "sse_format_rows_stride": (C.c_int64, [C.c_int32]),
     "sse_format_rows_f32": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P]),
     "sse_parse_rows_f64": (C.c_int, [C.c_char_p, _P, C.c_int64, C.c_int32, _P, C.POINTER(C.c_int64)]),
+    "sse_crc32c": (C.c_uint32, [_P, C.c_int64, C.c_uint32]),
 }
 
 _lib = None
@@ -247,6 +249,19 @@ class Handle(object):
         if table != (t.ndim == 1):
             raise ValueError("source-encoder-only / source_only_cnn train on [B] target-matrix rows, "
                              "dual- and shared-encoder on [B,T] target token ids")
+
+    def embedding_slice(self):
+        """(offset, V, E) of the dense word_embedding gradient inside the gradient arena (variable 0 comes first)."""
+        return 0, int(self.cfg.vocab_size), int(self.cfg.embedding_size)
+
+    @property
+    def max_seq_length(self):
+        return int(self.cfg.max_seq_length)
+
+    def set_stream(self, stream=0):
+        """The stream (hipStream_t as int; 0 = null stream) the train-step entry points enqueue on."""
+        self.check(self.lib.sse_set_stream(self._h, C.c_void_p(stream) if stream else None))
+        self._stream = int(stream or 0)
 
     def train_step(self, src_ids, tgt_ids, labels):
         s, t, z = self._train_batch(src_ids, tgt_ids, labels)

@@ -9,6 +9,7 @@
 //           with a two-digit exponent; the shortest digits come from std::to_chars (Ryu);
 //   parse:  correctly rounded decimal -> float64, as Python's float().
 // Rows are independent: both directions split the rows over std::threads.
+#include <mutex>
 #include <algorithm>
 #include <charconv>
 #include <cmath>
@@ -162,6 +163,37 @@ int sse_parse_rows_f64(const char *text, const int64_t *offsets, int64_t n_rows,
     }
   if (bad_row) *bad_row = first_bad;
   return first_bad >= 0 ? 2 : 0;
+}
+
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) of a byte range, slicing-by-8: the checksum of LevelDB table
+// blocks and of tensor bytes in TensorFlow V2 checkpoints (tf_checkpoint.py verifies both; a pure-Python loop takes
+// seconds per embedding table).  `seed` chains calls (0 for a fresh sum).
+uint32_t sse_crc32c(const void *data, int64_t n, uint32_t seed) {
+  static uint32_t tab[8][256];
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+      tab[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) tab[t][i] = (tab[t - 1][i] >> 8) ^ tab[0][tab[t - 1][i] & 0xFF];
+  });
+  const unsigned char *p = (const unsigned char *)data;
+  uint32_t crc = ~seed;
+  while (n >= 8) {
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4);
+    memcpy(&hi, p + 4, 4);
+    lo ^= crc;
+    crc = tab[7][lo & 0xFF] ^ tab[6][(lo >> 8) & 0xFF] ^ tab[5][(lo >> 16) & 0xFF] ^ tab[4][lo >> 24] ^ tab[3][hi & 0xFF] ^
+          tab[2][(hi >> 8) & 0xFF] ^ tab[1][(hi >> 16) & 0xFF] ^ tab[0][hi >> 24];
+    p += 8;
+    n -= 8;
+  }
+  while (n-- > 0) crc = tab[0][(crc ^ *p++) & 0xFF] ^ (crc >> 8);
+  return ~crc;
 }
 
 }  // extern "C"

@@ -163,7 +163,12 @@ __global__ __launch_bounds__(LP_NT) void lstm_persist_kernel(LstmPersistArgs a) 
   const float *vrow = av + (size_t)(lane_on ? lb : 0) * KAp;
   __syncthreads();
 
-  for (int t = t0; t < T; ++t) {
+  // A workgroup that owns no hidden unit (H not a multiple of UW: e.g. H = 40, NWG = 16 leaves p = 14, 15 empty) publishes
+  // nothing, so nobody ever waits for it -- and the two-buffer argument above ("whoever writes step t+2 has seen every
+  // workgroup's step t+1") does not cover its READS: lagging behind, it would find tag t+2 where it expects t.  It has no
+  // use for h_t before the projection, so it skips the steps and picks up h_T (the last write into its buffer) below.
+  const bool bystander = nu == 0;
+  for (int t = bystander ? T : t0; t < T; ++t) {
     // ---- gate pre-activation of (gate wv, sequence lb, unit lu): the matrix path's fma chain
     float acc = 0.0f;
 #pragma unroll 4
@@ -229,6 +234,15 @@ __global__ __launch_bounds__(LP_NT) void lstm_persist_kernel(LstmPersistArgs a) 
 
   // ---- projection: this workgroup's columns [s0, s0 + ns) of out = h_T . M, in the matrix path's k order
   const int s0 = p * SW, ns = max(0, min(SW, S - s0));
+  if (bystander) {
+    if (ns == 0 && p != 0) return;
+    const unsigned long long *src = hx + (size_t)(T & 1) * LP_RB * H;
+    for (int i = tid; i < nb * H; i += LP_NT) {
+      const int b = i / H, unit = i - b * H;
+      av[b * KAp + KX + unit] = lp_await(src + i, epoch | (unsigned)T, a.err);
+    }
+    __syncthreads();
+  }
   float *Ml = Wl;  // [H][SW]: the weight columns are no longer needed (region sized for both)
   for (int i = tid; i < H * SW; i += LP_NT) {
     const int k = i / SW, j = i - k * SW;

@@ -109,6 +109,9 @@ struct sse_handle {
   bool emb16_valid = false;
   int lstm_persist_rows = 32; // option "lstm_persist_rows": batches up to this many rows (<= 32) take the weights-in-LDS cluster kernel
   uint32_t persist_epoch = 0; // tag epoch of the cluster kernel's exchange buffers
+  hipStream_t stream = nullptr;  // sse_set_stream: the stream the train-step entry points enqueue on (default: the null stream)
+  bool persist_inject = false;   // testing aid (option lstm_persist_inject_miss): report a missing cluster workgroup after every cluster launch
+  int64_t persist_fallbacks = 0; // host-buffer encodes re-run on lstm_small because a cluster workgroup did not arrive
   int cu_count = 0;           // compute units of the device (co-residency check of the cluster kernel)
   int lstm_small_rows = 1024; // option "lstm_small_rows": batches up to this many rows take the few-sequences LSTM kernel
   bool score_bf16 = true;    // option "score_bf16" (default on): candidate pass on the bf16 matrix pipe; results stay exact
@@ -140,6 +143,8 @@ struct sse_handle {
   DevBuf s_ids, s_out, s_q, s_qp, s_ps, s_pi, s_cert, s_os, s_oi, s_tmp, s_tmp2, s_feat, s_zero, s_map;
   DevBuf s_qp32, s_fb_cnt;  // fp32 second chance of the bf16 candidate pass: fp32 query fragments, counter
   DevBuf s_persist;  // lstm_persist.hip: h_t / raw-encoding exchange buffers and arrival counters
+  void *pin = nullptr;  // pinned host staging of the host-buffer scoring entry points: [scores | ids | certificates]
+  size_t pin_cap = 0;
   DevBuf s_pb, s_cthr, s_cslot, s_ccnt, s_cbuf;  // per-split bounds; collect path: thresholds, slots, counters, row buffers
   const int32_t *cur_row_map = nullptr;  // set by sse_encode around its launch
   // training
@@ -503,6 +508,10 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
       pa.hx = (unsigned long long *)h->s_persist.p;
       pa.rawx = pa.hx + nhx;
       HIPCHECK(h, launch_lstm_persist(pa, st));
+      if (h->persist_inject) {  // testing aid: pretend a workgroup of the cluster never arrived
+        static const int32_t four = 4;
+        HIPCHECK(h, hipMemcpyAsync(h->err_flag, &four, sizeof four, hipMemcpyHostToDevice, st));
+      }
       return 0;
     }
   }
@@ -605,16 +614,21 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
   return 0;
 }
 
-int check_err_flag(sse_handle *h, hipStream_t st) {
+// bits: (optional) receives the raw flag; a flag that is exactly bit 2 (cluster kernel: a workgroup did not arrive) is then
+// cleared and reported through *bits with rc 0, so that the caller can re-run the batch on another kernel
+int check_err_flag(sse_handle *h, hipStream_t st, int32_t *bits = nullptr) {
   int32_t flag = 0;
   HIPCHECK(h, hipMemcpyAsync(&flag, h->err_flag, sizeof flag, hipMemcpyDeviceToHost, st));
   HIPCHECK(h, hipStreamSynchronize(st));
+  if (bits) *bits = flag;
   if (flag) {
     HIPCHECK(h, hipMemsetAsync(h->err_flag, 0, sizeof(int32_t), st));
+    if (bits && flag == 4) return 0;
     if (flag & 1) return fail(h, "token id out of range [0, %d) (tf.gather would raise; sse_model.py:163-164)", h->cfg.vocab_size);
     if (flag & 2) return fail(h, "corpus row out of range in a train step by rows");
-    if (flag & 4) return fail(h, "LSTM cluster kernel: a workgroup of a cluster did not arrive (device oversubscribed?); "
-                                 "set option lstm_persist_rows to 0");
+    if (flag & 4) return fail(h, "LSTM cluster kernel: a workgroup of a cluster did not arrive (device oversubscribed?); the "
+                                 "host-buffer entry points fall back to the few-sequences kernel by themselves, for "
+                                 "sse_encode_dev set option lstm_persist_rows to 0");
     return fail(h, "device error flag 0x%x", flag);
   }
   return 0;
@@ -770,11 +784,21 @@ static int score_select_locked(sse_handle *h, const float *q, int Q, int k, doub
   return 0;
 }
 
-int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s, int64_t *out_i, hipStream_t st) {
+// phase: SCORE_ALL queues every stage (the asynchronous *_dev entry point: no host sync, the follow-up stages return at once
+// when every query is certified).  The host-buffer entry points split the call: SCORE_FIRST = candidate sweep + float64
+// re-scoring (results and certificates final for every certified query), then -- only if the certificates they read back
+// with the results say so -- SCORE_REST = second chance / collect / select / brute force: the common call saves five to nine
+// empty launches (~4.5 us each: a third of a single-query call, profiles/r02z_demo_kernel_stats.csv).
+enum { SCORE_ALL = 0, SCORE_FIRST = 1, SCORE_REST = 2 };
+// *split (out, may be null): 1 when the call has a FIRST / REST split (k <= 16), 0 when SCORE_FIRST did everything
+int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s, int64_t *out_i, hipStream_t st,
+                     int phase = SCORE_ALL, int *split = nullptr) {
+  if (split) *split = 0;
   if (!h->idxp) return fail(h, "no index uploaded");
   if (Q < 0) return fail(h, "bad Q");
   if (Q == 0) return 0;
   if (k < 1 || k > h->idx_N) return fail(h, "k=%d must be in [1, N=%lld]", k, (long long)h->idx_N);
+  if ((k > 16) && phase == SCORE_REST) return 0;
   if (k > SSE_MAX_SELECT_K) {
     // beyond the collect path's buffers: exact float64 paging (correct for any k <= N, one workgroup per query)
     HIPCHECK(h, launch_exact_topk(q, h->idxp, h->idx64, nullptr, out_s, out_i, h->idx_base, h->idx_N, Q, h->idx_S, k, st));
@@ -819,8 +843,12 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   if (reserve(h, h->s_pb, (size_t)Q * nsplit * sizeof(float))) return 1;
   if (reserve(h, h->s_cert, (size_t)Q * sizeof(int32_t))) return 1;
   if (reserve_collect(h, Q, POOL)) return 1;
-  if (bf) HIPCHECK(h, launch_pack_rows_bf16(q, Q, S, h->s_qp.p, st));
-  else HIPCHECK(h, launch_pack_rows(q, Q, S, (float *)h->s_qp.p, st));
+  if (split) *split = 1;
+  const bool first = phase != SCORE_REST, rest = phase != SCORE_FIRST;
+  if (first) {
+    if (bf) HIPCHECK(h, launch_pack_rows_bf16(q, Q, S, h->s_qp.p, st));
+    else HIPCHECK(h, launch_pack_rows(q, Q, S, (float *)h->s_qp.p, st));
+  }
   ScoreArgs a;
   a.BF = bf ? 1 : 0;
   a.idxp = bf ? (const float *)h->idxp16 : h->idxp;
@@ -836,7 +864,7 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   a.NSPLIT = nsplit;
   a.KC = 16;
   a.NQ = NQ;
-  HIPCHECK(h, launch_score_topk(a, st));
+  if (first) HIPCHECK(h, launch_score_topk(a, st));
   RescoreArgs r;
   r.q = q;
   r.idx32 = h->idxp;
@@ -860,7 +888,8 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   r.col_thr = (float *)h->s_cthr.p;
   // bf16 operands: |q^.t^ - q.t| <= ((1+u)^2 - 1) sum|q_i t_i| <= (2^-8 + 2^-18) |q||t|, u = 2^-9 (round to nearest)
   if (bf) r.eps += (float)(1.02 * (1.0 / 256.0 + 1.0 / 262144.0) * h->idx_norm_max);
-  HIPCHECK(h, launch_rescore(r, st));
+  if (first) HIPCHECK(h, launch_rescore(r, st));
+  if (!rest) return 0;
   const float *qp32 = (const float *)h->s_qp.p;  // fp32 query fragments for the collect sweep
   if (bf) {
     // Second chance, entirely on the device (the call stays asynchronous): queries whose bf16-candidate result missed
@@ -1013,6 +1042,7 @@ void sse_destroy(sse_handle *h) {
     }
     if (e.Mp) hipFree(e.Mp);
   }
+  if (h->pin) (void)hipHostFree(h->pin);
   if (h->emb_pad) hipFree(h->emb_pad);
   if (h->emb16) (void)hipFree(h->emb16);
   if (h->err_flag) hipFree(h->err_flag);
@@ -1122,10 +1152,25 @@ static int encode_host_ids_locked(sse_handle *h, int side, const int32_t *ids_ho
   }
   HIPCHECK(h, hipMemcpyAsync(h->s_ids.p, ids_host, (size_t)B * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
   h->cur_row_map = row_map_dev;
-  const int rc = encode_dev_locked(h, side, (const int32_t *)h->s_ids.p, B, T, normalize, (float *)h->s_out.p, st);
+  int rc = encode_dev_locked(h, side, (const int32_t *)h->s_ids.p, B, T, normalize, (float *)h->s_out.p, st);
   h->cur_row_map = nullptr;
   if (rc) return 1;
-  return check_err_flag(h, st);
+  int32_t bits = 0;
+  if (check_err_flag(h, st, &bits)) return 1;
+  if (bits == 4) {
+    // the cluster kernel needs its 16 - 32 workgroups per cluster resident together; a device busy with other work (a
+    // train step on another handle, four serving routes at once) can keep one from arriving within the bounded spin.
+    // Nothing was written that the other kernels do not overwrite: run the batch again on the few-sequences kernel
+    // (bit-identical results) and count it.
+    h->persist_fallbacks += 1;
+    const int keep = h->lstm_persist_rows;
+    h->lstm_persist_rows = 0;
+    rc = encode_dev_locked(h, side, (const int32_t *)h->s_ids.p, B, T, normalize, (float *)h->s_out.p, st);
+    h->lstm_persist_rows = keep;
+    if (rc) return 1;
+    return check_err_flag(h, st);
+  }
+  return 0;
 }
 
 int sse_encode(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int32_t T, int32_t normalize,
@@ -1140,6 +1185,42 @@ int sse_encode(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int3
   return 0;
 }
 
+// Scores + ids of Q queries (device rows q_dev) into host buffers: first phase, ONE pinned read-back of [scores | ids |
+// certificates] with one synchronisation, and the follow-up stages only when some query is not certified.
+static int score_to_host_locked(sse_handle *h, const float *q_dev, int Q, int k, double *out_scores, int64_t *out_ids) {
+  hipStream_t st = nullptr;
+  if (reserve(h, h->s_os, (size_t)Q * k * sizeof(double))) return 1;
+  if (reserve(h, h->s_oi, (size_t)Q * k * sizeof(int64_t))) return 1;
+  const size_t nb = (size_t)Q * k * 8, need = 2 * nb + (size_t)Q * sizeof(int32_t);
+  if (need > h->pin_cap) {
+    if (h->pin) HIPCHECK(h, hipHostFree(h->pin));
+    h->pin = nullptr;
+    h->pin_cap = 0;
+    HIPCHECK(h, hipHostMalloc(&h->pin, need + need / 2 + 4096, hipHostMallocDefault));
+    h->pin_cap = need + need / 2 + 4096;
+  }
+  char *pin = (char *)h->pin;
+  int split = 0;
+  if (score_dev_locked(h, q_dev, Q, k, (double *)h->s_os.p, (int64_t *)h->s_oi.p, st, SCORE_FIRST, &split)) return 1;
+  for (int pass = 0; pass < 2; ++pass) {
+    HIPCHECK(h, hipMemcpyAsync(pin, h->s_os.p, nb, hipMemcpyDeviceToHost, st));
+    HIPCHECK(h, hipMemcpyAsync(pin + nb, h->s_oi.p, nb, hipMemcpyDeviceToHost, st));
+    if (split && pass == 0) HIPCHECK(h, hipMemcpyAsync(pin + 2 * nb, h->s_cert.p, (size_t)Q * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHECK(h, hipStreamSynchronize(st));
+    bool open_q = false;
+    if (split && pass == 0) {
+      const int32_t *cert = (const int32_t *)(pin + 2 * nb);
+      for (int i = 0; i < Q && !open_q; ++i) open_q = cert[i] == 0;
+    }
+    if (!open_q) break;
+    // rare: ties / near-ties at the k-th score, or scores packed closer than the bf16 bound
+    if (score_dev_locked(h, q_dev, Q, k, (double *)h->s_os.p, (int64_t *)h->s_oi.p, st, SCORE_REST)) return 1;
+  }
+  memcpy(out_scores, pin, nb);
+  memcpy(out_ids, pin + nb, nb);
+  return 0;
+}
+
 int sse_encode_score_topk(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int32_t T, int32_t normalize,
                           int32_t k, double *out_scores, int64_t *out_ids, float *enc_out_host) {
   if (!h) return 1;
@@ -1151,12 +1232,8 @@ int sse_encode_score_topk(sse_handle *h, int side, const int32_t *ids_host, int3
   if (h->cfg.encoding_size != h->idx_S)
     return fail(h, "index dimension %d != encoding_size %d", h->idx_S, h->cfg.encoding_size);
   if (encode_host_ids_locked(h, side, ids_host, B, T, normalize)) return 1;
-  if (reserve(h, h->s_os, (size_t)B * k * sizeof(double))) return 1;
-  if (reserve(h, h->s_oi, (size_t)B * k * sizeof(int64_t))) return 1;
   // the encodings never leave the device between the encoder and the scorer
-  if (score_dev_locked(h, (const float *)h->s_out.p, B, k, (double *)h->s_os.p, (int64_t *)h->s_oi.p, nullptr)) return 1;
-  HIPCHECK(h, hipMemcpy(out_scores, h->s_os.p, (size_t)B * k * sizeof(double), hipMemcpyDeviceToHost));
-  HIPCHECK(h, hipMemcpy(out_ids, h->s_oi.p, (size_t)B * k * sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (score_to_host_locked(h, (const float *)h->s_out.p, B, k, out_scores, out_ids)) return 1;
   if (enc_out_host)
     HIPCHECK(h, hipMemcpy(enc_out_host, h->s_out.p, (size_t)B * h->cfg.encoding_size * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
@@ -1165,6 +1242,10 @@ int sse_encode_score_topk(sse_handle *h, int side, const int32_t *ids_host, int3
 int sse_get_counter(sse_handle *h, const char *name, int64_t *value) {
   if (!h || !name || !value) return 1;
   std::lock_guard<std::mutex> lk(h->mu);
+  if (strcmp(name, "lstm_persist_fallbacks") == 0) {
+    *value = h->persist_fallbacks;
+    return 0;
+  }
   static const char *const names[3] = {"score_bf16_second_chance_queries", "score_collect_queries", "score_bruteforce_queries"};
   for (int i = 0; i < 3; ++i) {
     if (strcmp(name, names[i]) != 0) continue;
@@ -1230,6 +1311,10 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value) {
   if (strcmp(name, "lstm_persist_epoch") == 0) {  // testing aid: move the cluster kernel's 20-bit tag epoch (wrap-around path)
     if (value < 0 || value >= (1 << 20)) return fail(h, "lstm_persist_epoch must be in [0, 2^20)");
     h->persist_epoch = (uint32_t)value;
+    return 0;
+  }
+  if (strcmp(name, "lstm_persist_inject_miss") == 0) {  // testing aid for the fallback path of the host-buffer encodes
+    h->persist_inject = value != 0;
     return 0;
   }
   if (strcmp(name, "lstm_persist_rows") == 0) {
@@ -1311,13 +1396,8 @@ int sse_score_topk(sse_handle *h, const float *q_host, int32_t Q, int32_t k, dou
   if (!h->idxp) return fail(h, "no index uploaded");
   const size_t S = h->idx_S;
   if (reserve(h, h->s_q, (size_t)Q * S * sizeof(float))) return 1;
-  if (reserve(h, h->s_os, (size_t)Q * k * sizeof(double))) return 1;
-  if (reserve(h, h->s_oi, (size_t)Q * k * sizeof(int64_t))) return 1;
   HIPCHECK(h, hipMemcpy(h->s_q.p, q_host, (size_t)Q * S * sizeof(float), hipMemcpyHostToDevice));
-  if (score_dev_locked(h, (const float *)h->s_q.p, Q, k, (double *)h->s_os.p, (int64_t *)h->s_oi.p, nullptr)) return 1;
-  HIPCHECK(h, hipMemcpy(out_scores, h->s_os.p, (size_t)Q * k * sizeof(double), hipMemcpyDeviceToHost));
-  HIPCHECK(h, hipMemcpy(out_ids, h->s_oi.p, (size_t)Q * k * sizeof(int64_t), hipMemcpyDeviceToHost));
-  return 0;
+  return score_to_host_locked(h, (const float *)h->s_q.p, Q, k, out_scores, out_ids);
 }
 
 int sse_merge_topk_strided_dev(sse_handle *h, const double *in_scores_dev, const int64_t *in_ids_dev, int64_t shard_stride,
@@ -1429,7 +1509,7 @@ static int stage_ids(sse_handle *h, TrainState &ts, int side, const int32_t *hos
 static int cnn_train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const int32_t *tgt_rows_host,
                                   const float *labels_host, int32_t B, int32_t T, int64_t rows_global) {
   const sse_config &c = h->cfg;
-  hipStream_t st = nullptr;
+  hipStream_t st = h->stream;
   TrainState &ts = *h->train;
   const int E = c.embedding_size, S = c.encoding_size, V = c.vocab_size, Ep = emb_cols(c);
   const int Bp = round_up(B, 64);
@@ -1524,7 +1604,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   // tgt_ids_host is int32 [B] rows of the free target matrix.  nside = sequence encoders in the step.
   const bool table_tgt = c.network_mode == SSE_MODE_SOURCE_ENCODER_ONLY;
   const int nside = table_tgt ? 1 : 2;
-  hipStream_t st = nullptr;
+  hipStream_t st = h->stream;
   TrainState &ts = *h->train;
   if (!ts.side[0]) {
     for (int s = 0; s < 2; ++s) {
@@ -1815,7 +1895,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
 static int train_apply_locked(sse_handle *h, float *loss, float *train_acc) {
   if (!h->train || !h->train->grads_ready) return fail(h, "train apply: no gradients pending (call sse_train_grads first)");
   TrainState &ts = *h->train;
-  hipStream_t st = nullptr;
+  hipStream_t st = h->stream;
   const int NORM_BLOCKS = 64;
   float *tail = ts.arena + grad_arena_count(h) - 4;
   if (reserve(h, ts.scal, 4 * sizeof(float))) return 1;
@@ -1956,6 +2036,15 @@ int sse_get_global_step(sse_handle *h, int64_t *step) {
 int sse_set_global_step(sse_handle *h, int64_t step) {
   if (!h) return 1;
   h->global_step = step;
+  return 0;
+}
+
+int sse_set_stream(sse_handle *h, void *stream) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  HIPCHECK(h, hipStreamSynchronize(h->stream));  // nothing of an earlier step may still be in flight on the old stream
+  h->stream = (hipStream_t)stream;
   return 0;
 }
 

@@ -14,12 +14,21 @@ torch / torch.distributed are plumbing only.
 
 
 class DataParallelTrainer(object):
-    def __init__(self, engine, device=None, group=None, always_reduce=False):
-        """always_reduce: issue the collective even in a 1-rank group (exercises the RCCL path on one GPU)."""
+    def __init__(self, engine, device=None, group=None, always_reduce=False, sparse_embedding=None):
+        """always_reduce: issue the collective even in a 1-rank group (exercises the RCCL path on one GPU).
+        sparse_embedding: exchange the word-embedding gradient as (row id, gradient row) pairs -- SURVEY 8e's shape for
+        large vocabularies (the 1M-title ranking vocabulary, reference README.md:116) -- instead of all-reducing the
+        dense [V,E] block; None = automatic (sparse when a step touches fewer than V/4 rows: 2 * rows * T < V / 4)."""
         import torch
         self.engine, self.group, self.always_reduce = engine, group, bool(always_reduce)
+        self.sparse_embedding = sparse_embedding
         self.arena = torch.zeros(engine.train_grad_count(), dtype=torch.float32, device=device or "cpu")
         engine.train_bind_arena(self.arena)
+        self._stream = None
+        # where the dense word_embedding gradient sits in the arena: (offset, V, E); the HIP handle keeps it first
+        sl = getattr(engine, "embedding_slice", None)
+        self.emb_slice = tuple(sl()) if sl is not None else None
+        self.last_exchange = None          # "dense" | "sparse": what the last step put on the wire (tests, bench)
 
     @property
     def world(self):
@@ -43,10 +52,13 @@ class DataParallelTrainer(object):
         by_rows: src_ids / tgt_ids are row numbers into the corpora uploaded with engine.corpus_upload."""
         import torch
         import torch.distributed as dist
-        if self.arena.is_cuda and torch.cuda.current_stream(self.arena.device) != torch.cuda.default_stream(self.arena.device):
-            # the train step runs on the library's own streams forked from / joined to the null stream, and
-            # torch.distributed orders the all-reduce against torch's CURRENT stream: they must be the same one
-            raise RuntimeError("DataParallelTrainer.train_step must be called with the default CUDA stream current")
+        if self.arena.is_cuda and hasattr(self.engine, "set_stream"):
+            # the train step runs on the library's own streams forked from / joined to ONE stream, and torch.distributed
+            # orders the collective against torch's CURRENT stream: hand that stream to the library (sse_set_stream)
+            cur = torch.cuda.current_stream(self.arena.device).cuda_stream
+            if cur != self._stream:
+                self.engine.set_stream(cur)
+                self._stream = cur
         if rows_global is None:
             rows_global = self.global_rows(len(labels))
         if by_rows:
@@ -54,8 +66,57 @@ class DataParallelTrainer(object):
         else:
             self.engine.train_grads(src_ids, tgt_ids, labels, rows_global)
         if self.world > 1 or self.always_reduce:
-            dist.all_reduce(self.arena, group=self.group)          # ONE collective per step (sum)
+            if self._use_sparse(len(labels), src_ids, by_rows):
+                self._exchange_sparse()
+            else:
+                dist.all_reduce(self.arena, group=self.group)      # ONE collective per step (sum)
+                self.last_exchange = "dense"
         return self.engine.train_apply()
+
+    # ---- (row id, gradient row) exchange of the embedding gradient (SURVEY 8e "Training") ----------------------------
+    def _use_sparse(self, rows, src_ids, by_rows):
+        if self.emb_slice is None or self.sparse_embedding is False:
+            return False
+        if self.sparse_embedding:
+            return True
+        V = self.emb_slice[1]
+        T = getattr(self.engine, "max_seq_length", None)
+        if T is None:
+            import numpy as np
+            T = 1 if by_rows else int(np.asarray(src_ids).shape[-1])
+        return 2 * int(rows) * int(T) * self.world < V // 4
+
+    def _exchange_sparse(self):
+        """Same sums as the dense all-reduce: the dense variables and the tail go through one all-reduce of the arena
+        BEHIND the embedding block; the embedding block travels as the rows this rank touched (rows with any non-zero
+        gradient), all-gathered with their ids and scatter-added into a zeroed block on every rank."""
+        import torch
+        import torch.distributed as dist
+        off, V, E = self.emb_slice
+        emb = self.arena[off:off + V * E].view(V, E)
+        works = [dist.all_reduce(part, group=self.group, async_op=True)          # everything but the embedding block
+                 for part in (self.arena[:off], self.arena[off + V * E:]) if part.numel()]
+        ids = torch.nonzero((emb != 0).any(dim=1)).flatten()
+        n = torch.tensor([ids.numel()], dtype=torch.int64, device=emb.device)
+        counts = [torch.zeros_like(n) for _ in range(self.world)]
+        dist.all_gather(counts, n, group=self.group)
+        nmax = max(1, int(max(c.item() for c in counts)))
+        pad_ids = torch.full((nmax,), V, dtype=torch.int64, device=emb.device)       # V = "no row"
+        pad_rows = torch.zeros((nmax, E), dtype=torch.float32, device=emb.device)
+        pad_ids[:ids.numel()] = ids
+        pad_rows[:ids.numel()] = emb[ids]
+        all_ids = [torch.empty_like(pad_ids) for _ in range(self.world)]
+        all_rows = [torch.empty_like(pad_rows) for _ in range(self.world)]
+        dist.all_gather(all_ids, pad_ids, group=self.group)
+        dist.all_gather(all_rows, pad_rows, group=self.group)
+        emb.zero_()
+        buf = torch.zeros((V + 1, E), dtype=torch.float32, device=emb.device)
+        for r in range(self.world):                                   # fixed rank order: the same sum on every rank
+            buf.index_add_(0, all_ids[r], all_rows[r])
+        emb.copy_(buf[:V])
+        for w in works:
+            w.wait()
+        self.last_exchange = "sparse"
 
 
 def split_batch(src_ids, tgt_ids, labels, rank, world):

@@ -45,6 +45,7 @@ class Saver(object):
         self.model = model
         self.max_to_keep = max_to_keep
         self._kept = []
+        self.restored_from = None       # the file the last restore() read (.npz of this library, or a TensorFlow .index)
 
     def save(self, session, path, global_step=None):
         if global_step is not None:
@@ -73,10 +74,18 @@ class Saver(object):
         names) is read by tf_checkpoint.read_bundle -- no TensorFlow needed."""
         from . import tf_checkpoint
         npz = path if path.endswith(".npz") else path + ".npz"
-        if os.path.exists(npz):
+        has_tf = (not path.endswith(".npz")) and tf_checkpoint.is_tf_checkpoint(path)
+        if os.path.exists(npz) and has_tf and os.path.getmtime(path + ".index") > os.path.getmtime(npz):
+            # a converted .npz left behind by an earlier run must not shadow a checkpoint TensorFlow has re-written since
+            # under the same prefix: the newer file wins
+            self.restored_from = path + ".index"
+            arrays = tf_checkpoint.to_npz_arrays(tf_checkpoint.read_bundle(path))
+        elif os.path.exists(npz):
+            self.restored_from = npz
             z = np.load(npz)
             arrays = {k: z[k] for k in z.files}
-        elif tf_checkpoint.is_tf_checkpoint(path):
+        elif has_tf:
+            self.restored_from = path + ".index"
             arrays = tf_checkpoint.to_npz_arrays(tf_checkpoint.read_bundle(path))
         else:
             raise FileNotFoundError("no checkpoint at %s (.npz, or TensorFlow .index/.data-*)" % path)

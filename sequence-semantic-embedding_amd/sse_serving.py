@@ -17,6 +17,7 @@ import logging
 import os
 import queue
 import threading
+import time
 from urllib.parse import parse_qs
 
 import numpy as np
@@ -98,37 +99,51 @@ class MicroBatcher(object):
         self._t = threading.Thread(target=self._run, daemon=True)
         self._t.start()
 
-    def submit(self, tokens, nbest, normalize):
+    def submit(self, tokens, nbest, normalize, timeout_s=30.0):
         item = {"tokens": tokens, "nbest": nbest, "normalize": normalize, "done": threading.Event()}
         self.q.put(item)
-        item["done"].wait()
+        # never wait forever: a dead worker thread (or a wedged device) must turn into an error response, not a hung request
+        deadline = time.monotonic() + timeout_s
+        while not item["done"].wait(0.25):
+            if not self._t.is_alive():
+                raise RuntimeError("the batching worker thread has died; restart the server")
+            if time.monotonic() > deadline:
+                raise TimeoutError("no answer from the ranking worker within %.0f s" % timeout_s)
         if "error" in item:
             raise item["error"]
         return item["result"]
 
     def _run(self):
         while True:
-            items = [self.q.get()]
+            items = []
             try:
-                while len(items) < self.max_batch:
-                    items.append(self.q.get(timeout=self.max_wait_s))
-            except queue.Empty:
-                pass
-            groups = {}
-            for it in items:
-                groups.setdefault((bool(it["normalize"]), int(it["nbest"])), []).append(it)
-            for (norm, nbest), grp in groups.items():
+                items = [self.q.get()]
                 try:
-                    res = self.ranker.rank([it["tokens"] for it in grp], nbest, norm)
-                    for it, r in zip(grp, res):
-                        it["result"] = r
-                except Exception as e:                       # noqa: BLE001  (delivered to the waiting request)
+                    while len(items) < self.max_batch:
+                        items.append(self.q.get(timeout=self.max_wait_s))
+                except queue.Empty:
+                    pass
+                groups = {}
+                for it in items:
+                    groups.setdefault((bool(it["normalize"]), int(it["nbest"])), []).append(it)
+                for (norm, nbest), grp in groups.items():
+                    try:
+                        res = self.ranker.rank([it["tokens"] for it in grp], nbest, norm)
+                        for it, r in zip(grp, res):
+                            it["result"] = r
+                    except Exception as e:                       # noqa: BLE001  (delivered to the waiting request)
+                        for it in grp:
+                            it["error"] = e
+                    self.batches += 1
+                    self.requests += len(grp)
                     for it in grp:
+                        it["done"].set()
+            except Exception as e:                               # noqa: BLE001
+                # anything else (a malformed item, ...): every request of this wake-up gets the error, the worker lives on
+                for it in items:
+                    if isinstance(it, dict) and "done" in it and not it["done"].is_set():
                         it["error"] = e
-                self.batches += 1
-                self.requests += len(grp)
-                for it in grp:
-                    it["done"].set()
+                        it["done"].set()
 
 
 def handle_request(path, args, rank_fn, tokens_fn):

@@ -15,8 +15,13 @@ restart array, an index block mapping last-keys to block handles, a 48-byte foot
 magic 0xdb4775248b80fb57); every block is followed by a 1-byte compression type and a 4-byte masked CRC.  Key "" holds
 a BundleHeaderProto, every other key a BundleEntryProto {1: dtype, 2: shape {2: dim {1: size}}, 3: shard_id, 4: offset,
 5: size, 6: crc32c}; tensor bytes are raw little-endian at [offset, offset + size) of data shard `shard_id`.
+Every table block's masked CRC-32C (LevelDB: crc32c(block + type byte), rotated right by 15 plus 0xa282ead8) and every
+tensor's masked crc32c (entry field 6) are VERIFIED on read, and `offset + size` is checked against the shard length: a
+truncated or corrupted checkpoint raises instead of loading garbage.  The CRC itself is pinned by the RFC 3720
+known-answer vectors (tests/test_serving_and_checkpoint.py).
 NOT validated against a TensorFlow-written file in the build container (TensorFlow cannot be installed there); the
-unit test round-trips through `write_bundle` below, which follows the same description.  `tools/tf_checkpoint_to_npz.py`
+unit tests round-trip through `write_bundle` below and read a byte-for-byte hand-assembled two-shard fixture
+(tests/golden/tf_bundle/, built by tests/golden/make_tf_bundle_fixture.py from the format description alone).  `tools/tf_checkpoint_to_npz.py`
 is the alternative for a machine that has TensorFlow (`tf.train.load_checkpoint`).  Snappy-compressed blocks (not
 what BundleWriter emits) and V1 single-file checkpoints are rejected with a clear error.
 """
@@ -43,10 +48,18 @@ def _varint(buf, pos):
 
 
 def _read_block(data, offset, size):
+    if offset + size + 5 > len(data):
+        raise ValueError("checkpoint index is truncated: block [%d, %d) + 5-byte trailer exceeds %d bytes"
+                         % (offset, offset + size, len(data)))
     ctype = data[offset + size]
     if ctype != 0:
         raise ValueError("checkpoint index block is compressed (type %d): only uncompressed tensor bundles are "
                          "supported; convert with tools/tf_checkpoint_to_npz.py on a machine with TensorFlow" % ctype)
+    want = struct.unpack_from("<I", data, offset + size + 1)[0]
+    got = _masked_crc(data[offset:offset + size + 1])              # contents + the type byte (table/format.cc)
+    if got != want:
+        raise ValueError("checkpoint index block at offset %d fails its CRC-32C (stored %08x, computed %08x): the file is "
+                         "corrupt" % (offset, want, got))
     return data[offset:offset + size]
 
 
@@ -89,7 +102,7 @@ def _proto_fields(buf):
 
 
 def _parse_entry(buf):
-    e = {"dtype": 0, "shape": [], "shard_id": 0, "offset": 0, "size": 0, "slices": False}
+    e = {"dtype": 0, "shape": [], "shard_id": 0, "offset": 0, "size": 0, "slices": False, "crc32c": None}
     for field, wt, v in _proto_fields(buf):
         if field == 1:
             e["dtype"] = v
@@ -107,6 +120,8 @@ def _parse_entry(buf):
             e["offset"] = v
         elif field == 5:
             e["size"] = v
+        elif field == 6:                                      # fixed32, masked crc32c of the tensor bytes
+            e["crc32c"] = struct.unpack("<I", bytes(v))[0]
         elif field == 7:
             e["slices"] = True
     return e
@@ -154,8 +169,17 @@ def read_bundle(prefix):
         sid = e["shard_id"]
         if sid not in shards:
             shards[sid] = np.memmap("%s.data-%05d-of-%05d" % (prefix, sid, num_shards), dtype=np.uint8, mode="r")
-        raw = shards[sid][e["offset"]:e["offset"] + e["size"]]
-        out[name] = np.frombuffer(bytes(raw), dtype=DTYPES[e["dtype"]]).reshape(e["shape"]).copy()
+        if e["offset"] + e["size"] > shards[sid].shape[0]:
+            raise ValueError("variable %s: bytes [%d, %d) lie outside data shard %d (%d bytes): truncated checkpoint"
+                             % (name, e["offset"], e["offset"] + e["size"], sid, shards[sid].shape[0]))
+        raw = bytes(shards[sid][e["offset"]:e["offset"] + e["size"]])
+        if e["crc32c"] is not None and _masked_crc(raw) != e["crc32c"]:
+            raise ValueError("variable %s fails its CRC-32C (stored %08x, computed %08x): the data shard is corrupt"
+                             % (name, e["crc32c"], _masked_crc(raw)))
+        want_bytes = int(np.prod(e["shape"], dtype=np.int64)) * np.dtype(DTYPES[e["dtype"]]).itemsize
+        if want_bytes != e["size"]:
+            raise ValueError("variable %s: %d bytes stored for shape %s" % (name, e["size"], e["shape"]))
+        out[name] = np.frombuffer(raw, dtype=DTYPES[e["dtype"]]).reshape(e["shape"]).copy()
     return out
 
 
@@ -196,6 +220,14 @@ def _put_varint(v):
 
 
 def _crc32c(data, _table=[]):
+    """CRC-32C of a bytes-like object: the C routine of libsse_hip.so (csrc/index_io.cpp, host only) when the library is
+    built, else the table loop below (same values; seconds per embedding table)."""
+    data = bytes(data)
+    try:
+        from . import _lib
+        return int(_lib.load_library().sse_crc32c(data, len(data), 0))
+    except Exception:                                          # noqa: BLE001  (library not built: pure-Python fallback of a host-only checksum)
+        pass
     if not _table:
         for i in range(256):
             c = i

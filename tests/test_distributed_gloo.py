@@ -104,7 +104,7 @@ class _CpuShardHandle(object):
         self._view(oi_ptr, (Q, k), np.int64)[:] = np.take_along_axis(mi, order, 1)
 
 
-def _sharded_worker(rank, world, port, q_np, t_np, k, out_dir):
+def _sharded_worker(rank, world, port, q_np, t_np, k, out_dir, block=16):
     sys.path.insert(0, ROOT)
     os.environ["SSE_NO_TORCH"] = "1"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -113,7 +113,7 @@ def _sharded_worker(rank, world, port, q_np, t_np, k, out_dir):
     sh = sse_amd.ShardedIndex(_CpuShardHandle(t_np.shape[1]), rank, world, t_np.shape[0])
     rows = torch.from_numpy(t_np[sh.start:sh.end].copy())
     sh.set_local_rows(rows)
-    s, i = sh.score_topk(torch.from_numpy(q_np.copy()), k, block=16)      # 37 queries -> 3 blocks, gathers overlapped
+    s, i = sh.score_topk(torch.from_numpy(q_np.copy()), k, block=block)   # 37 queries -> 3 blocks, gathers overlapped
     np.savez(os.path.join(out_dir, "sh%d.npz" % rank), s=s.numpy(), i=i.numpy())
     dist.barrier()
     dist.destroy_process_group()
@@ -134,6 +134,26 @@ def test_two_rank_sharded_index_class_blocks_and_packed_gather(tmp_path):
         assert np.array_equal(z["i"], wids) and np.abs(z["s"] - wsc).max() < 1e-12   # (BLAS blocks a row slice differently)
 
 
+def test_eight_rank_sharded_index_uneven_blocks_and_shards(tmp_path):
+    """The node-level shape of BASELINE configs[3]: 8 ranks, N not divisible by 8 (shards of 51 and 50 rows), query
+    blocks that do not divide Q (37 = 5 x 7 + 2), ties across shard boundaries -- exactly the unsharded ranking."""
+    from oracle import sse_oracle as O
+    rng = np.random.RandomState(2)
+    Q, N, S, k, world = 37, 403, 16, 10, 8
+    q = rng.standard_normal((Q, S)).astype(np.float32)
+    t = rng.standard_normal((N, S)).astype(np.float32)
+    t[300] = t[5]
+    t[51] = t[50]                                                  # a tie across the boundary of shards 0 | 1
+    q[3] = t[50]
+    port = _free_port()
+    mp.spawn(_sharded_worker, args=(world, port, q, t, k, str(tmp_path), 7), nprocs=world, join=True)
+    wsc, wids = O.topk(O.scores_f64(q, t.astype(np.float64)), k)
+    assert wids[3, :2].tolist() == [50, 51]
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "sh%d.npz" % r))
+        assert np.array_equal(z["i"], wids) and np.abs(z["s"] - wsc).max() < 1e-12
+
+
 # --------------------------------------------------------------------------
 # data-parallel train step (sequence-semantic-embedding_amd/data_parallel.py): the product's exchange logic with
 # the numpy oracle as the gradient engine (on the GPU the engine is the HIP handle:
@@ -151,6 +171,10 @@ class OracleEngine(object):
 
     def train_grad_count(self):
         return sum(self.p[n].size for n in self.names) + 4
+
+    def embedding_slice(self):
+        off = sum(self.p[n].size for n in self.names[:self.names.index("word_embedding")])
+        return (off,) + tuple(self.p["word_embedding"].shape)
 
     def train_bind_arena(self, tensor):
         self.arena = tensor.numpy()                                # shares memory with the torch tensor
@@ -200,7 +224,7 @@ def _dp_batch(seed, rows):
     return src, tgt, (np.arange(rows) % 2 == 0).astype(np.float32)
 
 
-def _dp_worker(rank, world, port, out_dir, uneven):
+def _dp_worker(rank, world, port, out_dir, uneven, sparse=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["SSE_NO_TORCH"] = "1"
@@ -210,7 +234,7 @@ def _dp_worker(rank, world, port, out_dir, uneven):
     from oracle import sse_oracle as O
     cfg = _dp_cfg()
     eng = OracleEngine(O.init_params(cfg, seed=3), cfg, 0.9)
-    tr = sse_amd.DataParallelTrainer(eng)
+    tr = sse_amd.DataParallelTrainer(eng, sparse_embedding=sparse)
     hist = []
     for step in range(3):
         src, tgt, z = _dp_batch(step, 22)
@@ -219,19 +243,21 @@ def _dp_worker(rank, world, port, out_dir, uneven):
             hist.append(tr.train_step(src[sl], tgt[sl], z[sl]))
         else:
             hist.append(tr.train_step(*sse_amd.split_batch(src, tgt, z, rank, world), rows_global=22))
+    assert tr.last_exchange == ("sparse" if sparse else "dense")
     np.savez(os.path.join(out_dir, "dp%d.npz" % rank), hist=np.array(hist), **eng.p)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("uneven", [False, True])
-def test_two_rank_data_parallel_step_equals_single_process(tmp_path, uneven):
+@pytest.mark.parametrize("uneven,sparse", [(False, False), (True, False), (True, True)])
+def test_two_rank_data_parallel_step_equals_single_process(tmp_path, uneven, sparse):
     """2 gloo ranks x half a batch == the oracle's single-process step on the whole batch
-    (loss, train_acc and every parameter after 3 steps), and both ranks end bit-identical."""
+    (loss, train_acc and every parameter after 3 steps), and both ranks end bit-identical.  sparse: the embedding
+    gradient travels as (row id, gradient row) pairs instead of the dense [V,E] block."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import sse_oracle as O
     world, port = 2, _free_port()
-    mp.spawn(_dp_worker, args=(world, port, str(tmp_path), uneven), nprocs=world, join=True)
+    mp.spawn(_dp_worker, args=(world, port, str(tmp_path), uneven, sparse), nprocs=world, join=True)
     cfg = _dp_cfg()
     p = O.init_params(cfg, seed=3)
     acc = O.new_optimizer_state(p)

@@ -337,3 +337,94 @@ def test_concurrent_encode_and_score_from_threads():
     assert not errs
     for (we, (ws, wi)), (ge, (gs, gi)) in zip(want, got):
         assert np.array_equal(we, ge) and np.array_equal(wi, gi) and np.array_equal(ws, gs)
+
+
+def test_cluster_kernel_miss_falls_back_to_the_few_sequences_kernel():
+    """A cluster workgroup that does not arrive (device busy) used to fail the request; the host-buffer entry points now
+    re-run the batch on lstm_small -- bit-identical results -- and count it (option lstm_persist_inject_miss simulates
+    the condition after every cluster launch)."""
+    params = model_params("dual-encoder", 300, 50, 96, 96, 64, 20)
+    m, _ = make_pair(params, seed=13)
+    rng = np.random.RandomState(6)
+    ids = random_ids(rng, 5, 20, 300, 0.5)
+    tgt = random_ids(rng, 200, 20, 300, 0.5)
+    m.handle.index_upload(m.encode_target(tgt).astype(np.float64))
+    want = m.encode_source(ids)
+    want_s, want_i = m.handle.encode_score_topk(0, ids, False, 7)
+    assert m.handle.get_counter("lstm_persist_fallbacks") == 0
+    m.handle.set_option("lstm_persist_inject_miss", 1)
+    got = m.encode_source(ids)
+    got_s, got_i = m.handle.encode_score_topk(0, ids, False, 7)
+    m.handle.set_option("lstm_persist_inject_miss", 0)
+    assert np.array_equal(got, want) and np.array_equal(got_i, want_i) and np.array_equal(got_s, want_s)
+    assert m.handle.get_counter("lstm_persist_fallbacks") == 2
+    assert np.array_equal(m.encode_source(ids), want)
+    assert m.handle.get_counter("lstm_persist_fallbacks") == 2
+
+
+@pytest.mark.parametrize("H,S", [(40, 16), (100, 64), (72, 24)])
+def test_cluster_kernel_with_workgroups_that_own_no_hidden_unit(H, S):
+    """H = 40 on 16 workgroups leaves two of them without a unit: they skip the steps and pick h_T up for the
+    projection; results stay bit-identical to the few-sequences kernel over many calls."""
+    params = model_params("dual-encoder", 120, 20, H, H, S, 9)
+    m, p = make_pair(params, seed=14)
+    rng = np.random.RandomState(7)
+    for it in range(20):
+        ids = random_ids(rng, 1 + it % 7, 9, 120, 0.5)
+        got = m.encode_source(ids)
+        m.handle.set_option("lstm_persist_rows", 0)
+        want = m.encode_source(ids)
+        m.handle.set_option("lstm_persist_rows", 32)
+        assert np.array_equal(got, want), it
+    assert np.abs(got - O.encode(p, params, "src", ids)).max() <= TOL
+    assert m.handle.get_counter("lstm_persist_fallbacks") == 0
+
+
+def test_four_serving_handles_from_threads_while_a_fifth_trains():
+    """sse_serving.py creates one handle per route: four handles issue single-query encode + score calls (the cluster
+    kernel: 16 - 32 co-resident workgroups each) from four threads while a fifth handle runs train steps.  Every answer
+    equals the quiet-machine answer; a cluster miss, if the scheduler produces one, is absorbed by the fallback."""
+    import threading
+    params = model_params("dual-encoder", 400, 50, 96, 96, 64, 16)
+    rng = np.random.RandomState(9)
+    tgt = random_ids(rng, 571, 16, 400, 0.5)
+    servers = []
+    for _ in range(4):
+        m, _p = make_pair(params, seed=21)
+        m.handle.index_upload(m.encode_target(tgt).astype(np.float64))
+        servers.append(m)
+    queries = [random_ids(rng, 1, 16, 400, 0.5) for _ in range(12)]
+    want = [servers[0].handle.encode_score_topk(0, q, False, 10) for q in queries]
+    tparams = model_params("dual-encoder", 400, 50, 128, 128, 64, 16, lr=0.5)
+    trainer, _p = make_pair(tparams, seed=22)
+    tsrc = np.repeat(random_ids(rng, 128, 16, 400, 0.3), 2, axis=0)
+    ttgt = random_ids(rng, 256, 16, 400, 0.3)
+    tz = np.tile(np.array([1.0, 0.0], np.float32), 128)
+    errs, stop = [], threading.Event()
+
+    def train():
+        try:
+            while not stop.is_set():
+                trainer.train_step(tsrc, ttgt, tz)
+        except Exception as ex:                                 # pragma: no cover
+            errs.append(ex)
+
+    def serve(m):
+        try:
+            for _ in range(15):
+                for q, (ws, wi) in zip(queries, want):
+                    s, i = m.handle.encode_score_topk(0, q, False, 10)
+                    assert np.array_equal(i, wi) and np.array_equal(s, ws)
+        except Exception as ex:                                 # pragma: no cover
+            errs.append(ex)
+
+    tt = threading.Thread(target=train)
+    tt.start()
+    th = [threading.Thread(target=serve, args=(m,)) for m in servers]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    stop.set()
+    tt.join(60)
+    assert not errs, errs

@@ -64,3 +64,38 @@ def test_sharded_scoring_through_rccl_all_gather(nccl_group):
     wsc, wids = O.topk(O.scores_f64(q, t.astype(np.float64)), 10)
     assert np.array_equal(i.cpu().numpy(), wids)
     assert np.abs(s.cpu().numpy() - wsc).max() < 1e-12
+
+
+def test_data_parallel_on_a_side_stream_and_sparse_embedding_exchange(nccl_group):
+    """sse_set_stream: the trainer hands torch's CURRENT stream to the library, so a step issued inside
+    `with torch.cuda.stream(s)` orders its kernels, the RCCL collective and the update on that stream (round 2
+    raised unless the default stream was current).  sparse_embedding: the word-embedding gradient travels as
+    (row id, gradient row) pairs -- same update as the dense all-reduce."""
+    import torch
+    import sse_amd
+    params = model_params("dual-encoder", 5000, 50, 128, 128, 64, 12, lr=0.9)
+    (ma, p), (mb, _) = make_pair(params, seed=5), make_pair(params, seed=5)
+    rng = np.random.RandomState(2)
+    src = np.repeat(random_ids(rng, 32, 12, 5000, 0.5), 2, axis=0)
+    tgt = random_ids(rng, 64, 12, 5000, 0.5)
+    z = np.tile(np.array([1.0, 0.0], np.float32), 32)
+    dense = sse_amd.DataParallelTrainer(ma.handle, device="cuda:0", always_reduce=True, sparse_embedding=False)
+    sparse = sse_amd.DataParallelTrainer(mb.handle, device="cuda:0", always_reduce=True)      # automatic: 2*64*12 < 5000/4? no -> forced below
+    side = torch.cuda.Stream()
+    for step in range(3):
+        a = dense.train_step(src, tgt, z)
+        with torch.cuda.stream(side):
+            sparse.sparse_embedding = True
+            b = sparse.train_step(src, tgt, z)
+        assert dense.last_exchange == "dense" and sparse.last_exchange == "sparse"
+        assert b == pytest.approx(a, rel=1e-6, abs=1e-7)
+    side.synchronize()
+    va, vb = ma.get_variables(with_slots=True), mb.get_variables(with_slots=True)
+    for k in va:
+        assert np.abs(va[k] - vb[k]).max() < 2e-6, k
+    # automatic choice: sparse only when a step touches fewer than V/4 rows
+    assert sparse._use_sparse(64, src, False) is True or 2 * 64 * 12 >= 5000 // 4
+    auto = sse_amd.DataParallelTrainer(ma.handle, device="cuda:0", always_reduce=True)
+    assert auto._use_sparse(8, src[:8], False) == (2 * 8 * 12 < 5000 // 4)
+    ma.handle.set_stream(0)
+    mb.handle.set_stream(0)

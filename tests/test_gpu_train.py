@@ -329,3 +329,57 @@ def test_train_step_by_rows_equals_train_step_by_ids(mode):
         assert np.abs(ga[k] - gb[k]).max() < 1e-5, k
     with pytest.raises(sse_amd.SSEError):
         mb.handle.train_step_rows(np.array([0, 40], np.int32), np.array([0, 1], np.int32), np.array([1, 0], np.float32))
+
+
+def test_split_operand_training_converges_like_the_float32_step():
+    """the default train step runs its GEMMs on split bf16 operands.  300 steps of the same seeded
+    batches on both arithmetics: the loss curves stay together (the split path is a ~4e-6-per-product perturbation, not
+    a different optimiser), both fall, and the final weights agree to the level two float32 runs with different summation
+    orders would."""
+    params = model_params("dual-encoder", 400, 50, 96, 96, 64, 12, lr=0.3)
+    (mx, _), (mf, _) = make_pair(params, seed=31), make_pair(params, seed=31)
+    exact_fp32_training(mf)
+    mf.handle.set_option("train_bwd_x3", 0)
+    rng = np.random.RandomState(3)
+    corpus_s = random_ids(rng, 256, 12, 400, 0.4)
+    corpus_t = random_ids(rng, 256, 12, 400, 0.4)
+    lx, lf = [], []
+    for step in range(300):
+        rows = rng.randint(0, 256, size=64)
+        neg = rng.randint(0, 256, size=64)
+        src = np.repeat(corpus_s[rows], 2, axis=0)
+        tgt = np.empty((128, 12), np.int32)
+        tgt[0::2], tgt[1::2] = corpus_t[rows], corpus_t[neg]
+        z = np.tile(np.array([1.0, 0.0], np.float32), 64)
+        lx.append(mx.train_step(src, tgt, z)[0])
+        lf.append(mf.train_step(src, tgt, z)[0])
+    lx, lf = np.array(lx), np.array(lf)
+    assert lf[-20:].mean() < 0.5 * lf[:20].mean() and lx[-20:].mean() < 0.5 * lx[:20].mean()      # both learn
+    assert np.abs(lx[:50] - lf[:50]).max() < 2e-3 * max(1.0, lf[:50].max())                       # same trajectory early on
+    assert abs(lx[-50:].mean() - lf[-50:].mean()) < 0.05 * max(lf[-50:].mean(), 0.05)             # same place at the end
+    vx, vf = mx.get_variables(), mf.get_variables()
+    for k in vx:
+        assert np.abs(vx[k] - vf[k]).max() < 5e-2 * max(1.0, np.abs(vf[k]).max()), k
+
+
+def test_restore_prefers_the_newer_of_npz_and_tf_index(tmp_path):
+    """a stale converted .npz must not shadow a TensorFlow checkpoint re-written under the same prefix."""
+    import os
+    import time
+    from sse_amd import tf_checkpoint
+    params = model_params("shared-encoder", 60, 8, 16, 16, 8, 5)
+    m, p = make_pair(params, seed=3)
+    prefix = str(tmp_path / "SSE-LSTM.ckpt-5")
+    m.saver.save(None, str(tmp_path / "SSE-LSTM.ckpt"), global_step=5)            # writes <prefix>.npz (old weights)
+    newer = {k: (v + 1.0).astype(np.float32) for k, v in m.get_variables(with_slots=True).items()}
+    newer["global_step"] = np.array(9, np.int64)
+    newer["learning_rate"] = np.array(0.25, np.float32)
+    time.sleep(0.05)
+    tf_checkpoint.write_bundle(prefix, newer)
+    os.utime(prefix + ".index", (time.time() + 5, time.time() + 5))
+    m.saver.restore(None, prefix)
+    assert m.saver.restored_from.endswith(".index") and m.handle.global_step == 9
+    assert np.array_equal(m.get_variables()["word_embedding"], newer["word_embedding"])
+    os.utime(prefix + ".npz", (time.time() + 10, time.time() + 10))             # now the .npz is the newer one
+    m.saver.restore(None, prefix)
+    assert m.saver.restored_from.endswith(".npz") and m.handle.global_step == 5

@@ -129,3 +129,84 @@ def test_tf_bundle_roundtrip_and_npz_conversion(tmp_path):
     with pytest.raises(ValueError):
         open(prefix + ".index", "wb").write(b"\x00" * 64)
         tf_checkpoint.read_bundle(prefix)
+
+
+def test_micro_batcher_survives_a_broken_wakeup_and_never_hangs():
+    """an exception outside ranker.rank must not kill the worker thread (every later request would block
+    forever), and a request must not wait without bound."""
+    r = _StubRanker()
+    b = sse_serving.MicroBatcher(r, max_batch=4, max_wait_s=0.001)
+    with pytest.raises(Exception):
+        b.submit([1, 2, 3], "not-a-number", True)               # int(nbest) fails while the wake-up is grouped
+    assert b._t.is_alive()
+    assert b.submit(r.tokens("a b"), 3, True)[0][1].startswith("id")      # the worker still serves
+    # a wedged ranker: the request times out instead of hanging
+    gate = threading.Event()
+    r.rank = lambda rows, nbest, normalize: gate.wait(5.0) or []
+    with pytest.raises(TimeoutError):
+        b.submit(r.tokens("a"), 3, True, timeout_s=0.6)
+    gate.set()
+
+
+def test_crc32c_known_answers_and_library_routine_matches_python():
+    """RFC 3720 B.4 vectors pin the checksum the checkpoint reader verifies; the C routine of libsse_hip.so and the
+    pure-Python table loop agree, including across the slicing-by-8 tail."""
+    assert tf_checkpoint._crc32c(b"123456789") == 0xE3069283
+    assert tf_checkpoint._crc32c(bytes(32)) == 0x8A9136AA
+    assert tf_checkpoint._crc32c(bytes([0xFF] * 32)) == 0x62A8AB43
+    assert tf_checkpoint._crc32c(bytes(range(32))) == 0x46DD794E
+    lib = sse_amd.load_library()
+    rng = np.random.RandomState(0)
+
+    def py_crc(data):
+        crc = 0xFFFFFFFF
+        for byte in data:
+            crc ^= byte
+            for _ in range(8):
+                crc = (crc >> 1) ^ (0x82F63B78 if crc & 1 else 0)
+        return crc ^ 0xFFFFFFFF
+
+    for n in (0, 1, 7, 8, 9, 63, 64, 65, 1000):
+        data = rng.bytes(n)
+        assert int(lib.sse_crc32c(data, n, 0)) == py_crc(data), n
+    data = rng.bytes(300)                                        # chained calls == one call
+    assert int(lib.sse_crc32c(data[100:], 200, lib.sse_crc32c(data[:100], 100, 0))) == py_crc(data)
+
+
+def test_hand_assembled_two_shard_bundle_fixture():
+    """tests/golden/tf_bundle: written byte by byte by tests/golden/make_tf_bundle_fixture.py (its own varint / CRC / block
+    code) -- prefix-compressed keys, three data blocks, two data shards, proto3 zero-field omission."""
+    prefix = os.path.join(os.path.dirname(__file__), "golden", "tf_bundle", "model.ckpt-7")
+    got = tf_checkpoint.read_bundle(prefix)
+    z = np.load(os.path.join(os.path.dirname(prefix), "expected.npz"))
+    assert sorted(got) == sorted(k.replace("|", "/") for k in z.files)
+    for k in z.files:
+        a = got[k.replace("|", "/")]
+        assert a.dtype == z[k].dtype and a.shape == z[k].shape and np.array_equal(a, z[k]), k
+    arrays = tf_checkpoint.to_npz_arrays(got)
+    assert int(arrays["global_step"]) == 7 and float(arrays["learning_rate"]) == pytest.approx(0.81)
+
+
+def test_corrupt_or_truncated_checkpoints_are_rejected(tmp_path):
+    import shutil
+    src = os.path.join(os.path.dirname(__file__), "golden", "tf_bundle")
+    for name in os.listdir(src):
+        shutil.copy(os.path.join(src, name), str(tmp_path))
+    prefix = str(tmp_path / "model.ckpt-7")
+    assert len(tf_checkpoint.read_bundle(prefix)) == 10
+    shard = prefix + ".data-00001-of-00002"
+    blob = bytearray(open(shard, "rb").read())
+    blob[100] ^= 0x01                                            # one flipped bit in a tensor
+    open(shard, "wb").write(bytes(blob))
+    with pytest.raises(ValueError, match="CRC-32C"):
+        tf_checkpoint.read_bundle(prefix)
+    blob[100] ^= 0x01
+    open(shard, "wb").write(bytes(blob[:-40]))                   # truncated data shard
+    with pytest.raises(ValueError, match="truncated|outside data shard"):
+        tf_checkpoint.read_bundle(prefix)
+    open(shard, "wb").write(bytes(blob))
+    idx = bytearray(open(prefix + ".index", "rb").read())
+    idx[20] ^= 0x40                                              # a flipped bit inside the first table block
+    open(prefix + ".index", "wb").write(bytes(idx))
+    with pytest.raises(ValueError, match="CRC-32C"):
+        tf_checkpoint.read_bundle(prefix)
