@@ -343,12 +343,16 @@ def main():
     latency = None
     if rank == 0 and not args.no_scoring_leg:
         one = src_ids[:1].cpu().numpy()
-        def timed(fn, n=20):
+        def timed(fn, n=31):
+            # median of per-call times (one call in a few thousand stalls for tens of ms inside the HIP runtime with the
+            # GPU idle: a mean over 20 calls turns that into +1.7 ms on every call, profiles/r03_notes.txt)
             fn()
-            t0 = time.perf_counter()
+            ts = []
             for _ in range(n):
+                t0 = time.perf_counter()
                 fn()
-            return (time.perf_counter() - t0) / n
+                ts.append(time.perf_counter() - t0)
+            return sorted(ts)[n // 2]
         h.index_set_dev(tgt_enc.data_ptr(), N_TARGETS, S)
         e2e_small = timed(lambda: h.encode_score_topk(0, one, False, 10))
         enc_only = timed(lambda: h.encode(0, one, False))

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -143,6 +144,7 @@ struct sse_handle {
   DevBuf s_ids, s_out, s_q, s_qp, s_ps, s_pi, s_cert, s_os, s_oi, s_tmp, s_tmp2, s_feat, s_zero, s_map;
   DevBuf s_qp32, s_fb_cnt;  // fp32 second chance of the bf16 candidate pass: fp32 query fragments, counter
   DevBuf s_persist;  // lstm_persist.hip: h_t / raw-encoding exchange buffers and arrival counters
+  int32_t *pin_small = nullptr;  // 64 pinned host words: error flag / loss read-backs (a pageable target makes the copy a blocking one)
   void *pin = nullptr;  // pinned host staging of the host-buffer scoring entry points: [scores | ids | certificates]
   size_t pin_cap = 0;
   DevBuf s_pb, s_cthr, s_cslot, s_ccnt, s_cbuf;  // per-split bounds; collect path: thresholds, slots, counters, row buffers
@@ -171,6 +173,18 @@ int fail(sse_handle *h, const char *fmt, ...) {
     hipError_t e_ = (expr);                                                                       \
     if (e_ != hipSuccess) return fail(h, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
+
+// Wait for a stream: poll for up to ~3 ms (the latency-critical calls finish in 0.1 - 0.5 ms; the runtime's blocking wait
+// was seen to add 1 - 2 ms to some of them: an 8-token query against a 1.25 M-row index took 2.0 ms end to end with 0.3 ms
+// of device work), then block.
+hipError_t sync_stream(hipStream_t st) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipStreamQuery(st);
+    if (e != hipErrorNotReady) return e;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(3)) return hipStreamSynchronize(st);
+  }
+}
 
 int reserve(sse_handle *h, DevBuf &b, size_t bytes) {
   if (bytes <= b.cap) return 0;
@@ -617,9 +631,9 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
 // bits: (optional) receives the raw flag; a flag that is exactly bit 2 (cluster kernel: a workgroup did not arrive) is then
 // cleared and reported through *bits with rc 0, so that the caller can re-run the batch on another kernel
 int check_err_flag(sse_handle *h, hipStream_t st, int32_t *bits = nullptr) {
-  int32_t flag = 0;
-  HIPCHECK(h, hipMemcpyAsync(&flag, h->err_flag, sizeof flag, hipMemcpyDeviceToHost, st));
-  HIPCHECK(h, hipStreamSynchronize(st));
+  HIPCHECK(h, hipMemcpyAsync(h->pin_small, h->err_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIPCHECK(h, sync_stream(st));
+  const int32_t flag = h->pin_small[0];
   if (bits) *bits = flag;
   if (flag) {
     HIPCHECK(h, hipMemsetAsync(h->err_flag, 0, sizeof(int32_t), st));
@@ -1010,6 +1024,7 @@ int sse_create(const sse_config *cfg, sse_handle **out) {
     launch_fill(v.slot, v.count, 0.1f, nullptr);  // AdagradOptimizer initial_accumulator_value
   }
   if (hipMalloc((void **)&h->err_flag, sizeof(int32_t)) != hipSuccess) CREATE_FAIL("hipMalloc failed");
+  if (hipHostMalloc((void **)&h->pin_small, 64 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) CREATE_FAIL("hipHostMalloc failed");
   hipMemset(h->err_flag, 0, sizeof(int32_t));
   if (hipDeviceSynchronize() != hipSuccess) CREATE_FAIL("device initialisation failed");
 #undef CREATE_FAIL
@@ -1043,6 +1058,7 @@ void sse_destroy(sse_handle *h) {
     if (e.Mp) hipFree(e.Mp);
   }
   if (h->pin) (void)hipHostFree(h->pin);
+  if (h->pin_small) (void)hipHostFree(h->pin_small);
   if (h->emb_pad) hipFree(h->emb_pad);
   if (h->emb16) (void)hipFree(h->emb16);
   if (h->err_flag) hipFree(h->err_flag);
@@ -1206,7 +1222,7 @@ static int score_to_host_locked(sse_handle *h, const float *q_dev, int Q, int k,
     HIPCHECK(h, hipMemcpyAsync(pin, h->s_os.p, nb, hipMemcpyDeviceToHost, st));
     HIPCHECK(h, hipMemcpyAsync(pin + nb, h->s_oi.p, nb, hipMemcpyDeviceToHost, st));
     if (split && pass == 0) HIPCHECK(h, hipMemcpyAsync(pin + 2 * nb, h->s_cert.p, (size_t)Q * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIPCHECK(h, hipStreamSynchronize(st));
+    HIPCHECK(h, sync_stream(st));
     bool open_q = false;
     if (split && pass == 0) {
       const int32_t *cert = (const int32_t *)(pin + 2 * nb);
@@ -1930,12 +1946,11 @@ static int train_apply_locked(sse_handle *h, float *loss, float *train_acc) {
   ts.packed_dirty = ts.fp32_dirty = true;
   ts.grads_ready = false;
 
-  float out[4];
-  int32_t flag = 0;
-  HIPCHECK(h, hipMemcpyAsync(out, tail, sizeof out, hipMemcpyDeviceToHost, st));
-  HIPCHECK(h, hipMemcpyAsync(&flag, h->err_flag, sizeof flag, hipMemcpyDeviceToHost, st));
-  HIPCHECK(h, hipStreamSynchronize(st));
-  if (flag) return check_err_flag(h, st);  // (resets the flag; the update was cancelled on the device: variables unchanged)
+  float *out = reinterpret_cast<float *>(h->pin_small + 4);
+  HIPCHECK(h, hipMemcpyAsync(out, tail, 4 * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIPCHECK(h, hipMemcpyAsync(h->pin_small, h->err_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIPCHECK(h, sync_stream(st));
+  if (h->pin_small[0]) return check_err_flag(h, st);  // (resets the flag; the update was cancelled on the device: variables unchanged)
   h->global_step += 1;
   if (loss) *loss = out[1];
   if (train_acc) *train_acc = out[2];

@@ -370,6 +370,7 @@ def test_restore_prefers_the_newer_of_npz_and_tf_index(tmp_path):
     params = model_params("shared-encoder", 60, 8, 16, 16, 8, 5)
     m, p = make_pair(params, seed=3)
     prefix = str(tmp_path / "SSE-LSTM.ckpt-5")
+    m.handle.global_step = 5
     m.saver.save(None, str(tmp_path / "SSE-LSTM.ckpt"), global_step=5)            # writes <prefix>.npz (old weights)
     newer = {k: (v + 1.0).astype(np.float32) for k, v in m.get_variables(with_slots=True).items()}
     newer["global_step"] = np.array(9, np.int64)
