@@ -151,12 +151,91 @@ __device__ __forceinline__ void drain_parked(float (&ls)[KL], int (&li)[KL], int
 typedef short bf16x8_t __attribute__((ext_vector_type(8)));
 #define SC_KL 8
 #define SC_PEND 4  // parked entries per (wave, query tile, lane)
+// Final merge of a workgroup's lane lists (shared by the sweep kernels): (1) lane pairs 8 + 8 -> 16, (2) LDS tree over the 8
+// waves, (3) wave 0 writes the KC candidates of (query, split) and the bound every other row of the split stays under.
+template <int NQ>
+__device__ __forceinline__ void merge_lane_lists(const ScoreArgs &a, float (&ls)[NQ][SC_KL], int (&li)[NQ][SC_KL], float *smem, int w,
+                                                 int lane, int qb, int split) {
+  constexpr int KC = SC_KC, KL = SC_KL;
+  constexpr int WAVES = SC_THREADS / 64;
+  // (1) the two lane halves hold lists of the same query over different rows: merge into a 16-list in lanes 0-31;
+  //     bnd = largest 8th entry of a full lane list (see the header comment)
+  float ms16[NQ][KC];
+  int mi16[NQ][KC];
+  float bnd[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    float os[KL];
+    int oi[KL];
+#pragma unroll
+    for (int i = 0; i < KL; ++i) {
+      os[i] = __shfl_xor(ls[q][i], 32);
+      oi[i] = __shfl_xor(li[q][i], 32);
+    }
+    merge8_to16(ls[q], li[q], os, oi, ms16[q], mi16[q]);
+    bnd[q] = fmaxf(ls[q][KL - 1], os[KL - 1]);
+  }
+  // (2) tree over the 8 waves through LDS (the query block is no longer needed):
+  // scratch [wave][q][entry][32 queries], one (score, id) plane pair per sender wave, then the bounds
+  __syncthreads();
+  float *ms = smem;
+  int *mi = reinterpret_cast<int *>(smem) + (WAVES / 2) * NQ * KC * 32;
+  float *mb = smem + 2 * (WAVES / 2) * NQ * KC * 32;  // [wave][q][32]
+  for (int half = WAVES / 2; half >= 1; half >>= 1) {
+    if (w >= half && w < 2 * half && lane < 32) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int i = 0; i < KC; ++i) {
+          ms[(((w - half) * NQ + q) * KC + i) * 32 + lane] = ms16[q][i];
+          mi[(((w - half) * NQ + q) * KC + i) * 32 + lane] = mi16[q][i];
+        }
+        mb[((w - half) * NQ + q) * 32 + lane] = bnd[q];
+      }
+    }
+    __syncthreads();
+    if (w < half && lane < 32) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        float os[KC];
+        int oi[KC];
+#pragma unroll
+        for (int i = 0; i < KC; ++i) {
+          os[i] = ms[((w * NQ + q) * KC + i) * 32 + lane];
+          oi[i] = mi[((w * NQ + q) * KC + i) * 32 + lane];
+        }
+        merge_lists<KC>(ms16[q], mi16[q], os, oi);
+        bnd[q] = fmaxf(bnd[q], mb[(w * NQ + q) * 32 + lane]);
+      }
+    }
+    __syncthreads();
+  }
+  const int Qeff = a.q_count ? min(a.Q, *a.q_count) : a.Q;
+  if (w == 0 && lane < 32) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int query = (qb * NQ + q) * 32 + lane;
+      if (query < Qeff) {
+        float *ps = a.part_scores + ((size_t)query * a.NSPLIT + split) * KC;
+        int32_t *pi = a.part_ids + ((size_t)query * a.NSPLIT + split) * KC;
+#pragma unroll
+        for (int i = 0; i < KC; i += 4) {
+          *reinterpret_cast<f32x4 *>(ps + i) = f32x4{ms16[q][i], ms16[q][i + 1], ms16[q][i + 2], ms16[q][i + 3]};
+          *reinterpret_cast<int4 *>(pi + i) = int4{mi16[q][i], mi16[q][i + 1], mi16[q][i + 2], mi16[q][i + 3]};
+        }
+        // every row of this split outside the 16 candidates scores <= this
+        a.part_bnd[(size_t)query * a.NSPLIT + split] = fmaxf(bnd[q], ms16[q][KC - 1]);
+      }
+    }
+  }
+}
+
 struct TagZ { static constexpr bool value = true; };   // "accumulators start from zero" / "accumulate" tags of mma()
 struct TagA { static constexpr bool value = false; };
 template <int NQ, bool BF, bool COLLECT, bool RINGED>
 __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // query block [NQ][KG][256]; later merge scratch
-  constexpr int KC = SC_KC, KL = SC_KL;
+  constexpr int KL = SC_KL;
   constexpr bool DEFER = BF && !COLLECT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform (SGPR): tile numbers and load offsets derive from it
@@ -179,11 +258,15 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   }
   const int QB = (a.QT + NQ - 1) / NQ;
   if (qb >= QB) return;
-  if (COLLECT || a.skip_cert) {  // fp32 second chance after a bf16 candidate pass / collect pass: only blocks with an open query run
+  // q_count (second chance of the bf16 pass): the queries are a compacted set whose size is only known on the device; the
+  // launch is sized for the worst case and the workgroups past the set return at once
+  const int Qeff = a.q_count ? min(a.Q, *a.q_count) : a.Q;
+  if (qb * NQ * 32 >= Qeff) return;
+  if (COLLECT) {  // collect pass: only blocks with an open query run
     int open_q = 0;
     for (int i = tid; i < NQ * 32; i += SC_THREADS) {
       const int qq = qb * NQ * 32 + i;
-      if (qq < a.Q && (COLLECT ? a.col_slot[qq] >= 0 : a.skip_cert[qq] == 0)) open_q = 1;
+      if (qq < a.Q && a.col_slot[qq] >= 0) open_q = 1;
     }
     if (!__syncthreads_or(open_q)) return;
   }
@@ -194,7 +277,7 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   {
     const f32x4 *src = reinterpret_cast<const f32x4 *>(a.qp) + (size_t)qb * NQ * KG * 64;
     f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
-    const int valid = min(NQ, a.QT - qb * NQ) * KG * 64;
+    const int valid = min(NQ, (Qeff + 31) / 32 - qb * NQ) * KG * 64;
     for (int i = tid; i < NQ * KG * 64; i += SC_THREADS) {
       const int blk = i >> 6, qt = blk / KG, kg = blk - qt * KG;
       dst[(kg * NQ + qt) * 64 + (i & 63)] = (i < valid) ? src[i] : f32x4{0, 0, 0, 0};
@@ -501,76 +584,7 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
     for (int q = 0; q < NQ; ++q) drain_parked<KL>(ls[q], li[q], pcnt[q], pend_s + q * SC_PEND * 64);
   }
 
-  constexpr int WAVES = SC_THREADS / 64;
-  // (1) the two lane halves hold lists of the same query over different rows: merge into a 16-list in lanes 0-31;
-  //     bnd = largest 8th entry of a full lane list (see the header comment)
-  float ms16[NQ][KC];
-  int mi16[NQ][KC];
-  float bnd[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    float os[KL];
-    int oi[KL];
-#pragma unroll
-    for (int i = 0; i < KL; ++i) {
-      os[i] = __shfl_xor(ls[q][i], 32);
-      oi[i] = __shfl_xor(li[q][i], 32);
-    }
-    merge8_to16(ls[q], li[q], os, oi, ms16[q], mi16[q]);
-    bnd[q] = fmaxf(ls[q][KL - 1], os[KL - 1]);
-  }
-  // (2) tree over the 8 waves through LDS (the query block is no longer needed):
-  // scratch [wave][q][entry][32 queries], one (score, id) plane pair per sender wave, then the bounds
-  __syncthreads();
-  float *ms = smem;
-  int *mi = reinterpret_cast<int *>(smem) + (WAVES / 2) * NQ * KC * 32;
-  float *mb = smem + 2 * (WAVES / 2) * NQ * KC * 32;  // [wave][q][32]
-  for (int half = WAVES / 2; half >= 1; half >>= 1) {
-    if (w >= half && w < 2 * half && lane < 32) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-#pragma unroll
-        for (int i = 0; i < KC; ++i) {
-          ms[(((w - half) * NQ + q) * KC + i) * 32 + lane] = ms16[q][i];
-          mi[(((w - half) * NQ + q) * KC + i) * 32 + lane] = mi16[q][i];
-        }
-        mb[((w - half) * NQ + q) * 32 + lane] = bnd[q];
-      }
-    }
-    __syncthreads();
-    if (w < half && lane < 32) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        float os[KC];
-        int oi[KC];
-#pragma unroll
-        for (int i = 0; i < KC; ++i) {
-          os[i] = ms[((w * NQ + q) * KC + i) * 32 + lane];
-          oi[i] = mi[((w * NQ + q) * KC + i) * 32 + lane];
-        }
-        merge_lists<KC>(ms16[q], mi16[q], os, oi);
-        bnd[q] = fmaxf(bnd[q], mb[(w * NQ + q) * 32 + lane]);
-      }
-    }
-    __syncthreads();
-  }
-  if (w == 0 && lane < 32) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int query = (qb * NQ + q) * 32 + lane;
-      if (query < a.Q) {
-        float *ps = a.part_scores + ((size_t)query * a.NSPLIT + split) * KC;
-        int32_t *pi = a.part_ids + ((size_t)query * a.NSPLIT + split) * KC;
-#pragma unroll
-        for (int i = 0; i < KC; i += 4) {
-          *reinterpret_cast<f32x4 *>(ps + i) = f32x4{ms16[q][i], ms16[q][i + 1], ms16[q][i + 2], ms16[q][i + 3]};
-          *reinterpret_cast<int4 *>(pi + i) = int4{mi16[q][i], mi16[q][i + 1], mi16[q][i + 2], mi16[q][i + 3]};
-        }
-        // every row of this split outside the 16 candidates scores <= this
-        a.part_bnd[(size_t)query * a.NSPLIT + split] = fmaxf(bnd[q], ms16[q][KC - 1]);
-      }
-    }
-  }
+  merge_lane_lists<NQ>(a, ls, li, smem, w, lane, qb, split);
 }
 
 // dynamic LDS of one workgroup: query block (re-used as merge scratch) + shared thresholds + per-list bests (+ parked hits)
@@ -623,6 +637,37 @@ static hipError_t launch_score_ringed(const ScoreArgs &a_in, hipStream_t stream)
 template <int NQ, bool BF, bool COLLECT>
 static hipError_t launch_score_variant(const ScoreArgs &a, hipStream_t stream) {
   return (a.KG % 8 == 0) ? launch_score_ringed<NQ, BF, COLLECT, true>(a, stream) : launch_score_ringed<NQ, BF, COLLECT, false>(a, stream);
+}
+
+// Second chance of the bf16 candidate pass: the uncertified queries are gathered into a dense set (slot -> query in qmap,
+// size in *count, rows copied to qc[slot][S], zero rows up to a whole 32-query tile behind the set) so that the fp32 sweep
+// costs what THEY cost -- with the certified queries only skipped per 64- / 128-query block, 4 % of them scattered over the
+// blocks (index dimension 512, random rows) re-ran the whole fp32 sweep: 81 ms for a 10 ms bf16 pass.
+__global__ void compact_uncert_kernel(const int32_t *cert, int Q, int32_t *qmap, int32_t *count) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool open_q = q < Q && cert[q] == 0;
+  const unsigned long long m = __ballot(open_q);
+  if (m == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == __ffsll((long long)m) - 1) base = atomicAdd(count, __popcll(m));
+  base = __shfl(base, __ffsll((long long)m) - 1);
+  if (open_q) qmap[base + __popcll(m & ((1ull << lane) - 1ull))] = q;
+}
+__global__ void gather_query_rows_kernel(const float *q, const int32_t *qmap, const int32_t *count, int Q, int S, float *qc) {
+  const int slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int n = *count, padded = min(Q, (n + 31) & ~31);
+  if (slot >= padded) return;
+  const float *src = slot < n ? q + (size_t)qmap[slot] * S : nullptr;
+  for (int d = lane; d < S; d += 64) qc[(size_t)slot * S + d] = src ? src[d] : 0.0f;
+}
+hipError_t launch_compact_uncert(const float *q, const int32_t *cert, int Q, int S, int32_t *qmap, int32_t *count, float *qc,
+                                 hipStream_t st) {
+  hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(compact_uncert_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, cert, Q, qmap, count);
+  hipLaunchKernelGGL(gather_query_rows_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, q, qmap, count, Q, S, qc);
+  return hipGetLastError();
 }
 
 // diagnostic: number of queries of this call left uncertified by the bf16 pass, accumulated on the device
@@ -783,7 +828,8 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
   __shared__ double s_qn[RS_THREADS / 64];
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_key[];  // [NC] (dynamic: keeps occupancy for small NC)
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (a.skip && a.skip[q] != 0) return;  // (uniform per workgroup) already final
+  if (a.q_count && q >= *a.q_count) return;  // compacted second chance: slots past the set (uniform per workgroup)
+  const int qo = a.qmap ? a.qmap[q] : q;     // where this slot's results go
   const float *ps = a.part_scores + (size_t)q * a.NC;
   const int32_t *pi = a.part_ids + (size_t)q * a.NC;
   const float *qrow = a.q + (size_t)q * a.S;
@@ -908,8 +954,8 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
     int rank = 0;
     for (int j = 0; j < nwin; ++j) rank += before(s_ex[j], (int64_t)pi[s_win[j]], s, id);
     if (rank < a.k) {
-      a.out_scores[(size_t)q * a.k + rank] = s;
-      a.out_ids[(size_t)q * a.k + rank] = a.id_base + id;
+      a.out_scores[(size_t)qo * a.k + rank] = s;
+      a.out_ids[(size_t)qo * a.k + rank] = a.id_base + id;
     }
     if (rank == a.k - 1) theta = s;
   }
@@ -925,10 +971,10 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
     if (tid == 0) {
       t = fmax(fmax(s_ex[0], s_ex[1]), fmax(s_ex[2], s_ex[3]));
       const bool ok = (nwin_all <= RS_MAXWIN) && (nwin >= a.k) && ((double)mmax + (double)eps_q < t);
-      a.cert[q] = ok ? 1 : 0;
+      a.cert[qo] = ok ? 1 : 0;
       // t = exact score of the k-th best candidate (-inf with fewer than k): a lower bound of the true k-th best, so
       // every exact top-k row has fp32 score >= t - eps32*|q| (the collect pass gathers exactly those)
-      if (a.col_thr) a.col_thr[q] = ok ? __builtin_inff() : __double2float_rd(t - (double)(a.eps32 * qnorm));
+      if (a.col_thr) a.col_thr[qo] = ok ? __builtin_inff() : __double2float_rd(t - (double)(a.eps32 * qnorm));
     }
   }
 }
@@ -941,7 +987,8 @@ __global__ __launch_bounds__(256) void rescore_small_kernel(RescoreArgs a) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= a.Q) return;
-  if (a.skip && a.skip[q] != 0) return;  // already final (uniform per wave)
+  if (a.q_count && q >= *a.q_count) return;  // compacted second chance: slots past the set (uniform per wave)
+  const int qo = a.qmap ? a.qmap[q] : q;
   const float *qrow = a.q + (size_t)q * a.S;
   const int KG = (a.S + 7) / 8;
   double qn = 0.0;
@@ -984,16 +1031,16 @@ __global__ __launch_bounds__(256) void rescore_small_kernel(RescoreArgs a) {
     r2 += before(__shfl(ex, src), (int64_t)__shfl(id, src), ex, (int64_t)id) ? 1 : 0;
   }
   if (in_win && r2 < a.k) {
-    a.out_scores[(size_t)q * a.k + r2] = ex;
-    a.out_ids[(size_t)q * a.k + r2] = a.id_base + id;
+    a.out_scores[(size_t)qo * a.k + r2] = ex;
+    a.out_ids[(size_t)qo * a.k + r2] = a.id_base + id;
   }
   double theta = (in_win && r2 == a.k - 1) ? ex : -__builtin_inf();
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) theta = fmax(theta, __shfl_xor(theta, o));
   if (lane == 0) {
     const bool ok = (nwin >= a.k) && ((double)mmax + (double)eps_q < theta);
-    a.cert[q] = ok ? 1 : 0;
-    if (a.col_thr) a.col_thr[q] = ok ? __builtin_inff() : __double2float_rd(theta - (double)(a.eps32 * qnorm));
+    a.cert[qo] = ok ? 1 : 0;
+    if (a.col_thr) a.col_thr[qo] = ok ? __builtin_inff() : __double2float_rd(theta - (double)(a.eps32 * qnorm));
   }
 }
 

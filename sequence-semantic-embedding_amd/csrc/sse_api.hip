@@ -142,6 +142,7 @@ struct sse_handle {
   float idx_norm_max = 1.0f;
   // scratch
   DevBuf s_ids, s_out, s_q, s_qp, s_ps, s_pi, s_cert, s_os, s_oi, s_tmp, s_tmp2, s_feat, s_zero, s_map;
+  DevBuf s_qmap, s_qc;     // fp32 second chance of the bf16 candidate pass: the uncertified queries as a dense set
   DevBuf s_qp32, s_fb_cnt;  // fp32 second chance of the bf16 candidate pass: fp32 query fragments, counter
   DevBuf s_persist;  // lstm_persist.hip: h_t / raw-encoding exchange buffers and arrival counters
   int32_t *pin_small = nullptr;  // 64 pinned host words: error flag / loss read-backs (a pageable target makes the copy a blocking one)
@@ -834,7 +835,11 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   // the 16 lane lists of a workgroup are always merged in-kernel (a few tens of microseconds per workgroup): the
   // re-scoring pass ranks 16 candidates per split
   const int nsplit = choose_nsplit(NQ, QB, NT);
-  const int NC = nsplit * 16;
+  // the fp32 second chance of the bf16 pass sweeps for a dense set of FEW queries (typically a handful of query blocks): it
+  // takes its parallelism from the index instead -- at least 32 splits -- or three workgroups would walk 1.25 M rows alone
+  int nsplit2 = nsplit;
+  while (nsplit2 < 32 && NT / (nsplit2 * 2 * 2) >= 16) nsplit2 *= 2;
+  const int NC = nsplit * 16, NCmax = std::max(nsplit, nsplit2) * 16;
   const int KG16 = (S + 15) / 16;
   if (bf && !h->idxp16_valid) {
     const size_t need = (size_t)NT * KG16 * 1024;
@@ -852,9 +857,9 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   if (ensure_counters(h, st)) return 1;
   unsigned long long *counters = (unsigned long long *)h->s_fb_cnt.p;
   if (reserve(h, h->s_qp, (size_t)QB * NQ * KG * 256 * sizeof(float))) return 1;
-  if (reserve(h, h->s_ps, (size_t)Q * NC * sizeof(float))) return 1;
-  if (reserve(h, h->s_pi, (size_t)Q * NC * sizeof(int32_t))) return 1;
-  if (reserve(h, h->s_pb, (size_t)Q * nsplit * sizeof(float))) return 1;
+  if (reserve(h, h->s_ps, (size_t)Q * (bf ? NCmax : NC) * sizeof(float))) return 1;
+  if (reserve(h, h->s_pi, (size_t)Q * (bf ? NCmax : NC) * sizeof(int32_t))) return 1;
+  if (reserve(h, h->s_pb, (size_t)Q * (bf ? NCmax / 16 : nsplit) * sizeof(float))) return 1;
   if (reserve(h, h->s_cert, (size_t)Q * sizeof(int32_t))) return 1;
   if (reserve_collect(h, Q, POOL)) return 1;
   if (split) *split = 1;
@@ -911,20 +916,32 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
     // kernels, where a workgroup whose whole query block is certified returns at once and a certified query is left
     // alone -- before anything falls through to the collect path.
     if (reserve(h, h->s_qp32, (size_t)QB * NQ * KG * 256 * sizeof(float))) return 1;
+    if (reserve(h, h->s_qmap, (size_t)(Q + 1) * sizeof(int32_t))) return 1;
+    if (reserve(h, h->s_qc, (size_t)QT * 32 * S * sizeof(float))) return 1;
     HIPCHECK(h, launch_count_uncert(r.cert, Q, counters, st));
-    HIPCHECK(h, launch_pack_rows(q, Q, S, (float *)h->s_qp32.p, st));
-    qp32 = (const float *)h->s_qp32.p;
+    // the uncertified queries as a dense set: the sweep and the re-scoring below cost what THEY cost (launches sized for all
+    // Q; workgroups past the set return at once)
+    int32_t *qmap = (int32_t *)h->s_qmap.p, *qcount = qmap + Q;
+    HIPCHECK(h, launch_compact_uncert(q, r.cert, Q, S, qmap, qcount, (float *)h->s_qc.p, st));
+    HIPCHECK(h, launch_pack_rows((const float *)h->s_qc.p, Q, S, (float *)h->s_qp32.p, st));
     ScoreArgs a2 = a;
     a2.BF = 0;
     a2.idxp = h->idxp;
-    a2.qp = qp32;
+    a2.qp = (const float *)h->s_qp32.p;
     a2.KG = KG;
-    a2.skip_cert = r.cert;
+    a2.q_count = qcount;
+    a2.NSPLIT = nsplit2;
     HIPCHECK(h, launch_score_topk(a2, st));
     RescoreArgs r2 = r;
+    r2.q = (const float *)h->s_qc.p;
+    r2.NC = nsplit2 * 16;
     r2.eps = eps32;
-    r2.skip = r.cert;
+    r2.qmap = qmap;
+    r2.q_count = qcount;
     HIPCHECK(h, launch_rescore(r2, st));
+    // fp32 fragments of ALL queries for the collect sweep below
+    HIPCHECK(h, launch_pack_rows(q, Q, S, (float *)h->s_qp32.p, st));
+    qp32 = (const float *)h->s_qp32.p;
   }
   // What is still uncertified has its k-th score tied with (or within the fp32 bound of) rows outside the candidate
   // lists -- e.g. an index holding many exact duplicates of a query's best rows.  Collect path: every row whose fp32
@@ -938,7 +955,6 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   c.idxp = h->idxp;
   c.qp = qp32;
   c.KG = KG;
-  c.skip_cert = nullptr;
   c.COLLECT = 1;
   c.col_thr = (const float *)h->s_cthr.p;
   c.col_slot = (const int32_t *)h->s_cslot.p;

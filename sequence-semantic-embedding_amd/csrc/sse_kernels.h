@@ -192,7 +192,8 @@ struct ScoreArgs {
   int32_t Q, KG, NT, QT, NSPLIT, KC;
   int32_t NQ = 4;     // query tiles (of 32) per workgroup: 4 (128-query blocks), 2 (index dimension > 296) or 1 (Q <= 32, dimension > 616)
   int32_t thr_off = 0;  // set by the launcher: LDS offset (floats) of the shared per-query thresholds
-  const int32_t *skip_cert = nullptr;  // second-chance pass: a workgroup whose whole query block is already certified returns
+  const int32_t *q_count = nullptr;  // compacted second-chance pass: the real number of queries (<= Q) lives on the device;
+                                     // workgroups and lanes past it do nothing
   int32_t BF = 0;       // 1: idxp / qp are bf16 fragment copies, KG counts 16-k groups (candidate pass on bf16 MFMA)
   // collect pass (COLLECT = 1, fp32 only): rows with score >= col_thr[query] are appended to buffer col_slot[query]
   int32_t COLLECT = 0;
@@ -212,6 +213,10 @@ size_t score_lds_bytes(int NQ, int KG, int BF, int COLLECT);
 // rows [R][C] fp32 -> bf16 fragment blocks [ceil(R/32)][ceil(C/16)][1 KiB]; fp32 frag32 index -> the same
 hipError_t launch_pack_rows_bf16(const float *rows, int64_t R, int C, void *out, hipStream_t stream);
 hipError_t launch_count_uncert(const int32_t *cert, int Q, unsigned long long *count, hipStream_t st);
+// uncertified queries (cert[q] == 0) -> dense set: qmap[slot] = q, *count = size, qc[slot][S] = their rows (zero rows up to
+// a whole 32-query tile)
+hipError_t launch_compact_uncert(const float *q, const int32_t *cert, int Q, int S, int32_t *qmap, int32_t *count, float *qc,
+                                 hipStream_t st);
 hipError_t launch_frag32_to_bf16(const float *idxp, int64_t NT, int KG, void *out, hipStream_t stream);
 
 #define SSE_COLLECT_CAP 4096   // rows one query can collect (exact path); more -> float64 brute force
@@ -230,7 +235,9 @@ struct RescoreArgs {
   int64_t id_base, N;
   int32_t Q, S, NC, k;     // NC = NSPLIT*KC candidates per query
   float eps;               // bound on |candidate score - exact score| / |q|
-  const int32_t *skip = nullptr;  // second-chance pass: queries with skip[q] != 0 are already final
+  // compacted second-chance pass: q / part_* are indexed by slot, results (out_*, cert, col_thr) go to query qmap[slot];
+  // slots >= *q_count do not exist
+  const int32_t *qmap = nullptr, *q_count = nullptr;
   // optional: collect threshold of every processed query, +inf when certified, else (exact k-th of the
   // candidates) - eps32 * |q| rounded down: no exact top-k row has a smaller fp32 score
   float *col_thr = nullptr;

@@ -6,7 +6,6 @@ definition: "tight" accuracy per batch, batch accuracies averaged UNWEIGHTED,
 for n in (1, 3, 10).  Unlike the reference, sources are encoded and ranked
 once, not once per n -- the numbers are identical."""
 import codecs
-import math
 
 import numpy as np
 
@@ -66,13 +65,19 @@ class Evaluator(object):
         if h.index_gen != self._index_gen:      # predict()/similarity or another Evaluator replaced the handle's index
             h.index_upload(self.targetEncodings)
             self._index_gen = h.index_gen
+        # The reference feeds 600 sources per session.run (sse_evaluator.py:104-109).  Rows are independent and every
+        # encoder kernel returns the same bits for a row whatever batch it arrives in (tests/test_gpu_encode.py), so the
+        # sources go to the device in chunks of up to 32768 rows -- the 64-row-tile matrix kernel at full occupancy
+        # instead of 28 launches of the few-sequences kernel on crosslingual's 16,491 queries -- and the ranked lists are
+        # cut back into the reference's batches of 600 for its per-batch accuracy means.
+        chunk = max(batch, 32768 // batch * batch)
         out = []
-        for b in range(int(math.ceil(len(self.srcSeq_batch) / float(batch)))):
-            ids = np.array(self.srcSeq_batch[b * batch:(b + 1) * batch], dtype=np.int32)   # the feed dict's array
+        for c0 in range(0, len(self.srcSeq_batch), chunk):
+            ids = np.array(self.srcSeq_batch[c0:c0 + chunk], dtype=np.int32)               # the feed dict's array
             # session.run([norm_src_seq_embedding]) + np.dot + getSortedResults in one call: the encodings go from
             # the encoder to the scorer on the device
             _, idx = h.encode_score_topk(0, ids, True, k)
-            out.append(idx)
+            out.extend(idx[b0:b0 + batch] for b0 in range(0, len(ids), batch))
         return out
 
     def eval(self, top_n=(1, 3, 10), batch=600):
