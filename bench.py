@@ -35,6 +35,31 @@ V, E, H, S, T = 32000, 50, 256, 256, 32
 N_TARGETS = 571                       # classification target space, reference README.md:98
 FLOP_PER_SEQ = T * 8 * H * (E + H) + 2 * H * S     # SURVEY 8d algorithmic LSTM forward flops (20.18 MFLOP)
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+PMC = {}
+
+
+def csrc_sha():
+    """Hash of the kernel sources: the tracked PMC summary (profiles/pmc_summary.json) is only quoted while it describes
+    THIS code (traffic was read from a static file)."""
+    import hashlib
+    d = os.path.join(ROOT, "sequence-semantic-embedding_amd", "csrc")
+    hsh = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            hsh.update(name.encode())
+            hsh.update(open(os.path.join(d, name), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
+def pmc_summary():
+    """{kernel key: {...}} from the tracked rocprofv3 --pmc passes of this same command, or {} when the sources changed
+    since they were collected (tools/collect_profiles.sh + tools/summarize_profiles.py)."""
+    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if not os.path.exists(path):
+        return {}
+    d = json.load(open(path))
+    return d if d.get("csrc_sha") == csrc_sha() else {"stale": "profiles/pmc_summary.json was collected for csrc %s, this is %s"
+                                                      % (d.get("csrc_sha"), csrc_sha())}
 
 
 def cpu_baseline(batch=1024, budget_s=12.0):
@@ -151,6 +176,8 @@ def main():
     ap.add_argument("--no-x3-leg", action="store_true")
     args = ap.parse_args()
 
+    global PMC
+    PMC = pmc_summary()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -271,6 +298,11 @@ def main():
                   "bf16_mfma_tflops_per_gpu": 3 * B * FLOP_PER_SEQ / (x3_ms * 1e-3) / 1e12,
                   "frac_of_bf16_mfma_peak": 3 * B * FLOP_PER_SEQ / (x3_ms * 1e-3) / 1e12 / 2500.0,
                   "max_abs_diff_vs_exact_fp32_kernel": float((src_enc[:4096] - exact_enc).abs().max().item())}
+        x3_leg["roofline"] = {"kernel": "lstm_fwd_x3_kernel<8,false,2>", "bound": "mfma", "unit": "TFLOP/s",
+                              "achieved": 3 * B * FLOP_PER_SEQ / (x3_ms * 1e-3) / 1e12, "peak": 2500.0,
+                              "frac": 3 * B * FLOP_PER_SEQ / (x3_ms * 1e-3) / 1e12 / 2500.0,
+                              "note": "executed bf16 MFMA flops = 3 x algorithmic (hi*hi + hi*lo + lo*hi)",
+                              "mfma_busy": PMC.get("mfma_busy", {}).get("lstm_fwd_x3_kernel<8, false, 2>")}
         if rank == 0:
             x3_leg["max_abs_err_vs_oracle"] = float(np.abs(src_enc[:48].cpu().numpy() - want).max())
             x3_leg["top1_match_vs_oracle"] = float(np.mean(top_i[:48, 0].cpu().numpy() == wids[:, 0]))
@@ -329,13 +361,23 @@ def main():
         scoring_fp32 = {"scores_per_s": Q * Ns * world / fdt, "ms_per_pass": fdt * 1e3,
                         "achieved_tflops_per_gpu": 2.0 * S * Q * Ns / fdt / 1e12,
                         "frac_of_f32_mfma_peak": 2.0 * S * Q * Ns / fdt / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                        "identical_to_default": same}
+                        "identical_to_default": same,
+                        "roofline": {"kernel": "score_topk_kernel<4,false,false,true>", "bound": "mfma", "unit": "TFLOP/s",
+                                     "achieved": 2.0 * S * Q * Ns / fdt / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+                                     "frac": 2.0 * S * Q * Ns / fdt / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                     "note": "whole pass (sweep + float64 re-scoring + follow-up launches) over the sweep's algorithmic flops",
+                                     "mfma_busy": PMC.get("mfma_busy", {}).get("score_topk_kernel<4, false, false, true>")}}
         scoring = {"scores_per_s": Q * Ns * world / sdt, "ms_per_pass": sdt * 1e3, "queries": Q,
                    "index_rows_total": Ns * world, "index_rows_per_gpu": Ns, "S": S, "k": k,
                    "collective": "rccl all_gather of per-shard top-k + k-way merge" if world > 1 else "none (1 shard)",
                    "candidates": "bf16 MFMA (v_mfma_f32_32x32x16_bf16) + exact float64 re-scoring, fp32 second chance on the device",
                    "algorithmic_tflops_per_gpu": 2.0 * S * Q * Ns / sdt / 1e12,
-                   "top1_planted_acc": planted_ok}
+                   "top1_planted_acc": planted_ok, "identical_to_fp32_candidates": same,
+                   "roofline": {"kernel": "score_topk_kernel<4,true,false,true>", "bound": "mfma", "unit": "TFLOP/s",
+                                "achieved": 2.0 * S * Q * Ns / sdt / 1e12, "peak": 2500.0, "frac": 2.0 * S * Q * Ns / sdt / 1e12 / 2500.0,
+                                "note": "whole pass (bf16 sweep + float64 re-scoring + second-chance / collect launches) over the "
+                                        "sweep's algorithmic flops; the chip clocks ~1.7 GHz under this load",
+                                "mfma_busy": PMC.get("mfma_busy", {}).get("score_topk_kernel<4, true, false, true>")}}
 
     # ---- secondary leg: the demo / web path (sse_demo.py:112-134, webserver.py:124-161): ONE query, token ids in ->
     # top-10 out, against the 571-row classification index and against this rank's ranking shard.  The big sweep is
@@ -374,6 +416,13 @@ def main():
                    "ids_to_top10_ms_index_%d" % Ns: e2e_big * 1e3, "sweep_ms_index_%d" % Ns: sweep_s * 1e3,
                    "sweep_hbm": {"bound": "hbm", "algorithmic_bytes": Ns * S * 2, "achieved_gbps": Ns * S * 2 / sweep_s / 1e9,
                                  "peak_gbps": 8000.0, "hbm_frac": Ns * S * 2 / sweep_s / 8e12},
+                   "roofline": {"kernel": "score_topk_kernel<1,true,false,true> (+ re-scoring, one synchronisation)", "bound": "hbm",
+                                "unit": "GB/s", "achieved": Ns * S * 2 / sweep_s / 1e9, "peak": 8000.0,
+                                "frac": Ns * S * 2 / sweep_s / 8e12,
+                                "traffic": PMC.get("sweep_q1_hbm_bytes"),
+                                "note": "algorithmic bytes = the bf16 candidate copy of the index streamed once; the call also "
+                                        "holds the pack / re-score launches and the host round trip"},
+                   "timing": "median of 31 calls",
                    "note": "host buffers both ways (ids H2D, top-10 D2H, one synchronisation)"}
         h.index_set_dev(tgt_enc.data_ptr(), N_TARGETS, S)
 
@@ -394,30 +443,54 @@ def main():
         h.corpus_upload(1, ttgt)
         src_rows = np.repeat(np.arange(Bt // 2, dtype=np.int32), 2)          # data.py:95-115: pos,neg share a source
         tgt_rows = np.arange(Bt, dtype=np.int32)
-        tl = trainer.train_step(src_rows, tgt_rows, tz, rows_global=Bt * world, by_rows=True)
-        barrier()
-        ts = time.perf_counter()
-        for _ in range(args.train_iters):
-            tl = trainer.train_step(src_rows, tgt_rows, tz, rows_global=Bt * world, by_rows=True)
-        barrier()
-        tdt = (time.perf_counter() - ts) / args.train_iters
-        if use_dist:
-            t = torch.tensor([tdt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tdt = float(t.item())
+        def timed_steps():
+            t = trainer.train_step(src_rows, tgt_rows, tz, rows_global=Bt * world, by_rows=True)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.train_iters):
+                t = trainer.train_step(src_rows, tgt_rows, tz, rows_global=Bt * world, by_rows=True)
+            barrier()
+            d = (time.perf_counter() - t0) / args.train_iters
+            if use_dist:
+                tt = torch.tensor([d], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                d = float(tt.item())
+            return d, t
+        # exact fp32 arithmetic first (options off), then the library default (split bf16 operands): the default is `ms_per_step`
+        for opt in ("train_fwd_x3", "train_bwd_x3", "train_dk_x3"):
+            h.set_option(opt, 0)
+        fdt_train, _ = timed_steps()
+        for opt in ("train_fwd_x3", "train_bwd_x3", "train_dk_x3"):
+            h.set_option(opt, 1)
+        tdt, tl = timed_steps()
+        # MFMA flops the default step EXECUTES per GPU (paired batch: the source encoder's forward and weight-gradient GEMM run
+        # once per (pos, neg) pair; every product is three bf16 MFMAs): forward gates + projection, BPTT recurrence dG.Kh^T,
+        # dX = dG.Kx^T, dK = A^T dG
+        fwd = (Bt + Bt // 2) * FLOP_PER_SEQ
+        rec = 2 * Bt * T * 2 * H * 4 * H
+        dxf = 2 * Bt * T * 2 * 4 * H * E
+        dkf = (Bt + Bt // 2) * T * 2 * (E + H) * 4 * H
+        executed = 3.0 * (fwd + rec + dxf + dkf)
         training = {"pair_rows_per_s": Bt * world / tdt, "ms_per_step": tdt * 1e3, "pair_rows_per_gpu": Bt,
+                    "ms_per_step_exact_fp32": fdt_train * 1e3,
                     "collective": ("rccl all_reduce of one flat %.1f MB gradient buffer" % (trainer.arena.numel() * 4 / 1e6))
                     if world > 1 else "none (1 rank)",
                     "algorithmic_tflops_per_gpu": 3.0 * 2 * Bt * FLOP_PER_SEQ / tdt / 1e12,
+                    "algorithmic_note": "SURVEY 8d: train ~ 3 x forward flops for both encoders, no pair de-duplication (not a roofline figure)",
                     "loss_last": tl[0], "input": "corpus resident on the device; 2 x %d int32 row numbers H2D per step" % Bt,
-                    "arithmetic": "forward, BPTT and weight-gradient GEMMs: v_mfma_f32_32x32x16_bf16 on hi + lo split fp32 operands "
-                                  "(library defaults train_fwd_x3 / train_bwd_x3 / train_dk_x3 = 1; ~4e-6 relative per product); "
-                                  "dX, projections, loss, clip and Adagrad in fp32"}
+                    "arithmetic": "forward, BPTT (recurrence + dX) and weight-gradient GEMMs: v_mfma_f32_32x32x16_bf16 / 16x16x32 on hi + lo "
+                                  "split fp32 operands (library defaults train_fwd_x3 / train_bwd_x3 / train_dk_x3 = 1; ~4e-6 relative per "
+                                  "product); projections, loss, clip and Adagrad in fp32; ms_per_step_exact_fp32 = all three options 0",
+                    "roofline": {"kernel": "lstm_bwd_kernel<1,8,true,true> (dominant: two launches per step)", "bound": "mfma",
+                                 "unit": "TFLOP/s", "achieved": executed / tdt / 1e12, "peak": 2500.0, "frac": executed / tdt / 1e12 / 2500.0,
+                                 "executed_mfma_flop_per_step": executed,
+                                 "note": "whole step over the bf16 MFMA flops it executes (with pair de-duplication); the kernels are "
+                                         "bounded by the L2 -> CU weight stream of their 32-row tiles, not by the matrix pipe",
+                                 "mfma_busy": {k: PMC.get("mfma_busy", {}).get(k) for k in
+                                               ("lstm_bwd_kernel<1, 8, true, true>", "lstm_fwd_x3_kernel<8, true, 2>",
+                                                "dk_x3_kernel<10, false>", "dk_x3_kernel<10, true>")}}}
 
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and B == 16384:          # PMC pass of this same command (tools/summarize_profiles.py)
-        traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+    traffic = PMC.get("lstm_fwd_hbm_bytes_per_launch") if B == 16384 else None   # PMC pass of this same command, same sources
     if rank == 0:
         line = {
             "metric": "encoded seqs/sec (+ query x target cosine-scores/sec, top-1 vs ref)",
@@ -432,7 +505,10 @@ def main():
             "top1_match_vs_oracle": top1_match, "encode_max_abs_err_vs_oracle": enc_err,
             "roofline": {"kernel": "lstm_fwd_kernel<2>", "bound": "mfma", "achieved": achieved_tflops,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": traffic, "traffic_unit": "bytes/launch (PMC, separate rocprofv3 pass; null if no pass on record)",
+                         "traffic": traffic, "traffic_unit": "bytes/launch (PMC: (2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate rocprofv3 "
+                                                             "passes of this command; null when the kernel sources changed since)",
+                         "mfma_busy": PMC.get("mfma_busy", {}).get("lstm_fwd_kernel<2, 2, 1, false, true, false>"),
+                         "pmc_source": PMC.get("source", PMC.get("stale")),
                          "avg_kernel_ms": enc_ms_avg,
                          "algorithmic_flop_per_launch": B * FLOP_PER_SEQ},
         }

@@ -34,6 +34,8 @@ struct Encoder {
   float *Wp = nullptr, *Mp = nullptr;
   float *Waug = nullptr;      // few-sequences kernel: kernel rows in its k space incl. the bias row
   bool waug_valid = false;
+  float *Wc = nullptr;        // cluster kernel (lstm_cluster.hip): weight fragments per workgroup of a cluster
+  bool wc_valid = false;
   unsigned short *Wx3 = nullptr;  // option lstm_x3: hi / lo bf16 fragment copies of the kernel matrix
   bool x3_valid = false;
   unsigned short *Wx3t = nullptr;  // option train_fwd_x3: the same copies with the h part in unit order (training forward)
@@ -114,6 +116,9 @@ struct sse_handle {
   bool persist_inject = false;   // testing aid (option lstm_persist_inject_miss): report a missing cluster workgroup after every cluster launch
   int64_t persist_fallbacks = 0; // host-buffer encodes re-run on lstm_small because a cluster workgroup did not arrive
   int cu_count = 0;           // compute units of the device (co-residency check of the cluster kernel)
+  int lstm_cluster_rows = 1024; // option "lstm_cluster_rows": batches above lstm_persist_rows up to this many rows (<= 1024) take the MFMA cluster kernel
+  uint32_t cluster_epoch = 0;   // tag epoch of that kernel's exchange buffers
+  int lstm_cluster_wt = 0;      // option "lstm_cluster_write_through": force the any-placement publish path (tests)
   int lstm_small_rows = 1024; // option "lstm_small_rows": batches up to this many rows take the few-sequences LSTM kernel
   bool score_bf16 = true;    // option "score_bf16" (default on): candidate pass on the bf16 matrix pipe; results stay exact
   void *idxp16 = nullptr;    // bf16 fragment copy of the index (built on demand)
@@ -145,6 +150,7 @@ struct sse_handle {
   DevBuf s_qmap, s_qc;     // fp32 second chance of the bf16 candidate pass: the uncertified queries as a dense set
   DevBuf s_qp32, s_fb_cnt;  // fp32 second chance of the bf16 candidate pass: fp32 query fragments, counter
   DevBuf s_persist;  // lstm_persist.hip: h_t / raw-encoding exchange buffers and arrival counters
+  DevBuf s_cluster;  // lstm_cluster.hip: h_t / sum-of-squares exchange buffers
   int32_t *pin_small = nullptr;  // 64 pinned host words: error flag / loss read-backs (a pageable target makes the copy a blocking one)
   void *pin = nullptr;  // pinned host staging of the host-buffer scoring entry points: [scores | ids | certificates]
   size_t pin_cap = 0;
@@ -283,6 +289,7 @@ int ensure_packed(sse_handle *h, hipStream_t st) {
     e.pad_valid = false;
     e.pad_valid_small = false;
     e.waug_valid = false;
+    e.wc_valid = false;
     e.x3_valid = false;
     e.pad_valid_x3 = false;
     const int KG = e.KGx + e.KGh;
@@ -523,6 +530,67 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
       pa.hx = (unsigned long long *)h->s_persist.p;
       pa.rawx = pa.hx + nhx;
       HIPCHECK(h, launch_lstm_persist(pa, st));
+      if (h->persist_inject) {  // testing aid: pretend a workgroup of the cluster never arrived
+        static const int32_t four = 4;
+        HIPCHECK(h, hipMemcpyAsync(h->err_flag, &four, sizeof four, hipMemcpyHostToDevice, st));
+      }
+      return 0;
+    }
+  }
+  if (small_ok && B > 32 && B <= h->lstm_cluster_rows && B <= lstm_cluster_max_rows() && T <= lstm_persist_max_steps() &&
+      lstm_cluster_ok(c.embedding_size, e.H, c.encoding_size)) {
+    // mid-size batches (the evaluator's 600, the index builder's 1000): the hidden units of every 64-row tile spread over a
+    // cluster of 16 compute units, weights in LDS, h_t exchanged per step (lstm_cluster.hip); needs one CU per workgroup
+    if (h->cu_count == 0) {
+      hipDeviceProp_t prop;
+      HIPCHECK(h, hipGetDeviceProperties(&prop, c.device));
+      h->cu_count = prop.multiProcessorCount;
+    }
+    const int ncl = (B + 63) / 64;
+    if ((ncl <= 8 ? 128 : 256) <= h->cu_count) {
+      Encoder &own = e.shares_lstm_with >= 0 ? h->enc[e.shares_lstm_with] : e;
+      if (!own.wc_valid) {
+        if (!own.Wc) HIPCHECK(h, hipMalloc((void **)&own.Wc, lstm_cluster_weight_floats(c.embedding_size, own.H) * sizeof(float)));
+        HIPCHECK(h, launch_pack_lstm_cluster(h->vars[own.kernel].dev, h->vars[own.bias].dev, c.embedding_size, own.H, own.Wc, st));
+        own.wc_valid = true;
+      }
+      LstmClusterArgs ca;
+      ca.ids = ids;
+      ca.emb = h->emb_pad;
+      ca.Wc = own.Wc;
+      ca.Mp = e.Mp;
+      ca.out = out;
+      ca.err = h->err_flag;
+      ca.B = B;
+      ca.T = T;
+      ca.V = c.vocab_size;
+      ca.E = c.embedding_size;
+      ca.Ep = e.Ep;
+      ca.KGx = e.KGx;
+      ca.H = e.H;
+      ca.Hp = e.H <= 128 ? 128 : 256;
+      ca.KGh = ca.Hp / 8;
+      ca.S = c.encoding_size;
+      ca.NTS = (c.encoding_size + 31) / 32;
+      ca.normalize = normalize ? 1 : 0;
+      if (h->pad_skip && T > 1) {
+        if (ensure_pad_table_small(h, side, T, st)) return 1;  // lstm_small's table: the same arithmetic
+        ca.pad_h = own.pad_h_small;
+        ca.pad_c = own.pad_c_small;
+        ca.pad_stride = e.H;
+      }
+      const size_t nhx = lstm_cluster_hx_words(e.H), nsx = lstm_cluster_sx_words();
+      const size_t need = (nhx + nsx) * sizeof(unsigned long long);
+      if (h->cluster_epoch == 0 || h->cluster_epoch >= (1u << 20) - 1 || need > h->s_cluster.cap) {
+        if (reserve(h, h->s_cluster, need)) return 1;
+        HIPCHECK(h, hipMemsetAsync(h->s_cluster.p, 0, h->s_cluster.cap, st));
+        h->cluster_epoch = 0;
+      }
+      ca.epoch = ++h->cluster_epoch;
+      ca.write_through = h->lstm_cluster_wt;
+      ca.hx = (unsigned long long *)h->s_cluster.p;
+      ca.sx = ca.hx + nhx;
+      HIPCHECK(h, launch_lstm_cluster(ca, st));
       if (h->persist_inject) {  // testing aid: pretend a workgroup of the cluster never arrived
         static const int32_t four = 4;
         HIPCHECK(h, hipMemcpyAsync(h->err_flag, &four, sizeof four, hipMemcpyHostToDevice, st));
@@ -1064,6 +1132,7 @@ void sse_destroy(sse_handle *h) {
       if (e.pad_h) (void)hipFree(e.pad_h);
       if (e.pad_c) (void)hipFree(e.pad_c);
       if (e.Waug) (void)hipFree(e.Waug);
+      if (e.Wc) (void)hipFree(e.Wc);
       if (e.Wx3) (void)hipFree(e.Wx3);
       if (e.Wx3t) (void)hipFree(e.Wx3t);
       if (e.pad_h_x3) (void)hipFree(e.pad_h_x3);
@@ -1195,10 +1264,12 @@ static int encode_host_ids_locked(sse_handle *h, int side, const int32_t *ids_ho
     // Nothing was written that the other kernels do not overwrite: run the batch again on the few-sequences kernel
     // (bit-identical results) and count it.
     h->persist_fallbacks += 1;
-    const int keep = h->lstm_persist_rows;
+    const int keep = h->lstm_persist_rows, keep_c = h->lstm_cluster_rows;
     h->lstm_persist_rows = 0;
+    h->lstm_cluster_rows = 0;
     rc = encode_dev_locked(h, side, (const int32_t *)h->s_ids.p, B, T, normalize, (float *)h->s_out.p, st);
     h->lstm_persist_rows = keep;
+    h->lstm_cluster_rows = keep_c;
     if (rc) return 1;
     return check_err_flag(h, st);
   }
@@ -1352,6 +1423,15 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value) {
   if (strcmp(name, "lstm_persist_rows") == 0) {
     if (value < 0) return fail(h, "lstm_persist_rows must be >= 0");
     h->lstm_persist_rows = (int)value;
+    return 0;
+  }
+  if (strcmp(name, "lstm_cluster_write_through") == 0) {
+    h->lstm_cluster_wt = value != 0;
+    return 0;
+  }
+  if (strcmp(name, "lstm_cluster_rows") == 0) {
+    if (value < 0) return fail(h, "lstm_cluster_rows must be >= 0");
+    h->lstm_cluster_rows = value;
     return 0;
   }
   if (strcmp(name, "lstm_small_rows") == 0) {

@@ -181,6 +181,32 @@ size_t lstm_persist_hx_words(int H);
 size_t lstm_persist_raw_words(int S);
 hipError_t launch_lstm_persist(const LstmPersistArgs &a, hipStream_t stream);
 
+// mid-size batches (33 .. 1024 sequences) with the hidden units of a 64-row tile spread over a cluster of 16 workgroups that
+// keep their weight fragments in LDS and exchange h_t every step -- lstm_persist.hip's layout on MFMA (lstm_cluster.hip)
+struct LstmClusterArgs {
+  const int32_t *ids;    // [B][T]
+  const float *emb;      // padded embedding table [V][Ep], column E = 1.0 (the matrix kernel's)
+  const float *Wc;       // launch_pack_lstm_cluster
+  const float *Mp;       // packed projection [NTS][KGh][256] (the matrix kernel's)
+  float *out;            // [B][S]
+  int32_t *err;          // bit 0: token id out of range; bit 2: a cluster workgroup never arrived (bounded spin)
+  int32_t B, T, V, E, Ep, KGx, KGh, H, Hp, S, NTS, normalize;
+  const float *pad_h = nullptr, *pad_c = nullptr;  // the pad-prefix table of lstm_small.hip (same arithmetic)
+  int32_t pad_stride = 0;
+  unsigned long long *hx = nullptr;  // lstm_cluster_hx_words(H): h_t exchange, {value, tag} words
+  unsigned long long *sx = nullptr;  // lstm_cluster_sx_words(): per-tile row sums of squares
+  uint32_t epoch = 0;                // 1 .. 2^20-1, different for every launch on the same exchange buffers
+  int32_t NCL = 0;                   // set by the launcher
+  int32_t write_through = 0;         // 1: always publish h with write-through stores (the any-placement path; tests)
+};
+int lstm_cluster_ok(int E, int H, int S);
+int lstm_cluster_max_rows();
+size_t lstm_cluster_weight_floats(int E, int H);
+size_t lstm_cluster_hx_words(int H);
+size_t lstm_cluster_sx_words();
+hipError_t launch_pack_lstm_cluster(const float *K, const float *b, int E, int H, float *Wc, hipStream_t stream);
+hipError_t launch_lstm_cluster(const LstmClusterArgs &a, hipStream_t stream);
+
 // ------------------------------ scoring ------------------------------------
 struct ScoreArgs {
   const float *idxp;     // packed index  [NT][KG][256]  (frag32, rows = targets)

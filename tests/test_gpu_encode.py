@@ -428,3 +428,86 @@ def test_four_serving_handles_from_threads_while_a_fifth_trains():
     stop.set()
     tt.join(60)
     assert not errs, errs
+
+
+@pytest.mark.parametrize("mode,V,E,Hs,Ht,S,T", [
+    ("dual-encoder", 500, 50, 256, 256, 256, 32),          # configs[1]: 16 units per workgroup, two weight tiles
+    ("shared-encoder", 300, 50, 96, 96, 64, 80),           # reference defaults: Hp = 128, 8 units per workgroup, 4 of 16 own only padding
+    ("dual-encoder", 200, 40, 200, 130, 50, 50),           # crosslingual-like: padded cells, S not a multiple of 32
+    ("dual-encoder", 90, 8, 16, 40, 512, 9),               # tiny cells, widest encoding (16 projection tiles)
+])
+def test_mfma_cluster_kernel_equals_the_other_kernels(mode, V, E, Hs, Ht, S, T):
+    """lstm_cluster.hip (33 .. 1024 rows: hidden units of a 64-row tile over 16 workgroups, weights in LDS, h_t exchanged
+    per step, gate GEMM on fp32 MFMA): bit-identical to the few-sequences kernel and to the matrix kernel, with and
+    without the pad-prefix skip, for the evaluator's 600 and the index builder's 1000 rows and the ragged sizes around
+    the 64-row clusters; within the encoder tolerance of the oracle."""
+    params = model_params(mode, V, E, Hs, Ht, S, T)
+    m, p = make_pair(params, seed=8)
+    rng = np.random.RandomState(3)
+    for B in (33, 64, 65, 600, 1000, 1024):
+        ids = random_ids(rng, B, T, V, pad_frac=0.6)
+        ids[1, :] = 0
+        ids[1, -1] = 1                                     # only EOS
+        ids[2] = rng.randint(2, V, size=T)                 # no padding at all
+        for side, enc in (("src", m.encode_source), ("tgt", m.encode_target)):
+            for normalize in (True, False):
+                m.handle.set_option("lstm_cluster_rows", 0)
+                ref = enc(ids, normalize=normalize)                                   # few-sequences kernel
+                m.handle.set_option("lstm_cluster_rows", 1024)
+                got = enc(ids, normalize=normalize)
+                assert np.array_equal(got, ref), (B, side, normalize, np.abs(got - ref).max())
+                # the any-placement publish path (write-through stores; taken when a cluster is not on one XCD)
+                m.handle.set_option("lstm_cluster_write_through", 1)
+                got_wt = enc(ids, normalize=normalize)
+                m.handle.set_option("lstm_cluster_write_through", 0)
+                assert np.array_equal(got_wt, ref), (B, side, normalize, "write-through")
+            if B in (65, 600):
+                m.handle.set_option("pad_skip", 0)
+                got_noskip = enc(ids)
+                m.handle.set_option("pad_skip", 1)
+                assert np.array_equal(got_noskip, enc(ids))
+        if B == 600:
+            m.handle.set_option("lstm_small_rows", 0)
+            m.handle.set_option("lstm_cluster_rows", 0)
+            mat = m.encode_source(ids)                                                # 32-row matrix tiles
+            m.handle.set_option("lstm_small_rows", 1024)
+            m.handle.set_option("lstm_cluster_rows", 1024)
+            assert np.array_equal(m.encode_source(ids), mat)
+        if B <= 65:
+            assert np.abs(m.encode_source(ids) - O.encode(p, params, "src", ids)).max() <= TOL
+    assert m.handle.get_counter("lstm_persist_fallbacks") == 0
+    import sse_amd
+    bad = random_ids(rng, 70, T, V)
+    bad[69, -1] = V
+    with pytest.raises(sse_amd.SSEError):
+        m.encode_source(bad)
+    good = random_ids(rng, 70, T, V)
+    assert np.isfinite(m.encode_source(good)).all()
+    # a missing cluster workgroup falls back to the few-sequences kernel
+    m.handle.set_option("lstm_cluster_rows", 0)
+    want = m.encode_source(good)
+    m.handle.set_option("lstm_cluster_rows", 1024)
+    m.handle.set_option("lstm_persist_inject_miss", 1)
+    assert np.array_equal(m.encode_source(good), want)
+    m.handle.set_option("lstm_persist_inject_miss", 0)
+    assert m.handle.get_counter("lstm_persist_fallbacks") == 1
+
+
+def test_mfma_cluster_kernel_many_calls_alternating_shapes():
+    """Exchange buffers reused across calls (tag epochs), sides with different cell sizes, batch sizes on both sides of
+    the 8-cluster launch boundary (512 rows)."""
+    params = model_params("dual-encoder", 400, 50, 256, 96, 64, 16)
+    m, p = make_pair(params, seed=23)
+    rng = np.random.RandomState(8)
+    cases = []
+    for B, T in ((600, 16), (40, 16), (1024, 5), (513, 9), (100, 2)):
+        ids = random_ids(rng, B, T, 400, pad_frac=0.4)
+        m.handle.set_option("lstm_cluster_rows", 0)
+        cases.append((ids, (m.encode_source(ids), m.encode_target(ids))))
+    m.handle.set_option("lstm_cluster_rows", 1024)
+    for it in range(300):
+        ids, ref = cases[it % len(cases)]
+        side = it % 2
+        got = (m.encode_source if side == 0 else m.encode_target)(ids)
+        if it % 23 == 0 or it > 290:
+            assert np.array_equal(got, ref[side]), it

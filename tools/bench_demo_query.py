@@ -100,14 +100,13 @@ for n_idx in (571, N):
                   % (name, n_idx, kern, dt * 1e3, de * 1e3, cnt["lstm_persist_fallbacks"], cnt["score_bf16_second_chance_queries"],
                      cnt["score_collect_queries"], cnt["score_bruteforce_queries"]))
 # batch-size sweep of the encoder alone, the three kernels
-for B in (1, 4, 32, 128, 256, 512, 1024):
+for B in (1, 4, 32, 64, 128, 256, 512, 600, 1000, 1024):
     ids = rng.randint(2, V, size=(B, T)).astype(np.int32)
     ids[:, -1] = 1
     line = "encode B=%d dense T=32:" % B
     for kern, persist, small in (("cluster", 32, 4096), ("few-seq", 0, 4096), ("matrix", 0, 0)):
-        if kern == "cluster" and B > 32:
-            continue
         hh.set_option("lstm_persist_rows", persist)
+        hh.set_option("lstm_cluster_rows", 1024 if kern == "cluster" else 0)
         hh.set_option("lstm_small_rows", small)
         hh.encode(0, ids, True)
         t0 = time.perf_counter()

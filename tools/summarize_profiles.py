@@ -6,7 +6,7 @@ import csv
 import os
 import sys
 
-OURS = ("lstm_fwd", "lstm_bwd", "score_topk", "rescore", "exact_topk", "pack_", "merge_topk", "row_norm2", "pad_rows",
+OURS = ("lstm_fwd", "lstm_bwd", "dk_x3", "dx_hot", "compact_uncert", "gather_query", "multi_kernel", "proj_bwd_dm_mfma", "score_topk", "rescore", "exact_topk", "pack_", "merge_topk", "row_norm2", "pad_rows",
         "l2_normalize", "conv_pool", "proj_norm", "dk_gemm", "dx_kernel", "loss_", "adagrad", "sumsq", "clip_scale",
         "proj_bwd", "db_reduce", "dk_reduce")
 
@@ -31,7 +31,7 @@ def main():
         agg = collections.defaultdict(list)
         dur = collections.defaultdict(list)
         for r in csv.DictReader(open(os.path.join(d, "p_counter_collection.csv"))):
-            if any(k in r["Kernel_Name"] for k in ("lstm_fwd", "score_topk", "rescore_kernel")):
+            if any(k in r["Kernel_Name"] for k in ("lstm_fwd", "lstm_bwd", "dk_x3", "score_topk", "rescore_kernel")):
                 key = (r["Kernel_Name"].split("(")[0][:64], r["Grid_Size"])
                 agg[key + (r["Counter_Name"],)].append(float(r["Counter_Value"]))
                 dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -39,23 +39,41 @@ def main():
             out.append("%-56s grid=%-8s %-26s n=%-3d avg=%.5g  (avg dispatch %.3f ms)"
                        % (k, g, c, len(v), sum(v) / len(v), sum(dur[(k, g)]) / len(dur[(k, g)]) / 1e6))
     open(os.path.join(root, "%s_pmc.txt" % tag), "w").write("\n".join(out) + "\n")
-    # HBM traffic of the dominant kernel's full-size launches for bench.py's roofline.traffic:
-    # bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md)
+    # Tracked summary bench.py quotes in its roofline objects -- only while the kernel sources are the ones profiled:
+    #  * HBM bytes per launch of the dominant kernel = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE correction of
+    #    MI355X_MICROARCH.md), full-size inference launches only;
+    #  * MFMA-busy share per kernel = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs), largest-grid launches.
     import json
-    traffic = {}
+    sys.path.insert(0, os.path.dirname(root))
+    import bench
+    traffic, busy, gui, q1 = {}, collections.defaultdict(dict), collections.defaultdict(dict), []
     for d in pmc_dirs:
         for r in csv.DictReader(open(os.path.join(d, "p_counter_collection.csv"))):
-            # the inference configuration of the headline launches (<2, 2, 1, false, ..>), not the training-leg forward
-            if ("lstm_fwd_kernel<2, 2, 1, false" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE")
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+            if ("lstm_fwd_kernel<2, 2, 1, false" in name and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE")
                     and int(r["Grid_Size"]) >= 65536):
                 traffic.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            if "score_topk_kernel<1, true, false" in name and r["Counter_Name"] == "FETCH_SIZE" and float(r["Counter_Value"]) > 1e5:
+                q1.append(float(r["Counter_Value"]))
+            if r["Counter_Name"] in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
+                tgt = busy if r["Counter_Name"].startswith("SQ") else gui
+                tgt[name].setdefault(int(r["Grid_Size"]), []).append(float(r["Counter_Value"]))
+    summary = {"csrc_sha": bench.csrc_sha(), "source": "profiles/%s_pmc.txt" % tag, "mfma_busy": {}}
     if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
         f = sum(traffic["FETCH_SIZE"]) / len(traffic["FETCH_SIZE"])
         w_ = sum(traffic["WRITE_SIZE"]) / len(traffic["WRITE_SIZE"])
-        json.dump({"kernel": "lstm_fwd_kernel (16384-sequence launches)", "fetch_size_kb": f, "write_size_kb": w_,
-                   "hbm_bytes_per_launch": (2 * f + w_) * 1024, "source": "profiles/%s_pmc.txt" % tag,
-                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH doubled per the gfx950 correction"},
-                  open(os.path.join(root, "traffic.json"), "w"), indent=1)
+        summary["lstm_fwd_hbm_bytes_per_launch"] = (2 * f + w_) * 1024
+        summary["lstm_fwd_fetch_size_kb"], summary["lstm_fwd_write_size_kb"] = f, w_
+    if q1:
+        summary["sweep_q1_hbm_bytes"] = 2 * sum(q1) / len(q1) * 1024
+    for name in busy:
+        g = max(busy[name])
+        if g in gui.get(name, {}):
+            b = sum(busy[name][g]) / len(busy[name][g]) / 1024.0
+            a = sum(gui[name][g]) / len(gui[name][g]) / 8.0
+            if a > 0 and b / a > 0.005:
+                summary["mfma_busy"][name] = round(b / a, 4)
+    json.dump(summary, open(os.path.join(root, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
     print("\n".join(out))
 
 
