@@ -6,34 +6,44 @@
 // whether the launch holds 33 rows or 8192, with 600 rows keeping 19 of the 256 CUs busy.  lstm_small.hip streams the kernel
 // matrix through every workgroup of 4 rows (17 us per step, 0.55 ms).  Here the hidden units of a row tile are spread over a
 // CLUSTER of 16 compute units, the MFMA version of lstm_persist.hip:
-//   * a cluster serves 64 sequences; workgroup p owns hidden units [p*UW, (p+1)*UW), UW = Hp/16, all four gates of them, and
-//     keeps their weight fragments in LDS for the whole call (78 KiB at E = 50, H = 256): a step reads no weights from memory;
-//   * per step each of the 4 waves multiplies one [32 (gate, unit) rows] x [K] weight tile into one 32-sequence tile of
-//     [x_t | 1 | h_{t-1}] (LDS, 78 KiB): 156 v_mfma_f32_32x32x2_f32 per wave = 10 k cycles, 1/16 of the row tile's GEMM;
-//     the weights are the MFMA's A operand with rows ordered (gate, unit), so an accumulator lane holds all four gates of
-//     four units of ONE sequence: the gate formulas run lane-locally on all 64 lanes, c stays in 4 registers;
-//   * h_t crosses workgroups as {value, tag} 64-bit words (agent-scope atomic store / load, tag = (call epoch, step), two
-//     alternating buffers, bounded spin -> error flag instead of a hang): the exchange protocol of lstm_persist.hip, 16 KiB
-//     published and 128 KiB read per workgroup and step;
-//   * projection + l2-normalise: workgroup p computes the 32-column tile p of h_T . M on MFMA (the matrix kernel's tail), the
-//     per-tile row sums of squares travel the same way and are added in tile order.
-// Arithmetic: per output element the SAME fp32 fma chain as lstm_fwd.hip (frag32 operands, k = [x | bias row | h] in
-// k-group order, v_mfma_f32_32x32x2_f32 = fma(a[k0], b[k0], c) then fma(a[k1], b[k1], .)), the same gate formulas, projection
-// order and sum-of-squares tree: results are BIT-IDENTICAL to lstm_fwd.hip / lstm_small.hip / lstm_persist.hip
-// (tests/test_gpu_encode.py), and the pad-prefix table of lstm_small.hip serves the exact left-PAD skip here too.
-// All 16 workgroups of a cluster must be resident together (one per CU: the kernel uses 157 of 160 KiB of LDS); clusters are
+//   * a cluster serves 64 sequences as two independent GROUPS of 32; workgroup p owns hidden units [p*UW, (p+1)*UW), UW =
+//     Hp/16, all four gates of them, and keeps their weight fragments in LDS for the whole call (78 KiB at E = 50, H = 256):
+//     a step reads no weights from memory;
+//   * a workgroup is 8 waves: waves 0-3 step group 0, waves 4-7 step group 1, each group at its own pace (its own exchange
+//     buffers, its own LDS arrival counter instead of s_barrier).  A SIMD holds one wave of each group, so while one group
+//     waits for its h_t to arrive from the 15 other workgroups (~3 us) the other group's MFMAs have the matrix pipe: the
+//     exchange latency that made the single-group version spend 1/3 of every step idle is covered;
+//   * per step a wave multiplies two [16 (unit, gate) rows] x [K] weight fragments into one 16-sequence tile of
+//     [x_t | 1 | h_{t-1}] (LDS, 39 KiB per group): 312 v_mfma_f32_16x16x4_f32 per wave in two independent accumulator chains
+//     (a dependent fp32 MFMA issues ~18 cycles late; two chains hide that) = 5 k cycles, 1/32 of the cluster's GEMM.  The
+//     weights are the MFMA's A operand with rows ordered (unit, gate), so an accumulator lane holds the four gates of one
+//     unit of ONE sequence: the gate formulas run lane-locally, c stays in 2 registers;
+//   * h_t crosses workgroups as {value, tag} 64-bit words, two per 16-byte store (tag = (call epoch, step), two alternating
+//     buffers, bounded spin -> error flag instead of a hang), laid out so that a wave's stores and loads are contiguous KiBs
+//     and a loaded piece is one ds_write_b64 into the operand tile; 16 KiB published and 128 KiB read per workgroup and step.
+//     When the cluster's workgroups share an XCD (checked) the stores are plain and the lines stay in that XCD's L2;
+//   * projection + l2-normalise: h_T is re-laid into the matrix kernel's operand layout (LDS) and workgroup p computes the
+//     32-column tile p of h_T . M with the matrix kernel's tail; the per-tile row sums of squares travel like h and are added
+//     in tile order.
+// Arithmetic: per output element the SAME fp32 fma chain as lstm_fwd.hip (k = [x | bias row | h] ascending;
+// v_mfma_f32_16x16x4_f32 = four fmas in ascending k like v_mfma_f32_32x32x2_f32's two -- tools/mfma_chain_probe.hip), the
+// same gate formulas, projection order and sum-of-squares tree: results are BIT-IDENTICAL to lstm_fwd.hip / lstm_small.hip /
+// lstm_persist.hip (tests/test_gpu_encode.py), and the pad-prefix table of lstm_small.hip serves the exact left-PAD skip.
+// All 16 workgroups of a cluster must be resident together (one per CU: the kernel uses 156 of 160 KiB of LDS); clusters are
 // dealt to the XCDs (blockIdx % 8), two per XCD at most: 16 clusters = 1024 sequences fill the chip.
 #include "sse_kernels.h"
 
 #define LC_NWG 16
-#define LC_ROWS 64
-#define LC_NT 256
-#define LC_SPIN_LIMIT (1 << 22)
+#define LC_ROWS 64   // sequences per cluster: two groups of 32
+#define LC_NT 512    // 8 waves: group = wave >> 2
+#define LC_GT 256    // threads per group
+#define LC_WAIT_TICKS 1000000  // 10 ms of the 100 MHz wall clock without the awaited word: give up (error bit 2)
+
+typedef unsigned int lc_u32x4 __attribute__((ext_vector_type(4)));
+typedef float lc_f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float lc_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504089f * x)); }
 __device__ __forceinline__ float lc_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008178f * x)); }
-
-typedef unsigned int lc_u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void lc_publish(unsigned long long *p, float v, unsigned int tag) {
   __hip_atomic_store(p, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -41,21 +51,46 @@ __device__ __forceinline__ void lc_publish(unsigned long long *p, float v, unsig
 __device__ __forceinline__ unsigned long long lc_peek(const unsigned long long *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// A wait gives up when its word has not come for 10 ms, or as soon as anybody else has given up (the error word is polled
+// every 64 spins): a cluster that cannot become resident costs one time-out, not one per step and workgroup.
+__device__ __forceinline__ bool lc_give_up(int &spins, long long &since, int32_t *err) {
+  if ((++spins & 63) != 0) return false;
+  if (since == 0) since = wall_clock64();
+  if ((__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4) == 0 && wall_clock64() - since < LC_WAIT_TICKS) return false;
+  atomicOr(err, 4);
+  return true;
+}
 __device__ __forceinline__ float lc_await(const unsigned long long *p, unsigned int tag, int32_t *err) {
   unsigned long long w = lc_peek(p);
   int spins = 0;
+  long long since = 0;
   while ((unsigned int)(w >> 32) != tag) {
     __builtin_amdgcn_s_sleep(1);
     w = lc_peek(p);
-    if (++spins > LC_SPIN_LIMIT) {  // the producing workgroup never ran: report (bit 2), do not hang
-      atomicOr(err, 4);
-      break;
-    }
+    if (lc_give_up(spins, since, err)) break;
   }
   return __uint_as_float((unsigned int)w);
 }
 
-#ifdef SSE_LC_CLOCK  // measurement builds (tools/): cycles per phase of a step, summed over the steps, wave 0 of workgroup 0
+// k order.  The matrix kernel's operand layout feeds v_mfma_f32_32x32x2_f32 number e of a k-group of 8 with k offsets (e, e + 4):
+// its fma chain runs 0, 4, 1, 5, 2, 6, 3, 7 inside every k-group.  v_mfma_f32_16x16x4_f32 adds its four k slots (kq = lane >> 4)
+// in order 0..3, so slot kq of MFMA e (two per k-group) carries k offset 2e + (kq >> 1) + 4*(kq & 1): the same chain.
+__host__ __device__ __forceinline__ int lc_koff(int e, int kq) { return 2 * e + (kq >> 1) + 4 * (kq & 1); }
+__host__ __device__ __forceinline__ int lc_kq_of(int o) { return 2 * (o & 1) + (o >> 2); }  // slot of k offset o; its e = (o & 3) >> 1
+
+// The four waves of a group meet on an LDS counter (s_barrier would tie the two groups together).  A wave's LDS reads and
+// writes are executed by the LDS in program order ahead of its ds_add, so a wave that sees the count knows they are done.
+__device__ __forceinline__ void lc_group_barrier(int *cnt, int &target, int lane) {
+  asm volatile("" ::: "memory");
+  target += 4;
+  if (lane == 0) {
+    __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+}
+
+#ifdef SSE_LC_CLOCK  // measurement builds (tools/): cycles per phase of a step, summed over the steps
 #define LC_CLK_DECL long long ck_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ck_t = clock64();
 #define LC_CLK(i)                   \
   {                                 \
@@ -70,123 +105,109 @@ __device__ __forceinline__ float lc_await(const unsigned long long *p, unsigned 
 
 __global__ __launch_bounds__(LC_NT) void lstm_cluster_kernel(LstmClusterArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lcs[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x, lane = tid & 63, tg = tid & (LC_GT - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), G = wv >> 2, g = wv & 3;
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
   const int cluster = xcd + 8 * (jj >> 4), p = jj & 15;
   if (cluster >= a.NCL) return;  // launched only to keep a cluster's workgroups on one XCD
+  if (a.drop_wg && cluster == 0 && p == LC_NWG - 1) return;  // testing aid: a workgroup that never arrives
   const int T = a.T, H = a.H, Hp = a.Hp, S = a.S, KGx = a.KGx, KGh = a.KGh, KG = KGx + KGh, Ep = KGx * 8;
-  const int UW = Hp / LC_NWG, CT = UW / 8;           // units per workgroup (8 | 16), 8-unit weight tiles per workgroup
+  const int UW = Hp / LC_NWG, NQ = UW / 4;           // units per workgroup (8 | 16), 4-unit weight fragments per workgroup
   const int KGhe = min(KGh, (H + 7) / 8);            // h k-groups that can be non-zero
-  float *Wl = lcs;                                   // [CT][KG][256] weight fragments (A operand, rows = (gate, unit))
-  float *Xl = Wl + (size_t)CT * KG * 256;            // [2 row tiles][KG][256] [x_t | 1 | h_{t-1}] (B operand, rows = sequences)
-  int *red = reinterpret_cast<int *>(Xl + (size_t)2 * KG * 256);  // [64]
+  float *Wl = lcs;                                   // [NQ][KG][64 lanes][2]: A operand, rows (unit, gate), k = kg*8 + lc_koff(e, lane >> 4)
+  float *Xl = Wl + (size_t)NQ * KG * 128;            // [group][16-sequence half][KG][64 lanes][2]: B operand [x_t | 1 | h_{t-1}]
+  int *red = reinterpret_cast<int *>(Xl + (size_t)4 * KG * 128);  // [32]: 0,1 lead of a group; 8 publish mode; 10,11 arrival counters; 12,13 gave up
+  float *H32 = (2 * KGh * 256 <= NQ * KG * 128) ? Wl : reinterpret_cast<float *>(red + 32 + 3 * 128);  // h_T in the matrix kernel's layout
   const int b0 = cluster * LC_ROWS, nb = min(LC_ROWS, a.B - b0);
-  unsigned long long *hx = a.hx + (size_t)cluster * 2 * LC_ROWS * Hp;  // [2][64][Hp] {h, tag}
+#ifdef SSE_LC_SOLO  // measurement builds: group 1 idle (wrong results for its rows) -- a group's phases without the other group
+  const int gb0 = b0 + G * 32, gnb = G == 1 ? 0 : max(0, min(32, nb - G * 32));
+#else
+  const int gb0 = b0 + G * 32, gnb = max(0, min(32, nb - G * 32));     // this group's sequences
+#endif
+  unsigned long long *hx = a.hx + (size_t)cluster * 2 * LC_ROWS * Hp;  // [2 steps][group][Hp/8][4][32] x 2 {h, tag}
   unsigned long long *sx = a.sx + (size_t)cluster * 16 * LC_ROWS;      // [16 tiles][64] {sum of squares, tag}
   const unsigned int epoch = a.epoch << 12;                            // tag = epoch | step + 1 (T < 4095)
+  auto xslot = [&](int s32, int kg, int kq) -> float * {  // the 2 floats (k = kg*8 + lc_koff(0, kq), + 2) of sequence s32 of this group
+    return Xl + ((((size_t)(G * 2 + (s32 >> 4)) * KG + kg) * 64) + kq * 16 + (s32 & 15)) * 2;
+  };
 
-  // left-pad prefix skip, exactly as lstm_small.hip: the cluster starts at t0 = min leading-PAD count of its rows
+  if (tid < 32) red[tid] = (tid < 2) ? T : 0;
+  __syncthreads();
+  // left-pad prefix skip, exactly as lstm_small.hip: a group starts at t0 = min leading-PAD count of its rows
   int t0 = 0;
   if (a.pad_h != nullptr) {
-    int lead = T;
-    if (tid < LC_ROWS && tid < nb) {
-      const int32_t *row = a.ids + (size_t)(b0 + tid) * T;
-      lead = 0;
-      while (lead < T && row[lead] == 0) ++lead;
-    }
+    if (g == 0) {  // the group's 32 rows sit in the lower half of its first wave
+      int lead = T;
+      if (lane < gnb) {
+        const int32_t *row = a.ids + (size_t)(gb0 + lane) * T;
+        lead = 0;
+        while (lead < T && row[lead] == 0) ++lead;
+      }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) lead = min(lead, __shfl_xor(lead, o));
-    if (lane == 0) red[wv] = lead;
+      for (int o = 32; o > 0; o >>= 1) lead = min(lead, __shfl_xor(lead, o));
+      if (lane == 0) red[G] = lead;
+    }
     __syncthreads();
-    t0 = min(min(min(red[0], red[1]), min(red[2], red[3])), T - 1);
-    __syncthreads();
+    t0 = min(red[G], T - 1);
   }
-  auto fetch_id = [&](int s, int t) -> int {
-    int id = (s < nb) ? a.ids[(size_t)(b0 + s) * T + t] : 0;
+  auto fetch_id = [&](int s32, int t) -> int {
+    int id = (s32 < gnb) ? a.ids[(size_t)(gb0 + s32) * T + t] : 0;
     if (id < 0 || id >= a.V) {
       atomicOr(a.err, 1);
       id = 0;
     }
     return id;
   };
-  // x_t of the 64 rows into the x part of the operand tile: 16-byte piece q of a padded embedding row = k 4q .. 4q+3
-  auto gather_x = [&](int t) {
-    for (int i = tid; i < LC_ROWS * 2 * KGx; i += LC_NT) {
-      const int s = i & 63, q = i >> 6;  // a wave = one piece of 64 sequences: its LDS stores are contiguous
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(a.emb + (size_t)fetch_id(s, t) * Ep + q * 4);
-      *reinterpret_cast<f32x4 *>(Xl + ((size_t)(s >> 5) * KG + (q >> 1)) * 256 + ((q & 1) * 32 + (s & 31)) * 4) = v;
-    }
-  };
 
   // ---- this workgroup's weight fragments into LDS, once (contiguous in the packed array)
   {
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(a.Wc) + (size_t)p * CT * KG * 64;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(a.Wc) + (size_t)p * NQ * KG * 32;
     f32x4 *dst = reinterpret_cast<f32x4 *>(Wl);
-    for (int i = tid; i < CT * KG * 64; i += LC_NT) dst[i] = src[i];
+    for (int i = tid; i < NQ * KG * 32; i += LC_NT) dst[i] = src[i];
   }
-  // h_{t0-1}: zero, or the pad-prefix state (the same for every row)
-  for (int i = tid; i < LC_ROWS * (Hp / 4); i += LC_NT) {
-    const int s = i & 63, uq = i >> 6;
-    f32x4 v = {0, 0, 0, 0};
+  // h_{t0-1}: zero, or the pad-prefix state (the same for every row).  Piece i of a group = units (u, u + 2), u = (i >> 7)*8 +
+  // lc_koff(0, (i >> 5) & 3), of sequence i & 31: the unit pair one accumulator lane produces and one LDS slot holds.
+  const int npc = (Hp / 8) * 4 * 32;  // pieces per group and step
+  for (int i = tg; i < npc; i += LC_GT) {
+    const int s32 = i & 31, kq = (i >> 5) & 3, kgh = i >> 7, u = kgh * 8 + lc_koff(0, kq);
+    lc_f32x2 v = {0, 0};
     if (t0 > 0) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (uq * 4 + e < H) v[e] = a.pad_h[(size_t)t0 * a.pad_stride + uq * 4 + e];
+      if (u < H) v[0] = a.pad_h[(size_t)t0 * a.pad_stride + u];
+      if (u + 2 < H) v[1] = a.pad_h[(size_t)t0 * a.pad_stride + u + 2];
     }
-    *reinterpret_cast<f32x4 *>(Xl + ((size_t)(s >> 5) * KG + KGx + (uq >> 1)) * 256 + ((uq & 1) * 32 + (s & 31)) * 4) = v;
+    *reinterpret_cast<lc_f32x2 *>(xslot(s32, KGx + kgh, kq)) = v;
   }
-  gather_x(t0);
-  // wave -> (row tile, weight tile); an accumulator lane holds sequence rt*32 + (lane & 31), register 4g + j = gate g of
-  // unit p*UW + ct*8 + 4*(lane >> 5) + j
-  const bool active = wv < 2 * CT;
-  const int rt = active ? wv / CT : 0, ct = active ? wv % CT : 0;
-  const int seq = rt * 32 + (lane & 31), unit0 = p * UW + ct * 8 + 4 * (lane >> 5);
-  float c[4] = {0, 0, 0, 0};
-  if (active && t0 > 0) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (unit0 + j < H) c[j] = a.pad_c[(size_t)t0 * a.pad_stride + unit0 + j];
-  }
-  __syncthreads();
+  // x_t: 16-byte piece q of a padded embedding row = k 4q .. 4q+3 = k offsets 4*(q & 1) + j of k-group q >> 1
+  constexpr int XPT = 2;  // pieces per thread: 32 rows x 2*KGx <= 512 pieces (KGx <= 8)
+  auto put_x = [&](int i, const f32x4 &v) {
+    const int s32 = i & 31, q = i >> 5;
+    float *dst = xslot(s32, q >> 1, q & 1);  // offset 4*(q & 1) + j: slot kq = 2*(j & 1) + (q & 1), e = j >> 1
+    dst[0] = v[0];
+    dst[64] = v[1];
+    dst[1] = v[2];
+    dst[65] = v[3];
+  };
+  for (int i = tg; i < 32 * 2 * KGx; i += LC_GT)
+    put_x(i, *reinterpret_cast<const f32x4 *>(a.emb + (size_t)fetch_id(i & 31, t0) * Ep + (i >> 5) * 4));
 
-  // x_{t+1} is requested BEFORE the MFMA phase of step t and parked in registers; it goes into the operand tile once every
-  // wave has finished reading x_t (after the barrier).  Its token ids were requested a step earlier (ids of step t+2 ride
-  // along), so neither of the two dependent round trips (id -> embedding row) is waited for in front of the MFMAs.
-  constexpr int XPT = 4;  // 16-byte pieces per thread: 64 rows x 2*KGx <= 1024 pieces (KGx <= 8)
-  f32x4 xr[XPT];
-  int idn[XPT];           // token id of this thread's pieces at the step after next
-  auto prefetch_ids = [&](int t) {
-#pragma unroll
-    for (int u = 0; u < XPT; ++u) {
-      const int i = tid + u * LC_NT;
-      idn[u] = (i < LC_ROWS * 2 * KGx && t < T) ? fetch_id(i & 63, t) : 0;
-    }
-  };
-  auto prefetch_x = [&]() {  // embedding pieces of the ids in idn
-#pragma unroll
-    for (int u = 0; u < XPT; ++u) {
-      const int i = tid + u * LC_NT;
-      if (i < LC_ROWS * 2 * KGx) xr[u] = *reinterpret_cast<const f32x4 *>(a.emb + (size_t)idn[u] * Ep + (i >> 6) * 4);
-    }
-  };
-  auto store_x = [&]() {
-#pragma unroll
-    for (int u = 0; u < XPT; ++u) {
-      const int i = tid + u * LC_NT;
-      if (i < LC_ROWS * 2 * KGx) {
-        const int s = i & 63, q = i >> 6;
-        *reinterpret_cast<f32x4 *>(Xl + ((size_t)(s >> 5) * KG + (q >> 1)) * 256 + ((q & 1) * 32 + (s & 31)) * 4) = xr[u];
-      }
-    }
-  };
+  // wave g of a group: sequences half hf = g & 1 (16 of them), weight fragments qA = 2*(g >> 1) and qA + 1 = the 8 units
+  // p*UW + 8*(g >> 1) ..; an accumulator lane holds the four gates (register = gate) of units uA = that + lc_koff(0, lane >> 4)
+  // and uA + 2 for sequence 16*hf + (lane & 15) of the group
+  const bool active = 2 * (g >> 1) < NQ && gnb > 0;
+  const int hf = g & 1, qA = active ? 2 * (g >> 1) : 0;
+  const int s32w = 16 * hf + (lane & 15), uA = p * UW + 4 * qA + lc_koff(0, lane >> 4), uB = uA + 2;
+  float cA = 0.0f, cB = 0.0f;
+  if (active && t0 > 0) {
+    if (uA < H) cA = a.pad_c[(size_t)t0 * a.pad_stride + uA];
+    if (uB < H) cB = a.pad_c[(size_t)t0 * a.pad_stride + uB];
+  }
+
   // The h exchange is 16 KiB written and 128 KiB read per workgroup and step.  Write-through (sc1) stores are visible to every
   // XCD but drop the line from the writer's L2, so all 32 MiB a step would come back from the memory side; when the 16
   // workgroups of the cluster sit on ONE XCD (what the blockIdx % 8 dealing gives in practice -- HIP does not promise it, so
   // it is checked, through the write-through path) plain stores leave the lines in the L2 all 16 readers share, and their sc1
   // loads (L1 bypassed) are served from there.
   const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(hx, 0, 2 * LC_ROWS * Hp * 8, 0x00020000);
-  bool wthrough = true;
   if (!a.write_through) {
     unsigned int xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -198,124 +219,206 @@ __global__ __launch_bounds__(LC_NT) void lstm_cluster_kernel(LstmClusterArgs a) 
       const unsigned long long same = __ballot(other == xcc);
       if (tid == 0) red[8] = ((same & 0xFFFFull) == 0xFFFFull) ? 0 : 1;
     }
-    __syncthreads();
-    wthrough = red[8] != 0;
+  } else if (tid == 0) {
+    red[8] = 1;
   }
-  prefetch_ids(t0 + 1);
-  LC_CLK_DECL
-  for (int t = t0; t < T; ++t) {
-    if (t + 1 < T) prefetch_x();  // x_{t+1}: its ids arrived during the previous step
-    prefetch_ids(t + 2);
-    // ---- gate pre-activations of this wave's tile: the matrix kernel's fma chain (k-groups of x, bias row, h in order)
-    f32x16 acc;
+  __syncthreads();  // weights, h, x, the publish mode and the zeroed arrival counters are in LDS
+  const bool wthrough = red[8] != 0;
+  int *arrive = red + 10 + G;
+  int arrived = 0;
+
+  // x_{t+1} is requested BEFORE the MFMA phase of step t and parked in registers; it goes into the operand tile once every
+  // wave of the group has finished reading x_t.  Its token ids were requested a step earlier (ids of step t+2 ride along),
+  // so neither of the two dependent round trips (id -> embedding row) is waited for in front of the MFMAs.
+  f32x4 xr[XPT];
+  int idn[XPT];
+  auto prefetch_ids = [&](int t) {  // raw: the range check waits for the value, so it is made where the id is used
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    if (active) {
-      const float *wp = Wl + (size_t)ct * KG * 256 + lane * 4;
-      const float *xp = Xl + (size_t)rt * KG * 256 + lane * 4;
-      const int kend = KGx + KGhe;
-      // two operand register sets: the LDS reads of k-group kg+1 are in flight under the four MFMAs of k-group kg
-      auto ldw = [&](int kg) { return *reinterpret_cast<const f32x4 *>(wp + (size_t)kg * 256); };
-      auto ldx = [&](int kg) { return *reinterpret_cast<const f32x4 *>(xp + (size_t)kg * 256); };
-      f32x4 w0 = ldw(0), x0 = ldx(0), w1, x1;
-      int kg = 0;
-      for (; kg + 2 <= kend; kg += 2) {
-        w1 = ldw(kg + 1);
-        x1 = ldx(kg + 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], x0[e], acc, 0, 0, 0);
-        const int kn = min(kg + 2, kend - 1);
-        w0 = ldw(kn);
-        x0 = ldx(kn);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[e], x1[e], acc, 0, 0, 0);
-      }
-      if (kg < kend) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], x0[e], acc, 0, 0, 0);
-      }
+    for (int u = 0; u < XPT; ++u) {
+      const int i = tg + u * LC_GT;
+      idn[u] = (i < 32 * 2 * KGx && t < T && (i & 31) < gnb) ? a.ids[(size_t)(gb0 + (i & 31)) * T + t] : 0;
     }
-    LC_CLK(0)
-    __syncthreads();  // every wave has read the operand tile of step t
-    LC_CLK(1)
-    if (active) {
-      // BasicLSTMCell gates (forget bias folded into the packed bias row), lane-local
-      const unsigned int tag = epoch | (unsigned)(t + 1);
-      float hv[4];
+  };
+  auto prefetch_x = [&](const int (&idc)[XPT]) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float si = lc_sigmoid(acc[j]), tj = lc_tanh(acc[4 + j]), sf = lc_sigmoid(acc[8 + j]), so = lc_sigmoid(acc[12 + j]);
-        const float pij = __fmul_rn(si, tj);  // the matrix kernel parks this product (rounded) between its two passes
-        c[j] = __builtin_fmaf(c[j], sf, pij);
-        hv[j] = lc_tanh(c[j]) * so;
-      }
-      // 32 bytes per lane, 1 KiB contiguous per half wave: whole cache lines leave the CU
-      const int off = ((((t + 1) & 1) * (Hp / 4) + (unit0 >> 2)) * LC_ROWS + seq) * 32;
-      const lc_u32x4 w0 = {__float_as_uint(hv[0]), tag, __float_as_uint(hv[1]), tag}, w1 = {__float_as_uint(hv[2]), tag, __float_as_uint(hv[3]), tag};
-      if (wthrough) {
-        __builtin_amdgcn_raw_buffer_store_b128(w0, hrs, off, 0, 16);  // aux 16 = sc1: write-through, visible to every XCD
-        __builtin_amdgcn_raw_buffer_store_b128(w1, hrs, off + 16, 0, 16);
-      } else {
-        __builtin_amdgcn_raw_buffer_store_b128(w0, hrs, off, 0, 0);   // the line stays in the cluster's own L2
-        __builtin_amdgcn_raw_buffer_store_b128(w1, hrs, off + 16, 0, 0);
-      }
+    for (int u = 0; u < XPT; ++u) {
+      const int i = tg + u * LC_GT;
+      if (i < 32 * 2 * KGx) xr[u] = *reinterpret_cast<const f32x4 *>(a.emb + (size_t)idc[u] * Ep + (i >> 5) * 4);
     }
-    LC_CLK(2)
-    if (t + 1 < T) store_x();
-    LC_CLK(3)
-    // ---- h_t of the whole cluster into the h part of the operand tile.  ALL of a thread's pieces are requested at once
-    // (one memory round trip per step instead of four) as 16-byte loads of two {value, tag} words that bypass the L1
-    // (sc1: the producers are other CUs); an element whose tag is not this step's yet is re-read until it is.
-    {
+  };
+  // Gate pre-activations of this wave: the matrix kernel's fma chain (k-groups of x, bias row, h in order), two accumulator
+  // chains.  The k-groups [k0, k1) of a step go through a ring of four operand register sets: the LDS reads of k-group kg+3 go
+  // out under the MFMAs of k-group kg, 3 x 128 cycles ahead of their use.  A 16x16x4 fp32 MFMA holds the pipe for 32 cycles and
+  // the wave issues in order, so everything else in the loop must fit in those shadows: one read between two MFMAs, immediate
+  // offsets from three pointers that advance once per four k-groups, no clamping (the reads run up to 3 k-groups past k1:
+  // inside the tile, or into the padding behind the last one).
+  f32x4 accA = {0, 0, 0, 0}, accB = {0, 0, 0, 0};
+  auto mfma_range = [&](int k0, int k1) {
+    const float *wa = Wl + (((size_t)qA * KG + k0) * 64 + lane) * 2, *wb = wa + (size_t)KG * 128;
+    const float *xb = Xl + (((size_t)(G * 2 + hf) * KG + k0) * 64 + lane) * 2;
+    auto ld = [&](const float *q, int kg) { return *reinterpret_cast<const lc_f32x2 *>(q + (size_t)kg * 128); };
+#define LC_STEP(C, N, off)                                                    \
+  N##a = ld(wa, off);                                                         \
+  __builtin_amdgcn_sched_barrier(0);                                          \
+  accA = __builtin_amdgcn_mfma_f32_16x16x4f32(C##a[0], C##x[0], accA, 0, 0, 0); \
+  __builtin_amdgcn_sched_barrier(0);                                          \
+  N##b = ld(wb, off);                                                         \
+  __builtin_amdgcn_sched_barrier(0);                                          \
+  accB = __builtin_amdgcn_mfma_f32_16x16x4f32(C##b[0], C##x[0], accB, 0, 0, 0); \
+  __builtin_amdgcn_sched_barrier(0);                                          \
+  N##x = ld(xb, off);                                                         \
+  __builtin_amdgcn_sched_barrier(0);                                          \
+  accA = __builtin_amdgcn_mfma_f32_16x16x4f32(C##a[1], C##x[1], accA, 0, 0, 0); \
+  accB = __builtin_amdgcn_mfma_f32_16x16x4f32(C##b[1], C##x[1], accB, 0, 0, 0); \
+  __builtin_amdgcn_sched_barrier(0);
+#define LC_LAST(C)                                                            \
+  accA = __builtin_amdgcn_mfma_f32_16x16x4f32(C##a[0], C##x[0], accA, 0, 0, 0); \
+  accB = __builtin_amdgcn_mfma_f32_16x16x4f32(C##b[0], C##x[0], accB, 0, 0, 0); \
+  accA = __builtin_amdgcn_mfma_f32_16x16x4f32(C##a[1], C##x[1], accA, 0, 0, 0); \
+  accB = __builtin_amdgcn_mfma_f32_16x16x4f32(C##b[1], C##x[1], accB, 0, 0, 0);
+#define LC_PRE(N, off)                 \
+  N##a = ld(wa, off);                  \
+  __builtin_amdgcn_sched_barrier(0);   \
+  N##b = ld(wb, off);                  \
+  __builtin_amdgcn_sched_barrier(0);   \
+  N##x = ld(xb, off);                  \
+  __builtin_amdgcn_sched_barrier(0);
+    lc_f32x2 r0a, r0b, r0x, r1a, r1b, r1x, r2a, r2b, r2x, r3a, r3b, r3x;
+    LC_PRE(r0, 0)  // in the loop's order: its waits count outstanding reads
+    LC_PRE(r1, 1)
+    LC_PRE(r2, 2)
+    int kg = k0;
+    for (; kg + 4 <= k1; kg += 4) {
+      LC_STEP(r0, r3, 3)
+      LC_STEP(r1, r0, 4)
+      LC_STEP(r2, r1, 5)
+      LC_STEP(r3, r2, 6)
+      wa += 512;
+      wb += 512;
+      xb += 512;
+    }
+    if (kg < k1) { LC_LAST(r0) }
+    if (kg + 1 < k1) { LC_LAST(r1) }
+    if (kg + 2 < k1) { LC_LAST(r2) }
+#undef LC_STEP
+#undef LC_LAST
+#undef LC_PRE
+  };
+  if (gnb > 0) {
+    prefetch_ids(t0 + 1);
+    // Skew: group 1 starts once group 0 is through its first MFMA phase.  Two groups that start together share the matrix
+    // pipe during the MFMA phase and then both wait for their exchanges; half a phase apart each has the pipe to itself
+    // while the other waits, and nothing later pulls them back together.
+    if (G == 1 && lane == 0)
+      while (__hip_atomic_load(red + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(4);
+    if (active) mfma_range(0, KGx);  // x part of the first step
+    LC_CLK_DECL
+    for (int t = t0; t < T; ++t) {
+      // x_{t+1}: its ids arrived during the previous step.  Order matters: take the ids out of their registers first, THEN
+      // issue the loads of this step -- a wait placed after them (the id registers are reused) would wait for them
+      int idc[XPT];
+      bool bad = false;
+#pragma unroll
+      for (int u = 0; u < XPT; ++u) {
+        idc[u] = idn[u];
+        if (idc[u] < 0 || idc[u] >= a.V) {
+          bad = true;
+          idc[u] = 0;
+        }
+      }
+      if (bad) atomicOr(a.err, 1);
+      prefetch_ids(t + 2);
+      if (t + 1 < T) prefetch_x(idc);
+      // ---- gate pre-activations, h part (the x part of this step went in while the previous h was on its way)
+      if (active) mfma_range(KGx, KGx + KGhe);
+      LC_CLK(0)
       const unsigned int tag = epoch | (unsigned)(t + 1);
-      const int pbase = ((t + 1) & 1) * LC_ROWS * Hp * 8;
-      constexpr int QPT = 16;  // 4-unit pieces per thread at Hp = 256 (8 at Hp = 128)
-      const int nq = LC_ROWS * (Hp / 4), npt = nq / LC_NT;
-      lc_u32x4 w[QPT][2];
-      unsigned stale = (npt >= 32) ? 0xFFFFFFFFu : ((1u << npt) - 1u);  // pieces still to be (re)read
-      int spins = 0;
-      while (stale != 0u) {
+      const int pbase = ((t + 1) & 1) * LC_ROWS * Hp * 8 + G * npc * 16;  // this step's, this group's pieces
+      if (active) {
+        // BasicLSTMCell gates (forget bias folded into the packed bias row), lane-local; i*j is rounded before it meets
+        // c*f as in the matrix kernel (which parks the product between its two passes)
+        const float pA = __fmul_rn(lc_sigmoid(accA[0]), lc_tanh(accA[1])), pB = __fmul_rn(lc_sigmoid(accB[0]), lc_tanh(accB[1]));
+        cA = __builtin_fmaf(cA, lc_sigmoid(accA[2]), pA);
+        cB = __builtin_fmaf(cB, lc_sigmoid(accB[2]), pB);
+        const float hA = lc_tanh(cA) * lc_sigmoid(accA[3]), hB = lc_tanh(cB) * lc_sigmoid(accB[3]);
+        // one 16-byte piece per lane, 256 contiguous bytes per 16 lanes
+        const int off = pbase + ((((uA >> 3) * 4 + (lane >> 4)) * 32) + s32w) * 16;
+        const lc_u32x4 w = {__float_as_uint(hA), tag, __float_as_uint(hB), tag};
+        if (wthrough)
+          __builtin_amdgcn_raw_buffer_store_b128(w, hrs, off, 0, 16);  // aux 16 = sc1: write-through, visible to every XCD
+        else
+          __builtin_amdgcn_raw_buffer_store_b128(w, hrs, off, 0, 0);   // the line stays in the cluster's own L2
+      }
+      LC_CLK(1)
+      lc_group_barrier(arrive, arrived, lane);  // every wave of the group has read the operand tile of step t
+      LC_CLK(2)
+      if (t + 1 < T) {
 #pragma unroll
-        for (int u = 0; u < QPT; ++u)
-          if ((stale >> u) & 1u) {
-            const int i = tid + u * LC_NT;
-            w[u][0] = __builtin_amdgcn_raw_buffer_load_b128(hrs, i * 32, pbase, 16);  // aux 16 = sc1: served by the L2
-            w[u][1] = __builtin_amdgcn_raw_buffer_load_b128(hrs, i * 32 + 16, pbase, 16);
-          }
-        unsigned still = 0u;
+        for (int u = 0; u < XPT; ++u)
+          if (tg + u * LC_GT < 32 * 2 * KGx) put_x(tg + u * LC_GT, xr[u]);
+        // the x part of step t+1 while h_t is on its way: out of the next step's critical path, and the first read attempt
+        // below comes late enough to find most of h_t
+        lc_group_barrier(arrive, arrived, lane);
+        accA = f32x4{0, 0, 0, 0};
+        accB = f32x4{0, 0, 0, 0};
+        if (active) mfma_range(0, KGx);
+      }
+      LC_CLK(3)
+      // ---- h_t of the group from the whole cluster into the h part of the operand tile.  ALL of a thread's pieces are
+      // requested at once (one memory round trip per attempt) with loads that bypass the L1 (sc1: the producers are other
+      // CUs); pieces whose tags are not this step's yet are requested again.
+      {
+        constexpr int QPT = 16;  // pieces per thread at Hp = 256 (8 at Hp = 128)
+        const int npt = npc / LC_GT;
+        lc_u32x4 w[QPT];
+        unsigned stale = (1u << npt) - 1u;
+        int spins = 0;
+        long long since = 0;
+        while (stale != 0u) {
 #pragma unroll
-        for (int u = 0; u < QPT; ++u)
-          if ((stale >> u) & 1u) {
-            if (w[u][0][1] != tag || w[u][0][3] != tag || w[u][1][1] != tag || w[u][1][3] != tag) {
-              still |= 1u << u;
-            } else {
-              const int i = tid + u * LC_NT;
-              const int s = i & 63, uq = i >> 6;
-              *reinterpret_cast<f32x4 *>(Xl + ((size_t)(s >> 5) * KG + KGx + (uq >> 1)) * 256 + ((uq & 1) * 32 + (s & 31)) * 4) =
-                  f32x4{__uint_as_float(w[u][0][0]), __uint_as_float(w[u][0][2]), __uint_as_float(w[u][1][0]), __uint_as_float(w[u][1][2])};
+          for (int u = 0; u < QPT; ++u)
+            if ((stale >> u) & 1u) w[u] = __builtin_amdgcn_raw_buffer_load_b128(hrs, (tg + u * LC_GT) * 16, pbase, 16);
+          unsigned still = 0u;
+#pragma unroll
+          for (int u = 0; u < QPT; ++u)
+            if ((stale >> u) & 1u) {
+              if (w[u][1] != tag || w[u][3] != tag) {
+                still |= 1u << u;
+              } else {
+                const int i = tg + u * LC_GT;
+                *reinterpret_cast<lc_f32x2 *>(xslot(i & 31, KGx + (i >> 7), (i >> 5) & 3)) = lc_f32x2{__uint_as_float(w[u][0]), __uint_as_float(w[u][2])};
+              }
             }
-          }
-        stale = still;
-        if (stale != 0u) {
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > LC_SPIN_LIMIT) {  // a producing workgroup never ran: report (bit 2), do not hang
-            atomicOr(a.err, 4);
-            break;
+          stale = still;
+          if (stale != 0u) {
+            __builtin_amdgcn_s_sleep(2);
+            if (lc_give_up(spins, since, a.err)) {  // a producing workgroup never ran: report (bit 2), do not hang
+              red[12 + G] = 1;                      // and leave the step loop, the whole group together
+              break;
+            }
           }
         }
       }
+      LC_CLK(4)
+      lc_group_barrier(arrive, arrived, lane);
+      LC_CLK(5)
+      if (__hip_atomic_load(red + 12 + G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) break;  // written before the barrier
     }
-    LC_CLK(4)
-    __syncthreads();
-    LC_CLK(5)
-  }
 #ifdef SSE_LC_CLOCK
-  if (blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == 3))
-    printf("[cluster clock] wave %d cycles/step: mfma %lld | barrier1 %lld | gates+publish %lld | gather x %lld | exchange read %lld | barrier2 %lld\n",
-           wv, ck_[0] / (T - t0), ck_[1] / (T - t0), ck_[2] / (T - t0), ck_[3] / (T - t0), ck_[4] / (T - t0), ck_[5] / (T - t0));
+    if (blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == 7))
+      printf("[cluster clock] wave %d cycles/step: mfma %lld | gates+publish %lld | arrive1 %lld | store x %lld | exchange read %lld | arrive2 %lld\n",
+             wv, ck_[0] / (T - t0), ck_[1] / (T - t0), ck_[2] / (T - t0), ck_[3] / (T - t0), ck_[4] / (T - t0), ck_[5] / (T - t0));
 #endif
+  }
+  __syncthreads();  // both groups are through their last step
+
+  // ---- h_T of the 64 rows into the matrix kernel's A-operand layout [row tile][kg][64 lanes][4] (over the weights)
+  for (int i = tid; i < LC_ROWS * Hp; i += LC_NT) {
+    const int s = i & 63, u = i >> 6;
+    const float v = Xl[((((size_t)(s >> 4) * KG + KGx + (u >> 3)) * 64) + lc_kq_of(u & 7) * 16 + (s & 15)) * 2 + ((u & 3) >> 1)];
+    H32[((size_t)(s >> 5) * KGh + (u >> 3)) * 256 + (((u >> 2) & 1) * 32 + (s & 31)) * 4 + (u & 3)] = v;
+  }
+  __syncthreads();
 
   // ---- projection: column tile p of out = h_T . M, both row tiles (waves 0, 1), the matrix kernel's tail
   const int NTS = a.NTS;
@@ -325,7 +428,7 @@ __global__ __launch_bounds__(LC_NT) void lstm_cluster_kernel(LstmClusterArgs a) 
 #pragma unroll
   for (int r = 0; r < 16; ++r) pacc[r] = 0.0f;
   {
-    const float *hp = Xl + ((size_t)prt * KG + KGx) * 256 + lane * 4;
+    const float *hp = H32 + (size_t)prt * KGh * 256 + lane * 4;
     const float *mp = a.Mp + (size_t)nt * KGh * 256 + lane * 4;
     for (int kg = 0; kg < KGhe; ++kg) {
       const f32x4 ax = *reinterpret_cast<const f32x4 *>(hp + (size_t)kg * 256), bx = *reinterpret_cast<const f32x4 *>(mp + (size_t)kg * 256);
@@ -367,24 +470,25 @@ __global__ __launch_bounds__(LC_NT) void lstm_cluster_kernel(LstmClusterArgs a) 
   }
 }
 
-// Wc[p][ct][kg][lane][e]: weight fragment rows i = lane & 31 = (gate i >> 3, unit p*UW + ct*8 + (i & 7)), k = kg*8 + (lane >> 5)*4 + e
+// Wc[p][q][kg][lane][e]: weight fragment rows i = lane & 15 = (unit p*UW + 8*(q >> 1) + lc_koff(q & 1, i >> 2), gate i & 3),
+// k = kg*8 + lc_koff(e, lane >> 4)
 // in the matrix kernel's k space [x padded to Ep | h]: k-row E = bias (+1 for the forget gate), padding rows / units zero
 __global__ void pack_lstm_cluster_kernel(const float *__restrict__ K, const float *__restrict__ b, int E, int H, int Ep, int Hp,
-                                         int64_t total4, f32x4 *__restrict__ out) {
-  const int KG = (Ep + Hp) / 8, UW = Hp / LC_NWG, CT = UW / 8;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+                                         int64_t total2, lc_f32x2 *__restrict__ out) {
+  const int KG = (Ep + Hp) / 8, UW = Hp / LC_NWG, NQ = UW / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total2; i += (int64_t)gridDim.x * blockDim.x) {
     const int l = (int)(i & 63);
     int64_t blk = i >> 6;
     const int kg = (int)(blk % KG);
     blk /= KG;
-    const int ct = (int)(blk % CT), p = (int)(blk / CT);
-    const int row = l & 31, g = row >> 3, unit = p * UW + ct * 8 + (row & 7);
-    f32x4 v = {0, 0, 0, 0};
+    const int q = (int)(blk % NQ), p = (int)(blk / NQ);
+    const int row = l & 15, g = row & 3, unit = p * UW + 8 * (q >> 1) + lc_koff(q & 1, row >> 2);
+    lc_f32x2 v = {0, 0};
     if (unit < H) {
       const int col = g * H + unit;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int kk = kg * 8 + (l >> 5) * 4 + e;
+      for (int e = 0; e < 2; ++e) {
+        const int kk = kg * 8 + lc_koff(e, l >> 4);
         if (kk < E) v[e] = K[(size_t)kk * 4 * H + col];
         else if (kk == E) v[e] = b[col] + (g == 2 ? 1.0f : 0.0f);
         else if (kk >= Ep && kk - Ep < H) v[e] = K[(size_t)(E + kk - Ep) * 4 * H + col];
@@ -395,29 +499,32 @@ __global__ void pack_lstm_cluster_kernel(const float *__restrict__ K, const floa
 }
 
 static size_t lc_lds_bytes(int Ep, int Hp) {
-  const int KG = (Ep + Hp) / 8, CT = Hp / LC_NWG / 8;
-  return ((size_t)(CT + 2) * KG * 256 + 64) * sizeof(float);
+  const int KG = (Ep + Hp) / 8, NQ = Hp / LC_NWG / 4, KGh = Hp / 8;
+  size_t fl = (size_t)(NQ + 4) * KG * 128 + 32 + 3 * 128;  // + the operand ring's reads past the last k-group
+  if (2 * KGh * 256 > NQ * KG * 128) fl += (size_t)2 * KGh * 256;  // h_T re-laid for the projection does not fit over the weights
+  return fl * sizeof(float);
 }
 
 // 1: the shape runs on the cluster kernel (cell sizes up to 256, the operand tiles fit 160 KiB of LDS)
 int lstm_cluster_ok(int E, int H, int S) {
   if (H < 1 || H > 256 || S < 1 || S > 512) return 0;
   const int Ep = (E + 8) & ~7, Hp = H <= 128 ? 128 : 256;
+  if (Ep > 64) return 0;  // two x pieces per thread
   return lc_lds_bytes(Ep, Hp) <= 160 * 1024 ? 1 : 0;
 }
 int lstm_cluster_max_rows() { return 16 * LC_ROWS; }
 size_t lstm_cluster_weight_floats(int E, int H) {
   const int Ep = (E + 8) & ~7, Hp = H <= 128 ? 128 : 256;
-  return (size_t)LC_NWG * (Hp / LC_NWG / 8) * ((Ep + Hp) / 8) * 256;
+  return (size_t)LC_NWG * (Hp / LC_NWG / 4) * ((Ep + Hp) / 8) * 128;
 }
 size_t lstm_cluster_hx_words(int H) { return (size_t)16 * 2 * LC_ROWS * (H <= 128 ? 128 : 256); }
 size_t lstm_cluster_sx_words() { return (size_t)16 * 16 * LC_ROWS; }
 
 hipError_t launch_pack_lstm_cluster(const float *K, const float *b, int E, int H, float *Wc, hipStream_t stream) {
   const int Ep = (E + 8) & ~7, Hp = H <= 128 ? 128 : 256;
-  const int64_t total4 = (int64_t)lstm_cluster_weight_floats(E, H) / 4;
-  hipLaunchKernelGGL(pack_lstm_cluster_kernel, dim3((int)((total4 + 255) / 256)), dim3(256), 0, stream, K, b, E, H, Ep, Hp, total4,
-                     reinterpret_cast<f32x4 *>(Wc));
+  const int64_t total2 = (int64_t)lstm_cluster_weight_floats(E, H) / 2;
+  hipLaunchKernelGGL(pack_lstm_cluster_kernel, dim3((int)((total2 + 255) / 256)), dim3(256), 0, stream, K, b, E, H, Ep, Hp, total2,
+                     reinterpret_cast<lc_f32x2 *>(Wc));
   return hipGetLastError();
 }
 

@@ -24,7 +24,7 @@
 
 #define LP_RB 4      // sequences per cluster
 #define LP_NT 256    // threads per workgroup: wave g computes gate g of (sequence, unit) = lane
-#define LP_SPIN_LIMIT (1 << 22)
+#define LP_WAIT_TICKS 1000000  // 10 ms of the 100 MHz wall clock without the awaited word: give up (error bit 2)
 #define LP_EPT 8     // exchange elements per thread per step: RB * H / NT (H <= 512)
 
 __device__ __forceinline__ float lp_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504089f * x)); }
@@ -35,15 +35,21 @@ __device__ __forceinline__ float lp_tanh(float x) { return 1.0f - 2.0f * __built
 __device__ __forceinline__ void lp_publish(unsigned long long *p, float v, unsigned int tag) {
   __hip_atomic_store(p, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// A wait gives up when its word has not come for 10 ms, or as soon as any other wait of the launch has given up (the error
+// word is polled every 64 spins): a cluster that cannot become resident costs one time-out, not one per step and workgroup.
 __device__ __forceinline__ float lp_await(const unsigned long long *p, unsigned int tag, int32_t *err) {
   unsigned long long w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int spins = 0;
+  long long since = 0;
   while ((unsigned int)(w >> 32) != tag) {
     __builtin_amdgcn_s_sleep(1);
     w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (++spins > LP_SPIN_LIMIT) {  // the producing workgroup never ran: report, do not hang
-      atomicOr(err, 4);
-      break;
+    if ((++spins & 63) == 0) {
+      if (since == 0) since = wall_clock64();
+      if ((__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4) != 0 || wall_clock64() - since >= LP_WAIT_TICKS) {
+        atomicOr(err, 4);  // the producing workgroup never ran: report, do not hang
+        break;
+      }
     }
   }
   return __uint_as_float((unsigned int)w);

@@ -119,6 +119,7 @@ struct sse_handle {
   int lstm_cluster_rows = 1024; // option "lstm_cluster_rows": batches above lstm_persist_rows up to this many rows (<= 1024) take the MFMA cluster kernel
   uint32_t cluster_epoch = 0;   // tag epoch of that kernel's exchange buffers
   int lstm_cluster_wt = 0;      // option "lstm_cluster_write_through": force the any-placement publish path (tests)
+  int lstm_cluster_drop = 0;    // option "lstm_cluster_drop_wg": one workgroup of the cluster kernel exits at once (tests)
   int lstm_small_rows = 1024; // option "lstm_small_rows": batches up to this many rows take the few-sequences LSTM kernel
   bool score_bf16 = true;    // option "score_bf16" (default on): candidate pass on the bf16 matrix pipe; results stay exact
   void *idxp16 = nullptr;    // bf16 fragment copy of the index (built on demand)
@@ -588,6 +589,7 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
       }
       ca.epoch = ++h->cluster_epoch;
       ca.write_through = h->lstm_cluster_wt;
+      ca.drop_wg = h->lstm_cluster_drop;
       ca.hx = (unsigned long long *)h->s_cluster.p;
       ca.sx = ca.hx + nhx;
       HIPCHECK(h, launch_lstm_cluster(ca, st));
@@ -1423,6 +1425,10 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value) {
   if (strcmp(name, "lstm_persist_rows") == 0) {
     if (value < 0) return fail(h, "lstm_persist_rows must be >= 0");
     h->lstm_persist_rows = (int)value;
+    return 0;
+  }
+  if (strcmp(name, "lstm_cluster_drop_wg") == 0) {
+    h->lstm_cluster_drop = value != 0;
     return 0;
   }
   if (strcmp(name, "lstm_cluster_write_through") == 0) {

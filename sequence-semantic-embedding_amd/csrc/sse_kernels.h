@@ -198,6 +198,7 @@ struct LstmClusterArgs {
   uint32_t epoch = 0;                // 1 .. 2^20-1, different for every launch on the same exchange buffers
   int32_t NCL = 0;                   // set by the launcher
   int32_t write_through = 0;         // 1: always publish h with write-through stores (the any-placement path; tests)
+  int32_t drop_wg = 0;               // 1: the last workgroup of cluster 0 exits at once (tests of the give-up path)
 };
 int lstm_cluster_ok(int E, int H, int S);
 int lstm_cluster_max_rows();

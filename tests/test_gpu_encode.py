@@ -491,6 +491,24 @@ def test_mfma_cluster_kernel_equals_the_other_kernels(mode, V, E, Hs, Ht, S, T):
     assert np.array_equal(m.encode_source(good), want)
     m.handle.set_option("lstm_persist_inject_miss", 0)
     assert m.handle.get_counter("lstm_persist_fallbacks") == 1
+    # ... and for real: one workgroup of cluster 0 exits at once, the 15 others wait for its h.  The first wait gives up
+    # after 10 ms, every other wait of the launch (all clusters, both groups, the projection's exchange) as soon as it
+    # sees the error word: one time-out per launch, not one per step, then the few-sequences kernel.
+    import time
+    big = random_ids(rng, 600, T, V, pad_frac=0.3)
+    m.handle.set_option("lstm_cluster_rows", 0)
+    want = m.encode_source(big)
+    m.handle.set_option("lstm_cluster_rows", 1024)
+    m.handle.set_option("lstm_cluster_drop_wg", 1)
+    t0 = time.perf_counter()
+    got = m.encode_source(big)
+    dt = time.perf_counter() - t0
+    m.handle.set_option("lstm_cluster_drop_wg", 0)
+    assert np.array_equal(got, want)
+    assert m.handle.get_counter("lstm_persist_fallbacks") == 2
+    assert dt < 0.25, dt
+    assert np.array_equal(m.encode_source(big), want)          # and the next call is on the cluster kernel again
+    assert m.handle.get_counter("lstm_persist_fallbacks") == 2
 
 
 def test_mfma_cluster_kernel_many_calls_alternating_shapes():

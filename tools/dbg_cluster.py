@@ -19,4 +19,4 @@ for B in [int(x) for x in (sys.argv[1:] or ["600"])]:
     ts = []
     for _ in range(int(os.environ.get("N", "5"))):
         t0 = time.perf_counter(); m.encode_source(ids); ts.append(time.perf_counter() - t0)
-    print("B=%d: %.3f ms" % (B, sorted(ts)[len(ts) // 2] * 1e3))
+    print("B=%d: %.3f ms (fallbacks %d)" % (B, sorted(ts)[len(ts) // 2] * 1e3, m.handle.get_counter("lstm_persist_fallbacks")))
