@@ -118,6 +118,7 @@ struct sse_handle {
   int cu_count = 0;           // compute units of the device (co-residency check of the cluster kernel)
   int lstm_cluster_rows = 1024; // option "lstm_cluster_rows": batches above lstm_persist_rows up to this many rows (<= 1024) take the MFMA cluster kernel
   uint32_t cluster_epoch = 0;   // tag epoch of that kernel's exchange buffers
+  int lstm_cluster_chunks = 3;  // option "lstm_cluster_chunks": batches of up to this many times lstm_cluster_rows go through that kernel in launches of lstm_cluster_rows
   int lstm_cluster_wt = 0;      // option "lstm_cluster_write_through": force the any-placement publish path (tests)
   int lstm_cluster_drop = 0;    // option "lstm_cluster_drop_wg": one workgroup of the cluster kernel exits at once (tests)
   int lstm_small_rows = 1024; // option "lstm_small_rows": batches up to this many rows take the few-sequences LSTM kernel
@@ -443,6 +444,14 @@ int ensure_pad_table_small(sse_handle *h, int side, int T, hipStream_t st) {
   return 0;
 }
 
+// Batches the MFMA cluster kernel (lstm_cluster.hip) takes: 33 rows up to lstm_cluster_chunks launches of lstm_cluster_rows
+// (<= 1024) rows.  A launch costs about the same 0.3 ms whatever it holds (T = 32), a 32-row tile of the matrix kernel 1.2 ms
+// whether 33 or 8192 rows run beside it: three launches are still ahead of it, four are not.
+static int cluster_row_limit(const sse_handle *h) {
+  const int per = std::min(h->lstm_cluster_rows, lstm_cluster_max_rows());
+  return per * std::max(1, h->lstm_cluster_chunks);
+}
+
 int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T, int normalize, float *out,
                       hipStream_t st) {
   const sse_config &c = h->cfg;
@@ -538,7 +547,7 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
       return 0;
     }
   }
-  if (small_ok && B > 32 && B <= h->lstm_cluster_rows && B <= lstm_cluster_max_rows() && T <= lstm_persist_max_steps() &&
+  if (small_ok && B > 32 && B <= cluster_row_limit(h) && T <= lstm_persist_max_steps() &&
       lstm_cluster_ok(c.embedding_size, e.H, c.encoding_size)) {
     // mid-size batches (the evaluator's 600, the index builder's 1000): the hidden units of every 64-row tile spread over a
     // cluster of 16 compute units, weights in LDS, h_t exchanged per step (lstm_cluster.hip); needs one CU per workgroup
@@ -547,7 +556,8 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
       HIPCHECK(h, hipGetDeviceProperties(&prop, c.device));
       h->cu_count = prop.multiProcessorCount;
     }
-    const int ncl = (B + 63) / 64;
+    const int per = std::min(h->lstm_cluster_rows, lstm_cluster_max_rows());
+    const int ncl = (std::min(B, per) + 63) / 64;
     if ((ncl <= 8 ? 128 : 256) <= h->cu_count) {
       Encoder &own = e.shares_lstm_with >= 0 ? h->enc[e.shares_lstm_with] : e;
       if (!own.wc_valid) {
@@ -587,12 +597,21 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
         HIPCHECK(h, hipMemsetAsync(h->s_cluster.p, 0, h->s_cluster.cap, st));
         h->cluster_epoch = 0;
       }
-      ca.epoch = ++h->cluster_epoch;
       ca.write_through = h->lstm_cluster_wt;
       ca.drop_wg = h->lstm_cluster_drop;
       ca.hx = (unsigned long long *)h->s_cluster.p;
       ca.sx = ca.hx + nhx;
-      HIPCHECK(h, launch_lstm_cluster(ca, st));
+      for (int c0 = 0; c0 < B; c0 += per) {  // launches of the same stream reuse the exchange buffers under new epochs
+        if (h->cluster_epoch >= (1u << 20) - 1) {
+          HIPCHECK(h, hipMemsetAsync(h->s_cluster.p, 0, h->s_cluster.cap, st));
+          h->cluster_epoch = 0;
+        }
+        ca.epoch = ++h->cluster_epoch;
+        ca.ids = ids + (size_t)c0 * T;
+        ca.out = out + (size_t)c0 * c.encoding_size;
+        ca.B = std::min(per, B - c0);
+        HIPCHECK(h, launch_lstm_cluster(ca, st));
+      }
       if (h->persist_inject) {  // testing aid: pretend a workgroup of the cluster never arrived
         static const int32_t four = 4;
         HIPCHECK(h, hipMemcpyAsync(h->err_flag, &four, sizeof four, hipMemcpyHostToDevice, st));
@@ -1236,7 +1255,9 @@ static int encode_host_ids_locked(sse_handle *h, int side, const int32_t *ids_ho
   // 64-row tile can skip its whole common PAD prefix; results are scattered back in caller order.
   const bool lstm_side = h->cfg.network_mode != SSE_MODE_SOURCE_ONLY_CNN && !(side == SSE_SIDE_TARGET && h->tgt_table >= 0);
   const int32_t *row_map_dev = nullptr;
-  if (h->pad_skip && lstm_side && B > 64 && B > h->lstm_small_rows) {
+  const bool to_cluster = lstm_side && B <= cluster_row_limit(h) && T <= lstm_persist_max_steps() &&
+                          lstm_cluster_ok(h->cfg.embedding_size, h->enc[side].H, h->cfg.encoding_size);  // (takes rows as they come)
+  if (h->pad_skip && lstm_side && B > 64 && B > h->lstm_small_rows && !to_cluster) {
     // counting sort of the row numbers by leading-PAD count, longest prefix first
     std::vector<int32_t> lead(B), start(T + 2, 0), order(B);
     for (int b = 0; b < B; ++b) {
@@ -1425,6 +1446,11 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value) {
   if (strcmp(name, "lstm_persist_rows") == 0) {
     if (value < 0) return fail(h, "lstm_persist_rows must be >= 0");
     h->lstm_persist_rows = (int)value;
+    return 0;
+  }
+  if (strcmp(name, "lstm_cluster_chunks") == 0) {
+    if (value < 1) return fail(h, "lstm_cluster_chunks must be >= 1");
+    h->lstm_cluster_chunks = (int)value;
     return 0;
   }
   if (strcmp(name, "lstm_cluster_drop_wg") == 0) {

@@ -444,7 +444,7 @@ def test_mfma_cluster_kernel_equals_the_other_kernels(mode, V, E, Hs, Ht, S, T):
     params = model_params(mode, V, E, Hs, Ht, S, T)
     m, p = make_pair(params, seed=8)
     rng = np.random.RandomState(3)
-    for B in (33, 64, 65, 600, 1000, 1024):
+    for B in (33, 64, 65, 600, 1000, 1024, 1025, 2100):        # (above 1024: two / three launches of the kernel)
         ids = random_ids(rng, B, T, V, pad_frac=0.6)
         ids[1, :] = 0
         ids[1, -1] = 1                                     # only EOS
