@@ -77,6 +77,16 @@ __global__ __launch_bounds__(LP_NT) void lstm_persist_kernel(LstmPersistArgs a) 
   unsigned long long *hx = a.hx + (size_t)cluster * 2 * LP_RB * H;  // [2][RB][H] {h, tag}
   unsigned long long *rawx = a.rawx + (size_t)cluster * LP_RB * S;  // [RB][S] {raw encoding, tag}
   const unsigned int epoch = a.epoch << 12;               // tag = epoch | step + 1 (T < 4095), unique per call
+  // Where h_t is published.  A write-through (sc1) store is visible to every XCD but drops the line from the writer's L2,
+  // so each of the 32 hand-offs of a query goes out to the memory side and back.  When all workgroups of the cluster sit
+  // on ONE XCD (what blockIdx % 8 gives in practice; HIP promises nothing, so every workgroup publishes its XCC id here,
+  // write-through, and the ids are compared once the weights are in LDS) a plain store leaves the line in the L2 the readers
+  // share and their L1-bypassing loads are served from there.
+  unsigned int xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 0xF;
+  const bool xcc_check = !a.write_through && LP_RB * H >= NWG;  // (tiny cells: fewer even-buffer slots than workgroups)
+  if (tid == 0 && xcc_check) lp_publish(hx + p, __uint_as_float(xcc), epoch);  // slot p of the even buffer, tag "step 0": h tags start at 1
 
   // left-pad prefix skip, exactly as lstm_small.hip
   int t0 = 0;
@@ -174,6 +184,20 @@ __global__ __launch_bounds__(LP_NT) void lstm_persist_kernel(LstmPersistArgs a) 
   // workgroup's step t+1") does not cover its READS: lagging behind, it would find tag t+2 where it expects t.  It has no
   // use for h_t before the projection, so it skips the steps and picks up h_T (the last write into its buffer) below.
   const bool bystander = nu == 0;
+  // (a bystander publishes its XCC id like everybody -- it will READ h_T -- but does not wait for the others': the slots are
+  // reused by step 1, which the others reach without it)
+  bool wthrough = true;
+  if (xcc_check && !bystander) {
+    if (wv == 0) {
+      bool same = true;
+      for (int i = lane; i < NWG; i += 64) same = same && __float_as_uint(lp_await(hx + i, epoch, a.err)) == xcc;
+      const bool all_same = __all(same);
+      if (lane == 0) red[63] = all_same ? 0.0f : 1.0f;
+    }
+    __syncthreads();
+    wthrough = red[63] != 0.0f;
+  }
+  const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(hx, 0, 2 * LP_RB * H * 8, 0x00020000);
   for (int t = bystander ? T : t0; t < T; ++t) {
     // ---- gate pre-activation of (gate wv, sequence lb, unit lu): the matrix path's fma chain
     float acc = 0.0f;
@@ -202,7 +226,14 @@ __global__ __launch_bounds__(LP_NT) void lstm_persist_kernel(LstmPersistArgs a) 
         const float so = lp_sigmoid(gs[192 + lane]);
         const float pij = __fmul_rn(si, tj);  // the matrix kernel parks this product (rounded) between its two passes
         c = __builtin_fmaf(c, sf, pij);
-        lp_publish(hx + (size_t)(((t + 1) & 1) * LP_RB + lb) * H + u0 + lu, lp_tanh(c) * so, epoch | (unsigned)(t + 1));
+        const int slot = (((t + 1) & 1) * LP_RB + lb) * H + u0 + lu;
+        const float hv = lp_tanh(c) * so;
+        if (wthrough) {
+          lp_publish(hx + slot, hv, epoch | (unsigned)(t + 1));
+        } else {
+          typedef unsigned int lp_u32x2 __attribute__((ext_vector_type(2)));
+          __builtin_amdgcn_raw_buffer_store_b64(lp_u32x2{__float_as_uint(hv), epoch | (unsigned)(t + 1)}, hrs, slot * 8, 0, 0);
+        }
       }
     } else if (t + 1 < T) {  // the other waves bring x_{t+1}
       for (int i = tid - 64; i < LP_RB * E; i += LP_NT - 64) {

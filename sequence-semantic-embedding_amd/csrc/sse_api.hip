@@ -537,6 +537,7 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
         h->persist_epoch = 0;
       }
       pa.epoch = ++h->persist_epoch;
+      pa.write_through = h->lstm_cluster_wt;
       pa.hx = (unsigned long long *)h->s_persist.p;
       pa.rawx = pa.hx + nhx;
       HIPCHECK(h, launch_lstm_persist(pa, st));

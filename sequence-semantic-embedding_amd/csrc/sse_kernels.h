@@ -173,6 +173,7 @@ struct LstmPersistArgs {
   uint32_t epoch = 0;           // 1 .. 2^20-1, different for every launch on the same exchange buffers
   int32_t NWG = 0;              // set by the launcher
   int32_t map_mode = 0;         // 0: cluster = blockIdx % 8 (one XCD per cluster); 1: consecutive blocks (measurement aid)
+  int32_t write_through = 0;    // 1: always publish h with write-through stores (the any-placement path)
 };
 int lstm_persist_nwg(int E, int H, int S);   // workgroups per cluster, 0: shape not supported
 int lstm_persist_max_rows();

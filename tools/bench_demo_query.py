@@ -66,6 +66,8 @@ params = dict(forward_only=True, network_mode="dual-encoder", predict_nbest=10, 
 m = sse_amd.SSEModel(params)
 m.init_variables(seed=0)
 hh = m.handle
+if os.environ.get("WT"):                                    # the any-placement (write-through) publish path of the cluster kernels
+    hh.set_option("lstm_cluster_write_through", 1)
 rng = np.random.RandomState(0)
 dense = rng.randint(2, V, size=(1, T)).astype(np.int32)
 dense[:, -1] = 1
