@@ -308,6 +308,35 @@ def main():
             x3_leg["top1_match_vs_oracle"] = float(np.mean(top_i[:48, 0].cpu().numpy() == wids[:, 0]))
         h.set_option("lstm_x3", 0)
 
+    # ---- secondary leg: mid-size encode batches (the evaluator's 600 rows, sse_evaluator.py:104-109; the index builder's
+    # 1000, sse_index.py:66,90-92): the MFMA cluster kernel (lstm_cluster.hip), the exact fp32 chain of the matrix kernel
+    mid_leg = None
+    if not args.no_x3_leg:
+        mid_leg = {"arithmetic": "v_mfma_f32_16x16x4_f32, the matrix kernel's fp32 fma chain (bit-identical results)", "rows": {}}
+        for rows in (600, 1024, 2048):
+            ref = torch.empty((rows, S), dtype=torch.float32, device=dev)
+            h.set_option("lstm_cluster_rows", 0)
+            h.set_option("lstm_small_rows", 0)                   # 32-row tiles of the matrix kernel
+            h.encode_dev(0, src_ids.data_ptr(), rows, T, True, ref.data_ptr())
+            h.set_option("lstm_small_rows", 1024)
+            h.set_option("lstm_cluster_rows", 1024)
+            for _ in range(3):
+                h.encode_dev(0, src_ids.data_ptr(), rows, T, True, src_enc.data_ptr())
+            n_it = 20
+            for i in range(n_it):
+                h.timer_record(2 * i)
+                h.encode_dev(0, src_ids.data_ptr(), rows, T, True, src_enc.data_ptr())
+                h.timer_record(2 * i + 1)
+            h.synchronize()
+            ms = sorted(h.timer_elapsed_ms(2 * i, 2 * i + 1) for i in range(n_it))[n_it // 2]
+            tf = rows * FLOP_PER_SEQ / (ms * 1e-3) / 1e12
+            mid_leg["rows"][str(rows)] = {"encode_ms": ms, "seqs_per_s": rows / (ms * 1e-3), "launches": (rows + 1023) // 1024,
+                                          "identical_to_matrix_kernel": bool(torch.equal(src_enc[:rows], ref)),
+                                          "roofline": {"kernel": "lstm_cluster_kernel", "bound": "mfma", "unit": "TFLOP/s",
+                                                       "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "frac": tf / PEAK_F32_MFMA_TFLOPS}}
+        mid_leg["fallbacks"] = h.get_counter("lstm_persist_fallbacks")
+        mid_leg["timing"] = "HIP events around the call on the library's stream, median of 20 (device-resident ids and output)"
+
     # ---- secondary leg: ranking-scale sharded scoring with RCCL all-gather of per-shard top-k
     scoring = None
     if not args.no_scoring_leg:
@@ -517,6 +546,8 @@ def main():
             line["scoring_leg_fp32_candidates"] = scoring_fp32
         if x3_leg is not None:
             line["encode_leg_split_bf16"] = x3_leg
+        if mid_leg is not None:
+            line["encode_leg_mid_batch"] = mid_leg
         if latency is not None:
             line["latency_leg"] = latency
         if training is not None:

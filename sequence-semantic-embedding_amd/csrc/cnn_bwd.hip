@@ -48,7 +48,7 @@ __device__ __forceinline__ float bf16_rne(float f) {  // nearest bfloat16 (ties 
 }
 
 template <int FS, int NF>
-__device__ void dw_body(const CnnBwdArgs &a, float *xs) {
+__device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
   constexpr int PARTS = 256 / NF;
   constexpr int KMAX = (FS * 64 + PARTS - 1) / PARTS;  // E <= 64
   const int tid = threadIdx.x, f = tid % NF, part = tid / NF;
@@ -85,6 +85,7 @@ __device__ void dw_body(const CnnBwdArgs &a, float *xs) {
   if (part == 0) a.db_part[(size_t)chunk * 576 + fo] = bsum;
 }
 
+// (the four bodies are inlined: as calls they took the argument block through scratch and spilled around the call)
 __global__ __launch_bounds__(256) void cnn_dw_kernel(CnnBwdArgs a) {
   extern __shared__ float xs[];  // [2][T*E]
   switch (blockIdx.y) {
