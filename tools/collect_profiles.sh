@@ -3,6 +3,7 @@
 # own run, kernel-trace only, as MI355X_MICROARCH.md prescribes), all under gpurun_out/<tag>/.
 # usage: tools/collect_profiles.sh <tag>;  then: python tools/summarize_profiles.py <tag> gpurun_out/<tag>/stats gpurun_out/<tag>/pmc_*
 set -u
+exec </dev/null
 tag=${1:-prof}
 root=$(pwd)
 out=$root/gpurun_out/$tag

@@ -5,6 +5,7 @@
 #   tools/collect_profiles_extra.sh <tag>
 # then on the build box:  python tools/summarize_extra.py <tag>   (writes profiles/<tag>_*.txt|csv)
 set -u
+exec </dev/null
 tag=${1:-extra}
 root=$(pwd)
 out=$root/gpurun_out/$tag
@@ -12,13 +13,24 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 run() {  # name, command...
   name=$1; shift
-  ( cd "$root" && "$@" > "$out/$name.txt" 2>&1 )
-  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${name}_stats" -o p -- "$@" > "$out/${name}_stats.log" 2>&1 )
+  ( cd "$root" && timeout 300 "$@" > "$out/$name.txt" 2>&1 )
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${name}_stats" -o p -- "$@" > "$out/${name}_stats.log" 2>&1 )
 }
 pmc() {  # name, counters, command...
   name=$1; ctr=$2; shift 2
-  ( cd /tmp && rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$out/${name}_pmc_$(echo $ctr | tr ' ' '_' | cut -c1-24)" -o p -- "$@" > /dev/null 2>&1 )
+  ( cd /tmp && timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$out/${name}_pmc_$(echo $ctr | tr ' ' '_' | cut -c1-24)" -o p -- "$@" > /dev/null 2>&1 )
 }
+if [ -n "${QUICK:-}" ]; then
+  # round-3 set (GPU-minutes were short): the kernels that changed this round, one plain + one --stats run each, and the
+  # MFMA-busy pass of the training step
+  run demo python "$root/tools/bench_demo_query.py" 2500000
+  run mid_batch env N=20 python "$root/tools/dbg_cluster.py" 64 600 1000 1024 2048 3072
+  SSE_TRAIN_SERIAL=1 run train python "$root/tools/bench_train.py" 8192
+  SSE_TRAIN_SERIAL=1 pmc train "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" python "$root/tools/bench_train.py" 8192
+  run train_default python "$root/tools/bench_train_default.py"
+  run cnn python "$root/tools/bench_cnn.py"
+  run train_concurrent python "$root/tools/bench_train.py" 128 1024 8192
+else
 run demo python "$root/tools/bench_demo_query.py" 10000000
 pmc demo FETCH_SIZE python "$root/tools/bench_demo_query.py" 10000000
 run hbm python "$root/tools/bench_hbm_kernels.py"
@@ -32,5 +44,6 @@ run x3 python "$root/tools/bench_x3.py"
 pmc x3 "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" python "$root/tools/bench_x3.py"
 run x3_default_shape python "$root/tools/bench_x3.py" 16384 96 64 80
 run train_concurrent python "$root/tools/bench_train.py" 128 1024 8192
+fi
 find "$out" -name "*.csv" -size +20M -delete
 ls "$out"

@@ -50,8 +50,35 @@ def main():
                 continue
             out.append("%-60s grid=%-9s %-10s n=%-3d avg=%.5g KB  (avg dispatch %.3f ms)"
                        % (k, g, c, len(v), sum(v) / len(v), sum(dur[(k, g, c)]) / len(v) / 1e6))
-    open(os.path.join(dst, "%s_hbm_pmc.txt" % tag), "w").write("\n".join(out) + "\n")
+    if len(out) > 3:
+        open(os.path.join(dst, "%s_hbm_pmc.txt" % tag), "w").write("\n".join(out) + "\n")
     print("\n".join(out[-40:]))
+    # MFMA-busy share of the training kernels: (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs) per dispatch
+    for d in sorted(glob.glob(os.path.join(src, "train_pmc_SQ_VALU*"))):
+        f = os.path.join(d, "p_counter_collection.csv")
+        if not os.path.exists(f):
+            continue
+        busy, gui, dur = collections.defaultdict(list), collections.defaultdict(list), collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if any(k in r["Kernel_Name"] for k in SKIP):
+                continue
+            key = (r["Kernel_Name"].split("(")[0].replace("void ", "")[:60], r["Grid_Size"])
+            if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
+                busy[key].append(float(r["Counter_Value"]))
+                dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            elif r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                gui[key].append(float(r["Counter_Value"]))
+        lines = ["# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- SSE_TRAIN_SERIAL=1 python tools/bench_train.py 8192",
+                 "# MFMA-busy = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs), averaged over the dispatches of a (kernel, grid)"]
+        for key in sorted(busy, key=lambda k: -sum(dur[k])):
+            if key not in gui or sum(dur[key]) / len(dur[key]) < 20000:
+                continue
+            b = sum(busy[key]) / len(busy[key]) / 1024.0
+            g = sum(gui[key]) / len(gui[key]) / 8.0
+            lines.append("%-60s grid=%-9s n=%-3d MFMA-busy %.3f  (avg dispatch %.3f ms)"
+                         % (key[0], key[1], len(busy[key]), b / g if g else 0.0, sum(dur[key]) / len(dur[key]) / 1e6))
+        open(os.path.join(dst, "%s_train_pmc.txt" % tag), "w").write("\n".join(lines) + "\n")
+        print("\n".join(lines))
 
 
 if __name__ == "__main__":
