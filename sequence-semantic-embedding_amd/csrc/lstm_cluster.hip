@@ -116,7 +116,9 @@ __global__ __launch_bounds__(LC_NT) void lstm_cluster_kernel(LstmClusterArgs a) 
   const int KGhe = min(KGh, (H + 7) / 8);            // h k-groups that can be non-zero
   float *Wl = lcs;                                   // [NQ][KG][64 lanes][2]: A operand, rows (unit, gate), k = kg*8 + lc_koff(e, lane >> 4)
   float *Xl = Wl + (size_t)NQ * KG * 128;            // [group][16-sequence half][KG][64 lanes][2]: B operand [x_t | 1 | h_{t-1}]
-  int *red = reinterpret_cast<int *>(Xl + (size_t)4 * KG * 128);  // [32]: 0,1 lead of a group; 8 publish mode; 10,11 arrival counters; 12,13 gave up
+  const int XS = KG * 128 + 32;  // floats per (group, half) operand tile: + 128 bytes, so that the two halves a 32-lane store
+                                 // pass of the exchange covers land on different LDS banks
+  int *red = reinterpret_cast<int *>(Xl + (size_t)4 * XS);  // [32]: 0,1 lead of a group; 8 publish mode; 10,11 arrival counters; 12,13 gave up
   float *H32 = (2 * KGh * 256 <= NQ * KG * 128) ? Wl : reinterpret_cast<float *>(red + 32 + 3 * 128);  // h_T in the matrix kernel's layout
   const int b0 = cluster * LC_ROWS, nb = min(LC_ROWS, a.B - b0);
 #ifdef SSE_LC_SOLO  // measurement builds: group 1 idle (wrong results for its rows) -- a group's phases without the other group
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(LC_NT) void lstm_cluster_kernel(LstmClusterArgs a) 
   unsigned long long *sx = a.sx + (size_t)cluster * 16 * LC_ROWS;      // [16 tiles][64] {sum of squares, tag}
   const unsigned int epoch = a.epoch << 12;                            // tag = epoch | step + 1 (T < 4095)
   auto xslot = [&](int s32, int kg, int kq) -> float * {  // the 2 floats (k = kg*8 + lc_koff(0, kq), + 2) of sequence s32 of this group
-    return Xl + ((((size_t)(G * 2 + (s32 >> 4)) * KG + kg) * 64) + kq * 16 + (s32 & 15)) * 2;
+    return Xl + (size_t)(G * 2 + (s32 >> 4)) * XS + ((size_t)kg * 64 + kq * 16 + (s32 & 15)) * 2;
   };
 
   if (tid < 32) red[tid] = (tid < 2) ? T : 0;
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(LC_NT) void lstm_cluster_kernel(LstmClusterArgs a) 
   f32x4 accA = {0, 0, 0, 0}, accB = {0, 0, 0, 0};
   auto mfma_range = [&](int k0, int k1) {
     const float *wa = Wl + (((size_t)qA * KG + k0) * 64 + lane) * 2, *wb = wa + (size_t)KG * 128;
-    const float *xb = Xl + (((size_t)(G * 2 + hf) * KG + k0) * 64 + lane) * 2;
+    const float *xb = Xl + (size_t)(G * 2 + hf) * XS + ((size_t)k0 * 64 + lane) * 2;
     auto ld = [&](const float *q, int kg) { return *reinterpret_cast<const lc_f32x2 *>(q + (size_t)kg * 128); };
 #define LC_STEP(C, N, off)                                                    \
   N##a = ld(wa, off);                                                         \
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(LC_NT) void lstm_cluster_kernel(LstmClusterArgs a) 
   // ---- h_T of the 64 rows into the matrix kernel's A-operand layout [row tile][kg][64 lanes][4] (over the weights)
   for (int i = tid; i < LC_ROWS * Hp; i += LC_NT) {
     const int s = i & 63, u = i >> 6;
-    const float v = Xl[((((size_t)(s >> 4) * KG + KGx + (u >> 3)) * 64) + lc_kq_of(u & 7) * 16 + (s & 15)) * 2 + ((u & 3) >> 1)];
+    const float v = Xl[(size_t)(s >> 4) * XS + (((size_t)KGx + (u >> 3)) * 64 + lc_kq_of(u & 7) * 16 + (s & 15)) * 2 + ((u & 3) >> 1)];
     H32[((size_t)(s >> 5) * KGh + (u >> 3)) * 256 + (((u >> 2) & 1) * 32 + (s & 31)) * 4 + (u & 3)] = v;
   }
   __syncthreads();
@@ -500,7 +502,7 @@ __global__ void pack_lstm_cluster_kernel(const float *__restrict__ K, const floa
 
 static size_t lc_lds_bytes(int Ep, int Hp) {
   const int KG = (Ep + Hp) / 8, NQ = Hp / LC_NWG / 4, KGh = Hp / 8;
-  size_t fl = (size_t)(NQ + 4) * KG * 128 + 32 + 3 * 128;  // + the operand ring's reads past the last k-group
+  size_t fl = (size_t)(NQ + 4) * KG * 128 + 4 * 32 + 32 + 3 * 128;  // + the operand ring's reads past the last k-group
   if (2 * KGh * 256 > NQ * KG * 128) fl += (size_t)2 * KGh * 256;  // h_T re-laid for the projection does not fit over the weights
   return fl * sizeof(float);
 }
