@@ -447,9 +447,14 @@ int ensure_pad_table_small(sse_handle *h, int side, int T, hipStream_t st) {
 // Batches the MFMA cluster kernel (lstm_cluster.hip) takes: 33 rows up to lstm_cluster_chunks launches of lstm_cluster_rows
 // (<= 1024) rows.  A launch costs about the same 0.3 ms whatever it holds (T = 32), a 32-row tile of the matrix kernel 1.2 ms
 // whether 33 or 8192 rows run beside it: three launches are still ahead of it, four are not.
-static int cluster_row_limit(const sse_handle *h) {
+// With the split-bf16 matrix kernel opted in (lstm_x3: ~0.45 ms for anything up to 8192 rows, ~1e-5 from fp32) a second
+// launch no longer pays: one launch only.
+static bool x3_applies(const sse_handle *h, const Encoder &e) {
+  return h->lstm_x3 && e.Hp <= 256 && e.H >= 64 && h->cfg.embedding_size < 64;
+}
+static int cluster_row_limit(const sse_handle *h, const Encoder &e) {
   const int per = std::min(h->lstm_cluster_rows, lstm_cluster_max_rows());
-  return per * std::max(1, h->lstm_cluster_chunks);
+  return per * (x3_applies(h, e) ? 1 : std::max(1, h->lstm_cluster_chunks));
 }
 
 int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T, int normalize, float *out,
@@ -548,7 +553,7 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
       return 0;
     }
   }
-  if (small_ok && B > 32 && B <= cluster_row_limit(h) && T <= lstm_persist_max_steps() &&
+  if (small_ok && B > 32 && B <= cluster_row_limit(h, e) && T <= lstm_persist_max_steps() &&
       lstm_cluster_ok(c.embedding_size, e.H, c.encoding_size)) {
     // mid-size batches (the evaluator's 600, the index builder's 1000): the hidden units of every 64-row tile spread over a
     // cluster of 16 compute units, weights in LDS, h_t exchanged per step (lstm_cluster.hip); needs one CU per workgroup
@@ -639,7 +644,7 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
     HIPCHECK(h, launch_lstm_small(sa, st));
     return 0;
   }
-  if (h->lstm_x3 && e.Hp <= 256 && e.H >= 64 && c.embedding_size < 64) {  // (tiny cells: nothing to gain, and their raw
+  if (x3_applies(h, e)) {  // (tiny cells: nothing to gain, and their raw
     // encodings can be small enough for the 2e-6 absolute error to matter after normalisation)
     // opt-in: the gate GEMMs on the bf16 matrix pipe with hi + lo split operands (lstm_fwd_x3.hip); ~1e-5 from the fp32 path
     Encoder &own = e.shares_lstm_with >= 0 ? h->enc[e.shares_lstm_with] : e;
@@ -1247,7 +1252,25 @@ int sse_encode_dev(sse_handle *h, int side, const int32_t *ids_dev, int32_t B, i
 }
 
 // host ids -> encodings [B][S] in h->s_out (device); the handle mutex is held by the caller
-static int encode_host_ids_locked(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int32_t T, int32_t normalize) {
+// Re-run of a batch whose cluster-kernel launch reported a missing workgroup (error bit 2), on the kernels that need no
+// co-residency.  The cluster kernels need their 16 - 32 workgroups per cluster resident together; a device busy with other
+// work (a train step on another handle, four serving routes at once) can keep one from arriving within the give-up time.
+// Nothing was written that the other kernels do not overwrite; results are bit-identical.
+static int encode_fallback_locked(sse_handle *h, int side, int32_t B, int32_t T, int32_t normalize, hipStream_t st) {
+  h->persist_fallbacks += 1;
+  const int keep = h->lstm_persist_rows, keep_c = h->lstm_cluster_rows;
+  h->lstm_persist_rows = 0;
+  h->lstm_cluster_rows = 0;
+  const int rc = encode_dev_locked(h, side, (const int32_t *)h->s_ids.p, B, T, normalize, (float *)h->s_out.p, st);
+  h->lstm_persist_rows = keep;
+  h->lstm_cluster_rows = keep_c;
+  if (rc) return 1;
+  return check_err_flag(h, st);
+}
+
+// defer_check: leave the device error flag unread (no synchronisation here); the caller reads it with its own read-back
+static int encode_host_ids_locked(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int32_t T, int32_t normalize,
+                                  bool defer_check = false) {
   const size_t S = h->cfg.encoding_size;
   if (reserve(h, h->s_ids, (size_t)B * T * sizeof(int32_t))) return 1;
   if (reserve(h, h->s_out, (size_t)B * S * sizeof(float))) return 1;
@@ -1256,7 +1279,7 @@ static int encode_host_ids_locked(sse_handle *h, int side, const int32_t *ids_ho
   // 64-row tile can skip its whole common PAD prefix; results are scattered back in caller order.
   const bool lstm_side = h->cfg.network_mode != SSE_MODE_SOURCE_ONLY_CNN && !(side == SSE_SIDE_TARGET && h->tgt_table >= 0);
   const int32_t *row_map_dev = nullptr;
-  const bool to_cluster = lstm_side && B <= cluster_row_limit(h) && T <= lstm_persist_max_steps() &&
+  const bool to_cluster = lstm_side && B <= cluster_row_limit(h, h->enc[side]) && T <= lstm_persist_max_steps() &&
                           lstm_cluster_ok(h->cfg.embedding_size, h->enc[side].H, h->cfg.encoding_size);  // (takes rows as they come)
   if (h->pad_skip && lstm_side && B > 64 && B > h->lstm_small_rows && !to_cluster) {
     // counting sort of the row numbers by leading-PAD count, longest prefix first
@@ -1280,23 +1303,10 @@ static int encode_host_ids_locked(sse_handle *h, int side, const int32_t *ids_ho
   int rc = encode_dev_locked(h, side, (const int32_t *)h->s_ids.p, B, T, normalize, (float *)h->s_out.p, st);
   h->cur_row_map = nullptr;
   if (rc) return 1;
+  if (defer_check) return 0;
   int32_t bits = 0;
   if (check_err_flag(h, st, &bits)) return 1;
-  if (bits == 4) {
-    // the cluster kernel needs its 16 - 32 workgroups per cluster resident together; a device busy with other work (a
-    // train step on another handle, four serving routes at once) can keep one from arriving within the bounded spin.
-    // Nothing was written that the other kernels do not overwrite: run the batch again on the few-sequences kernel
-    // (bit-identical results) and count it.
-    h->persist_fallbacks += 1;
-    const int keep = h->lstm_persist_rows, keep_c = h->lstm_cluster_rows;
-    h->lstm_persist_rows = 0;
-    h->lstm_cluster_rows = 0;
-    rc = encode_dev_locked(h, side, (const int32_t *)h->s_ids.p, B, T, normalize, (float *)h->s_out.p, st);
-    h->lstm_persist_rows = keep;
-    h->lstm_cluster_rows = keep_c;
-    if (rc) return 1;
-    return check_err_flag(h, st);
-  }
+  if (bits == 4) return encode_fallback_locked(h, side, B, T, normalize, st);
   return 0;
 }
 
@@ -1314,11 +1324,14 @@ int sse_encode(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int3
 
 // Scores + ids of Q queries (device rows q_dev) into host buffers: first phase, ONE pinned read-back of [scores | ids |
 // certificates] with one synchronisation, and the follow-up stages only when some query is not certified.
-static int score_to_host_locked(sse_handle *h, const float *q_dev, int Q, int k, double *out_scores, int64_t *out_ids) {
+// err_bits: (optional) the device error flag rides along in the first read-back (an encoder launched just before on the
+// same stream with its check deferred); when it comes back non-zero the outputs are not written.
+static int score_to_host_locked(sse_handle *h, const float *q_dev, int Q, int k, double *out_scores, int64_t *out_ids,
+                                int32_t *err_bits = nullptr) {
   hipStream_t st = nullptr;
   if (reserve(h, h->s_os, (size_t)Q * k * sizeof(double))) return 1;
   if (reserve(h, h->s_oi, (size_t)Q * k * sizeof(int64_t))) return 1;
-  const size_t nb = (size_t)Q * k * 8, need = 2 * nb + (size_t)Q * sizeof(int32_t);
+  const size_t nb = (size_t)Q * k * 8, need = 2 * nb + (size_t)Q * sizeof(int32_t) + sizeof(int32_t);
   if (need > h->pin_cap) {
     if (h->pin) HIPCHECK(h, hipHostFree(h->pin));
     h->pin = nullptr;
@@ -1333,7 +1346,13 @@ static int score_to_host_locked(sse_handle *h, const float *q_dev, int Q, int k,
     HIPCHECK(h, hipMemcpyAsync(pin, h->s_os.p, nb, hipMemcpyDeviceToHost, st));
     HIPCHECK(h, hipMemcpyAsync(pin + nb, h->s_oi.p, nb, hipMemcpyDeviceToHost, st));
     if (split && pass == 0) HIPCHECK(h, hipMemcpyAsync(pin + 2 * nb, h->s_cert.p, (size_t)Q * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    int32_t *flag = (int32_t *)(pin + 2 * nb + (size_t)Q * sizeof(int32_t));
+    if (err_bits && pass == 0) HIPCHECK(h, hipMemcpyAsync(flag, h->err_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHECK(h, sync_stream(st));
+    if (err_bits && pass == 0) {
+      *err_bits = *flag;
+      if (*flag) return 0;  // the queries were not what the caller meant: it looks at the flag first
+    }
     bool open_q = false;
     if (split && pass == 0) {
       const int32_t *cert = (const int32_t *)(pin + 2 * nb);
@@ -1358,9 +1377,19 @@ int sse_encode_score_topk(sse_handle *h, int side, const int32_t *ids_host, int3
   if (!h->idxp) return fail(h, "no index uploaded");
   if (h->cfg.encoding_size != h->idx_S)
     return fail(h, "index dimension %d != encoding_size %d", h->idx_S, h->cfg.encoding_size);
-  if (encode_host_ids_locked(h, side, ids_host, B, T, normalize)) return 1;
+  // One synchronisation for the whole call: the encoder's error flag (token id out of range, a cluster workgroup that did
+  // not arrive) is not waited for before the scorer is launched -- it comes back with the scores.
+  if (encode_host_ids_locked(h, side, ids_host, B, T, normalize, /*defer_check=*/true)) return 1;
   // the encodings never leave the device between the encoder and the scorer
-  if (score_to_host_locked(h, (const float *)h->s_out.p, B, k, out_scores, out_ids)) return 1;
+  int32_t bits = 0;
+  if (score_to_host_locked(h, (const float *)h->s_out.p, B, k, out_scores, out_ids, &bits)) return 1;
+  if (bits) {
+    if (check_err_flag(h, nullptr, &bits)) return 1;  // reports what is reportable, resets the flag
+    if (bits == 4) {
+      if (encode_fallback_locked(h, side, B, T, normalize, nullptr)) return 1;
+      if (score_to_host_locked(h, (const float *)h->s_out.p, B, k, out_scores, out_ids)) return 1;
+    }
+  }
   if (enc_out_host)
     HIPCHECK(h, hipMemcpy(enc_out_host, h->s_out.p, (size_t)B * h->cfg.encoding_size * sizeof(float), hipMemcpyDeviceToHost));
   return 0;

@@ -360,6 +360,15 @@ def test_cluster_kernel_miss_falls_back_to_the_few_sequences_kernel():
     assert m.handle.get_counter("lstm_persist_fallbacks") == 2
     assert np.array_equal(m.encode_source(ids), want)
     assert m.handle.get_counter("lstm_persist_fallbacks") == 2
+    # sse_encode_score_topk reads the encoder's error flag together with the scores (one synchronisation per call): an id
+    # out of range still raises, nothing is returned, and the next call is clean
+    import sse_amd
+    bad = ids.copy()
+    bad[3, -1] = 300
+    with pytest.raises(sse_amd.SSEError):
+        m.handle.encode_score_topk(0, bad, False, 7)
+    again_s, again_i = m.handle.encode_score_topk(0, ids, False, 7)
+    assert np.array_equal(again_i, want_i) and np.array_equal(again_s, want_s)
 
 
 @pytest.mark.parametrize("H,S", [(40, 16), (100, 64), (72, 24)])
