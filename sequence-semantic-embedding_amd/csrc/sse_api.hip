@@ -1252,6 +1252,17 @@ int sse_encode_dev(sse_handle *h, int side, const int32_t *ids_dev, int32_t B, i
 }
 
 // host ids -> encodings [B][S] in h->s_out (device); the handle mutex is held by the caller
+// the handle's pinned read-back buffer, grown on demand
+static int ensure_pin(sse_handle *h, size_t need) {
+  if (need <= h->pin_cap) return 0;
+  if (h->pin) HIPCHECK(h, hipHostFree(h->pin));
+  h->pin = nullptr;
+  h->pin_cap = 0;
+  HIPCHECK(h, hipHostMalloc(&h->pin, need + need / 2 + 4096, hipHostMallocDefault));
+  h->pin_cap = need + need / 2 + 4096;
+  return 0;
+}
+
 // Re-run of a batch whose cluster-kernel launch reported a missing workgroup (error bit 2), on the kernels that need no
 // co-residency.  The cluster kernels need their 16 - 32 workgroups per cluster resident together; a device busy with other
 // work (a train step on another handle, four serving routes at once) can keep one from arriving within the give-up time.
@@ -1317,8 +1328,30 @@ int sse_encode(sse_handle *h, int side, const int32_t *ids_host, int32_t B, int3
   HIPCHECK(h, hipSetDevice(h->cfg.device));
   if (B == 0) return 0;
   if (B < 0 || T < 1 || !ids_host || !out_host) return fail(h, "bad arguments to sse_encode");
-  if (encode_host_ids_locked(h, side, ids_host, B, T, normalize)) return 1;
-  HIPCHECK(h, hipMemcpy(out_host, h->s_out.p, (size_t)B * h->cfg.encoding_size * sizeof(float), hipMemcpyDeviceToHost));
+  const size_t nbytes = (size_t)B * h->cfg.encoding_size * sizeof(float);
+  if (nbytes <= (64u << 10)) {
+    // small results (a few queries): the encodings and the error flag come back in ONE pinned read-back with one
+    // synchronisation, 0.155 -> 0.144 ms for a query.  (Measured the other way for larger ones: 600 x 256 floats 0.340 ->
+    // 0.364 ms, 1024 rows 0.364 -> 0.440 ms -- the runtime's staged copy into a pageable target beats pinned + memcpy.)
+    if (encode_host_ids_locked(h, side, ids_host, B, T, normalize, /*defer_check=*/true)) return 1;
+    const size_t need = nbytes + sizeof(int32_t);
+    if (ensure_pin(h, need)) return 1;
+    char *pin = (char *)h->pin;
+    hipStream_t st = nullptr;
+    HIPCHECK(h, hipMemcpyAsync(pin, h->s_out.p, nbytes, hipMemcpyDeviceToHost, st));
+    HIPCHECK(h, hipMemcpyAsync(pin + nbytes, h->err_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHECK(h, sync_stream(st));
+    int32_t bits = *(const int32_t *)(pin + nbytes);
+    if (bits == 0) {
+      memcpy(out_host, pin, nbytes);
+      return 0;
+    }
+    if (check_err_flag(h, st, &bits)) return 1;  // reports what is reportable, resets the flag
+    if (bits == 4 && encode_fallback_locked(h, side, B, T, normalize, st)) return 1;
+  } else if (encode_host_ids_locked(h, side, ids_host, B, T, normalize)) {
+    return 1;
+  }
+  HIPCHECK(h, hipMemcpy(out_host, h->s_out.p, nbytes, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -1332,13 +1365,7 @@ static int score_to_host_locked(sse_handle *h, const float *q_dev, int Q, int k,
   if (reserve(h, h->s_os, (size_t)Q * k * sizeof(double))) return 1;
   if (reserve(h, h->s_oi, (size_t)Q * k * sizeof(int64_t))) return 1;
   const size_t nb = (size_t)Q * k * 8, need = 2 * nb + (size_t)Q * sizeof(int32_t) + sizeof(int32_t);
-  if (need > h->pin_cap) {
-    if (h->pin) HIPCHECK(h, hipHostFree(h->pin));
-    h->pin = nullptr;
-    h->pin_cap = 0;
-    HIPCHECK(h, hipHostMalloc(&h->pin, need + need / 2 + 4096, hipHostMallocDefault));
-    h->pin_cap = need + need / 2 + 4096;
-  }
+  if (ensure_pin(h, need)) return 1;
   char *pin = (char *)h->pin;
   int split = 0;
   if (score_dev_locked(h, q_dev, Q, k, (double *)h->s_os.p, (int64_t *)h->s_oi.p, st, SCORE_FIRST, &split)) return 1;
