@@ -6,22 +6,27 @@
 // whether the launch holds 33 rows or 8192, with 600 rows keeping 19 of the 256 CUs busy.  lstm_small.hip streams the kernel
 // matrix through every workgroup of 4 rows (17 us per step, 0.55 ms).  Here the hidden units of a row tile are spread over a
 // CLUSTER of 16 compute units, the MFMA version of lstm_persist.hip:
-//   * a cluster serves 64 sequences as two independent GROUPS of 32; workgroup p owns hidden units [p*UW, (p+1)*UW), UW =
+//   * a cluster serves 64 sequences as four independent GROUPS of 16; workgroup p owns hidden units [p*UW, (p+1)*UW), UW =
 //     Hp/16, all four gates of them, and keeps their weight fragments in LDS for the whole call (78 KiB at E = 50, H = 256):
 //     a step reads no weights from memory;
-//   * a workgroup is 8 waves: waves 0-3 step group 0, waves 4-7 step group 1, each group at its own pace (its own exchange
-//     buffers, its own LDS arrival counter instead of s_barrier).  A SIMD holds one wave of each group, so while one group
-//     waits for its h_t to arrive from the 15 other workgroups (~3 us) the other group's MFMAs have the matrix pipe: the
-//     exchange latency that made the single-group version spend 1/3 of every step idle is covered;
-//   * per step a wave multiplies two [16 (unit, gate) rows] x [K] weight fragments into one 16-sequence tile of
-//     [x_t | 1 | h_{t-1}] (LDS, 39 KiB per group): 312 v_mfma_f32_16x16x4_f32 per wave in two independent accumulator chains
-//     (a dependent fp32 MFMA issues ~18 cycles late; two chains hide that) = 5 k cycles, 1/32 of the cluster's GEMM.  The
-//     weights are the MFMA's A operand with rows ordered (unit, gate), so an accumulator lane holds the four gates of one
-//     unit of ONE sequence: the gate formulas run lane-locally, c stays in 2 registers;
-//   * h_t crosses workgroups as {value, tag} 64-bit words, two per 16-byte store (tag = (call epoch, step), two alternating
-//     buffers, bounded spin -> error flag instead of a hang), laid out so that a wave's stores and loads are contiguous KiBs
-//     and a loaded piece is one ds_write_b64 into the operand tile; 16 KiB published and 128 KiB read per workgroup and step.
-//     When the cluster's workgroups share an XCD (checked) the stores are plain and the lines stay in that XCD's L2;
+//   * a workgroup is 16 waves: waves 4G .. 4G+3 step group G, each group at its own pace (its own exchange buffers, its own
+//     LDS arrival counter instead of s_barrier).  A SIMD holds one wave of each group, so while one group waits for its h_t
+//     to arrive from the 15 other workgroups (~3 us) the other groups' MFMAs have the matrix pipe: the exchange latency that
+//     made the single-group version spend 1/3 of every step idle is mostly covered (two groups of 32: 0.29 ms at 1024 rows,
+//     four of 16: 0.27 ms);
+//   * per step a wave multiplies one [16 (unit, gate) rows] x [K] weight fragment into the group's 16-sequence tile of
+//     [x_t | 1 | h_{t-1}] (LDS, 19.5 KiB per group): 78 v_mfma_f32_16x16x4_f32 = 2.5 k cycles, 1/64 of the cluster's GEMM (the
+//     instruction issues back to back at 32 cycles with a single accumulator chain: tools/mfma_rate_probe.hip).  The weights
+//     are the MFMA's A operand with rows ordered (unit, gate), so an accumulator lane holds the four gates of one unit of ONE
+//     sequence: the gate formulas run lane-locally, c stays in 1 register;
+//   * h_t crosses workgroups as {value, tag} 64-bit words (tag = (call epoch, step), two alternating buffers, waits that
+//     give up -> error flag instead of a hang), stored 8 bytes per lane and read 16 bytes at a time (the unit pair of one LDS
+//     slot), laid out so that a wave's loads are contiguous KiBs and a loaded piece is one ds_write_b64 into the operand
+//     tile; 16 KiB published and 128 KiB read per workgroup and step.  When the cluster's workgroups share an XCD (checked)
+//     the stores are plain and the lines stay in that XCD's L2;
+//   * two group barriers per step: after the h part of the MFMAs + gates + publish + the x_{t+1} stores (nobody reads the x
+//     part of the tile then), and after h_t has been written into the tile; the x part of step t+1 is multiplied between
+//     them, while h_t is on its way;
 //   * projection + l2-normalise: h_T is re-laid into the matrix kernel's operand layout (LDS) and workgroup p computes the
 //     32-column tile p of h_T . M with the matrix kernel's tail; the per-tile row sums of squares travel like h and are added
 //     in tile order.
@@ -29,18 +34,19 @@
 // v_mfma_f32_16x16x4_f32 = four fmas in ascending k like v_mfma_f32_32x32x2_f32's two -- tools/mfma_chain_probe.hip), the
 // same gate formulas, projection order and sum-of-squares tree: results are BIT-IDENTICAL to lstm_fwd.hip / lstm_small.hip /
 // lstm_persist.hip (tests/test_gpu_encode.py), and the pad-prefix table of lstm_small.hip serves the exact left-PAD skip.
-// All 16 workgroups of a cluster must be resident together (one per CU: the kernel uses 156 of 160 KiB of LDS); clusters are
+// All 16 workgroups of a cluster must be resident together (one per CU: the kernel uses 158 of 160 KiB of LDS); clusters are
 // dealt to the XCDs (blockIdx % 8), two per XCD at most: 16 clusters = 1024 sequences fill the chip.
 #include "sse_kernels.h"
 
 #define LC_NWG 16
-#define LC_ROWS 64   // sequences per cluster: two groups of 32
-#define LC_NT 512    // 8 waves: group = wave >> 2
+#define LC_ROWS 64   // sequences per cluster: four groups of 16
+#define LC_NT 1024   // 16 waves: group = wave >> 2
 #define LC_GT 256    // threads per group
 #define LC_WAIT_TICKS 1000000  // 10 ms of the 100 MHz wall clock without the awaited word: give up (error bit 2)
 
 typedef unsigned int lc_u32x4 __attribute__((ext_vector_type(4)));
 typedef float lc_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int lc_u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float lc_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504089f * x)); }
 __device__ __forceinline__ float lc_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008178f * x)); }
@@ -115,30 +121,25 @@ __global__ __launch_bounds__(LC_NT) void lstm_cluster_kernel(LstmClusterArgs a) 
   const int UW = Hp / LC_NWG, NQ = UW / 4;           // units per workgroup (8 | 16), 4-unit weight fragments per workgroup
   const int KGhe = min(KGh, (H + 7) / 8);            // h k-groups that can be non-zero
   float *Wl = lcs;                                   // [NQ][KG][64 lanes][2]: A operand, rows (unit, gate), k = kg*8 + lc_koff(e, lane >> 4)
-  float *Xl = Wl + (size_t)NQ * KG * 128;            // [group][16-sequence half][KG][64 lanes][2]: B operand [x_t | 1 | h_{t-1}]
-  const int XS = KG * 128 + 32;  // floats per (group, half) operand tile: + 128 bytes, so that the two halves a 32-lane store
-                                 // pass of the exchange covers land on different LDS banks
-  int *red = reinterpret_cast<int *>(Xl + (size_t)4 * XS);  // [32]: 0,1 lead of a group; 8 publish mode; 10,11 arrival counters; 12,13 gave up
+  float *Xl = Wl + (size_t)NQ * KG * 128;            // [group][KG][64 lanes][2] (+ pad): B operand [x_t | 1 | h_{t-1}] of 16 sequences
+  const int XS = KG * 128 + 32;  // floats per group operand tile (+ 128 bytes: consecutive tiles start on different LDS banks)
+  int *red = reinterpret_cast<int *>(Xl + (size_t)4 * XS);  // [32]: 0..3 lead of a group; 8 publish mode; 10..13 arrival counters; 14..17 gave up
   float *H32 = (2 * KGh * 256 <= NQ * KG * 128) ? Wl : reinterpret_cast<float *>(red + 32 + 3 * 128);  // h_T in the matrix kernel's layout
   const int b0 = cluster * LC_ROWS, nb = min(LC_ROWS, a.B - b0);
-#ifdef SSE_LC_SOLO  // measurement builds: group 1 idle (wrong results for its rows) -- a group's phases without the other group
-  const int gb0 = b0 + G * 32, gnb = G == 1 ? 0 : max(0, min(32, nb - G * 32));
-#else
-  const int gb0 = b0 + G * 32, gnb = max(0, min(32, nb - G * 32));     // this group's sequences
-#endif
-  unsigned long long *hx = a.hx + (size_t)cluster * 2 * LC_ROWS * Hp;  // [2 steps][group][Hp/8][4][32] x 2 {h, tag}
+  const int gb0 = b0 + G * 16, gnb = max(0, min(16, nb - G * 16));     // this group's sequences
+  unsigned long long *hx = a.hx + (size_t)cluster * 2 * LC_ROWS * Hp;  // [2 steps][group][Hp/8][4][16] x 2 {h, tag}
   unsigned long long *sx = a.sx + (size_t)cluster * 16 * LC_ROWS;      // [16 tiles][64] {sum of squares, tag}
   const unsigned int epoch = a.epoch << 12;                            // tag = epoch | step + 1 (T < 4095)
-  auto xslot = [&](int s32, int kg, int kq) -> float * {  // the 2 floats (k = kg*8 + lc_koff(0, kq), + 2) of sequence s32 of this group
-    return Xl + (size_t)(G * 2 + (s32 >> 4)) * XS + ((size_t)kg * 64 + kq * 16 + (s32 & 15)) * 2;
+  auto xslot = [&](int s16, int kg, int kq) -> float * {  // the 2 floats (k = kg*8 + lc_koff(0, kq), + 2) of sequence s16 of this group
+    return Xl + (size_t)G * XS + ((size_t)kg * 64 + kq * 16 + s16) * 2;
   };
 
-  if (tid < 32) red[tid] = (tid < 2) ? T : 0;
+  if (tid < 32) red[tid] = (tid < 4) ? T : 0;
   __syncthreads();
   // left-pad prefix skip, exactly as lstm_small.hip: a group starts at t0 = min leading-PAD count of its rows
   int t0 = 0;
   if (a.pad_h != nullptr) {
-    if (g == 0) {  // the group's 32 rows sit in the lower half of its first wave
+    if (g == 0) {  // the group's 16 rows sit in the first lanes of its first wave
       int lead = T;
       if (lane < gnb) {
         const int32_t *row = a.ids + (size_t)(gb0 + lane) * T;
@@ -152,8 +153,8 @@ __global__ __launch_bounds__(LC_NT) void lstm_cluster_kernel(LstmClusterArgs a) 
     __syncthreads();
     t0 = min(red[G], T - 1);
   }
-  auto fetch_id = [&](int s32, int t) -> int {
-    int id = (s32 < gnb) ? a.ids[(size_t)(gb0 + s32) * T + t] : 0;
+  auto fetch_id = [&](int s16, int t) -> int {
+    int id = (s16 < gnb) ? a.ids[(size_t)(gb0 + s16) * T + t] : 0;
     if (id < 0 || id >= a.V) {
       atomicOr(a.err, 1);
       id = 0;
@@ -167,42 +168,37 @@ __global__ __launch_bounds__(LC_NT) void lstm_cluster_kernel(LstmClusterArgs a) 
     f32x4 *dst = reinterpret_cast<f32x4 *>(Wl);
     for (int i = tid; i < NQ * KG * 32; i += LC_NT) dst[i] = src[i];
   }
-  // h_{t0-1}: zero, or the pad-prefix state (the same for every row).  Piece i of a group = units (u, u + 2), u = (i >> 7)*8 +
-  // lc_koff(0, (i >> 5) & 3), of sequence i & 31: the unit pair one accumulator lane produces and one LDS slot holds.
-  const int npc = (Hp / 8) * 4 * 32;  // pieces per group and step
+  // h_{t0-1}: zero, or the pad-prefix state (the same for every row).  Piece i of a group = units (u, u + 2), u = (i >> 6)*8 +
+  // lc_koff(0, (i >> 4) & 3), of sequence i & 15: the unit pair one LDS slot holds (two waves produce its halves).
+  const int npc = (Hp / 8) * 4 * 16;  // pieces per group and step
   for (int i = tg; i < npc; i += LC_GT) {
-    const int s32 = i & 31, kq = (i >> 5) & 3, kgh = i >> 7, u = kgh * 8 + lc_koff(0, kq);
+    const int s16 = i & 15, kq = (i >> 4) & 3, kgh = i >> 6, u = kgh * 8 + lc_koff(0, kq);
     lc_f32x2 v = {0, 0};
     if (t0 > 0) {
       if (u < H) v[0] = a.pad_h[(size_t)t0 * a.pad_stride + u];
       if (u + 2 < H) v[1] = a.pad_h[(size_t)t0 * a.pad_stride + u + 2];
     }
-    *reinterpret_cast<lc_f32x2 *>(xslot(s32, KGx + kgh, kq)) = v;
+    *reinterpret_cast<lc_f32x2 *>(xslot(s16, KGx + kgh, kq)) = v;
   }
   // x_t: 16-byte piece q of a padded embedding row = k 4q .. 4q+3 = k offsets 4*(q & 1) + j of k-group q >> 1
-  constexpr int XPT = 2;  // pieces per thread: 32 rows x 2*KGx <= 512 pieces (KGx <= 8)
+  constexpr int XPT = 1;  // pieces per thread: 16 rows x 2*KGx <= 256 pieces (KGx <= 8)
   auto put_x = [&](int i, const f32x4 &v) {
-    const int s32 = i & 31, q = i >> 5;
-    float *dst = xslot(s32, q >> 1, q & 1);  // offset 4*(q & 1) + j: slot kq = 2*(j & 1) + (q & 1), e = j >> 1
+    const int s16 = i & 15, q = i >> 4;
+    float *dst = xslot(s16, q >> 1, q & 1);  // offset 4*(q & 1) + j: slot kq = 2*(j & 1) + (q & 1), e = j >> 1
     dst[0] = v[0];
     dst[64] = v[1];
     dst[1] = v[2];
     dst[65] = v[3];
   };
-  for (int i = tg; i < 32 * 2 * KGx; i += LC_GT)
-    put_x(i, *reinterpret_cast<const f32x4 *>(a.emb + (size_t)fetch_id(i & 31, t0) * Ep + (i >> 5) * 4));
+  for (int i = tg; i < 16 * 2 * KGx; i += LC_GT)
+    put_x(i, *reinterpret_cast<const f32x4 *>(a.emb + (size_t)fetch_id(i & 15, t0) * Ep + (i >> 4) * 4));
 
-  // wave g of a group: sequences half hf = g & 1 (16 of them), weight fragments qA = 2*(g >> 1) and qA + 1 = the 8 units
-  // p*UW + 8*(g >> 1) ..; an accumulator lane holds the four gates (register = gate) of units uA = that + lc_koff(0, lane >> 4)
-  // and uA + 2 for sequence 16*hf + (lane & 15) of the group
-  const bool active = 2 * (g >> 1) < NQ && gnb > 0;
-  const int hf = g & 1, qA = active ? 2 * (g >> 1) : 0;
-  const int s32w = 16 * hf + (lane & 15), uA = p * UW + 4 * qA + lc_koff(0, lane >> 4), uB = uA + 2;
-  float cA = 0.0f, cB = 0.0f;
-  if (active && t0 > 0) {
-    if (uA < H) cA = a.pad_c[(size_t)t0 * a.pad_stride + uA];
-    if (uB < H) cB = a.pad_c[(size_t)t0 * a.pad_stride + uB];
-  }
+  // wave g of a group: weight fragment g = units p*UW + 8*(g >> 1) + lc_koff(g & 1, .); an accumulator lane holds the four
+  // gates (register = gate) of unit uW = that with . = lane >> 4, for sequence lane & 15 of the group
+  const bool active = g < NQ && gnb > 0;
+  const int qW = active ? g : 0, s16w = lane & 15, uW = p * UW + 8 * (qW >> 1) + lc_koff(qW & 1, lane >> 4);
+  float cW = 0.0f;
+  if (active && t0 > 0 && uW < H) cW = a.pad_c[(size_t)t0 * a.pad_stride + uW];
 
   // The h exchange is 16 KiB written and 128 KiB read per workgroup and step.  Write-through (sc1) stores are visible to every
   // XCD but drop the line from the writer's L2, so all 32 MiB a step would come back from the memory side; when the 16
@@ -226,7 +222,7 @@ __global__ __launch_bounds__(LC_NT) void lstm_cluster_kernel(LstmClusterArgs a) 
   }
   __syncthreads();  // weights, h, x, the publish mode and the zeroed arrival counters are in LDS
   const bool wthrough = red[8] != 0;
-  int *arrive = red + 10 + G;
+  int *arrive = red + 10 + G;  // (10 .. 13)
   int arrived = 0;
 
   // x_{t+1} is requested BEFORE the MFMA phase of step t and parked in registers; it goes into the operand tile once every
@@ -238,54 +234,45 @@ __global__ __launch_bounds__(LC_NT) void lstm_cluster_kernel(LstmClusterArgs a) 
 #pragma unroll
     for (int u = 0; u < XPT; ++u) {
       const int i = tg + u * LC_GT;
-      idn[u] = (i < 32 * 2 * KGx && t < T && (i & 31) < gnb) ? a.ids[(size_t)(gb0 + (i & 31)) * T + t] : 0;
+      idn[u] = (i < 16 * 2 * KGx && t < T && (i & 15) < gnb) ? a.ids[(size_t)(gb0 + (i & 15)) * T + t] : 0;
     }
   };
   auto prefetch_x = [&](const int (&idc)[XPT]) {
 #pragma unroll
     for (int u = 0; u < XPT; ++u) {
       const int i = tg + u * LC_GT;
-      if (i < 32 * 2 * KGx) xr[u] = *reinterpret_cast<const f32x4 *>(a.emb + (size_t)idc[u] * Ep + (i >> 5) * 4);
+      if (i < 16 * 2 * KGx) xr[u] = *reinterpret_cast<const f32x4 *>(a.emb + (size_t)idc[u] * Ep + (i >> 4) * 4);
     }
   };
-  // Gate pre-activations of this wave: the matrix kernel's fma chain (k-groups of x, bias row, h in order), two accumulator
-  // chains.  The k-groups [k0, k1) of a step go through a ring of four operand register sets: the LDS reads of k-group kg+3 go
-  // out under the MFMAs of k-group kg, 3 x 128 cycles ahead of their use.  A 16x16x4 fp32 MFMA holds the pipe for 32 cycles and
-  // the wave issues in order, so everything else in the loop must fit in those shadows: one read between two MFMAs, immediate
-  // offsets from three pointers that advance once per four k-groups, no clamping (the reads run up to 3 k-groups past k1:
-  // inside the tile, or into the padding behind the last one).
-  f32x4 accA = {0, 0, 0, 0}, accB = {0, 0, 0, 0};
+  // Gate pre-activations of this wave: the matrix kernel's fma chain (k-groups of x, bias row, h in order), one accumulator.
+  // The k-groups [k0, k1) of a step go through a ring of four operand register sets: the LDS reads of k-group kg+3 go out
+  // under the MFMAs of k-group kg, 3 x 64 cycles ahead of their use.  A 16x16x4 fp32 MFMA holds the pipe for 32 cycles and the
+  // wave issues in order, so everything else in the loop must fit in those shadows (or run while another group's wave has
+  // the pipe): one read after each MFMA, immediate offsets from two pointers that advance once per four k-groups, no
+  // clamping (the reads run up to 3 k-groups past k1: inside the tile, or into the padding behind the last one).
+  f32x4 acc = {0, 0, 0, 0};
   auto mfma_range = [&](int k0, int k1) {
-    const float *wa = Wl + (((size_t)qA * KG + k0) * 64 + lane) * 2, *wb = wa + (size_t)KG * 128;
-    const float *xb = Xl + (size_t)(G * 2 + hf) * XS + ((size_t)k0 * 64 + lane) * 2;
+    const float *wa = Wl + (((size_t)qW * KG + k0) * 64 + lane) * 2;
+    const float *xb = Xl + (size_t)G * XS + ((size_t)k0 * 64 + lane) * 2;
     auto ld = [&](const float *q, int kg) { return *reinterpret_cast<const lc_f32x2 *>(q + (size_t)kg * 128); };
-#define LC_STEP(C, N, off)                                                    \
-  N##a = ld(wa, off);                                                         \
-  __builtin_amdgcn_sched_barrier(0);                                          \
-  accA = __builtin_amdgcn_mfma_f32_16x16x4f32(C##a[0], C##x[0], accA, 0, 0, 0); \
-  __builtin_amdgcn_sched_barrier(0);                                          \
-  N##b = ld(wb, off);                                                         \
-  __builtin_amdgcn_sched_barrier(0);                                          \
-  accB = __builtin_amdgcn_mfma_f32_16x16x4f32(C##b[0], C##x[0], accB, 0, 0, 0); \
-  __builtin_amdgcn_sched_barrier(0);                                          \
-  N##x = ld(xb, off);                                                         \
-  __builtin_amdgcn_sched_barrier(0);                                          \
-  accA = __builtin_amdgcn_mfma_f32_16x16x4f32(C##a[1], C##x[1], accA, 0, 0, 0); \
-  accB = __builtin_amdgcn_mfma_f32_16x16x4f32(C##b[1], C##x[1], accB, 0, 0, 0); \
+#define LC_STEP(C, N, off)                                                  \
+  N##a = ld(wa, off);                                                       \
+  __builtin_amdgcn_sched_barrier(0);                                        \
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(C##a[0], C##x[0], acc, 0, 0, 0); \
+  __builtin_amdgcn_sched_barrier(0);                                        \
+  N##x = ld(xb, off);                                                       \
+  __builtin_amdgcn_sched_barrier(0);                                        \
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(C##a[1], C##x[1], acc, 0, 0, 0); \
   __builtin_amdgcn_sched_barrier(0);
-#define LC_LAST(C)                                                            \
-  accA = __builtin_amdgcn_mfma_f32_16x16x4f32(C##a[0], C##x[0], accA, 0, 0, 0); \
-  accB = __builtin_amdgcn_mfma_f32_16x16x4f32(C##b[0], C##x[0], accB, 0, 0, 0); \
-  accA = __builtin_amdgcn_mfma_f32_16x16x4f32(C##a[1], C##x[1], accA, 0, 0, 0); \
-  accB = __builtin_amdgcn_mfma_f32_16x16x4f32(C##b[1], C##x[1], accB, 0, 0, 0);
+#define LC_LAST(C)                                                          \
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(C##a[0], C##x[0], acc, 0, 0, 0); \
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(C##a[1], C##x[1], acc, 0, 0, 0);
 #define LC_PRE(N, off)                 \
   N##a = ld(wa, off);                  \
   __builtin_amdgcn_sched_barrier(0);   \
-  N##b = ld(wb, off);                  \
-  __builtin_amdgcn_sched_barrier(0);   \
   N##x = ld(xb, off);                  \
   __builtin_amdgcn_sched_barrier(0);
-    lc_f32x2 r0a, r0b, r0x, r1a, r1b, r1x, r2a, r2b, r2x, r3a, r3b, r3x;
+    lc_f32x2 r0a, r0x, r1a, r1x, r2a, r2x, r3a, r3x;
     LC_PRE(r0, 0)  // in the loop's order: its waits count outstanding reads
     LC_PRE(r1, 1)
     LC_PRE(r2, 2)
@@ -296,7 +283,6 @@ __global__ __launch_bounds__(LC_NT) void lstm_cluster_kernel(LstmClusterArgs a) 
       LC_STEP(r2, r1, 5)
       LC_STEP(r3, r2, 6)
       wa += 512;
-      wb += 512;
       xb += 512;
     }
     if (kg < k1) { LC_LAST(r0) }
@@ -308,12 +294,8 @@ __global__ __launch_bounds__(LC_NT) void lstm_cluster_kernel(LstmClusterArgs a) 
   };
   if (gnb > 0) {
     prefetch_ids(t0 + 1);
-    // Skew: group 1 starts once group 0 is through its first MFMA phase.  Two groups that start together share the matrix
-    // pipe during the MFMA phase and then both wait for their exchanges; half a phase apart each has the pipe to itself
-    // while the other waits, and nothing later pulls them back together.
-    if (G == 1 && lane == 0)
-      while (__hip_atomic_load(red + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(4);
     if (active) mfma_range(0, KGx);  // x part of the first step
+    lc_group_barrier(arrive, arrived, lane);  // (the first x_{t+1} store below must not overtake another wave's x part)
     LC_CLK_DECL
     for (int t = t0; t < T; ++t) {
       // x_{t+1}: its ids arrived during the previous step.  Order matters: take the ids out of their registers first, THEN
@@ -339,30 +321,31 @@ __global__ __launch_bounds__(LC_NT) void lstm_cluster_kernel(LstmClusterArgs a) 
       if (active) {
         // BasicLSTMCell gates (forget bias folded into the packed bias row), lane-local; i*j is rounded before it meets
         // c*f as in the matrix kernel (which parks the product between its two passes)
-        const float pA = __fmul_rn(lc_sigmoid(accA[0]), lc_tanh(accA[1])), pB = __fmul_rn(lc_sigmoid(accB[0]), lc_tanh(accB[1]));
-        cA = __builtin_fmaf(cA, lc_sigmoid(accA[2]), pA);
-        cB = __builtin_fmaf(cB, lc_sigmoid(accB[2]), pB);
-        const float hA = lc_tanh(cA) * lc_sigmoid(accA[3]), hB = lc_tanh(cB) * lc_sigmoid(accB[3]);
-        // one 16-byte piece per lane, 256 contiguous bytes per 16 lanes
-        const int off = pbase + ((((uA >> 3) * 4 + (lane >> 4)) * 32) + s32w) * 16;
-        const lc_u32x4 w = {__float_as_uint(hA), tag, __float_as_uint(hB), tag};
+        const float pW = __fmul_rn(lc_sigmoid(acc[0]), lc_tanh(acc[1]));
+        cW = __builtin_fmaf(cW, lc_sigmoid(acc[2]), pW);
+        const float hW = lc_tanh(cW) * lc_sigmoid(acc[3]);
+        // half (unit offset + 2 or not) of the 16-byte piece (k-group, slot lane >> 4, sequence): 8 bytes per lane
+        const int off = pbase + ((((uW >> 3) * 4 + (lane >> 4)) * 16) + s16w) * 16 + (qW & 1) * 8;
+        const lc_u32x2 w = {__float_as_uint(hW), tag};
         if (wthrough)
-          __builtin_amdgcn_raw_buffer_store_b128(w, hrs, off, 0, 16);  // aux 16 = sc1: write-through, visible to every XCD
+          __builtin_amdgcn_raw_buffer_store_b64(w, hrs, off, 0, 16);  // aux 16 = sc1: write-through, visible to every XCD
         else
-          __builtin_amdgcn_raw_buffer_store_b128(w, hrs, off, 0, 0);   // the line stays in the cluster's own L2
+          __builtin_amdgcn_raw_buffer_store_b64(w, hrs, off, 0, 0);   // the line stays in the cluster's own L2
       }
       LC_CLK(1)
-      lc_group_barrier(arrive, arrived, lane);  // every wave of the group has read the operand tile of step t
-      LC_CLK(2)
+      // x_{t+1} into the x part of the tile: nobody reads that part now (the x part of step t was multiplied before the
+      // previous step's last barrier, the h part is all that the MFMAs above read)
       if (t + 1 < T) {
 #pragma unroll
         for (int u = 0; u < XPT; ++u)
-          if (tg + u * LC_GT < 32 * 2 * KGx) put_x(tg + u * LC_GT, xr[u]);
+          if (tg + u * LC_GT < 16 * 2 * KGx) put_x(tg + u * LC_GT, xr[u]);
+      }
+      lc_group_barrier(arrive, arrived, lane);  // every wave of the group has read h_{t-1} and stored its pieces of x_{t+1}
+      LC_CLK(2)
+      if (t + 1 < T) {
         // the x part of step t+1 while h_t is on its way: out of the next step's critical path, and the first read attempt
         // below comes late enough to find most of h_t
-        lc_group_barrier(arrive, arrived, lane);
-        accA = f32x4{0, 0, 0, 0};
-        accB = f32x4{0, 0, 0, 0};
+        acc = f32x4{0, 0, 0, 0};
         if (active) mfma_range(0, KGx);
       }
       LC_CLK(3)
@@ -370,7 +353,7 @@ __global__ __launch_bounds__(LC_NT) void lstm_cluster_kernel(LstmClusterArgs a) 
       // requested at once (one memory round trip per attempt) with loads that bypass the L1 (sc1: the producers are other
       // CUs); pieces whose tags are not this step's yet are requested again.
       {
-        constexpr int QPT = 16;  // pieces per thread at Hp = 256 (8 at Hp = 128)
+        constexpr int QPT = 8;  // pieces per thread at Hp = 256 (4 at Hp = 128)
         const int npt = npc / LC_GT;
         lc_u32x4 w[QPT];
         unsigned stale = (1u << npt) - 1u;
@@ -388,14 +371,14 @@ __global__ __launch_bounds__(LC_NT) void lstm_cluster_kernel(LstmClusterArgs a) 
                 still |= 1u << u;
               } else {
                 const int i = tg + u * LC_GT;
-                *reinterpret_cast<lc_f32x2 *>(xslot(i & 31, KGx + (i >> 7), (i >> 5) & 3)) = lc_f32x2{__uint_as_float(w[u][0]), __uint_as_float(w[u][2])};
+                *reinterpret_cast<lc_f32x2 *>(xslot(i & 15, KGx + (i >> 6), (i >> 4) & 3)) = lc_f32x2{__uint_as_float(w[u][0]), __uint_as_float(w[u][2])};
               }
             }
           stale = still;
           if (stale != 0u) {
             __builtin_amdgcn_s_sleep(2);
             if (lc_give_up(spins, since, a.err)) {  // a producing workgroup never ran: report (bit 2), do not hang
-              red[12 + G] = 1;                      // and leave the step loop, the whole group together
+              red[14 + G] = 1;                      // and leave the step loop, the whole group together
               break;
             }
           }
@@ -404,10 +387,10 @@ __global__ __launch_bounds__(LC_NT) void lstm_cluster_kernel(LstmClusterArgs a) 
       LC_CLK(4)
       lc_group_barrier(arrive, arrived, lane);
       LC_CLK(5)
-      if (__hip_atomic_load(red + 12 + G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) break;  // written before the barrier
+      if (__hip_atomic_load(red + 14 + G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) break;  // written before the barrier
     }
 #ifdef SSE_LC_CLOCK
-    if (blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == 7))
+    if (blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == 15))
       printf("[cluster clock] wave %d cycles/step: mfma %lld | gates+publish %lld | arrive1 %lld | store x %lld | exchange read %lld | arrive2 %lld\n",
              wv, ck_[0] / (T - t0), ck_[1] / (T - t0), ck_[2] / (T - t0), ck_[3] / (T - t0), ck_[4] / (T - t0), ck_[5] / (T - t0));
 #endif
