@@ -119,6 +119,8 @@ struct sse_handle {
   int lstm_cluster_rows = 1024; // option "lstm_cluster_rows": batches above lstm_persist_rows up to this many rows (<= 1024) take the MFMA cluster kernel
   uint32_t cluster_epoch = 0;   // tag epoch of that kernel's exchange buffers
   int lstm_cluster_chunks = 3;  // option "lstm_cluster_chunks": batches of up to this many times lstm_cluster_rows go through that kernel in launches of lstm_cluster_rows
+  int cluster_backoff = 16;     // option "lstm_cluster_backoff": after a cluster-kernel launch gave up (a workgroup not resident in 10 ms: the device is shared), this many following eligible calls go straight to the kernels that need no co-residency
+  int cluster_skip[2] = {0, 0}; // calls still to skip: [0] single-query kernel (lstm_persist), [1] mid-batch kernel (lstm_cluster)
   int lstm_cluster_wt = 0;      // option "lstm_cluster_write_through": force the any-placement publish path (tests)
   int lstm_cluster_drop = 0;    // option "lstm_cluster_drop_wg": one workgroup of the cluster kernel exits at once (tests)
   int lstm_small_rows = 1024; // option "lstm_small_rows": batches up to this many rows take the few-sequences LSTM kernel
@@ -499,7 +501,12 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
   if (e.kernel < 0) return fail(h, "network mode has no %s sequence encoder (sse_model.py:231-233)", side ? "target" : "source");
   if (ensure_packed(h, st)) return 1;
   const bool small_ok = !h->cur_row_map && lstm_small_lds_bytes(c.embedding_size, e.H, c.encoding_size) <= 160 * 1024;
-  if (small_ok && B <= h->lstm_persist_rows && B <= lstm_persist_max_rows() && T <= lstm_persist_max_steps()) {
+  bool persist_shape = small_ok && B <= h->lstm_persist_rows && B <= lstm_persist_max_rows() && T <= lstm_persist_max_steps();
+  if (persist_shape && h->cluster_skip[0] > 0) {  // backing off after a launch that gave up
+    --h->cluster_skip[0];
+    persist_shape = false;
+  }
+  if (persist_shape) {
     // one to a few queries (sse_demo / webserver): a cluster of workgroups with the weights resident in LDS, see
     // lstm_persist.hip.  Needs every workgroup of the launch resident at once: at most half the CUs are asked for.
     const int nwg = lstm_persist_nwg(c.embedding_size, e.H, c.encoding_size);
@@ -553,8 +560,13 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
       return 0;
     }
   }
-  if (small_ok && B > 32 && B <= cluster_row_limit(h, e) && T <= lstm_persist_max_steps() &&
-      lstm_cluster_ok(c.embedding_size, e.H, c.encoding_size)) {
+  bool cluster_shape = small_ok && B > 32 && B <= cluster_row_limit(h, e) && T <= lstm_persist_max_steps() &&
+                       lstm_cluster_ok(c.embedding_size, e.H, c.encoding_size);
+  if (cluster_shape && h->cluster_skip[1] > 0) {
+    --h->cluster_skip[1];
+    cluster_shape = false;
+  }
+  if (cluster_shape) {
     // mid-size batches (the evaluator's 600, the index builder's 1000): the hidden units of every 64-row tile spread over a
     // cluster of 16 compute units, weights in LDS, h_t exchanged per step (lstm_cluster.hip); needs one CU per workgroup
     if (h->cu_count == 0) {
@@ -1269,6 +1281,7 @@ static int ensure_pin(sse_handle *h, size_t need) {
 // Nothing was written that the other kernels do not overwrite; results are bit-identical.
 static int encode_fallback_locked(sse_handle *h, int side, int32_t B, int32_t T, int32_t normalize, hipStream_t st) {
   h->persist_fallbacks += 1;
+  h->cluster_skip[B <= 32 ? 0 : 1] = h->cluster_backoff;  // a time-out costs 10 ms: do not pay it on every call of a busy device
   const int keep = h->lstm_persist_rows, keep_c = h->lstm_cluster_rows;
   h->lstm_persist_rows = 0;
   h->lstm_cluster_rows = 0;
@@ -1503,6 +1516,12 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value) {
   if (strcmp(name, "lstm_persist_rows") == 0) {
     if (value < 0) return fail(h, "lstm_persist_rows must be >= 0");
     h->lstm_persist_rows = (int)value;
+    return 0;
+  }
+  if (strcmp(name, "lstm_cluster_backoff") == 0) {
+    if (value < 0) return fail(h, "lstm_cluster_backoff must be >= 0");
+    h->cluster_backoff = (int)value;
+    h->cluster_skip[0] = h->cluster_skip[1] = 0;
     return 0;
   }
   if (strcmp(name, "lstm_cluster_chunks") == 0) {

@@ -352,6 +352,7 @@ def test_cluster_kernel_miss_falls_back_to_the_few_sequences_kernel():
     want = m.encode_source(ids)
     want_s, want_i = m.handle.encode_score_topk(0, ids, False, 7)
     assert m.handle.get_counter("lstm_persist_fallbacks") == 0
+    m.handle.set_option("lstm_cluster_backoff", 0)              # (every call tries the cluster kernel again: counted below)
     m.handle.set_option("lstm_persist_inject_miss", 1)
     got = m.encode_source(ids)
     got_s, got_i = m.handle.encode_score_topk(0, ids, False, 7)
@@ -369,6 +370,19 @@ def test_cluster_kernel_miss_falls_back_to_the_few_sequences_kernel():
         m.handle.encode_score_topk(0, bad, False, 7)
     again_s, again_i = m.handle.encode_score_topk(0, ids, False, 7)
     assert np.array_equal(again_i, want_i) and np.array_equal(again_s, want_s)
+    # back-off (the default, 16 calls): after a launch that gave up the following calls do not try the cluster kernel --
+    # a time-out costs 10 ms, a busy device would charge it to every query -- and then it is tried again
+    m.handle.set_option("lstm_cluster_backoff", 3)
+    m.handle.set_option("lstm_persist_inject_miss", 1)
+    assert np.array_equal(m.encode_source(ids), want)
+    assert m.handle.get_counter("lstm_persist_fallbacks") == 3
+    for _ in range(3):                                          # skipped: no launch, no (injected) miss, same bits
+        assert np.array_equal(m.encode_source(ids), want)
+    assert m.handle.get_counter("lstm_persist_fallbacks") == 3
+    assert np.array_equal(m.encode_source(ids), want)           # tried again (and "misses" again)
+    assert m.handle.get_counter("lstm_persist_fallbacks") == 4
+    m.handle.set_option("lstm_persist_inject_miss", 0)
+    m.handle.set_option("lstm_cluster_backoff", 16)
 
 
 @pytest.mark.parametrize("H,S", [(40, 16), (100, 64), (72, 24)])
@@ -493,6 +507,7 @@ def test_mfma_cluster_kernel_equals_the_other_kernels(mode, V, E, Hs, Ht, S, T):
     good = random_ids(rng, 70, T, V)
     assert np.isfinite(m.encode_source(good)).all()
     # a missing cluster workgroup falls back to the few-sequences kernel
+    m.handle.set_option("lstm_cluster_backoff", 0)
     m.handle.set_option("lstm_cluster_rows", 0)
     want = m.encode_source(good)
     m.handle.set_option("lstm_cluster_rows", 1024)
