@@ -1,0 +1,48 @@
+"""bench.py's evidence plumbing (no GPU): the PMC-derived roofline fields are quoted only while profiles/pmc_summary.json
+describes the kernel sources in the tree (traffic used to come from a static file)."""
+import json
+import os
+
+import bench
+
+
+def test_csrc_sha_follows_the_kernel_sources(tmp_path, monkeypatch):
+    root = tmp_path
+    csrc = root / "sequence-semantic-embedding_amd" / "csrc"
+    csrc.mkdir(parents=True)
+    (csrc / "a.hip").write_text("kernel one\n")
+    (csrc / "b.h").write_text("header\n")
+    (csrc / "notes.txt").write_text("not a source\n")
+    monkeypatch.setattr(bench, "ROOT", str(root))
+    first = bench.csrc_sha()
+    assert len(first) == 16 and first == bench.csrc_sha()
+    (csrc / "notes.txt").write_text("still not a source\n")
+    assert bench.csrc_sha() == first
+    (csrc / "a.hip").write_text("kernel one, edited\n")
+    assert bench.csrc_sha() != first
+
+
+def test_pmc_summary_is_dropped_when_the_sources_changed(tmp_path, monkeypatch):
+    root = tmp_path
+    csrc = root / "sequence-semantic-embedding_amd" / "csrc"
+    csrc.mkdir(parents=True)
+    (csrc / "a.hip").write_text("kernel\n")
+    (root / "profiles").mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(root))
+    assert bench.pmc_summary() == {}                                     # nothing collected yet
+    summary = {"csrc_sha": bench.csrc_sha(), "lstm_fwd_hbm_bytes_per_launch": 1.0, "mfma_busy": {"k": 0.5}}
+    (root / "profiles" / "pmc_summary.json").write_text(json.dumps(summary))
+    assert bench.pmc_summary() == summary
+    (csrc / "a.hip").write_text("kernel, edited after the profile run\n")
+    stale = bench.pmc_summary()
+    assert set(stale) == {"stale"} and summary["csrc_sha"] in stale["stale"]
+    assert stale.get("mfma_busy", {}).get("k") is None                   # what bench.py's .get() chains then report: null
+
+
+def test_tracked_summary_matches_the_tree():
+    """The committed summary should describe the committed sources (re-run tools/collect_profiles.sh after kernel edits)."""
+    path = os.path.join(bench.ROOT, "profiles", "pmc_summary.json")
+    if not os.path.exists(path):
+        return
+    d = json.load(open(path))
+    assert "csrc_sha" in d and isinstance(d.get("mfma_busy", {}), dict)
