@@ -71,6 +71,30 @@ def golden_scoring(data_utils):
         print("scoring_%s: top1 %.4f eval_acc %s" % (name, accs_tight[0], eval_acc))
 
 
+def wide_inputs(seed=4321, Q=600, N=571, S=512):
+    """Seeded inputs of the wide fixture (configs[4]: encoding_size 512; one evaluator batch of 600 against 571 targets).
+    Only the reference's OUTPUTS are stored; the tests regenerate the inputs with this function's recipe."""
+    rng = np.random.RandomState(seed)
+    src = rng.standard_normal((Q, S)).astype(np.float32)
+    src /= np.linalg.norm(src, axis=1, keepdims=True)
+    tgt32 = rng.standard_normal((N, S)).astype(np.float32)
+    tgt32 /= np.linalg.norm(tgt32, axis=1, keepdims=True)
+    tgt = np.array([[float(str(v)) for v in row] for row in tgt32])   # the index as re-parsed from text (sse_evaluator.py:87)
+    labels = [sorted(set(rng.randint(0, N, size=rng.randint(1, 4)).tolist())) for _ in range(Q)]
+    return src, tgt32, tgt, labels
+
+
+def golden_scoring_wide(data_utils):
+    src, tgt32, tgt, labels = wide_inputs()
+    scores = np.dot(src, tgt.T)                                        # sse_evaluator.py:110
+    ranked_score, ranked_idx = data_utils.getSortedResults(scores)      # :111
+    accs_tight = [data_utils.computeTopK_TightVersion_accuracy(k, labels, ranked_idx) for k in (1, 3, 10)]
+    np.savez_compressed(os.path.join(OUT, "scoring_wide512.npz"), ranked_score=ranked_score[:, :16],
+                        ranked_idx=ranked_idx[:, :16], accs_tight=np.array(accs_tight),
+                        src_sum=np.float64(src.astype(np.float64).sum()), tgt_sum=np.float64(tgt.sum()))
+    print("scoring_wide512: top1 %.4f" % accs_tight[0])
+
+
 def golden_prep(data_utils, ref, task, vocab_size, max_seq_length, n_sample):
     with tempfile.TemporaryDirectory() as work:
         with contextlib.redirect_stdout(io.StringIO()):
@@ -152,6 +176,7 @@ def main():
     data_utils, text_encoder, tokenizer = import_reference(args.ref)
     assert tokenizer.encode(u"Dude - that's so cool.") == [u"Dude", u" - ", u"that", u"'", u"s", u"so", u"cool", u"."]
     golden_scoring(data_utils)
+    golden_scoring_wide(data_utils)
     golden_prep(data_utils, args.ref, "qna", 8000, 1000, 40)            # makefile:17
     golden_prep(data_utils, args.ref, "crosslingual", 32000, 50, 120)    # makefile:42
 

@@ -29,3 +29,16 @@ def test_index_text_roundtrip_matches_reference_parse():
     lines = [O.format_index_line("t%d" % i, "Sentence %d" % i, v) for i, v in enumerate(z["tgt32"])]
     _, _, enc = O.parse_index_lines(lines)
     assert np.array_equal(enc, z["tgt64"])        # float(str(np.float32)) exactly as sse_evaluator.py:87
+
+
+def test_oracle_scoring_matches_reference_at_encoding_size_512():
+    """configs[4] (encoding_size 512): one evaluator batch, 600 queries x 571 targets, ranked by the reference's own
+    np.dot + getSortedResults (fixture scoring_wide512.npz holds its outputs; the seeded inputs are regenerated)."""
+    from oracle.make_golden import wide_inputs
+    z = np.load(os.path.join(G, "scoring_wide512.npz"))
+    src, _, tgt64, labels = wide_inputs()
+    assert float(src.astype(np.float64).sum()) == float(z["src_sum"]) and float(tgt64.sum()) == float(z["tgt_sum"])
+    sc, idx = O.sorted_results(O.scores_f64(src, tgt64))
+    assert np.array_equal(idx[:, :16], z["ranked_idx"]) and np.array_equal(sc[:, :16], z["ranked_score"])
+    for j, k in enumerate((1, 3, 10)):
+        assert O.topk_tight_accuracy(k, labels, idx) == pytest.approx(z["accs_tight"][j], abs=1e-15)

@@ -267,6 +267,20 @@ def test_bf16_candidate_pass_keeps_results_exact(Q, N, S):
     assert np.array_equal(ids, ids32) and np.array_equal(sc, sc32)
 
 
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_reference_ranking_at_encoding_size_512(bf16):
+    """configs[4]: the reference's own ranking (np.dot + getSortedResults, fixture from oracle/make_golden.py) of one
+    evaluator batch -- 600 queries x 571 targets x 512 -- reproduced by the HIP scorer: ids exact, float64 scores to 1e-12."""
+    from oracle.make_golden import wide_inputs
+    z = np.load(os.path.join(G, "scoring_wide512.npz"))
+    src, _, tgt64, _ = wide_inputs()
+    h = _scorer_bf16() if bf16 else _scorer()
+    h.index_upload(tgt64)
+    sc, ids = h.score_topk(src, 10)
+    assert np.array_equal(ids, z["ranked_idx"][:, :10])
+    assert np.abs(sc - z["ranked_score"][:, :10]).max() < 1e-12
+
+
 def test_bf16_candidate_pass_golden_ties_and_near_ties():
     z = np.load(os.path.join(G, "scoring_eval.npz"))
     h = _scorer_bf16()
