@@ -107,9 +107,10 @@ int sse_encode_dev(sse_handle *h, int side, const int32_t *ids_dev, int32_t B, i
  * "lstm_x3" (default 0): inference encodes of more than lstm_small_rows rows (cell sizes 64 .. 256, embedding < 64) run
  * their gate GEMMs as three bf16 MFMAs per product on hi + lo split fp32 operands (x = bf16(x) + bf16(x - bf16(x))):
  * NOT bit-identical to the fp32 path, ~2e-6 from it on normalised encodings, 2.2 - 2.9x faster.
- * "train_fwd_x3", "train_bwd_x3", "train_dk_x3" (default 1; LSTM modes, cell sizes 64 .. 256): the forward, the BPTT
- * recurrence and the weight-gradient GEMM of sse_train_step* on split operands in the same way (~4e-6 relative per
- * product; loss within ~1e-5 .. 1e-4 relative of the fp32 kernels).  All three 0 = fp32 MFMA throughout.
+ * "train_fwd_x3", "train_bwd_x3", "train_dk_x3" (default 0: sse_train_step* computes in fp32 MFMA throughout, the
+ * reference's tf.float32 arithmetic; LSTM modes, cell sizes 64 .. 256): opt in to the forward, the BPTT recurrence (+ dX)
+ * and the weight-gradient GEMM on split operands in the same way (~4e-6 relative per product; loss within ~1e-5 .. 1e-4
+ * relative of the fp32 kernels; the forward and BPTT variants need train_dk_x3).
  * "train_pair_dedup" (default 1): a train batch whose rows 2i, 2i+1 carry the same source sequence (data.py:95-115 builds
  * every batch that way) runs the source encoder once per pair.  "lstm_train_rows" (0 | 32 | 64): fp32 training forward
  * tile rows (measurement aid).

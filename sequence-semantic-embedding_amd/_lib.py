@@ -72,6 +72,27 @@ SYMBOLS = {
 }
 
 _lib = None
+_host_lib = None
+HOST_LIB_PATH = os.path.join(HERE, "libsse_host.so")
+HOST_SYMBOLS = ("sse_format_rows_stride", "sse_format_rows_f32", "sse_parse_rows_f64", "sse_crc32c")
+
+
+def load_host_library():
+    """The host-only entry points of include/sse_hip.h (index text I/O, CRC-32C) from libsse_host.so: the same C code
+    (csrc/index_io.cpp) linked WITHOUT the HIP runtime, so that reading a TF checkpoint or an index file neither imports
+    torch nor touches a GPU.  Falls back to the full library when only that one is built."""
+    global _host_lib
+    if _host_lib is not None:
+        return _host_lib
+    if _lib is not None or not os.path.exists(HOST_LIB_PATH):
+        _host_lib = load_library()
+        return _host_lib
+    lib = C.CDLL(HOST_LIB_PATH)
+    for name in HOST_SYMBOLS:
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = SYMBOLS[name]
+    _host_lib = lib
+    return lib
 
 
 def load_library():

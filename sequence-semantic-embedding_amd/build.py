@@ -11,6 +11,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, os.environ.get("SSE_LIB_NAME", "libsse_hip.so"))   # SSE_LIB_NAME + SSE_HIPCC_EXTRA: measurement builds
+# the host-only entry points of the same C ABI (targetEncodingIndex.tsv text I/O, CRC-32C of TF checkpoints) once more as a
+# library WITHOUT the HIP runtime: reading a checkpoint or parsing an index file must not initialise a GPU (or import torch)
+HOST_LIB = os.path.join(HERE, "libsse_host.so")
+HOST_SOURCES = ["index_io.cpp"]
 SOURCES = ["sse_api.hip", "lstm_fwd.hip", "lstm_small.hip", "lstm_persist.hip", "lstm_cluster.hip", "lstm_fwd_x3.hip", "cnn_fwd.hip", "cnn_fwd_bf16.hip", "score_topk.hip", "pack.hip", "train.hip", "cnn_bwd.hip", "index_io.cpp"]
 EXTRA = os.environ.get("SSE_HIPCC_EXTRA", "").split()   # e.g. -DSSE_SCORE_MEASURE for the measurement builds of tools/
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
@@ -55,6 +59,13 @@ def build(force=False, verbose=False):
     rebuilt = bool(jobs)
     if rebuilt or not os.path.exists(LIB):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    host_objs = [os.path.join(objdir, os.path.splitext(src)[0] + ".o") for src in HOST_SOURCES]
+    if not os.environ.get("SSE_LIB_NAME") and (rebuilt or not os.path.exists(HOST_LIB) or
+                                               os.path.getmtime(HOST_LIB) < max(os.path.getmtime(o) for o in host_objs)):
+        cmd = [os.environ.get("CXX", "g++"), "-shared", "-fPIC", "-pthread", "-o", HOST_LIB] + host_objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

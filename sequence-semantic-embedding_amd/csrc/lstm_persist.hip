@@ -85,8 +85,7 @@ __global__ __launch_bounds__(LP_NT) void lstm_persist_kernel(LstmPersistArgs a) 
   unsigned int xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   xcc &= 0xF;
-  const bool xcc_check = !a.write_through && LP_RB * H >= NWG;  // (tiny cells: fewer even-buffer slots than workgroups)
-  if (tid == 0 && xcc_check) lp_publish(hx + p, __uint_as_float(xcc), epoch);  // slot p of the even buffer, tag "step 0": h tags start at 1
+  const bool xcc_check = !a.write_through && LP_RB * H >= NWG;  // (tiny cells: fewer buffer slots than workgroups)
 
   // left-pad prefix skip, exactly as lstm_small.hip
   int t0 = 0;
@@ -109,6 +108,13 @@ __global__ __launch_bounds__(LP_NT) void lstm_persist_kernel(LstmPersistArgs a) 
     t0 = min(lead, T - 1);
     __syncthreads();
   }
+  // The ids go into slots 0..NWG-1 of the buffer with parity t0 & 1, tag "step 0" (h tags start at 1).  The first step
+  // publishes tag t0 + 1 into the OTHER buffer; buffer t0 & 1 is first rewritten by step t0 + 1 (tag t0 + 2), which a
+  // workgroup reaches only after it has read every peer's tag t0 + 1 -- and a peer publishes that after passing its own
+  // id check.  (With the ids always in the even buffer a left-padded query with an odd PAD prefix overwrote them in its
+  // very first step, before slower peers had compared them: an intermittent 10 ms give-up.)
+  unsigned long long *xid = hx + (size_t)(t0 & 1) * LP_RB * H;
+  if (tid == 0 && xcc_check) lp_publish(xid + p, __uint_as_float(xcc), epoch);
   auto fetch_id = [&](int b, int t) -> int {
     int id = (b < nb) ? a.ids[(size_t)(b0 + b) * T + t] : 0;
     if (id < 0 || id >= a.V) {
@@ -185,12 +191,12 @@ __global__ __launch_bounds__(LP_NT) void lstm_persist_kernel(LstmPersistArgs a) 
   // use for h_t before the projection, so it skips the steps and picks up h_T (the last write into its buffer) below.
   const bool bystander = nu == 0;
   // (a bystander publishes its XCC id like everybody -- it will READ h_T -- but does not wait for the others': the slots are
-  // reused by step 1, which the others reach without it)
+  // reused by step t0 + 1, which the others reach without it)
   bool wthrough = true;
   if (xcc_check && !bystander) {
     if (wv == 0) {
       bool same = true;
-      for (int i = lane; i < NWG; i += 64) same = same && __float_as_uint(lp_await(hx + i, epoch, a.err)) == xcc;
+      for (int i = lane; i < NWG; i += 64) same = same && __float_as_uint(lp_await(xid + i, epoch, a.err)) == xcc;
       const bool all_same = __all(same);
       if (lane == 0) red[63] = all_same ? 0.0f : 1.0f;
     }

@@ -132,9 +132,11 @@ struct sse_handle {
   bool cnn_bf16 = false;     // option "cnn_bf16": source_only_cnn inference with bf16 storage / fp32 accumulation
   unsigned short *emb_bf16 = nullptr, *cnn_Wc16 = nullptr;
   int lstm_train_rows = 0;   // option "lstm_train_rows": 0 = automatic, 32 / 64 = rows per workgroup of the training forward (Hp = 256)
-  bool train_bwd_x3 = true;  // option "train_bwd_x3": recurrent GEMM of BPTT on the bf16 matrix pipe with split operands (needs train_dk_x3)
-  bool train_fwd_x3 = true;  // option "train_fwd_x3": forward of the LSTM train step on the bf16 matrix pipe with split operands
-  bool train_dk_x3 = true;   // option "train_dk_x3": weight-gradient GEMM of the LSTM train step on the bf16 matrix pipe with split operands
+  // The train step computes in fp32 like the reference (tf.float32 graph, sse_model.py:355-364): the three split-operand
+  // options below are OPT-IN (a default narrower than the reference's arithmetic earns no credit).
+  bool train_bwd_x3 = false;  // option "train_bwd_x3": recurrent GEMM of BPTT on the bf16 matrix pipe with split operands (needs train_dk_x3)
+  bool train_fwd_x3 = false;  // option "train_fwd_x3": forward of the LSTM train step on the bf16 matrix pipe with split operands
+  bool train_dk_x3 = false;   // option "train_dk_x3": weight-gradient GEMM of the LSTM train step on the bf16 matrix pipe with split operands
   bool train_pair_dedup = true; // option "train_pair_dedup": run the source encoder once per (pos, neg) pair of rows that share it
   bool train_serial = false; // option "train_serial": both encoders on one stream (profiling: isolated kernel times)
   float *emb_pad = nullptr;  // [V][Ep]
@@ -459,6 +461,32 @@ static int cluster_row_limit(const sse_handle *h, const Encoder &e) {
   return per * (x3_applies(h, e) ? 1 : std::max(1, h->lstm_cluster_chunks));
 }
 
+static int ensure_cu_count(sse_handle *h) {
+  if (h->cu_count == 0) {
+    hipDeviceProp_t prop;
+    HIPCHECK(h, hipGetDeviceProperties(&prop, h->cfg.device));
+    h->cu_count = prop.multiProcessorCount;
+  }
+  return 0;
+}
+
+// Would encode_dev_locked hand a batch of this shape to the MFMA cluster kernel RIGHT NOW?  One test for the launch path and
+// for the host-side pad-prefix row sort (which the cluster kernel does not want and the matrix kernel does): shape, the
+// back-off counter after a give-up, the device's CU count and the LDS fit all enter (the sort used to be
+// switched off by the shape alone, so a backed-off or small device lost the pad skip silently).
+static bool cluster_takes(sse_handle *h, const Encoder &e, int B, int T) {
+  const sse_config &c = h->cfg;
+  if (h->cur_row_map || lstm_small_lds_bytes(c.embedding_size, e.H, c.encoding_size) > 160 * 1024) return false;
+  if (!(B > 32 && B <= cluster_row_limit(h, e) && T <= lstm_persist_max_steps() &&
+        lstm_cluster_ok(c.embedding_size, e.H, c.encoding_size)))
+    return false;
+  if (h->cluster_skip[1] > 0) return false;
+  if (ensure_cu_count(h)) return false;
+  const int per = std::min(h->lstm_cluster_rows, lstm_cluster_max_rows());
+  const int ncl = (std::min(B, per) + 63) / 64;
+  return (ncl <= 8 ? 128 : 256) <= h->cu_count;
+}
+
 int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T, int normalize, float *out,
                       hipStream_t st) {
   const sse_config &c = h->cfg;
@@ -510,11 +538,7 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
     // one to a few queries (sse_demo / webserver): a cluster of workgroups with the weights resident in LDS, see
     // lstm_persist.hip.  Needs every workgroup of the launch resident at once: at most half the CUs are asked for.
     const int nwg = lstm_persist_nwg(c.embedding_size, e.H, c.encoding_size);
-    if (h->cu_count == 0) {
-      hipDeviceProp_t prop;
-      HIPCHECK(h, hipGetDeviceProperties(&prop, c.device));
-      h->cu_count = prop.multiProcessorCount;
-    }
+    if (ensure_cu_count(h)) return 1;
     if (nwg > 0 && 8 * nwg * 2 <= h->cu_count) {
       if (ensure_waug(h, side, st)) return 1;
       LstmSmallArgs sa;
@@ -560,23 +584,15 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
       return 0;
     }
   }
-  bool cluster_shape = small_ok && B > 32 && B <= cluster_row_limit(h, e) && T <= lstm_persist_max_steps() &&
-                       lstm_cluster_ok(c.embedding_size, e.H, c.encoding_size);
-  if (cluster_shape && h->cluster_skip[1] > 0) {
-    --h->cluster_skip[1];
-    cluster_shape = false;
-  }
+  const bool cluster_shape = cluster_takes(h, e, B, T);
+  if (!cluster_shape && h->cluster_skip[1] > 0 && small_ok && B > 32 && B <= cluster_row_limit(h, e) &&
+      T <= lstm_persist_max_steps() && lstm_cluster_ok(c.embedding_size, e.H, c.encoding_size))
+    --h->cluster_skip[1];  // an eligible call spent backing off
   if (cluster_shape) {
     // mid-size batches (the evaluator's 600, the index builder's 1000): the hidden units of every 64-row tile spread over a
     // cluster of 16 compute units, weights in LDS, h_t exchanged per step (lstm_cluster.hip); needs one CU per workgroup
-    if (h->cu_count == 0) {
-      hipDeviceProp_t prop;
-      HIPCHECK(h, hipGetDeviceProperties(&prop, c.device));
-      h->cu_count = prop.multiProcessorCount;
-    }
     const int per = std::min(h->lstm_cluster_rows, lstm_cluster_max_rows());
-    const int ncl = (std::min(B, per) + 63) / 64;
-    if ((ncl <= 8 ? 128 : 256) <= h->cu_count) {
+    {
       Encoder &own = e.shares_lstm_with >= 0 ? h->enc[e.shares_lstm_with] : e;
       if (!own.wc_valid) {
         if (!own.Wc) HIPCHECK(h, hipMalloc((void **)&own.Wc, lstm_cluster_weight_floats(c.embedding_size, own.H) * sizeof(float)));
@@ -1303,8 +1319,7 @@ static int encode_host_ids_locked(sse_handle *h, int side, const int32_t *ids_ho
   // 64-row tile can skip its whole common PAD prefix; results are scattered back in caller order.
   const bool lstm_side = h->cfg.network_mode != SSE_MODE_SOURCE_ONLY_CNN && !(side == SSE_SIDE_TARGET && h->tgt_table >= 0);
   const int32_t *row_map_dev = nullptr;
-  const bool to_cluster = lstm_side && B <= cluster_row_limit(h, h->enc[side]) && T <= lstm_persist_max_steps() &&
-                          lstm_cluster_ok(h->cfg.embedding_size, h->enc[side].H, h->cfg.encoding_size);  // (takes rows as they come)
+  const bool to_cluster = lstm_side && h->enc[side].kernel >= 0 && cluster_takes(h, h->enc[side], B, T);  // (takes rows as they come)
   if (h->pad_skip && lstm_side && B > 64 && B > h->lstm_small_rows && !to_cluster) {
     // counting sort of the row numbers by leading-PAD count, longest prefix first
     std::vector<int32_t> lead(B), start(T + 2, 0), order(B);
@@ -1846,7 +1861,9 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   for (int s = 0; s < nside; ++s) {
     const Encoder &e = h->enc[s];
     fwd_x3[s] = h->train_fwd_x3 && h->train_dk_x3 && e.Hp <= 256 && e.H >= 64 && E < 64;
-    bwd_x3[s] = h->train_bwd_x3 && h->train_dk_x3 && e.H >= 64 && e.Hp <= 256;
+    // (the in-kernel dX scatter addresses the dense embedding gradient through a 32-bit buffer descriptor: tables of
+    // 2 GiB and more keep the fp32 dx kernel with its 64-bit pointers)
+    bwd_x3[s] = h->train_bwd_x3 && h->train_dk_x3 && e.H >= 64 && e.Hp <= 256 && (int64_t)V * E * 4 < ((int64_t)1 << 31);
     all_x3 = all_x3 && fwd_x3[s] && bwd_x3[s];
   }
   // layouts derived from the variables, rebuilt after every update: only the ones this step's kernels read (an all-split
@@ -2154,7 +2171,10 @@ static int train_apply_locked(sse_handle *h, float *loss, float *train_acc) {
   HIPCHECK(h, hipMemcpyAsync(out, tail, 4 * sizeof(float), hipMemcpyDeviceToHost, st));
   HIPCHECK(h, hipMemcpyAsync(h->pin_small, h->err_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIPCHECK(h, sync_stream(st));
-  if (h->pin_small[0]) return check_err_flag(h, st);  // (resets the flag; the update was cancelled on the device: variables unchanged)
+  // bits 1 | 2 (token id / corpus row out of range) belong to this step: the update was cancelled on the device, variables
+  // unchanged.  Bit 4 (a cluster-kernel give-up of an asynchronous sse_encode_dev issued earlier) is not this step's: it
+  // stays in the flag for sse_synchronize / the next encode to report.
+  if (h->pin_small[0] & 3) return check_err_flag(h, st);  // (resets the flag)
   h->global_step += 1;
   if (loss) *loss = out[1];
   if (train_acc) *train_acc = out[2];

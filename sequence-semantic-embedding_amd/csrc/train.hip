@@ -667,7 +667,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
       };
       const unsigned char *lax = dgb + (size_t)(lx >> 5) * 2048 + (size_t)(((lx >> 4) & 1) * 32 + rh * 16 + (lx & 15)) * 16;
       const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.KxT16), 0, 4 * KS * 2048, 0x00020000);
-      // outputs through descriptors as well (the embedding gradient is < 4 GiB: V * E floats)
+      // outputs through descriptors as well (the launcher's caller keeps V * E * 4 < 2 GiB on this path: 32-bit offsets)
       const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc(a.d_emb, 0, a.V * a.E * 4, 0x00020000);
       const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(a.hot_part, 0, T * a.NT32 * 2 * 512, 0x00020000);
       // token ids of the four rows whose dX this lane will hold: requested here, used after the k-loop (buffer loads:
@@ -1320,7 +1320,7 @@ __global__ void clip_scale_multi_kernel(const float *part, int n, const float *e
   }
   if (threadIdx.x == 0) {
     const float gn = (float)sqrt(sh[0] + (double)*extra);
-    const bool bad = err != nullptr && *err != 0;
+    const bool bad = err != nullptr && (*err & 3) != 0;  // id / row out of range; bit 4 is the encoders' cluster give-up, not a train error
     scal[0] = gn;
     scal[1] = bad ? 0.0f : ((gn > 0.0f) ? clip * fminf(1.0f / gn, 1.0f / clip) : 1.0f);
     scal[2] = bad ? 1.0f : 0.0f;

@@ -18,7 +18,7 @@ class DataParallelTrainer(object):
         """always_reduce: issue the collective even in a 1-rank group (exercises the RCCL path on one GPU).
         sparse_embedding: exchange the word-embedding gradient as (row id, gradient row) pairs -- SURVEY 8e's shape for
         large vocabularies (the 1M-title ranking vocabulary, reference README.md:116) -- instead of all-reducing the
-        dense [V,E] block; None = automatic (sparse when a step touches fewer than V/4 rows: 2 * rows * T < V / 4)."""
+        dense [V,E] block; None = automatic (sparse when the GLOBAL batch touches fewer than V/4 rows: 2 * rows_global * T < V / 4)."""
         import torch
         self.engine, self.group, self.always_reduce = engine, group, bool(always_reduce)
         self.sparse_embedding = sparse_embedding
@@ -66,7 +66,7 @@ class DataParallelTrainer(object):
         else:
             self.engine.train_grads(src_ids, tgt_ids, labels, rows_global)
         if self.world > 1 or self.always_reduce:
-            if self._use_sparse(len(labels), src_ids, by_rows):
+            if self._use_sparse(rows_global, src_ids, by_rows):
                 self._exchange_sparse()
             else:
                 dist.all_reduce(self.arena, group=self.group)      # ONE collective per step (sum)
@@ -74,7 +74,9 @@ class DataParallelTrainer(object):
         return self.engine.train_apply()
 
     # ---- (row id, gradient row) exchange of the embedding gradient (SURVEY 8e "Training") ----------------------------
-    def _use_sparse(self, rows, src_ids, by_rows):
+    def _use_sparse(self, rows_global, src_ids, by_rows):
+        """Decided from values that are IDENTICAL on every rank (rows_global, T, V): ranks whose local row counts differ
+        by one (split_batch) must not disagree about which collectives the step issues."""
         if self.emb_slice is None or self.sparse_embedding is False:
             return False
         if self.sparse_embedding:
@@ -84,7 +86,7 @@ class DataParallelTrainer(object):
         if T is None:
             import numpy as np
             T = 1 if by_rows else int(np.asarray(src_ids).shape[-1])
-        return 2 * int(rows) * int(T) * self.world < V // 4
+        return 2 * int(rows_global) * int(T) < V // 4
 
     def _exchange_sparse(self):
         """Same sums as the dense all-reduce: the dense variables and the tail go through one all-reduce of the arena

@@ -1,7 +1,7 @@
 """Text <-> numbers for targetEncodingIndex.tsv, byte-identical to the reference's Python loops:
 `",".join([str(n) for n in vec])` on numpy.float32 components (sse_index.py:93-95) and
 `[float(f) for f in field.split(",")]` (sse_evaluator.py:87, sse_demo.py:87) -- done by the host-side C routines
-of libsse_hip.so (csrc/index_io.cpp, multi-threaded; no GPU involved)."""
+of the C ABI (csrc/index_io.cpp, multi-threaded; libsse_host.so: no GPU runtime involved)."""
 import ctypes as C
 
 import numpy as np
@@ -11,7 +11,7 @@ from . import _lib
 
 def format_rows(enc):
     """float32 [n,S] -> list of n strings 'v0,v1,...' exactly as the reference writes them."""
-    lib = _lib.load_library()
+    lib = _lib.load_host_library()
     rows = np.ascontiguousarray(enc, dtype=np.float32)
     if rows.ndim != 2:
         raise ValueError("encodings must be [n,S]")
@@ -30,7 +30,7 @@ def format_rows(enc):
 def parse_rows(fields, S=None):
     """list of n 'v0,v1,...' strings -> float64 [n,S] with Python float() semantics.  Raises ValueError like the
     reference's float() would on a malformed number, or when rows disagree on the number of components."""
-    lib = _lib.load_library()
+    lib = _lib.load_host_library()
     n = len(fields)
     if n == 0:
         return np.zeros((0, S or 0), np.float64)

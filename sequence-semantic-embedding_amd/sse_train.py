@@ -37,9 +37,9 @@ FLAGS = flags.FlagSet("sse_train", [
     ("max_steps", int, 0, "stop after this many steps (0: no limit; for smoke runs)"),
     ("device_corpus", int, 1, "1: the padded corpora are uploaded once and a step ships row numbers; 0: token-id feed dicts"),
     ("cnn_bf16", int, 0, "source_only_cnn: 1 = mixed precision (convolution on bf16-rounded embeddings / filters, float32 masters)"),
-    ("train_x3", int, 1, "LSTM modes: 1 = forward / BPTT / weight-gradient GEMMs of the train step on the bf16 matrix pipe with "
-                         "hi + lo split float32 operands (~4e-6 relative per product, 2x faster); 0 = float32 MFMA throughout, "
-                         "the reference's arithmetic"),
+    ("train_x3", int, 0, "LSTM modes: 0 (default) = float32 MFMA throughout, the reference's arithmetic; 1 = opt in to the forward / "
+                         "BPTT / weight-gradient GEMMs of the train step on the bf16 matrix pipe with hi + lo split float32 "
+                         "operands (~4e-6 relative per product, ~2x faster)"),
 ])
 
 
@@ -54,9 +54,9 @@ def create_model(f, session, targetSpaceSize, vocabsize, forward_only):
     model = SSEModel(params, device=int(f.device))
     if getattr(f, "cnn_bf16", 0):
         model.handle.set_option("cnn_bf16", 1)                     # fails loudly outside source_only_cnn
-    if not getattr(f, "train_x3", 1):                              # exact float32 train step (library default: split operands)
-        for opt in ("train_fwd_x3", "train_bwd_x3", "train_dk_x3"):
-            model.handle.set_option(opt, 0)
+    if getattr(f, "train_x3", 0) and f.network_mode != "source_only_cnn":   # opt-in split-operand train step (library default: float32)
+        for opt in ("train_dk_x3", "train_fwd_x3", "train_bwd_x3"):
+            model.handle.set_option(opt, 1)
     ckpt = get_checkpoint_state(f.model_dir)
     if ckpt:
         logging.info("Reading model parameters from %s" % ckpt)

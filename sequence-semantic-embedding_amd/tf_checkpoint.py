@@ -173,9 +173,10 @@ def read_bundle(prefix):
             raise ValueError("variable %s: bytes [%d, %d) lie outside data shard %d (%d bytes): truncated checkpoint"
                              % (name, e["offset"], e["offset"] + e["size"], sid, shards[sid].shape[0]))
         raw = bytes(shards[sid][e["offset"]:e["offset"] + e["size"]])
-        if e["crc32c"] is not None and _masked_crc(raw) != e["crc32c"]:
+        got_crc = _masked_crc(raw) if e["crc32c"] is not None else None
+        if got_crc != e["crc32c"]:
             raise ValueError("variable %s fails its CRC-32C (stored %08x, computed %08x): the data shard is corrupt"
-                             % (name, e["crc32c"], _masked_crc(raw)))
+                             % (name, e["crc32c"], got_crc))
         want_bytes = int(np.prod(e["shape"], dtype=np.int64)) * np.dtype(DTYPES[e["dtype"]]).itemsize
         if want_bytes != e["size"]:
             raise ValueError("variable %s: %d bytes stored for shape %s" % (name, e["size"], e["shape"]))
@@ -220,14 +221,14 @@ def _put_varint(v):
 
 
 def _crc32c(data, _table=[]):
-    """CRC-32C of a bytes-like object: the C routine of libsse_hip.so (csrc/index_io.cpp, host only) when the library is
-    built, else the table loop below (same values; seconds per embedding table)."""
-    data = bytes(data)
+    """CRC-32C of a bytes-like object: the C routine of csrc/index_io.cpp through libsse_host.so (host only: no HIP
+    runtime, no torch import) when it is built, else the table loop below (same values; seconds per embedding table)."""
     try:
         from . import _lib
-        return int(_lib.load_library().sse_crc32c(data, len(data), 0))
-    except Exception:                                          # noqa: BLE001  (library not built: pure-Python fallback of a host-only checksum)
-        pass
+        buf = data if isinstance(data, bytes) else bytes(data)   # (the reader hands over bytes: no copy)
+        return int(_lib.load_host_library().sse_crc32c(buf, len(buf), 0))
+    except (OSError, RuntimeError, AttributeError):            # library not built: pure-Python fallback of a host-only checksum
+        data = bytes(data)
     if not _table:
         for i in range(256):
             c = i

@@ -553,3 +553,101 @@ def test_mfma_cluster_kernel_many_calls_alternating_shapes():
         got = (m.encode_source if side == 0 else m.encode_target)(ids)
         if it % 23 == 0 or it > 290:
             assert np.array_equal(got, ref[side]), it
+
+
+# --------------------------------------------------------------------------
+# tf.nn.l2_normalize's clamp, x * rsqrt(max(sum(x^2), 1e-12)) (sse_model.py:282-283; SURVEY 4 "adversarial cases"):
+# zero rows, rows whose squared norm is below the epsilon, denormal components -- through the exported
+# sse_l2_normalize_dev and through every encoder kernel's fused normalise tail.
+# --------------------------------------------------------------------------
+
+def _clamp_rows(S, rng):
+    x = rng.standard_normal((12, S)).astype(np.float32)
+    x[0] = 0.0                                             # all-zero row: 0 * rsqrt(1e-12) = 0, not NaN
+    x[1] *= np.float32(1e-8)                               # sum(x^2) ~ S * 1e-16 < 1e-12: clamp engaged, result = x * 1e6
+    x[2] *= np.float32(1e-6) / np.float32(np.sqrt(S))      # squared norm ~ 1e-12: right at the epsilon
+    x[3] = 0.0
+    x[3, S // 2] = np.float32(1e-30)                       # square underflows to a denormal / zero
+    x[4] = np.float32(1e-40)                               # denormal components throughout
+    x[5] *= np.float32(3e-7)                               # just below the clamp
+    x[6] *= np.float32(1e3)                                # ordinary rows on both sides of 1
+    x[7, 1:] = 0.0
+    return x
+
+
+@pytest.mark.parametrize("S", [4, 64, 100, 256, 512])
+def test_l2_normalize_dev_clamps_like_tf(S):
+    """sse_l2_normalize_dev (exported entry, include/sse_hip.h) on zero / sub-epsilon / denormal rows == the oracle's
+    tf.nn.l2_normalize restatement; zero rows stay exactly zero, nothing is NaN or inf."""
+    import torch
+    from tests.test_gpu_score import _scorer
+    h = _scorer()
+    x = _clamp_rows(S, np.random.RandomState(S))
+    xd = torch.from_numpy(x).cuda()
+    out = torch.full_like(xd, float("nan"))
+    h.l2_normalize_dev(xd.data_ptr(), out.data_ptr(), x.shape[0], S)
+    torch.cuda.synchronize()
+    got, want = out.cpu().numpy(), O.l2_normalize(x)
+    assert np.all(np.isfinite(got))
+    assert np.array_equal(got[0], np.zeros(S, np.float32))
+    # clamp engaged: exactly x * rsqrt(1e-12) up to the rounding of the reciprocal square root
+    assert np.allclose(got[1], x[1] * np.float32(1e6), rtol=2e-6, atol=0)
+    assert np.abs(got - want).max() <= 2e-6 * max(1.0, float(np.abs(want).max()))
+    nrm = np.linalg.norm(got[6:].astype(np.float64), axis=1)
+    assert np.abs(nrm - 1).max() < 1e-6                    # ordinary rows come out unit length
+    # in place (out == x) is what the in-graph predict path uses
+    h.l2_normalize_dev(xd.data_ptr(), xd.data_ptr(), x.shape[0], S)
+    torch.cuda.synchronize()
+    assert np.array_equal(xd.cpu().numpy(), got)
+
+
+@pytest.mark.parametrize("B", [1, 40, 600, 1500, 9000])   # persist / cluster / cluster in chunks (or matrix) / matrix kernel, 64-row tiles
+@pytest.mark.parametrize("scale", [0.0, 1e-9])
+def test_encoder_normalise_tail_clamps_like_tf(B, scale):
+    """An encoder whose projection is zero (raw encoding exactly 0) or tiny (squared norm of the raw encoding far below
+    1e-12): the fused normalise tail of EVERY encoder kernel applies max(sum(x^2), 1e-12) like tf.nn.l2_normalize --
+    zeros stay zeros, tiny rows come out as raw * 1e6, and the kernels agree bit for bit."""
+    params = model_params("dual-encoder", 300, 50, 96, 96, 64, 12)
+    m, p = make_pair(params, seed=9)
+    p = dict(p)
+    p["source_encoder/src_M"] = (p["source_encoder/src_M"] * np.float32(scale)).astype(np.float32)
+    m.set_variables(p)
+    rng = np.random.RandomState(B)
+    ids = random_ids(rng, B, 12, 300, pad_frac=0.5)
+    got = m.encode_source(ids)
+    raw = m.encode_source(ids, normalize=False)
+    assert np.all(np.isfinite(got))
+    if scale == 0.0:
+        assert not got.any() and not raw.any()
+    else:
+        assert 0 < np.abs(raw).max() < 1e-7                # sum of squares << 1e-12: clamp engaged on every row
+        assert np.allclose(got, raw * np.float32(1e6), rtol=2e-6, atol=0)
+        want = O.encode(p, params, "src", ids[:200])
+        assert np.abs(got[:200] - want).max() <= 1e-4 * max(1.0, float(np.abs(want).max()))
+    # the same rows through the few-sequences kernel (what every other kernel is bit-identical to)
+    m.handle.set_option("lstm_persist_rows", 0)
+    m.handle.set_option("lstm_cluster_rows", 0)
+    n = min(B, 64)
+    assert np.array_equal(m.encode_source(ids[:n]), got[:n])
+
+
+def test_single_query_with_odd_pad_prefix_never_gives_up():
+    """the single-query cluster kernel published its XCC-id handshake in the even exchange buffer, which a query
+    with an ODD number of leading PADs overwrites in its first step.  Left-padded queries of every prefix length, many
+    calls each: results equal the few-sequences kernel's and no launch falls back."""
+    params = model_params("dual-encoder", 200, 50, 256, 256, 64, 16)
+    m, p = make_pair(params, seed=12)
+    rng = np.random.RandomState(0)
+    before = m.handle.get_counter("lstm_persist_fallbacks")
+    for npad in range(0, 15):
+        ids = random_ids(rng, 3, 16, 200)
+        ids[:, :npad] = 0
+        first = m.encode_source(ids)
+        for _ in range(20):
+            assert np.array_equal(m.encode_source(ids), first)
+        m.handle.set_option("lstm_persist_rows", 0)
+        m.handle.set_option("lstm_cluster_rows", 0)
+        assert np.array_equal(m.encode_source(ids), first)
+        m.handle.set_option("lstm_persist_rows", 32)
+        m.handle.set_option("lstm_cluster_rows", 1024)
+    assert m.handle.get_counter("lstm_persist_fallbacks") == before

@@ -60,13 +60,18 @@ def test_c3_crosslingual_full_index_and_queries():
     sc2, ids2 = m.handle.score_topk(src, 10)
     assert np.abs(sc2[:, 0] - wsc[:, 0]).max() < 1e-3
     clear = (wsc[:, 0] - wsc[:, 1]) > 1e-4
-    assert clear.mean() > 0.9 and np.array_equal(ids2[clear, 0], wids[clear, 0])
+    assert np.array_equal(ids2[clear, 0], wids[clear, 0])
     # the observed agreement, all queries (shown with pytest -s / in the captured output of a failure)
     print("C3 crosslingual: top-1 id agreement device encodings vs oracle encodings %.5f (%d of %d queries; %d with a top-2 "
           "margin above 1e-4, all of those equal); top-10 set agreement %.5f; max |cosine diff| %.2e"
           % (np.mean(ids2[:, 0] == wids[:, 0]), int(np.sum(ids2[:, 0] == wids[:, 0])), len(wids), int(clear.sum()),
              np.mean([len(set(a) & set(b)) / 10.0 for a, b in zip(ids2, wids)]), np.abs(sc2[:, 0] - wsc[:, 0]).max()))
-    assert np.mean(ids2[:, 0] == wids[:, 0]) > 0.9
+    # north_star: "top-1 id bit-exact".  Observed on this data: 16491 of 16491 (profiles/r03x_c3_agreement.txt).  A query
+    # may legitimately flip only where the oracle's own top-2 margin is below the encoder tolerance (none here: `clear`
+    # covers > 99.9 % of the queries and all of those are asserted equal above); pin the count so that a regression shows.
+    assert clear.mean() > 0.999
+    assert int(np.sum(ids2[:, 0] == wids[:, 0])) >= len(wids) - 1          # agreement >= 0.9999
+    assert np.mean([len(set(a) & set(b)) / 10.0 for a, b in zip(ids2, wids)]) > 0.9999
 
 
 def test_qna_real_data_T1000():
@@ -255,3 +260,52 @@ def test_c5_cnn_train_step_1024_rows():
     for name, w in p.items():
         assert np.abs(got[name].reshape(w.shape) - w).max() < 5e-4, name
         assert np.abs(got[name + "/Adagrad"].reshape(w.shape) - st[name]).max() < 5e-4, name + "/Adagrad"
+
+
+def test_c5_cnn_train_step_8192_rows():
+    """configs[4] at its LARGE global batch (B_rows in {1024, 8192}): 8192 pair rows, T = 64, S = 512, E = 50,
+    571 target rows, fp32.  2048 chunks of the gather / scatter backward, 32 projection-backward chunks; same tolerances as
+    the 1024-row step.  (The oracle's step takes ~40 s of host time here.)"""
+    V, E, S, T, B, N = 3000, 50, 512, 64, 8192, 571
+    params = model_params("source_only_cnn", V, E, 96, 96, S, T, N=N, lr=0.9)
+    m, p = make_pair(params, seed=16)
+    st = O.new_optimizer_state(p)
+    rng = np.random.RandomState(23)
+    src = np.repeat(random_ids(rng, B // 2, T, V, 0.5), 2, axis=0)
+    rows = rng.randint(0, N, size=B).astype(np.int32)
+    z = np.tile(np.array([1.0, 0.0], np.float32), B // 2)
+    want_loss, want_acc = O.train_step(p, st, params, src, rows, z, 0.9)
+    loss, acc = m.train_step(src, rows, z)
+    assert loss == pytest.approx(float(want_loss), rel=1e-5, abs=1e-6)
+    assert acc == pytest.approx(float(want_acc), abs=1e-6)
+    got = m.get_variables(with_slots=True)
+    for name, w in p.items():
+        assert np.abs(got[name].reshape(w.shape) - w).max() < 5e-4, name
+        assert np.abs(got[name + "/Adagrad"].reshape(w.shape) - st[name]).max() < 5e-4, name + "/Adagrad"
+
+
+def test_c2_encode_131072_rows():
+    """configs[1] at the largest batch of SURVEY 8d C2's sweep (B = 131072; 2048 workgroups of 64 rows = 8 rounds over the
+    256 CUs), dense ids, device-resident in and out (sse_encode_dev).  Size-independent property: a row's encoding does not
+    depend on the batch it sits in -- the 131072 rows are 32 shuffled copies of 4096 distinct sequences; every copy must
+    be BIT-identical to the first, and the 4096 distinct ones are checked against the oracle."""
+    import torch
+    V, E, H, S, T, B, D = 32000, 50, 256, 256, 32, 131072, 4096
+    params = model_params("dual-encoder", V, E, H, H, S, T)
+    m, p = make_pair(params, seed=2)
+    rng = np.random.RandomState(77)
+    base = random_ids(rng, D, T, V)                                  # dense (no PAD): the bench's worst case
+    base[::7, :5] = 0                                                 # ... plus some left-padded rows
+    perm = np.concatenate([rng.permutation(D) for _ in range(B // D)])
+    ids = torch.from_numpy(base[perm]).cuda()
+    for side, enc in ((0, "src"), (1, "tgt")):
+        out = torch.empty((B, S), dtype=torch.float32, device="cuda")
+        m.handle.encode_dev(side, ids.data_ptr(), B, T, True, out.data_ptr())
+        m.handle.synchronize()
+        got = out.cpu().numpy()
+        first = np.empty((D, S), np.float32)
+        first[perm[:D]] = got[:D]
+        assert np.array_equal(got, first[perm]), enc                  # batch position never changes a bit
+        want = O.encode(p, params, enc, base)
+        assert np.abs(first - want).max() <= 1e-4
+        assert np.sum(first.astype(np.float64) * want, axis=1).min() > 1 - 1e-6

@@ -33,15 +33,23 @@ def random_ids(rng, B, T, V, pad_frac=0.0):
     return ids
 
 
-# Loss tolerance of the LSTM train step against the oracle.  By default the training forward and the weight-gradient GEMM
-# run on the bf16 matrix pipe with hi + lo split fp32 operands (options train_fwd_x3 / train_dk_x3): encodings within
-# ~2e-6 of the fp32 path, i.e. <= 64 * 2 * 2e-6 on a logit; relative to the north-star budget (1e-3 on a cosine = 6e-2 on
-# a logit) that is 1/250.  The exact fp32 path (both options 0) is held to LOSS_REL_EXACT.
-LOSS_REL = 1e-4
+# Loss tolerance of the LSTM train step against the oracle.  The DEFAULT train step is fp32 MFMA throughout -- the
+# reference's arithmetic (tf.float32, sse_model.py:355-364) -- and is held to LOSS_REL = LOSS_REL_EXACT.  The opt-in
+# split-operand path (options train_fwd_x3 / train_bwd_x3 / train_dk_x3: the three GEMM families on the bf16 matrix pipe
+# with hi + lo split fp32 operands) leaves encodings within ~2e-6 of the fp32 path, i.e. <= 64 * 2 * 2e-6 on a logit;
+# relative to the north-star budget (1e-3 on a cosine = 6e-2 on a logit) that is 1/250: LOSS_REL_SPLIT.
 LOSS_REL_EXACT = 1e-5
+LOSS_REL = LOSS_REL_EXACT
+LOSS_REL_SPLIT = 1e-4
 
 
 def exact_fp32_training(model):
-    """Switch a model's train step to the fp32-MFMA kernels throughout."""
-    model.handle.set_option("train_fwd_x3", 0)
-    model.handle.set_option("train_dk_x3", 0)
+    """A model's train step on the fp32-MFMA kernels throughout (the library default since round 4; explicit here)."""
+    for opt in ("train_fwd_x3", "train_bwd_x3", "train_dk_x3"):
+        model.handle.set_option(opt, 0)
+
+
+def split_bf16_training(model):
+    """Opt a model's train step into the split-operand bf16-pipe GEMMs (forward, BPTT recurrence + dX, weight gradient)."""
+    for opt in ("train_dk_x3", "train_fwd_x3", "train_bwd_x3"):
+        model.handle.set_option(opt, 1)
