@@ -206,6 +206,19 @@ int sse_train_set_grad_arena(sse_handle *h, float *arena_dev, int64_t count);
 int sse_train_grads(sse_handle *h, const int32_t *src_ids_host, const int32_t *tgt_ids_host,
                     const float *labels_host, int32_t B, int32_t T, int64_t rows_global);
 int sse_train_apply(sse_handle *h, float *loss, float *train_acc);
+/* The word-embedding gradient of a data-parallel step as (row id, gradient row) pairs (SURVEY 8e "Training": "all-gather
+ * of (row-id, grad-row) for the sparse embedding grads") -- for vocabularies where the dense [V,E] block dwarfs the rows a
+ * step touches.  Between sse_train_grads and sse_train_apply, on the stream of sse_set_stream, no host synchronisation:
+ *   sse_train_pack_embedding_grad   compacts the rows of the arena's dense block that carry any non-zero gradient into
+ *       packed_dev = [ count (int32), 0, 0, 0 | ids (int32 x cap, padded to a multiple of 4) | rows (cap x E floats) ],
+ *       sse_train_packed_embedding_floats(cap) floats in all; cap = an upper bound of the rows one rank can touch that is
+ *       IDENTICAL on all ranks (min(V, 2 * max rows per rank * T)): the caller all-gathers the fixed-size buffers;
+ *   sse_train_unpack_embedding_grad zeroes the dense block and adds the `world` gathered buffers in rank order -- the same
+ *       sums in the same order on every rank; the rest of the arena is all-reduced as before.
+ * A slot overflow or a row id out of range raises device error bit 8: sse_train_apply cancels the update and reports it. */
+int64_t sse_train_packed_embedding_floats(sse_handle *h, int32_t cap);
+int sse_train_pack_embedding_grad(sse_handle *h, int32_t cap, float *packed_dev);
+int sse_train_unpack_embedding_grad(sse_handle *h, const float *gathered_dev, int32_t world, int32_t cap);
 /* Batches by row number: the padded source / target corpora (the token-id matrices Data builds
  * from TrainPairs / targetIDs, data.py:95-115) are uploaded once with sse_corpus_upload (side 0 = source corpus
  * [N,T], side 1 = target corpus) and a step ships 2*B row numbers instead of 2*B*T token ids; the batch's id matrix

@@ -54,6 +54,9 @@ SYMBOLS = {
     "sse_train_set_grad_arena": (C.c_int, [_P, _P, C.c_int64]),
     "sse_train_grads": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int64]),
     "sse_train_apply": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "sse_train_packed_embedding_floats": (C.c_int64, [_P, C.c_int32]),
+    "sse_train_pack_embedding_grad": (C.c_int, [_P, C.c_int32, _P]),
+    "sse_train_unpack_embedding_grad": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     "sse_corpus_upload": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int32]),
     "sse_train_step_rows": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sse_train_grads_rows": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int64]),
@@ -345,6 +348,18 @@ class Handle(object):
         loss, acc = C.c_float(), C.c_float()
         self.check(self.lib.sse_train_apply(self._h, C.byref(loss), C.byref(acc)))
         return float(loss.value), float(acc.value)
+
+    # ---- (row id, gradient row) exchange of the word-embedding gradient (data_parallel.py)
+    def dp_packed_floats(self, cap):
+        return int(self.lib.sse_train_packed_embedding_floats(self._h, int(cap)))
+
+    def dp_pack_embedding(self, cap, packed):
+        """packed: contiguous float32 CUDA tensor of dp_packed_floats(cap) elements."""
+        self.check(self.lib.sse_train_pack_embedding_grad(self._h, int(cap), C.c_void_p(packed.data_ptr())))
+
+    def dp_unpack_embedding(self, gathered, world, cap):
+        """gathered: the `world` packed buffers back to back (all_gather_into_tensor), float32 CUDA."""
+        self.check(self.lib.sse_train_unpack_embedding_grad(self._h, C.c_void_p(gathered.data_ptr()), int(world), int(cap)))
 
     @property
     def learning_rate(self):

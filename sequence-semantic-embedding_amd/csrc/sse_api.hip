@@ -764,6 +764,8 @@ int check_err_flag(sse_handle *h, hipStream_t st, int32_t *bits = nullptr) {
     if (bits && flag == 4) return 0;
     if (flag & 1) return fail(h, "token id out of range [0, %d) (tf.gather would raise; sse_model.py:163-164)", h->cfg.vocab_size);
     if (flag & 2) return fail(h, "corpus row out of range in a train step by rows");
+    if (flag & 8) return fail(h, "data-parallel embedding-gradient exchange: more touched rows than the packed buffer holds, or a row id "
+                                 "out of range in a gathered buffer (sse_train_pack_embedding_grad / sse_train_unpack_embedding_grad)");
     if (flag & 4) return fail(h, "LSTM cluster kernel: a workgroup of a cluster did not arrive (device oversubscribed?); the "
                                  "host-buffer entry points fall back to the few-sequences kernel by themselves, for "
                                  "sse_encode_dev set option lstm_persist_rows to 0");
@@ -2171,10 +2173,10 @@ static int train_apply_locked(sse_handle *h, float *loss, float *train_acc) {
   HIPCHECK(h, hipMemcpyAsync(out, tail, 4 * sizeof(float), hipMemcpyDeviceToHost, st));
   HIPCHECK(h, hipMemcpyAsync(h->pin_small, h->err_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIPCHECK(h, sync_stream(st));
-  // bits 1 | 2 (token id / corpus row out of range) belong to this step: the update was cancelled on the device, variables
+  // bits 1 | 2 | 8 (token id / corpus row out of range, sparse gradient exchange overflow) belong to this step: the update was cancelled on the device, variables
   // unchanged.  Bit 4 (a cluster-kernel give-up of an asynchronous sse_encode_dev issued earlier) is not this step's: it
   // stays in the flag for sse_synchronize / the next encode to report.
-  if (h->pin_small[0] & 3) return check_err_flag(h, st);  // (resets the flag)
+  if (h->pin_small[0] & 11) return check_err_flag(h, st);  // (resets the flag)
   h->global_step += 1;
   if (loss) *loss = out[1];
   if (train_acc) *train_acc = out[2];
@@ -2229,6 +2231,32 @@ int sse_train_step_rows(sse_handle *h, const int32_t *src_rows_host, const int32
   h->train->defer_err = false;
   if (rc) return 1;
   return train_apply_locked(h, loss, train_acc);
+}
+
+int64_t sse_train_packed_embedding_floats(sse_handle *h, int32_t cap) {
+  if (!h || cap < 1) return 0;
+  return emb_grad_packed_floats(h->cfg.embedding_size, cap);
+}
+
+int sse_train_pack_embedding_grad(sse_handle *h, int32_t cap, float *packed_dev) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  if (!h->train || !h->train->grads_ready) return fail(h, "pack embedding gradient: no gradients pending (call sse_train_grads first)");
+  if (cap < 1 || !packed_dev) return fail(h, "bad arguments to sse_train_pack_embedding_grad");
+  HIPCHECK(h, launch_emb_grad_pack(h->vars[0].grad, h->cfg.vocab_size, h->cfg.embedding_size, cap, packed_dev, h->err_flag, h->stream));
+  return 0;
+}
+
+int sse_train_unpack_embedding_grad(sse_handle *h, const float *gathered_dev, int32_t world, int32_t cap) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  if (!h->train || !h->train->grads_ready) return fail(h, "unpack embedding gradient: no gradients pending (call sse_train_grads first)");
+  if (cap < 1 || world < 1 || !gathered_dev) return fail(h, "bad arguments to sse_train_unpack_embedding_grad");
+  HIPCHECK(h, launch_emb_grad_unpack(gathered_dev, world, h->cfg.vocab_size, h->cfg.embedding_size, cap, h->vars[0].grad, h->err_flag,
+                                     h->stream));
+  return 0;
 }
 
 int sse_train_apply(sse_handle *h, float *loss, float *train_acc) {

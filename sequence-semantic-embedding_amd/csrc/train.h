@@ -59,6 +59,11 @@ hipError_t launch_adagrad(float *w, float *accum, const float *grad, const float
                           hipStream_t st);
 hipError_t launch_pack_kT(const float *K, int row0, int nrows, int RT, int H, int Hp, float *out, hipStream_t stream);
 
+// data-parallel exchange of the word-embedding gradient as (row id, gradient row) pairs: see train.hip
+int64_t emb_grad_packed_floats(int E, int cap);
+hipError_t launch_emb_grad_pack(const float *g, int V, int E, int cap, float *packed, int32_t *err, hipStream_t st);
+hipError_t launch_emb_grad_unpack(const float *gathered, int world, int V, int E, int cap, float *g, int32_t *err, hipStream_t st);
+
 // text-CNN training path (cnn_bwd.hip)
 int cnn_bwd_chunks(int B);
 size_t cnn_dw_part_floats(int E, int B);

@@ -1320,7 +1320,7 @@ __global__ void clip_scale_multi_kernel(const float *part, int n, const float *e
   }
   if (threadIdx.x == 0) {
     const float gn = (float)sqrt(sh[0] + (double)*extra);
-    const bool bad = err != nullptr && (*err & 3) != 0;  // id / row out of range; bit 4 is the encoders' cluster give-up, not a train error
+    const bool bad = err != nullptr && (*err & 11) != 0;  // id / row out of range, sparse-exchange overflow; bit 4 is the encoders' cluster give-up, not a train error
     scal[0] = gn;
     scal[1] = bad ? 0.0f : ((gn > 0.0f) ? clip * fminf(1.0f / gn, 1.0f / clip) : 1.0f);
     scal[2] = bad ? 1.0f : 0.0f;
@@ -1605,5 +1605,71 @@ __global__ void gather_id_rows_kernel(const int32_t *__restrict__ corpus, const 
 hipError_t launch_gather_id_rows(const int32_t *corpus, const int32_t *rows, int B, int T, int64_t N, int32_t *out,
                                  int32_t *err, hipStream_t st) {
   hipLaunchKernelGGL(gather_id_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, st, corpus, rows, B, T, N, out, err);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Data-parallel exchange of the word-embedding gradient as (row id, gradient row) pairs (SURVEY 8e "Training": all-gather
+// of the sparse embedding gradients instead of all-reducing the dense [V,E] block; data_parallel.py).
+// packed = [count (int32), 0, 0, 0 | ids[cap4] (int32) | rows[cap][E]], cap4 = cap rounded up to 4.
+// Pack: one wave per embedding row; a row with any non-zero gradient takes the next slot (atomic counter: the order of the
+// slots is not deterministic, the SET is, and the ids of one rank are distinct -- the sums below do not depend on it).
+__global__ __launch_bounds__(256) void emb_grad_pack_kernel(const float *__restrict__ g, int V, int E, int cap, float *__restrict__ packed,
+                                                            int32_t *err) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= V) return;
+  const float *src = g + (size_t)row * E;
+  bool nz = false;
+  for (int e = lane; e < E; e += 64) nz = nz || src[e] != 0.0f;
+  if (__ballot(nz) == 0) return;
+  int slot = 0;
+  if (lane == 0) slot = atomicAdd(reinterpret_cast<int32_t *>(packed), 1);
+  slot = __shfl(slot, 0);
+  if (slot >= cap) {  // cannot happen while cap >= min(V, ids of this rank's batch); never write past the buffer
+    if (lane == 0) atomicOr(err, 8);
+    return;
+  }
+  const int cap4 = (cap + 3) & ~3;
+  if (lane == 0) reinterpret_cast<int32_t *>(packed)[4 + slot] = row;
+  float *dst = packed + 4 + cap4 + (size_t)slot * E;
+  for (int e = lane; e < E; e += 64) dst[e] = src[e];
+}
+
+// Unpack one rank's buffer: g[id] += row for its count slots (distinct ids: no atomics).  Launched once per rank, in rank
+// order, after the block has been zeroed: the same sums in the same order on every rank.
+__global__ __launch_bounds__(256) void emb_grad_unpack_kernel(const float *__restrict__ packed, int V, int E, int cap, float *__restrict__ g,
+                                                              int32_t *err) {
+  const int count = min(reinterpret_cast<const int32_t *>(packed)[0], cap);
+  const int cap4 = (cap + 3) & ~3;
+  const int64_t n = (int64_t)count * E;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int slot = (int)(i / E), e = (int)(i - (int64_t)slot * E);
+    const int id = reinterpret_cast<const int32_t *>(packed)[4 + slot];
+    if (id < 0 || id >= V) {
+      atomicOr(err, 8);
+      continue;
+    }
+    g[(size_t)id * E + e] += packed[4 + cap4 + (size_t)slot * E + e];
+  }
+}
+
+int64_t emb_grad_packed_floats(int E, int cap) { return 4 + (int64_t)((cap + 3) & ~3) + (int64_t)cap * E; }
+
+hipError_t launch_emb_grad_pack(const float *g, int V, int E, int cap, float *packed, int32_t *err, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(packed, 0, 16, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(emb_grad_pack_kernel, dim3((V + 3) / 4), dim3(256), 0, st, g, V, E, cap, packed, err);
+  return hipGetLastError();
+}
+
+hipError_t launch_emb_grad_unpack(const float *gathered, int world, int V, int E, int cap, float *g, int32_t *err, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(g, 0, (size_t)V * E * sizeof(float), st);
+  if (e != hipSuccess) return e;
+  const int64_t stride = emb_grad_packed_floats(E, cap);
+  const int64_t work = (int64_t)cap * E;
+  const int blocks = (int)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048);
+  for (int r = 0; r < world; ++r)
+    hipLaunchKernelGGL(emb_grad_unpack_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, gathered + (size_t)r * stride, V, E, cap, g, err);
   return hipGetLastError();
 }

@@ -29,6 +29,7 @@ class DataParallelTrainer(object):
         sl = getattr(engine, "embedding_slice", None)
         self.emb_slice = tuple(sl()) if sl is not None else None
         self.last_exchange = None          # "dense" | "sparse": what the last step put on the wire (tests, bench)
+        self._packed = self._gathered = None   # the packed (row id, gradient row) buffers of the sparse exchange
 
     @property
     def world(self):
@@ -38,17 +39,26 @@ class DataParallelTrainer(object):
     def global_rows(self, local_rows):
         """Sum of the ranks' row counts (ranks may hold different numbers of rows: the reference's batches are
         truncated at the end of the corpus, data.py:98)."""
+        return self._rows_sum_max(local_rows)[0]
+
+    def _rows_sum_max(self, local_rows):
+        """(sum, max) of the ranks' row counts: one tiny all-gather (both are needed: the loss is a mean over the sum,
+        the packed embedding exchange is sized by the max)."""
         import torch
         import torch.distributed as dist
         if self.world == 1:
-            return int(local_rows)
+            return int(local_rows), int(local_rows)
         t = torch.tensor([int(local_rows)], dtype=torch.int64, device=self.arena.device)
-        dist.all_reduce(t, group=self.group)
-        return int(t.item())
+        out = torch.empty(self.world, dtype=torch.int64, device=self.arena.device)
+        dist.all_gather_into_tensor(out, t, group=self.group)
+        out = out.cpu()
+        return int(out.sum()), int(out.max())
 
     def train_step(self, src_ids, tgt_ids, labels, rows_global=None, by_rows=False):
         """One step on this rank's rows; returns the GLOBAL (loss, train_acc), evaluated before the update.
-        Pass rows_global when it is known (equal batches: world * len(labels)) to save the tiny extra all-reduce.
+        Pass rows_global when it is known and the batch is split evenly (split_batch: every rank holds at most
+        ceil(rows_global / world) rows) to save the tiny extra all-gather of the row counts; ranks with arbitrary row counts
+        (the reference's truncated batches, data.py:98) leave it None.
         by_rows: src_ids / tgt_ids are row numbers into the corpora uploaded with engine.corpus_upload."""
         import torch
         import torch.distributed as dist
@@ -60,20 +70,34 @@ class DataParallelTrainer(object):
                 self.engine.set_stream(cur)
                 self._stream = cur
         if rows_global is None:
-            rows_global = self.global_rows(len(labels))
+            rows_global, rows_cap = self._rows_sum_max(len(labels))
+        else:
+            rows_cap = -(-int(rows_global) // self.world)
+            if len(labels) > rows_cap:
+                raise ValueError("rank holds %d rows, more than ceil(rows_global / world) = %d: leave rows_global=None for "
+                                 "unevenly split batches" % (len(labels), rows_cap))
         if by_rows:
             self.engine.train_grads_rows(src_ids, tgt_ids, labels, rows_global)
         else:
             self.engine.train_grads(src_ids, tgt_ids, labels, rows_global)
         if self.world > 1 or self.always_reduce:
             if self._use_sparse(rows_global, src_ids, by_rows):
-                self._exchange_sparse()
+                self._exchange_sparse(rows_cap, self._seq_len(src_ids, by_rows))
             else:
                 dist.all_reduce(self.arena, group=self.group)      # ONE collective per step (sum)
                 self.last_exchange = "dense"
         return self.engine.train_apply()
 
     # ---- (row id, gradient row) exchange of the embedding gradient (SURVEY 8e "Training") ----------------------------
+    def _seq_len(self, src_ids, by_rows):
+        T = getattr(self.engine, "max_seq_length", None)
+        if T is None:
+            import numpy as np
+            if by_rows:
+                raise ValueError("engine without max_seq_length: cannot size the packed exchange of a step by rows")
+            T = int(np.asarray(src_ids).shape[-1])
+        return int(T)
+
     def _use_sparse(self, rows_global, src_ids, by_rows):
         """Decided from values that are IDENTICAL on every rank (rows_global, T, V): ranks whose local row counts differ
         by one (split_batch) must not disagree about which collectives the step issues."""
@@ -82,43 +106,35 @@ class DataParallelTrainer(object):
         if self.sparse_embedding:
             return True
         V = self.emb_slice[1]
-        T = getattr(self.engine, "max_seq_length", None)
-        if T is None:
-            import numpy as np
-            T = 1 if by_rows else int(np.asarray(src_ids).shape[-1])
-        return 2 * int(rows_global) * int(T) < V // 4
+        return 2 * int(rows_global) * self._seq_len(src_ids, by_rows) < V // 4
 
-    def _exchange_sparse(self):
-        """Same sums as the dense all-reduce: the dense variables and the tail go through one all-reduce of the arena
-        BEHIND the embedding block; the embedding block travels as the rows this rank touched (rows with any non-zero
-        gradient), all-gathered with their ids and scatter-added into a zeroed block on every rank."""
+    def _exchange_sparse(self, rows_cap, T):
+        """Same sums as the dense all-reduce.  The dense variables and the tail go through one all-reduce of the arena
+        BEHIND the embedding block (two when the block is not at the start); the embedding block travels as the rows this
+        rank touched: compacted on the device into a FIXED-size packed buffer (cap = min(V, 2 * rows_cap * T) slots, the
+        same on every rank: no count has to cross the host), ONE all-gather, then added into the zeroed block in rank
+        order by the engine (HIP kernels behind the C ABI: sse_train_pack / unpack_embedding_grad) -- no torch kernels, no
+        host synchronisation."""
         import torch
         import torch.distributed as dist
         off, V, E = self.emb_slice
-        emb = self.arena[off:off + V * E].view(V, E)
+        cap = max(1, min(V, 2 * int(rows_cap) * int(T)))
+        n = self.engine.dp_packed_floats(cap)
+        if self._packed is None or self._packed.numel() != n or self._gathered.numel() != n * self.world:
+            self._packed = torch.zeros(n, dtype=torch.float32, device=self.arena.device)
+            self._gathered = torch.zeros(n * self.world, dtype=torch.float32, device=self.arena.device)
         works = [dist.all_reduce(part, group=self.group, async_op=True)          # everything but the embedding block
                  for part in (self.arena[:off], self.arena[off + V * E:]) if part.numel()]
-        ids = torch.nonzero((emb != 0).any(dim=1)).flatten()
-        n = torch.tensor([ids.numel()], dtype=torch.int64, device=emb.device)
-        counts = [torch.zeros_like(n) for _ in range(self.world)]
-        dist.all_gather(counts, n, group=self.group)
-        nmax = max(1, int(max(c.item() for c in counts)))
-        pad_ids = torch.full((nmax,), V, dtype=torch.int64, device=emb.device)       # V = "no row"
-        pad_rows = torch.zeros((nmax, E), dtype=torch.float32, device=emb.device)
-        pad_ids[:ids.numel()] = ids
-        pad_rows[:ids.numel()] = emb[ids]
-        all_ids = [torch.empty_like(pad_ids) for _ in range(self.world)]
-        all_rows = [torch.empty_like(pad_rows) for _ in range(self.world)]
-        dist.all_gather(all_ids, pad_ids, group=self.group)
-        dist.all_gather(all_rows, pad_rows, group=self.group)
-        emb.zero_()
-        buf = torch.zeros((V + 1, E), dtype=torch.float32, device=emb.device)
-        for r in range(self.world):                                   # fixed rank order: the same sum on every rank
-            buf.index_add_(0, all_ids[r], all_rows[r])
-        emb.copy_(buf[:V])
+        self.engine.dp_pack_embedding(cap, self._packed)
+        if self.world == 1 and not self.always_reduce:
+            self._gathered.copy_(self._packed)
+        else:
+            dist.all_gather_into_tensor(self._gathered, self._packed, group=self.group)
+        self.engine.dp_unpack_embedding(self._gathered, self.world, cap)
         for w in works:
             w.wait()
         self.last_exchange = "sparse"
+        self.last_cap = cap
 
 
 def split_batch(src_ids, tgt_ids, labels, rank, world):

@@ -179,6 +179,37 @@ class OracleEngine(object):
     def train_bind_arena(self, tensor):
         self.arena = tensor.numpy()                                # shares memory with the torch tensor
 
+    # the (row id, gradient row) exchange of data_parallel.py, numpy restatement of csrc/train.hip's emb_grad_pack /
+    # emb_grad_unpack kernels (same packed layout: [count, 0, 0, 0 | ids (cap padded to x4) | rows cap x E])
+    @property
+    def max_seq_length(self):
+        return int(self.cfg["max_seq_length"])
+
+    def dp_packed_floats(self, cap):
+        return 4 + ((cap + 3) & ~3) + cap * self.p["word_embedding"].shape[1]
+
+    def dp_pack_embedding(self, cap, packed):
+        off, V, E = self.embedding_slice()
+        emb = self.arena[off:off + V * E].reshape(V, E)
+        ids = np.nonzero((emb != 0).any(axis=1))[0][::-1]           # (any slot order: the device's is not deterministic either)
+        assert len(ids) <= cap, "packed exchange buffer too small"
+        buf = packed.numpy()
+        cap4 = (cap + 3) & ~3
+        buf[:4].view(np.int32)[:] = (len(ids), 0, 0, 0)
+        buf[4:4 + len(ids)].view(np.int32)[:] = ids
+        buf[4 + cap4:4 + cap4 + len(ids) * E] = emb[ids].ravel()
+
+    def dp_unpack_embedding(self, gathered, world, cap):
+        off, V, E = self.embedding_slice()
+        emb = self.arena[off:off + V * E].reshape(V, E)
+        emb[:] = 0
+        n, cap4 = self.dp_packed_floats(cap), (cap + 3) & ~3
+        for r in range(world):                                      # rank order: the same sums on every rank
+            buf = gathered.numpy()[r * n:(r + 1) * n]
+            cnt = int(buf[:1].view(np.int32)[0])
+            ids = buf[4:4 + cnt].view(np.int32)
+            emb[ids] += buf[4 + cap4:4 + cap4 + cnt * E].reshape(cnt, E)
+
     def train_grads(self, src, tgt, labels, rows_global):
         O = self.O
         loss, acc, grads = O.gradients(self.p, self.cfg, src, tgt, labels)
@@ -266,4 +297,54 @@ def test_two_rank_data_parallel_step_equals_single_process(tmp_path, uneven, spa
     assert np.allclose(z0["hist"], np.array(want), rtol=1e-5, atol=1e-6)
     for n in p:
         assert np.array_equal(z0[n], z1[n]), n                     # ranks stay in lock-step, bit for bit
+        assert np.abs(z0[n] - p[n]).max() < 2e-5, n
+
+
+def _dp_threshold_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["SSE_NO_TORCH"] = "1"
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sse_amd
+    from oracle import sse_oracle as O
+    from util import model_params
+    cfg = model_params("dual-encoder", 2000, 8, 12, 16, 16, 6)
+    eng = OracleEngine(O.init_params(cfg, seed=3), cfg, 0.9)
+    tr = sse_amd.DataParallelTrainer(eng)                           # sparse_embedding=None: automatic
+    kinds = []
+    for rows in (41, 42):                                           # 2 * 41 * 6 = 492 < 2000 // 4 <= 2 * 42 * 6
+        rng = np.random.RandomState(rows)
+        src = rng.randint(2, 2000, size=(rows, 6)).astype(np.int32)
+        tgt = rng.randint(2, 2000, size=(rows, 6)).astype(np.int32)
+        z = (np.arange(rows) % 2 == 0).astype(np.float32)
+        tr.train_step(*sse_amd.split_batch(src, tgt, z, rank, world), rows_global=rows)
+        kinds.append(tr.last_exchange)
+    np.savez(os.path.join(out_dir, "thr%d.npz" % rank), kinds=np.array(kinds), **eng.p)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sparse_or_dense_is_decided_identically_on_every_rank(tmp_path):
+    """the automatic sparse / dense choice used the LOCAL row count; with 41 global rows split 21 / 20
+    over two ranks at V = 2000, T = 6 one rank chose the dense all-reduce and the other the sparse exchange -- mismatched
+    collectives.  Now decided from (rows_global, T, V): both ranks go sparse at 41 rows, dense at 42, stay bit-identical,
+    and match the single-process steps."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import sse_oracle as O
+    from util import model_params
+    world, port = 2, _free_port()
+    mp.spawn(_dp_threshold_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    z0, z1 = (np.load(os.path.join(str(tmp_path), "thr%d.npz" % r)) for r in range(2))
+    assert z0["kinds"].tolist() == z1["kinds"].tolist() == ["sparse", "dense"]
+    cfg = model_params("dual-encoder", 2000, 8, 12, 16, 16, 6)
+    p = O.init_params(cfg, seed=3)
+    acc = O.new_optimizer_state(p)
+    for rows in (41, 42):
+        rng = np.random.RandomState(rows)
+        src = rng.randint(2, 2000, size=(rows, 6)).astype(np.int32)
+        tgt = rng.randint(2, 2000, size=(rows, 6)).astype(np.int32)
+        O.train_step(p, acc, cfg, src, tgt, (np.arange(rows) % 2 == 0).astype(np.float32), 0.9)
+    for n in p:
+        assert np.array_equal(z0[n], z1[n]), n
         assert np.abs(z0[n] - p[n]).max() < 2e-5, n

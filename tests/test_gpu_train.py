@@ -167,6 +167,66 @@ def test_data_parallel_two_logical_ranks():
     assert m0.handle.global_step == 1
 
 
+def test_packed_embedding_gradient_exchange_three_logical_ranks():
+    """sse_train_pack_embedding_grad / sse_train_unpack_embedding_grad (the embedding gradient as (row id,
+    gradient row) pairs): three handles = three logical ranks on one GPU.  The packed buffers laid back to back (what the
+    all-gather delivers) and unpacked give, on every rank, exactly the sum of the three dense blocks in rank order; an
+    undersized buffer raises error bit 8 and cancels the update."""
+    import torch
+    import sse_amd
+    V, E, T = 3000, 50, 10
+    params = model_params("dual-encoder", V, E, 128, 128, 64, T, lr=0.9)
+    rng = np.random.RandomState(14)
+    src, tgt, z = _batch(rng, 90, T, V)
+    ms = [make_pair(params, seed=7)[0] for _ in range(3)]
+    arenas, dense = [], []
+    for r, m in enumerate(ms):
+        a = torch.zeros(m.handle.train_grad_count(), dtype=torch.float32, device="cuda:0")
+        m.handle.train_bind_arena(a)
+        m.handle.train_grads(*sse_amd.split_batch(src, tgt, z, r, 3), rows_global=90)
+        arenas.append(a)
+    torch.cuda.synchronize()
+    dense = [a[:V * E].clone() for a in arenas]
+    cap = min(V, 2 * 30 * T)
+    n = ms[0].handle.dp_packed_floats(cap)
+    assert n == 4 + ((cap + 3) & ~3) + cap * E
+    gathered = torch.zeros(3 * n, dtype=torch.float32, device="cuda:0")
+    for r, m in enumerate(ms):
+        m.handle.dp_pack_embedding(cap, gathered[r * n:(r + 1) * n])
+    torch.cuda.synchronize()
+    counts = [int(gathered[r * n:r * n + 1].view(torch.int32)[0]) for r in range(3)]
+    for r in range(3):
+        touched = int((dense[r].view(V, E) != 0).any(dim=1).sum())
+        assert counts[r] == touched and 0 < touched <= cap
+        ids = gathered[r * n + 4:r * n + 4 + counts[r]].view(torch.int32).cpu().numpy()
+        assert len(set(ids.tolist())) == counts[r]                 # every touched row once
+    want = (dense[0] + dense[1]) + dense[2]                        # rank order
+    for m, a in zip(ms, arenas):
+        m.handle.dp_unpack_embedding(gathered, 3, cap)
+    torch.cuda.synchronize()
+    for a in arenas:
+        assert torch.equal(a[:V * E], want)
+    # the rest of the arena is summed as the dense exchange does it; the three ranks then apply the same update
+    tail = sum(a[V * E:] for a in arenas)
+    for a in arenas:
+        a[V * E:] = tail
+    res = [m.handle.train_apply() for m in ms]
+    assert res[0] == res[1] == res[2]
+    g = [m.get_variables(with_slots=True) for m in ms]
+    assert all(np.array_equal(g[0][k], g[1][k]) and np.array_equal(g[0][k], g[2][k]) for k in g[0])
+    # undersized buffer: flagged on the device, the update is cancelled and the error names the exchange
+    m = ms[0]
+    before = m.get_variables()
+    m.handle.train_grads(*sse_amd.split_batch(src, tgt, z, 0, 3), rows_global=90)
+    small = torch.zeros(m.handle.dp_packed_floats(8), dtype=torch.float32, device="cuda:0")
+    m.handle.dp_pack_embedding(8, small)
+    with pytest.raises(sse_amd.SSEError, match="embedding-gradient exchange"):
+        m.handle.train_apply()
+    after = m.get_variables()
+    assert all(np.array_equal(before[k], after[k]) for k in before)
+    assert int(small[:1].view(torch.int32)[0]) > 8                 # the counter kept counting; nothing past slot 8 was written
+
+
 def test_data_parallel_trainer_world1_and_arena_ownership():
     import sse_amd
     params = model_params("shared-encoder", 80, 16, 32, 32, 16, 5, lr=0.5)
