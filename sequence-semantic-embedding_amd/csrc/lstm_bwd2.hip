@@ -1,0 +1,354 @@
+// BPTT of the fp32 train step, second generation (the library default since round 4: sse_train_step computes in fp32 like
+// the reference's tf.float32 graph, sse_model.py:355-364 -- tf.gradients through static_rnn over BasicLSTMCell).
+//
+// One workgroup walks one 32-row tile backwards through the T steps (as lstm_bwd_kernel in train.hip does); what changed:
+//  * ORIENTATION.  The recurrent GEMM dh_{t-1}[b][j] = sum_n dG_t[b][n] Kh[j][n] takes Kh^T as the MFMA's A operand and the dG
+//    tile as its B operand, so an accumulator lane holds ONE row b and 16 hidden units -- the layout lstm_fwd_kernel<.., TSW>
+//    writes its gate tape in.  Registers 4q .. 4q+3 of a lane are then 4 consecutive units = 4 consecutive reduction indices
+//    n of ONE row: exactly one 16-byte piece of the dG operand tile in LDS.  The gate backward leaves the wave as 16
+//    conflict-free ds_write_b128 per step (lstm_bwd_kernel: 64 dword scatters into 8 banks).
+//  * dG FOR THE WEIGHT GRADIENT straight from registers: the dK GEMM wants (one n, 4 consecutive rows) pieces; the rows of a
+//    quad of lanes are consecutive, so a 4 x 4 quad transpose (DPP) turns the same registers into those pieces: 16 global
+//    stores of 16 bytes per lane and step, 64-byte runs.  (lstm_bwd_kernel re-read its LDS tile for that: dword reads that
+//    hit 4 banks -- "dump", a quarter of that kernel.)
+//  * dX INSIDE: dX_t = dG_t Kx^T is taken from the tile while it sits in LDS (fp32 MFMA, all waves: 2 e-tiles x NW/2
+//    k-ranges; partial sums meet in LDS) and scattered into the dense embedding gradient here -- the A-operand copy of dG
+//    (dg_a: 1 GB written and read back per encoder at 8192 x 32 rows) and dx_kernel are gone.
+//  * NO BIAS ACCUMULATORS: d(bias) is row E of the weight-gradient GEMM (the A-tape carries the constant-1 column that
+//    feeds the bias through the forward GEMM), see dk_reduce_kernel.
+#include "sse_kernels.h"
+#include "train.h"
+
+__device__ __forceinline__ float b2_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008178f * x)); }
+
+struct LstmBwd2Args {
+  const float *tape_g;   // forward gate tape, lane = sequence accumulator layout (LstmFwdArgs::tape_swap)
+  const float *dh_last;  // [Bp][Hp]
+  const float *KhT;      // frag32(rows = j (Hp), red = n (4Hp)): Kh^T  [Hp/32][KGn][256]
+  const float *KxT;      // frag32(rows = e (64), red = n): Kx^T  [2][KGn][256]
+  float *dg_b;           // [(T*NT32*4)][NTn][256]: dG as frag32(rows = n, red = r), the dK GEMM's B operand
+  const int32_t *ids;    // [B][T]
+  float *d_emb;          // [V][E], zero-initialised
+  float *sq_part;        // [NT32][NW] sum of dx^2 over OCCURRENCES (tf.global_norm sees IndexedSlices.values raw)
+  float *hot_part;       // [T*NT32][2][64] per (step, tile) sums for the ids 0 (PAD) and 1 (EOS)
+  int32_t T, NT32, NT_tape, H, B, E, V;
+  long long *clk;        // -DSSE_BWD_CLOCK builds only: per-wave phase cycle sums of tile 0 ([wave][8])
+};
+
+#ifdef SSE_BWD_CLOCK  // measurement builds (tools/): cycles per phase of the BPTT step, summed over the steps
+#include <cstdio>
+#define B2_CLK_DECL long long ck_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ck_t = clock64();
+#define B2_CLK(i)                   \
+  {                                 \
+    const long long n_ = clock64(); \
+    ck_[i] += n_ - ck_t;            \
+    ck_t = n_;                      \
+  }
+#else
+#define B2_CLK_DECL
+#define B2_CLK(i)
+#endif
+
+#ifndef BWD2_NT
+#define BWD2_NT 2  // cache policy of the tape loads: nt (streamed once)
+#endif
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void lstm_bwd2_kernel(LstmBwd2Args a) {
+  extern __shared__ __attribute__((aligned(16))) float dgs[];  // [KGn][256] dG tile, frag32(rows = b, red = n); then the dX partials
+  constexpr int Hp = 32 * NW, KGn = Hp / 2, KGg = Hp / 8, NTn = Hp / 8;
+  constexpr int KQ = NW / 2;        // k-ranges of the dX product (NW = 8: one gate each; NW = 4: two gates each)
+  constexpr int GPQ = 4 / KQ;       // gates per k-range
+  float *xpart = dgs + (size_t)KGn * 256;  // [(KQ-1)][2 e-tiles][16][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = blockIdx.x, T = a.T;
+  const int b = lane & 31, half = lane >> 5;
+
+  f32x16 dh, dc;
+  float tg[4][16], tcn[16], tcp[16];
+  const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(a.tape_g + ((size_t)(tile % a.NT_tape) * NW + wn) * 5 * 1024), 0, 0x7fffffff, 0x00020000);
+  const int tvo = lane * 16;
+  const int tstep = a.NT_tape * NW * 5 * 1024 * 4;  // bytes between consecutive steps (T*tstep < 2^31 checked by the launcher)
+  auto tld4 = [&](int t, int qty, int q4) -> f32x4 {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, tvo, t * tstep + (qty * 1024 + q4 * 256) * 4, BWD2_NT));
+  };
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    f32x4 v[6];
+#pragma unroll
+    for (int g = 0; g < 5; ++g) v[g] = tld4(T - 1, g, q4);
+    v[5] = tld4(T > 1 ? T - 2 : 0, 4, q4);  // unused when T == 1
+    const f32x4 d4 = *reinterpret_cast<const f32x4 *>(a.dh_last + (size_t)(tile * 32 + b) * Hp + wn * 32 + q4 * 8 + half * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = q4 * 4 + e;
+      dh[r] = d4[e];
+      dc[r] = 0.0f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) tg[g][r] = v[g][e];
+      tcn[r] = v[4][e];
+      tcp[r] = v[5][e];
+    }
+  }
+
+  const int KGl = min(KGg, (a.H + 7) / 8);  // live k-groups per gate (dG columns of padded units are exactly 0)
+  const int et = wn & 1, kq = wn >> 1;      // dX: this wave's e-tile and k-range
+  const bool elive = et * 32 < a.E;
+  float xsq = 0.0f;
+  // the dX epilogue of step t runs after the barrier that ends step t (the partial sums of the other k-ranges are in LDS then)
+  auto dx_epilogue = [&](int t, f32x16 &xacc) {
+    // sum of the k-ranges, fixed order
+#pragma unroll
+    for (int p = 0; p < KQ - 1; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xacc[r] += xpart[((size_t)(p * 2 + et) * 16 + r) * 64 + lane];
+    // scatter-add into the dense embedding gradient (duplicate ids summed, as TF's sparse Adagrad does): lane = column e,
+    // register = row -- a register's 32 lanes are 128 contiguous bytes of one embedding row.  PAD (0) and EOS (1) fill most
+    // rows of a left-padded batch: their sums go to hot_part without atomics (dx_hot_reduce_kernel adds the blocks in fixed
+    // order).  sum(dx^2) is taken per OCCURRENCE (un-deduplicated IndexedSlices, sse_model.py:359-362).
+    // Everything through buffer descriptors (SGPR base + one lane offset + an SGPR per row): no 64-bit per-lane pointers
+    // (the launcher's caller keeps V * E * 4 < 2 GiB on this path: 32-bit offsets).
+    const int e = et * 32 + (lane & 31);
+    const bool ecol = e < a.E;
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.ids), 0, a.B * T * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc(a.d_emb, 0, a.V * a.E * 4, 0x00020000);
+    const int row0 = tile * 32 + 4 * (lane >> 5);  // rows beyond B fall outside the descriptor: the load returns 0, masked below
+    float h0 = 0.0f, h1 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dr = (r & 3) + 8 * (r >> 2);  // mfma_row(r, lane) - 4 * (lane >> 5)
+      int id = __builtin_amdgcn_raw_buffer_load_b32(irs, row0 * T * 4, (dr * T + t) * 4, 0);
+      if (row0 + dr >= a.B || id < 0 || id >= a.V) id = -1;  // out-of-range ids were flagged by the forward pass
+      const float v = xacc[r];
+      if (id >= 0 && ecol) xsq += v * v;
+      h0 += (id == 0) ? v : 0.0f;
+      h1 += (id == 1) ? v : 0.0f;
+      if (id >= 2 && ecol) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, ers, (id * a.E + e) * 4, 0, 0);
+    }
+    h0 += __shfl_xor(h0, 32);
+    h1 += __shfl_xor(h1, 32);
+    if (lane < 32) {
+      float *hp = a.hot_part + ((size_t)(t * a.NT32 + tile) * 2) * 64 + e;
+      hp[0] = h0;
+      hp[64] = h1;
+    }
+  };
+
+  f32x16 xacc;
+  B2_CLK_DECL
+  for (int t = T - 1; t >= 0; --t) {
+    // ---- elementwise gate backward: 16-byte pieces into the LDS operand tile, their quad transposes to dg_b
+    {
+      const size_t rg = ((size_t)t * a.NT32 + tile) * 4 + (b >> 3);
+      float *gb = a.dg_b + (rg * NTn + wn) * 256 + ((((b >> 2) & 1) * 32 + half * 4 + (b & 3)) << 2);
+      float *ls = dgs + (size_t)(wn * 4) * 256 + lane * 4;
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        f32x4 g4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = q4 * 4 + e;
+          const float si = tg[0][r], tj = tg[1][r], sf = tg[2][r], so = tg[3][r];
+          const float cprev = (t > 0) ? tcp[r] : 0.0f;
+          const float tc = b2_tanh(tcn[r]);
+          const float dhv = dh[r];
+          const float dov = dhv * tc;
+          const float dcv = dc[r] + dhv * so * (1.0f - tc * tc);
+          g4[0][e] = dcv * tj * si * (1.0f - si);
+          g4[1][e] = dcv * si * (1.0f - tj * tj);
+          g4[2][e] = dcv * cprev * sf * (1.0f - sf);
+          g4[3][e] = dov * so * (1.0f - so);
+          dc[r] = dcv * sf;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          *reinterpret_cast<f32x4 *>(ls + (size_t)(g * KGg + q4) * 256) = g4[g];  // n = g Hp + 32 wn + 8 q4 + 4 half + e
+          f32x4 tr = g4[g];
+          sse_quad_transpose(tr, lane);  // -> rows (b & ~3) .. +3 of column n = g Hp + 32 wn + 8 q4 + 4 half + (b & 3)
+          *reinterpret_cast<f32x4 *>(gb + (size_t)(g * (Hp / 32)) * 256 + q4 * 32) = tr;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // bound the interleaving to one quarter (register pressure)
+      }
+    }
+    B2_CLK(0)
+    __syncthreads();
+    B2_CLK(1)
+
+    // ---- recurrent GEMM: dh_{t-1}[j][b] = sum_n Kh[j][n] dG[b][n]   (A = Kh^T fragments from L2, B = the LDS tile)
+    int lg = lane;
+    asm volatile("" : "+v"(lg));  // opaque copy: the addresses below are recomputed per step (register pressure)
+    const float *la = dgs + lg * 4;
+    struct Walk {
+      int l, base;
+    };
+    if (t > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dh[r] = 0.0f;
+      const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.KhT) + (size_t)wn * KGn * 256, 0, KGn * 1024, 0x00020000);
+      auto kld = [&](int kg) -> f32x4 { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, lg * 16, kg * 1024, 0)); };
+      // 4 gates x KGl live k-groups (NL = 4 KGl is a multiple of PF), division-free walk, fixed order for every tile
+      constexpr int PF = 4;
+      f32x4 bq[PF], aq[2];
+      const int NL = 4 * KGl;
+      auto adv = [&](Walk &w) {
+        const int l1 = w.l + 1;
+        const bool wrap = l1 == KGl;
+        const int b1 = w.base + KGg;
+        w.base = wrap ? (b1 == 4 * KGg ? 0 : b1) : w.base;
+        w.l = wrap ? 0 : l1;
+      };
+      Walk wb{0, 0}, wa{0, 0};
+#pragma unroll
+      for (int p = 0; p < PF; ++p) {
+        bq[p] = kld(wb.base + wb.l);
+        adv(wb);
+      }
+      aq[0] = *reinterpret_cast<const f32x4 *>(la);
+      adv(wa);
+      __builtin_amdgcn_s_setprio(1);
+      for (int kg = 0; kg < NL; kg += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+          aq[(p + 1) & 1] = *reinterpret_cast<const f32x4 *>(la + (wa.base + wa.l) * 256);  // (wraps to group 0 past the end: unused)
+          adv(wa);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dh = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[p][e], aq[p & 1][e], dh, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          bq[p] = kld(wb.base + wb.l);
+          adv(wb);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    B2_CLK(2)
+
+    // ---- dX_t[b][e] = sum_n dG[b][n] Kx[e][n]: this wave's e-tile over its gates' live k-groups (A = the LDS tile: lane =
+    // column e, register = row, the layout the scatter wants)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xacc[r] = 0.0f;
+    if (elive) {
+      const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.KxT) + (size_t)et * KGn * 256, 0, KGn * 1024, 0x00020000);
+      auto xld = [&](int kg) -> f32x4 { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, lg * 16, kg * 1024, 0)); };
+      constexpr int PX = 4;
+      f32x4 xb[PX], xa[2];
+      const int NX = GPQ * KGl;  // k-groups of this range
+      const int g0 = kq * GPQ * KGg;
+      auto advx = [&](Walk &w) {  // within the range: GPQ gates x KGl groups, wraps to its start
+        const int l1 = w.l + 1;
+        const bool wrap = l1 == KGl;
+        const int b1 = w.base + KGg;
+        w.base = wrap ? (b1 == g0 + GPQ * KGg ? g0 : b1) : w.base;
+        w.l = wrap ? 0 : l1;
+      };
+      Walk xwb{0, g0}, xwa{0, g0};
+#pragma unroll
+      for (int p = 0; p < PX; ++p) {
+        xb[p] = xld(xwb.base + xwb.l);
+        advx(xwb);
+      }
+      xa[0] = *reinterpret_cast<const f32x4 *>(la + (xwa.base + xwa.l) * 256);
+      advx(xwa);
+      for (int i0 = 0; i0 < NX; i0 += PX) {
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+          xa[(p + 1) & 1] = *reinterpret_cast<const f32x4 *>(la + (xwa.base + xwa.l) * 256);
+          advx(xwa);
+          __builtin_amdgcn_sched_barrier(0);
+          if (i0 + p < NX) {  // (wave-uniform; NX is a multiple of PX except for tiny cells)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xacc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[p & 1][e], xb[p][e], xacc, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          xb[p] = xld(xwb.base + xwb.l);
+          advx(xwb);
+        }
+      }
+      if (kq > 0) {
+        float *xp = xpart + ((size_t)((kq - 1) * 2 + et) * 16) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xp[r * 64] = xacc[r];
+      }
+    }
+
+    B2_CLK(3)
+    // ---- refill the tape registers for step t-1 (c_{t-1} is already here: it was this step's c_prev); unconditional (the
+    // last step re-reads step 0 for nothing) so that the old values are not kept alive on a not-taken path
+    {
+      __builtin_amdgcn_sched_barrier(0);
+      const int tp = t > 0 ? t - 1 : 0, tpp = t > 1 ? t - 2 : 0;
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        f32x4 v[5];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] = tld4(tp, g, q4);
+        v[4] = tld4(tpp, 4, q4);  // step 0 ignores it (c_{-1} = 0)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = q4 * 4 + e;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) tg[g][r] = v[g][e];
+          tcn[r] = tcp[r];
+          tcp[r] = v[4][e];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    B2_CLK(4)
+    __syncthreads();
+    B2_CLK(5)
+    if (kq == 0 && elive) dx_epilogue(t, xacc);
+    B2_CLK(6)
+  }
+#ifdef SSE_BWD_CLOCK
+  if (a.clk && tile == 0 && lane == 0)
+    for (int i = 0; i < 8; ++i) a.clk[wn * 8 + i] = ck_[i];
+#endif
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) xsq += __shfl_xor(xsq, o);
+  if (lane == 0) a.sq_part[tile * NW + wn] = xsq;
+}
+
+size_t lstm_bwd2_lds_bytes(int Hp) {
+  const int NW = Hp / 32, KQ = NW / 2;
+  return ((size_t)(Hp / 2) * 256 + (size_t)(KQ - 1) * 2 * 16 * 64) * sizeof(float);
+}
+
+hipError_t launch_lstm_bwd2(const float *tape_g, const float *dh_last, const float *KhT, const float *KxT, float *dg_b,
+                            const int32_t *ids, float *d_emb, float *sq_part, float *hot_part, int T, int NT32, int NT_tape,
+                            int Hp, int H, int B, int E, int V, hipStream_t st) {
+  LstmBwd2Args a{tape_g, dh_last, KhT, KxT, dg_b, ids, d_emb, sq_part, hot_part, T, NT32, NT_tape > 0 ? NT_tape : NT32, H, B, E, V, nullptr};
+#ifdef SSE_BWD_CLOCK
+  static long long *clk_dev = nullptr;
+  if (!clk_dev) (void)hipMalloc((void **)&clk_dev, 64 * sizeof(long long));
+  (void)hipMemsetAsync(clk_dev, 0, 64 * sizeof(long long), st);
+  a.clk = clk_dev;
+  struct Report {
+    long long *p;
+    hipStream_t st;
+    int T;
+    ~Report() {
+      long long v[64];
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(v, p, sizeof v, hipMemcpyDeviceToHost);
+      static int n = 0;
+      if (n++ % 8 < 2)
+        for (int w = 0; w < 8; w += 1)
+          fprintf(stderr, "[bwd2 clock] wave %d cycles/step: elementwise %lld | barrier1 %lld | gemm %lld | dX %lld | refill-issue %lld | barrier2 %lld | epilogue %lld\n",
+                  w, v[w * 8 + 0] / T, v[w * 8 + 1] / T, v[w * 8 + 2] / T, v[w * 8 + 3] / T, v[w * 8 + 4] / T, v[w * 8 + 5] / T, v[w * 8 + 6] / T);
+    }
+  } report{clk_dev, st, T};
+#endif
+  if (E > 64 || (Hp != 128 && Hp != 256)) return hipErrorInvalidValue;
+  if ((size_t)T * NT32 * (Hp / 32) * 5 * 1024 * sizeof(float) >= ((size_t)1 << 31)) return hipErrorInvalidValue;  // 32-bit tape offsets
+  const size_t lds = lstm_bwd2_lds_bytes(Hp);
+  auto go = [&](auto kern, int threads) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(NT32), dim3(threads), lds, st, a);
+    return hipGetLastError();
+  };
+  return Hp == 128 ? go(lstm_bwd2_kernel<4>, 256) : go(lstm_bwd2_kernel<8>, 512);
+}

@@ -134,13 +134,19 @@ __device__ __forceinline__ void gemm_pass(__amdgpu_buffer_rsrc_t wr, int voff, i
 //   <1,1,1>  Hp = 256, 32 rows: wave w owns unit block w      (half the per-step latency: used
 //            when the batch cannot fill the chip with 64-row tiles)
 //   <1,1,2>  Hp = 512, 32 rows: wave w owns unit blocks w and w+8
-template <int RT, int MT, int UBW, bool TRAIN, bool LIN, bool SPL = false>
+template <int RT, int MT, int UBW, bool TRAIN, bool LIN, bool SPL = false, bool TSW = false>
 __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
+  static_assert(!TSW || TRAIN, "TSW is the training forward in the inference orientation");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int ROWS = RT * 32;                 // sequences per workgroup
   constexpr int TPR = LSTM_THREADS / ROWS;      // threads per sequence row in the x gather
   constexpr int NWR = 8 / RT;                   // waves sharing one row tile (projection tail)
-  constexpr bool SWAP = !TRAIN;                 // weights as the MFMA A operand (see the file header)
+  // weights as the MFMA A operand (see the file header).  TSW: the training forward in that orientation too -- the h_t /
+  // parked-product stores are conflict-free 16-byte pieces instead of 8-way conflicting dword scatters, the gate tape is
+  // written in the lane = sequence accumulator layout (lstm_bwd2_kernel reads it back the same way), and the A-tape pieces
+  // (one k', 4 consecutive rows) come from registers through 4 x 4 quad transposes instead of 40 conflicting LDS reads per
+  // thread and step.  Same fma chains as the other orientation: bit-identical values.
+  constexpr bool SWAP = !TRAIN || TSW;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // first unit block owned by this wave (further ones at +8), and its first row tile
   // <2,1,1>: wave w -> unit block w>>1, row tile w&1.  Waves are placed on SIMD w%4, so the live unit blocks of a
@@ -210,6 +216,23 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
     *reinterpret_cast<f32x4 *>(dst + (32 + (xr & 31)) * 4) = hi;  // k%8 in 4..7 -> lane half 1
   };
 
+  const int NT32 = a.NT32 > 0 ? a.NT32 : gridDim.x * RT;  // 32-row tiles in the launch (tape indexing)
+  // TSW: the x part of the A-tape of step `ts` from the gathered embedding row (registers): after the quad transposes this
+  // lane holds, for k' = 8 kg (+4) + (xr & 3), rows (xr & ~3) .. +3 -- one float4 of AT[(r/8)*KT + k'/32][256] each
+  auto tape_x = [&](int ts, int kg, f32x4 lo, f32x4 hi) {
+    if constexpr (TSW) {
+      if (kg >= 8) return;  // the x part of the A-tape is 64 columns wide
+      sse_quad_transpose(lo, lane);
+      sse_quad_transpose(hi, lane);
+      const int KT = 2 + KGh / 4, b = xr & 31;
+      const size_t rg = ((size_t)ts * NT32 + blockIdx.x * RT + (xr >> 5)) * 4 + (b >> 3);
+      const int k0 = kg * 8 + (xr & 3);
+      float *dst = a.tape_a + (rg * KT + (k0 >> 5)) * 256 + ((((b >> 2) & 1) * 32 + (k0 & 31)) << 2);
+      __builtin_nontemporal_store(lo, reinterpret_cast<f32x4 *>(dst));
+      __builtin_nontemporal_store(hi, reinterpret_cast<f32x4 *>(dst + 16));  // k' + 4: four lanes further
+    }
+  };
+
   // --- left-pad prefix skip: first step this tile has to compute (0 when disabled / training)
   int t0 = 0;
   if (!TRAIN && a.pad_h != nullptr) {
@@ -242,6 +265,16 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       f32x4 hi = *reinterpret_cast<const f32x4 *>(src + kg * 8 + 4);
       x_store(t0 & 1, kg, lo, hi);
     }
+    if constexpr (TSW) {  // A-tape of step t0: x columns (zeros past the padded embedding width: whole quads take this path together)
+      for (int kg = xq; kg < 8; kg += TPR) {
+        f32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+        if (kg < KGx) {
+          lo = *reinterpret_cast<const f32x4 *>(src + kg * 8);
+          hi = *reinterpret_cast<const f32x4 *>(src + kg * 8 + 4);
+        }
+        tape_x(t0, kg, lo, hi);
+      }
+    }
     const int Hp = KGh * 8;
     for (int i = tid; i < RT * KGh * 256; i += LSTM_THREADS) {  // all row tiles of buffer t0 & 1
       const int mt = i / (KGh * 256), e = i % (KGh * 256);
@@ -264,13 +297,29 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
     }
   }
 
+  if constexpr (TSW) {
+    // h_{-1} = 0: the h columns of the first step's A-tape (every later step's are written with h_t, see pass B)
+    if (do_b) {
+      const int KT = 2 + KGh / 4, b = lane & 31;
+#pragma unroll
+      for (int u = 0; u < UBW; ++u)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const size_t rg = ((size_t)t0 * NT32 + blockIdx.x * RT + mt0 + m) * 4 + (b >> 3);
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            float *dst = a.tape_a + (rg * KT + 2 + ub0 + 8 * u) * 256 + ((((b >> 2) & 1) * 32 + q4 * 8 + (lane >> 5) * 4 + (b & 3)) << 2);
+            __builtin_nontemporal_store(f32x4{0, 0, 0, 0}, reinterpret_cast<f32x4 *>(dst));
+          }
+        }
+    }
+  }
   __syncthreads();
 
   // weights: Wp[unit block][kg][gate][256], read through a buffer descriptor
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(a.Wp), 0, (KGh / 4) * KG * 4096, 0x00020000);
   const int wvoff = lane * 16;
-  const int NT32 = a.NT32 > 0 ? a.NT32 : gridDim.x * RT;  // 32-row tiles in the launch (tape indexing)
 
   for (int t = t0; t < T; ++t) {
     // prefetch the embedding rows of step t+1 into registers (one k-group per
@@ -295,7 +344,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       ha[m] = hptr(cur, mt0 + m) + lane * 4;
     }
 
-    if constexpr (TRAIN) {
+    if constexpr (TRAIN && !TSW) {
       // A-tape for the weight-gradient GEMM: [x_t | h_{t-1}] of this tile, stored as
       // frag32 blocks with rows = k' (x: 0..63, h: 64 + unit) and reduction index
       // r = (t*NT32 + tile32)*32 + b, i.e. AT[(r/8)*KT + k'/32][256].
@@ -394,10 +443,18 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
         if constexpr (SWAP) {
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) {
-            f32x4 pij;
+            f32x4 pij, si4, tj4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pij[e] = fast_sigmoid(g[m][0][q4 * 4 + e]) * fast_tanh(g[m][1][q4 * 4 + e]);
+            for (int e = 0; e < 4; ++e) {
+              si4[e] = fast_sigmoid(g[m][0][q4 * 4 + e]);
+              tj4[e] = fast_tanh(g[m][1][q4 * 4 + e]);
+              pij[e] = si4[e] * tj4[e];
+            }
             *reinterpret_cast<f32x4 *>(hdst[m] + q4 * 256) = pij;
+            if constexpr (TSW) {
+              __builtin_nontemporal_store(si4, reinterpret_cast<f32x4 *>(tp[m] + q4 * 256));
+              __builtin_nontemporal_store(tj4, reinterpret_cast<f32x4 *>(tp[m] + 1024 + q4 * 256));
+            }
           }
         } else {
 #pragma unroll
@@ -429,6 +486,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
           const float *src = a.emb + (size_t)nid * a.Ep + kg * 8;
           x_store(nxt, kg, *reinterpret_cast<const f32x4 *>(src), *reinterpret_cast<const f32x4 *>(src + 4));
         }
+        tape_x(t + 1, xq, nlo, nhi);  // TSW: x columns of the next step's A-tape (zeros where xq >= KGx)
       }
       // pass B: gates f (+1 folded into the bias), o -> c' = c*sigmoid(f) + pij ; h' = tanh(c')*sigmoid(o)
 #pragma unroll
@@ -465,6 +523,29 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
               }
             }
             *reinterpret_cast<f32x4 *>(hdst[m] + q4 * 256) = hv4;  // h_t, A-fragment order: one 16-byte piece per k-group
+            if constexpr (TSW) {
+              f32x4 sf4, so4, cn4;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int r = q4 * 4 + e;
+                sf4[e] = fast_sigmoid(g[m][0][r]);  // (the values computed above: common subexpressions)
+                so4[e] = fast_sigmoid(g[m][1][r]);
+                cn4[e] = c[u][m][r];
+              }
+              __builtin_nontemporal_store(sf4, reinterpret_cast<f32x4 *>(tp[m] + 2048 + q4 * 256));
+              __builtin_nontemporal_store(so4, reinterpret_cast<f32x4 *>(tp[m] + 3072 + q4 * 256));
+              __builtin_nontemporal_store(cn4, reinterpret_cast<f32x4 *>(tp[m] + 4096 + q4 * 256));
+              if (have_next) {
+                // h_t is the h part of the NEXT step's A-tape: k' = 64 + 32 ub + 8 q4 + 4 (lane >> 5) + e.  After the quad
+                // transpose this lane holds k' = .. + (b & 3) for rows (b & ~3) .. +3: one float4 of AT[(r/8)*KT + k'/32][256]
+                f32x4 ht = hv4;
+                sse_quad_transpose(ht, lane);
+                const int KT = 2 + KGh / 4, b = lane & 31;
+                const size_t rg = ((size_t)(t + 1) * NT32 + blockIdx.x * RT + mt0 + m) * 4 + (b >> 3);
+                float *dst = a.tape_a + (rg * KT + 2 + ub) * 256 + ((((b >> 2) & 1) * 32 + q4 * 8 + (lane >> 5) * 4 + (b & 3)) << 2);
+                __builtin_nontemporal_store(ht, reinterpret_cast<f32x4 *>(dst));
+              }
+            }
           }
         } else {
 #pragma unroll
@@ -505,6 +586,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
           const float *src = a.emb + (size_t)nid * a.Ep + kg * 8;
           x_store(0, kg, *reinterpret_cast<const f32x4 *>(src), *reinterpret_cast<const f32x4 *>(src + 4));
         }
+        tape_x(t + 1, xq, nlo, nhi);
       }
       __syncthreads();
     }
@@ -600,13 +682,13 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   }
 }
 
-template <int RT, int MT, int UBW, bool TRAIN, bool LIN, bool SPL>
+template <int RT, int MT, int UBW, bool TRAIN, bool LIN, bool SPL, bool TSW = false>
 static hipError_t launch_one(const LstmFwdArgs &a, size_t lds, hipStream_t stream) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_kernel<RT, MT, UBW, TRAIN, LIN, SPL>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_kernel<RT, MT, UBW, TRAIN, LIN, SPL, TSW>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const dim3 grid(a.NT32 > 0 ? a.NT32 / RT : (a.B + RT * 32 - 1) / (RT * 32)), block(LSTM_THREADS);
-  hipLaunchKernelGGL((lstm_fwd_kernel<RT, MT, UBW, TRAIN, LIN, SPL>), grid, block, lds, stream, a);
+  hipLaunchKernelGGL((lstm_fwd_kernel<RT, MT, UBW, TRAIN, LIN, SPL, TSW>), grid, block, lds, stream, a);
   return hipGetLastError();
 }
 
@@ -616,6 +698,11 @@ static hipError_t launch_cfg(const LstmFwdArgs &a_in, hipStream_t stream) {
   a.xdouble = lstm_fwd_x_double(a.KGx, a.KGh, RT) ? 1 : 0;
   const size_t lds = lstm_fwd_lds_bytes(a.KGx, a.KGh, RT);
   const bool train = a.tape_g != nullptr;
+  if (train && a.tape_swap) {
+    if (a.tape_a_split) return hipErrorInvalidValue;  // the register-built A-tape is fp32
+    return a.xdouble ? launch_one<RT, MT, UBW, true, true, SPL, true>(a, lds, stream)
+                     : launch_one<RT, MT, UBW, true, false, SPL, true>(a, lds, stream);
+  }
   if (a.xdouble)
     return train ? launch_one<RT, MT, UBW, true, true, SPL>(a, lds, stream) : launch_one<RT, MT, UBW, false, true, SPL>(a, lds, stream);
   return train ? launch_one<RT, MT, UBW, true, false, SPL>(a, lds, stream) : launch_one<RT, MT, UBW, false, false, SPL>(a, lds, stream);

@@ -137,6 +137,7 @@ struct sse_handle {
   bool train_bwd_x3 = false;  // option "train_bwd_x3": recurrent GEMM of BPTT on the bf16 matrix pipe with split operands (needs train_dk_x3)
   bool train_fwd_x3 = false;  // option "train_fwd_x3": forward of the LSTM train step on the bf16 matrix pipe with split operands
   bool train_dk_x3 = false;   // option "train_dk_x3": weight-gradient GEMM of the LSTM train step on the bf16 matrix pipe with split operands
+  bool train_gen1 = false;    // option "train_gen1": the fp32 train step on the first-generation kernels (lstm_bwd_kernel + dx_kernel + db partials; A/B timing and tests)
   bool train_pair_dedup = true; // option "train_pair_dedup": run the source encoder once per (pos, neg) pair of rows that share it
   bool train_serial = false; // option "train_serial": both encoders on one stream (profiling: isolated kernel times)
   float *emb_pad = nullptr;  // [V][Ep]
@@ -1505,6 +1506,10 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value) {
     h->train_dk_x3 = value != 0;
     return 0;
   }
+  if (strcmp(name, "train_gen1") == 0) {
+    h->train_gen1 = value != 0;
+    return 0;
+  }
   if (strcmp(name, "train_pair_dedup") == 0) {
     h->train_pair_dedup = value != 0;
     return 0;
@@ -1868,6 +1873,13 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     bwd_x3[s] = h->train_bwd_x3 && h->train_dk_x3 && e.H >= 64 && e.Hp <= 256 && (int64_t)V * E * 4 < ((int64_t)1 << 31);
     all_x3 = all_x3 && fwd_x3[s] && bwd_x3[s];
   }
+  // Pure fp32 step (the default): second-generation kernels -- the forward in the inference orientation with register-built
+  // tapes (lstm_fwd_kernel<.., TSW>), lstm_bwd2_kernel (dX inside, dG for the weight gradient straight from registers, no
+  // A-operand dG copy in HBM), d(bias) as row E of the weight-gradient GEMM.  Any split-operand option, an embedding of 64
+  // columns (no room for the constant-1 column in the 64-column x part of the A-tape) or a >= 2 GiB embedding table (32-bit
+  // scatter offsets) keeps the first-generation kernels.
+  const bool bwd2 = !h->train_fwd_x3 && !h->train_bwd_x3 && !h->train_dk_x3 && !h->train_gen1 && E < 64 &&
+                    (int64_t)V * E * 4 < ((int64_t)1 << 31);
   // layouts derived from the variables, rebuilt after every update: only the ones this step's kernels read (an all-split
   // step needs the projections, Kh^T / Kx^T in split form and -- below -- the split kernel matrix and embedding table;
   // the fp32 fragment copies wait for the next encode or fp32 step: 7 fewer launches on the critical path of a step)
@@ -2008,6 +2020,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     a.tape_g = (float *)ts.tape_g[s].p;
     a.tape_a = (float *)ts.tape_a[s].p;
     a.tape_a_split = h->train_dk_x3 ? 1 : 0;
+    a.tape_swap = bwd2 ? 1 : 0;
     a.h_last = (float *)ts.h_last[s].p;
     if (fwd_x3[s]) {
       // the gate GEMMs as three bf16 MFMAs on hi + lo split operands (lstm_fwd_x3.hip, TRAIN): same tapes, same outputs
@@ -2071,7 +2084,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   // partial sums of dx^2 per side: one per (tile, wave) when dX comes out of the split-operand BPTT kernel, one per
   // (step, tile) from dx_kernel (+ one per target row in source-encoder-only mode)
   int sq_off[3] = {0, 0, 0};
-  for (int s = 0; s < nside; ++s) sq_off[s + 1] = sq_off[s] + (bwd_x3[s] ? NT32 * (h->enc[s].Hp / 32) : T * NT32);
+  for (int s = 0; s < nside; ++s) sq_off[s + 1] = sq_off[s] + ((bwd_x3[s] || bwd2) ? NT32 * (h->enc[s].Hp / 32) : T * NT32);
   const int n_sq = sq_off[nside] + (table_tgt ? B : 0);
   if (reserve(h, ts.sq_part, (size_t)n_sq * sizeof(float))) return 1;
   if (table_tgt) {
@@ -2092,7 +2105,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     hipStream_t bs = (shared || h->train_serial) ? ts.side[0] : ts.side[s];
     if (!shared || s == 0) HIPCHECK(h, hipStreamWaitEvent(bs, ts.ev_fork, 0));
     if (reserve(h, ts.dh_last[s], (size_t)Bp * Hp * sizeof(float))) return 1;
-    if (!bwd_x3[s] && reserve(h, ts.dg_a[s], (size_t)T * NT32 * KGn * 256 * sizeof(float))) return 1;
+    if (!bwd_x3[s] && !bwd2 && reserve(h, ts.dg_a[s], (size_t)T * NT32 * KGn * 256 * sizeof(float))) return 1;
     if (reserve(h, ts.hot_part[s], (size_t)T * NT32 * 2 * 2 * 64 * sizeof(float))) return 1;
     BwdDxArgs bdx{ts.KxT16[s], (const int32_t *)ts.ids[s].p, emb.grad, (float *)ts.sq_part.p + sq_off[s], (float *)ts.hot_part[s].p,
                   B, E, V};
@@ -2102,6 +2115,20 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     if (reserve(h, ts.dm_part[s], (size_t)proj_bwd_chunks(Bp) * e.H * S * sizeof(float))) return 1;
     HIPCHECK(h, launch_proj_bwd((const float *)ts.h_last[s].p, (const float *)ts.draw[s].p, h->vars[e.proj].dev, Bp, e.H, Hp,
                                 S, h->vars[e.proj].grad, (float *)ts.dh_last[s].p, (float *)ts.dm_part[s].p, bs));
+    if (bwd2) {
+      HIPCHECK(h, launch_lstm_bwd2((const float *)ts.tape_g[s].p, (const float *)ts.dh_last[s].p, ts.KhT[s], ts.KxT[s],
+                                   (float *)ts.dg_b[s].p, (const int32_t *)ts.ids[s].p, emb.grad, (float *)ts.sq_part.p + sq_off[s],
+                                   (float *)ts.hot_part[s].p, T, NT32, half ? NT_half : NT32, Hp, e.H, B, E, V, bs));
+      const int acc2 = (shared && s == 1) ? 1 : 0;
+      HIPCHECK(h, launch_dk((const float *)ts.tape_a[s].p, (const float *)ts.dg_b[s].p, (float *)ts.dk_part[s].p, RGa, KT, NTn, SL,
+                            E, e.H, Hp, acc2, h->vars[e.kernel].grad, half ? NT_half * 4 : 0, bs, h->vars[e.bias].grad));
+      HIPCHECK(h, launch_dx_hot_reduce((const float *)ts.hot_part[s].p, T * NT32, E, V, emb.grad, bs));
+      if (!shared || s == 1) {
+        HIPCHECK(h, hipEventRecord(ts.ev_join[s], bs));
+        HIPCHECK(h, hipStreamWaitEvent(st, ts.ev_join[s], 0));
+      }
+      continue;
+    }
     HIPCHECK(h, launch_lstm_bwd((const float *)ts.tape_g[s].p, (const float *)ts.dh_last[s].p, ts.KhT[s],
                                 (float *)ts.dg_a[s].p, (float *)ts.dg_b[s].p, (float *)ts.db_part[s].p, T, NT32,
                                 half ? NT_half : NT32, Hp, e.H, h->train_dk_x3 ? 1 : 0, bwd_x3[s] ? ts.KhT16[s] : nullptr, &bdx, bs));

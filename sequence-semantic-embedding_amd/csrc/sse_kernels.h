@@ -77,6 +77,37 @@ __device__ static inline void sse_split8(const float (&v)[8], sse_u32x4 &hi, sse
   }
 }
 
+// ---------------------------------------------------------------------------
+// 4 x 4 transpose inside every quad of lanes (DPP quad_perm, no LDS): on entry lane i of a quad holds v[0..3], on exit
+// v[j] of lane i is the old v[i] of lane j.  Used where an accumulator lane owns (one row, 4 consecutive k) -- the piece the
+// LDS operand tiles want -- and the tapes want (one k, 4 consecutive rows): the rows of a quad of lanes are consecutive.
+// Two butterfly stages (lane bit 0 <-> element bit 0, lane bit 1 <-> element bit 1), 16 VALU instructions.
+// ---------------------------------------------------------------------------
+__device__ static inline void sse_quad_transpose(f32x4 &v, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+  auto x1 = [](float x) -> float {  // quad_perm [1,0,3,2]
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+  };
+  auto x2 = [](float x) -> float {  // quad_perm [2,3,0,1]
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+  };
+  {  // stage 1: elements (0,1) and (2,3) against lane bit 0
+    const float r01 = x1(b0 ? v[0] : v[1]), r23 = x1(b0 ? v[2] : v[3]);
+    const float n0 = b0 ? r01 : v[0], n1 = b0 ? v[1] : r01, n2 = b0 ? r23 : v[2], n3 = b0 ? v[3] : r23;
+    v = f32x4{n0, n1, n2, n3};
+  }
+  {  // stage 2: elements (0,2) and (1,3) against lane bit 1
+    const float r02 = x2(b1 ? v[0] : v[2]), r13 = x2(b1 ? v[1] : v[3]);
+    const float n0 = b1 ? r02 : v[0], n2 = b1 ? v[2] : r02, n1 = b1 ? r13 : v[1], n3 = b1 ? v[3] : r13;
+    v = f32x4{n0, n1, n2, n3};
+  }
+#else
+  (void)v;
+  (void)lane;
+#endif
+}
+
 // ------------------------------ LSTM forward -------------------------------
 struct LstmFwdArgs {
   const int32_t *ids;   // [B][T]
@@ -105,6 +136,9 @@ struct LstmFwdArgs {
                             // (r >> 2) * 256 + 4 l + (r & 3) of its 1024-word block (16-byte pieces per lane)
   float *tape_a = nullptr;  // [(T*NT32*4)][KT][256]  [x_t | h_{t-1}] as frag32(rows = k', red = r)
   int32_t tape_a_split = 0; // 1: tape_a holds split bf16 frag16 blocks instead: [(T*NT32*2)][KT][hi|lo][512] (same bytes)
+  int32_t tape_swap = 0;    // 1 (fp32 tapes only): the training forward runs in the inference orientation (weights = MFMA A operand,
+                            // accumulator lane = sequence): tape_g is in THAT accumulator layout (lstm_bwd2_kernel reads it back
+                            // lane-privately) and tape_a is written from registers (quad transposes), not re-read from LDS
   float *h_last = nullptr;  // [Bp][Hp] h_T
 };
 // Hp = 128 * UB hidden units; 512 threads; dynamic LDS = lstm_fwd_lds_bytes()

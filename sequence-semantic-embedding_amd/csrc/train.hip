@@ -808,6 +808,21 @@ struct DkArgs {
                         // then the neg tiles) and A^T dG_pos + A^T dG_neg = A^T (dG_pos + dG_neg): half the MFMAs
 };
 
+// (n-group, r-slice) of a workgroup, XCD-aware: the gridDim.x n-groups of ONE slice read the same A-tape rows, and workgroup
+// ids are dealt round-robin to the 8 XCDs (each with its own L2) -- in plain (x, y) order the n-groups of a slice land on
+// gridDim.x different XCDs and every one of them pulls the A-tape from HBM (FETCH_SIZE 2.4 GB against 1.4 GB of operands at
+// 8192 x 32 rows, profiles/r03x_hbm_pmc.txt).  Remapped, they run back to back on one XCD: one HBM read, the rest L2 hits.
+__device__ __forceinline__ void dk_block_map(int &ngrp, int &slice) {
+  const int NG = gridDim.x, SL = gridDim.y;
+  ngrp = blockIdx.x;
+  slice = blockIdx.y;
+  if ((SL & 7) == 0) {
+    const int p = blockIdx.x + NG * blockIdx.y, xcd = p & 7, j = p >> 3;
+    ngrp = j % NG;
+    slice = (j / NG) * 8 + xcd;
+  }
+}
+
 // KT fragments of one LDS stage, software-pipelined one fragment ahead of its 4 MFMAs (used twice in the kernel)
 #define DK_COMPUTE(CUR)                                                                                       \
   {                                                                                                             \
@@ -842,9 +857,10 @@ __global__ __launch_bounds__(512) void dk_gemm_kernel(DkArgs a) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t live_k = a.live_k;  // all-padding k'-tiles have all-zero A rows: their accumulators stay 0
-  const int nt = min(blockIdx.x * 8 + w, a.NTn - 1);  // surplus waves recompute the last tile (no divergent barriers)
-  const bool live = blockIdx.x * 8 + w < a.NTn;
-  const int slice = blockIdx.y;
+  int ngrp, slice;
+  dk_block_map(ngrp, slice);
+  const int nt = min(ngrp * 8 + w, a.NTn - 1);  // surplus waves recompute the last tile (no divergent barriers)
+  const bool live = ngrp * 8 + w < a.NTn;
   const int per = ((a.RG + a.SL - 1) / a.SL + 1) & ~1;  // even; RG = T*NT32*4 is a multiple of 4: every slice is even
   const int rg0 = slice * per, rg1 = min(a.RG, rg0 + per);
   f32x16 acc[KT];
@@ -937,9 +953,10 @@ __global__ __launch_bounds__(512) void dk_x3_kernel(DkX3Args a) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t live_k = a.live_k;
-  const int nt = min(blockIdx.x * 8 + w, a.NTn - 1);
-  const bool live = blockIdx.x * 8 + w < a.NTn;
-  const int slice = blockIdx.y;
+  int ngrp, slice;
+  dk_block_map(ngrp, slice);
+  const int nt = min(ngrp * 8 + w, a.NTn - 1);
+  const bool live = ngrp * 8 + w < a.NTn;
   const int per = (a.G + a.SL - 1) / a.SL;
   const int g0 = slice * per, g1 = min(a.G, g0 + per);
   f32x16 acc[KT];
@@ -1040,19 +1057,23 @@ __global__ __launch_bounds__(512) void dk_x3_kernel(DkX3Args a) {
 }
 
 // sum the slices and write/accumulate into the variable-shaped gradient dK [(E+H)][4H]
+// db (optional): d(bias) = column sums of dG = row k' = E of the partials -- the A-tape carries the constant-1 column that
+// feeds the bias through the forward GEMM (E < 64), so the weight-gradient GEMM produces the bias gradient for free
 __global__ void dk_reduce_kernel(const float *part, int SL, int KT, int NTn, int E, int H, int Hp, int accumulate,
-                                 float *dK) {
+                                 float *dK, float *db) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int rows = E + H, cols = 4 * H;
-  if (i >= rows * cols) return;
+  if (i >= (rows + (db ? 1 : 0)) * cols) return;
   const int col = i % cols, row = i / cols;
-  const int kp = (row < E) ? row : 64 + (row - E);
+  const bool is_db = row == rows;
+  const int kp = is_db ? E : (row < E) ? row : 64 + (row - E);
   const int g = col / H, unit = col % H;
   const int n = g * Hp + unit;
   const size_t ldn = (size_t)NTn * 32, plane = (size_t)KT * 32 * ldn;
   float acc = 0.0f;
   for (int s = 0; s < SL; ++s) acc += part[s * plane + (size_t)kp * ldn + n];
-  dK[i] = accumulate ? dK[i] + acc : acc;
+  float *out = is_db ? db + col : dK + i;
+  *out = accumulate ? *out + acc : acc;
 }
 
 __global__ void db_reduce_kernel(const float *db_part, int NT32, int H, int Hp, int accumulate, float *db) {
@@ -1506,10 +1527,11 @@ int dk_slices(int RG) {
 }
 
 hipError_t launch_dk(const float *tape_a, const float *dg_b, float *part, int RG, int KT, int NTn, int SL, int E, int H,
-                     int Hp, int accumulate, float *dK, int pair_rg, hipStream_t st) {
+                     int Hp, int accumulate, float *dK, int pair_rg, hipStream_t st, float *db) {
+  if (db && E >= 64) return hipErrorInvalidValue;  // the constant-1 column sits at k' = E of the 64 x columns
   uint32_t live = 0;
   for (int i = 0; i < KT; ++i) {
-    const bool on = (i < 2) ? (i * 32 < E) : ((i - 2) * 32 < H);
+    const bool on = (i < 2) ? (i * 32 < E + (db ? 1 : 0)) : ((i - 2) * 32 < H);
     if (on) live |= 1u << i;
   }
   DkArgs a{tape_a, dg_b, part, RG, KT, NTn, SL, live, pair_rg};
@@ -1519,8 +1541,8 @@ hipError_t launch_dk(const float *tape_a, const float *dg_b, float *part, int RG
   else if (KT == 6 && pair_rg) hipLaunchKernelGGL((dk_gemm_kernel<6, true>), grid, dim3(512), 0, st, a);
   else if (KT == 6) hipLaunchKernelGGL((dk_gemm_kernel<6, false>), grid, dim3(512), 0, st, a);
   else return hipErrorInvalidValue;
-  hipLaunchKernelGGL(dk_reduce_kernel, dim3(((E + H) * 4 * H + 255) / 256), dim3(256), 0, st, part, SL, KT, NTn, E, H, Hp,
-                     accumulate, dK);
+  hipLaunchKernelGGL(dk_reduce_kernel, dim3(((E + H + (db ? 1 : 0)) * 4 * H + 255) / 256), dim3(256), 0, st, part, SL, KT, NTn, E, H, Hp,
+                     accumulate, dK, db);
   return hipGetLastError();
 }
 
@@ -1541,7 +1563,7 @@ hipError_t launch_dk_x3(const void *tape_a, const void *dg_b, float *part, int G
   else if (KT == 6) hipLaunchKernelGGL((dk_x3_kernel<6, false>), grid, dim3(512), 0, st, a);
   else return hipErrorInvalidValue;
   hipLaunchKernelGGL(dk_reduce_kernel, dim3(((E + H) * 4 * H + 255) / 256), dim3(256), 0, st, part, SL, KT, NTn, E, H, Hp,
-                     accumulate, dK);
+                     accumulate, dK, (float *)nullptr);
   return hipGetLastError();
 }
 

@@ -67,9 +67,12 @@ def test_c3_crosslingual_full_index_and_queries():
           % (np.mean(ids2[:, 0] == wids[:, 0]), int(np.sum(ids2[:, 0] == wids[:, 0])), len(wids), int(clear.sum()),
              np.mean([len(set(a) & set(b)) / 10.0 for a, b in zip(ids2, wids)]), np.abs(sc2[:, 0] - wsc[:, 0]).max()))
     # north_star: "top-1 id bit-exact".  Observed on this data: 16491 of 16491 (profiles/r03x_c3_agreement.txt).  A query
-    # may legitimately flip only where the oracle's own top-2 margin is below the encoder tolerance (none here: `clear`
-    # covers > 99.9 % of the queries and all of those are asserted equal above); pin the count so that a regression shows.
-    assert clear.mean() > 0.999
+    # may legitimately flip only where the oracle's own top-2 margin is below the encoder tolerance (observed max cosine
+    # difference 1.8e-7; the 94 % of the queries whose margin exceeds 1e-4 are asserted equal above, and so are all those
+    # above 10x the observed difference); pin the overall count so that a regression shows.
+    assert clear.mean() > 0.9
+    clear5 = (wsc[:, 0] - wsc[:, 1]) > 2e-6
+    assert np.array_equal(ids2[clear5, 0], wids[clear5, 0])
     assert int(np.sum(ids2[:, 0] == wids[:, 0])) >= len(wids) - 1          # agreement >= 0.9999
     assert np.mean([len(set(a) & set(b)) / 10.0 for a, b in zip(ids2, wids)]) > 0.9999
 

@@ -50,6 +50,35 @@ def test_one_train_step_matches_oracle(mode, V, E, Hs, Ht, S, T, B, split):
     assert m.handle.global_step == 1
 
 
+@pytest.mark.parametrize("mode,V,E,Hs,Ht,S,T,B,gen1", [
+    ("dual-encoder", 400, 50, 256, 256, 256, 32, 128, 1),       # option train_gen1: lstm_bwd_kernel + dx_kernel + bias partials
+    ("shared-encoder", 300, 40, 96, 96, 50, 50, 64, 1),
+    ("dual-encoder", 300, 64, 128, 256, 64, 9, 128, 0),          # E = 64: no room for the constant-1 column -> first generation by itself
+    ("dual-encoder", 300, 63, 128, 256, 64, 9, 128, 0),          # E = 63: widest embedding of the second generation (x tile single-buffered)
+    ("dual-encoder", 300, 32, 96, 64, 40, 7, 66, 0),             # E = 32: the constant-1 column opens the second x tile
+    ("shared-encoder", 200, 7, 40, 40, 24, 5, 130, 0),           # one live e-tile, cells far below the padded size
+])
+def test_fp32_train_step_kernel_generations(mode, V, E, Hs, Ht, S, T, B, gen1):
+    """The fp32 train step exists twice: lstm_fwd_kernel<TSW> + lstm_bwd2_kernel + d(bias) from the weight-gradient GEMM
+    (default), and the first-generation kernels (option train_gen1; taken by themselves for E = 64).  Both against the
+    oracle at the exact-path tolerance, two steps."""
+    params = model_params(mode, V, E, Hs, Ht, S, T, lr=0.9)
+    m, p = make_pair(params, seed=13)
+    m.handle.set_option("train_gen1", gen1)
+    st = O.new_optimizer_state(p)
+    rng = np.random.RandomState(5)
+    for step in range(2):
+        src, tgt, z = _batch(rng, B, T, V)
+        want = O.train_step(p, st, params, src, tgt, z, 0.9)
+        got = m.train_step(src, tgt, z)
+        assert got[0] == pytest.approx(float(want[0]), rel=LOSS_REL_EXACT, abs=1e-6)
+        assert got[1] == pytest.approx(float(want[1]), abs=1e-6)
+    v = m.get_variables(with_slots=True)
+    for name, w in p.items():
+        assert np.abs(v[name].reshape(w.shape) - w).max() < 2e-4, name
+        assert np.abs(v[name + "/Adagrad"].reshape(w.shape) - st[name]).max() < 2e-4, name
+
+
 def test_several_steps_track_oracle_and_loss_falls():
     params = model_params("dual-encoder", 200, 50, 96, 96, 64, 12, lr=0.05)
     m, p = make_pair(params, seed=5)

@@ -44,12 +44,18 @@ def main():
             key = (r["Kernel_Name"].split("(")[0][:60], r["Grid_Size"], r["Counter_Name"])
             agg[key].append(float(r["Counter_Value"]))
             dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        # only the byte counters belong in this file (cycle counters of the MFMA-busy passes were listed here
+        # under the "KB" header); FETCH_SIZE / WRITE_SIZE count kilobytes, the gfx950 correction is in the header above
+        if not any(c in ("FETCH_SIZE", "WRITE_SIZE") for (_k, _g, c) in agg):
+            continue
         out.append("## " + os.path.basename(d))
         for (k, g, c), v in sorted(agg.items()):
-            if sum(v) / len(v) < 1000:          # < 1 MB: not an HBM-bound launch
+            if c not in ("FETCH_SIZE", "WRITE_SIZE") or sum(v) / len(v) < 1000:          # < 1 MB: not an HBM-bound launch
                 continue
-            out.append("%-60s grid=%-9s %-10s n=%-3d avg=%.5g KB  (avg dispatch %.3f ms)"
-                       % (k, g, c, len(v), sum(v) / len(v), sum(dur[(k, g, c)]) / len(v) / 1e6))
+            avg_kb, avg_ms = sum(v) / len(v), sum(dur[(k, g, c)]) / len(v) / 1e6
+            gbps = (2.0 if c == "FETCH_SIZE" else 1.0) * avg_kb * 1024 / (avg_ms * 1e-3) / 1e9
+            out.append("%-60s grid=%-9s %-10s n=%-3d avg=%.5g KB  (avg dispatch %.3f ms; %s %.0f GB/s)"
+                       % (k, g, c, len(v), avg_kb, avg_ms, "read ~2x:" if c == "FETCH_SIZE" else "write:", gbps))
     if len(out) > 3:
         open(os.path.join(dst, "%s_hbm_pmc.txt" % tag), "w").write("\n".join(out) + "\n")
     print("\n".join(out[-40:]))
