@@ -11,11 +11,14 @@
 //    quad of lanes are consecutive, so a 4 x 4 quad transpose (DPP) turns the same registers into those pieces: 16 global
 //    stores of 16 bytes per lane and step, 64-byte runs.  (lstm_bwd_kernel re-read its LDS tile for that: dword reads that
 //    hit 4 banks -- "dump", a quarter of that kernel.)
-//  * dX INSIDE: dX_t = dG_t Kx^T is taken from the tile while it sits in LDS (fp32 MFMA, all waves: 2 e-tiles x NW/2
-//    k-ranges; partial sums meet in LDS) and scattered into the dense embedding gradient here -- the A-operand copy of dG
-//    (dg_a: 1 GB written and read back per encoder at 8192 x 32 rows) and dx_kernel are gone.
+//  * dX INSIDE: dX_t = dG_t Kx^T is taken from the tile while it sits in LDS -- the dG fragment a wave has just read for the
+//    recurrent GEMM is also the A operand of its share of dX (wave = e-tile x one of NW/2 k-ranges, walked FIRST; partial
+//    sums meet in LDS) -- and scattered into the dense embedding gradient one step later by two waves, behind their GEMM.
+//    The A-operand copy of dG (dg_a: 1 GB written and read back per encoder at 8192 x 32 rows) and dx_kernel are gone.
 //  * NO BIAS ACCUMULATORS: d(bias) is row E of the weight-gradient GEMM (the A-tape carries the constant-1 column that
 //    feeds the bias through the forward GEMM), see dk_reduce_kernel.
+#include <type_traits>
+
 #include "sse_kernels.h"
 #include "train.h"
 
@@ -27,11 +30,8 @@ struct LstmBwd2Args {
   const float *KhT;      // frag32(rows = j (Hp), red = n (4Hp)): Kh^T  [Hp/32][KGn][256]
   const float *KxT;      // frag32(rows = e (64), red = n): Kx^T  [2][KGn][256]
   float *dg_b;           // [(T*NT32*4)][NTn][256]: dG as frag32(rows = n, red = r), the dK GEMM's B operand
-  const int32_t *ids;    // [B][T]
-  float *d_emb;          // [V][E], zero-initialised
-  float *sq_part;        // [NT32][NW] sum of dx^2 over OCCURRENCES (tf.global_norm sees IndexedSlices.values raw)
-  float *hot_part;       // [T*NT32][2][64] per (step, tile) sums for the ids 0 (PAD) and 1 (EOS)
-  int32_t T, NT32, NT_tape, H, B, E, V;
+  float *dx;             // [T][NT32*32][64]: dX_t rows (columns >= E: unspecified when E <= 32), scattered by dx_scatter_kernel
+  int32_t T, NT32, NT_tape, H, E;
   long long *clk;        // -DSSE_BWD_CLOCK builds only: per-wave phase cycle sums of tile 0 ([wave][8])
 };
 
@@ -49,6 +49,12 @@ struct LstmBwd2Args {
 #define B2_CLK(i)
 #endif
 
+#ifndef B2_PFV  // operand ring depth of the fused loops and the order of their first loads (measurement builds override them)
+#define B2_PFV 4
+#endif
+#ifndef B2_INTERLEAVE
+#define B2_INTERLEAVE 0
+#endif
 #ifndef BWD2_NT
 #define BWD2_NT 2  // cache policy of the tape loads: nt (streamed once)
 #endif
@@ -57,9 +63,15 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void lstm_bwd2_kernel(LstmBwd2Args a) {
   extern __shared__ __attribute__((aligned(16))) float dgs[];  // [KGn][256] dG tile, frag32(rows = b, red = n); then the dX partials
   constexpr int Hp = 32 * NW, KGn = Hp / 2, KGg = Hp / 8, NTn = Hp / 8;
-  constexpr int KQ = NW / 2;        // k-ranges of the dX product (NW = 8: one gate each; NW = 4: two gates each)
-  constexpr int GPQ = 4 / KQ;       // gates per k-range
-  float *xpart = dgs + (size_t)KGn * 256;  // [(KQ-1)][2 e-tiles][16][64]
+  // dX: every wave forms the partial product of ONE e-tile over ONE of KQ k-ranges (GPQ gates each) inside its GEMM loop --
+  // both products read the same dG fragment -- so that the two waves of a SIMD carry the same number of MFMAs and neither
+  // runs alone (a separate dX phase on four waves left them issuing one MFMA per ~125 cycles while their partners waited at
+  // the barrier: 112 k cycles per step for 82 k of MFMA).  Two waves (one per e-tile) keep their own partial in
+  // registers, add the others' (parked in LDS after the barrier that ends the step) and scatter ONE STEP LATER, behind their
+  // GEMM -- off the critical path (first version: in front of the next step's gate backward, 18 k cycles with everyone else
+  // waiting at the barrier).  (The keeper / scatterer is k-range 1, see `scat` below.)
+  constexpr int KQ = NW / 2, GPQ = 4 / KQ;
+  float *xpart = dgs + (size_t)KGn * 256;  // [KQ - 1][2 e-tiles][16][64]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile = blockIdx.x, T = a.T;
@@ -94,49 +106,45 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd2_kernel(LstmBwd2Args a) {
   }
 
   const int KGl = min(KGg, (a.H + 7) / 8);  // live k-groups per gate (dG columns of padded units are exactly 0)
-  const int et = wn & 1, kq = wn >> 1;      // dX: this wave's e-tile and k-range
+  const int et = wn & 1, kq = wn >> 1;      // dX: this wave's e-tile and k-range (gates kq * GPQ .. + GPQ - 1)
   const bool elive = et * 32 < a.E;
-  float xsq = 0.0f;
-  // the dX epilogue of step t runs after the barrier that ends step t (the partial sums of the other k-ranges are in LDS then)
-  auto dx_epilogue = [&](int t, f32x16 &xacc) {
-    // sum of the k-ranges, fixed order
-#pragma unroll
-    for (int p = 0; p < KQ - 1; ++p)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) xacc[r] += xpart[((size_t)(p * 2 + et) * 16 + r) * 64 + lane];
-    // scatter-add into the dense embedding gradient (duplicate ids summed, as TF's sparse Adagrad does): lane = column e,
-    // register = row -- a register's 32 lanes are 128 contiguous bytes of one embedding row.  PAD (0) and EOS (1) fill most
-    // rows of a left-padded batch: their sums go to hot_part without atomics (dx_hot_reduce_kernel adds the blocks in fixed
-    // order).  sum(dx^2) is taken per OCCURRENCE (un-deduplicated IndexedSlices, sse_model.py:359-362).
-    // Everything through buffer descriptors (SGPR base + one lane offset + an SGPR per row): no 64-bit per-lane pointers
-    // (the launcher's caller keeps V * E * 4 < 2 GiB on this path: 32-bit offsets).
-    const int e = et * 32 + (lane & 31);
-    const bool ecol = e < a.E;
-    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.ids), 0, a.B * T * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc(a.d_emb, 0, a.V * a.E * 4, 0x00020000);
-    const int row0 = tile * 32 + 4 * (lane >> 5);  // rows beyond B fall outside the descriptor: the load returns 0, masked below
-    float h0 = 0.0f, h1 = 0.0f;
+  // the scatter falls to the waves of k-range 1 (waves 2 / 3): measured, they leave the MFMA loops ~14 k cycles before waves
+  // 0 / 1 and their SIMD partners, so the ~6 k cycles of the scatter stay off the step's critical path
+  const bool scat = kq == 1 && elive;       // this wave scatters e-tile et
+  // dX_t leaves the kernel as plain rows (during step t-1: own partial from registers + the other k-ranges' from LDS, fixed
+  // order; lane = column e, register = row: 128 contiguous bytes per register and row half) and dx_scatter_kernel adds them
+  // into the embedding gradient afterwards.  First version: buffer atomics from here -- agent-scope float atomics complete
+  // slowly, and the in-order vmcnt of the wave that issued them then held back its tape and weight loads (its MFMA loop
+  // ran 16 k cycles longer than its neighbours').
+  auto dx_store = [&](int t, const f32x16 &own) {
+    const float *xp = xpart + ((size_t)et * 16) * 64 + lane;
+    float *dst = a.dx + ((size_t)t * a.NT32 + tile) * 32 * 64 + et * 32 + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int dr = (r & 3) + 8 * (r >> 2);  // mfma_row(r, lane) - 4 * (lane >> 5)
-      int id = __builtin_amdgcn_raw_buffer_load_b32(irs, row0 * T * 4, (dr * T + t) * 4, 0);
-      if (row0 + dr >= a.B || id < 0 || id >= a.V) id = -1;  // out-of-range ids were flagged by the forward pass
-      const float v = xacc[r];
-      if (id >= 0 && ecol) xsq += v * v;
-      h0 += (id == 0) ? v : 0.0f;
-      h1 += (id == 1) ? v : 0.0f;
-      if (id >= 2 && ecol) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, ers, (id * a.E + e) * 4, 0, 0);
-    }
-    h0 += __shfl_xor(h0, 32);
-    h1 += __shfl_xor(h1, 32);
-    if (lane < 32) {
-      float *hp = a.hot_part + ((size_t)(t * a.NT32 + tile) * 2) * 64 + e;
-      hp[0] = h0;
-      hp[64] = h1;
+      float v = own[r];
+#pragma unroll
+      for (int p = 0; p < KQ - 1; ++p) v += xp[((size_t)p * 2 * 16 + r) * 64];
+      dst[mfma_row(r, lane) * 64] = v;
     }
   };
 
-  f32x16 xacc;
+  // division-free walk over the live k-groups: (gate base, group in gate), wrapping from the last gate to the first
+  struct Walk {
+    int l, base;
+  };
+  auto adv = [&](Walk &w) {
+    const int l1 = w.l + 1;
+    const bool wrap = l1 == KGl;
+    const int b1 = w.base + KGg;
+    w.base = wrap ? (b1 == 4 * KGg ? 0 : b1) : w.base;
+    w.l = wrap ? 0 : l1;
+  };
+  const int NL = 4 * KGl;    // live k-groups of the recurrent GEMM: a multiple of 4
+  const int NA = GPQ * KGl;  // ... of which the first NA (this wave's own gates: the walk starts there) also feed its dX partial
+  const bool fused = (NA & (B2_PFV - 1)) == 0 && (NL & (B2_PFV - 1)) == 0;  // rings of 8 k-groups; other cell sizes take the plain loops (rings of 4)
+  const int g0 = kq * GPQ * KGg;
+
+  f32x16 xacc, xprev;
   B2_CLK_DECL
   for (int t = T - 1; t >= 0; --t) {
     // ---- elementwise gate backward: 16-byte pieces into the LDS operand tile, their quad transposes to dg_b
@@ -176,42 +184,88 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd2_kernel(LstmBwd2Args a) {
     __syncthreads();
     B2_CLK(1)
 
-    // ---- recurrent GEMM: dh_{t-1}[j][b] = sum_n Kh[j][n] dG[b][n]   (A = Kh^T fragments from L2, B = the LDS tile)
+    const bool scatter_now = scat && t < T - 1;  // dX of step t+1: own partial in xprev, the others' parked in LDS
+
+    // ---- recurrent GEMM dh_{t-1}[j][b] = sum_n Kh[j][n] dG[b][n] (A = Kh^T fragments from L2, B = the LDS tile) and, over this
+    // wave's own gates, dX_t[b][e] += sum_n dG[b][n] Kx[e][n] (A = the SAME tile fragment: lane = column e, register = row,
+    // the layout the scatter wants; B = Kx^T fragments from L2)
     int lg = lane;
     asm volatile("" : "+v"(lg));  // opaque copy: the addresses below are recomputed per step (register pressure)
     const float *la = dgs + lg * 4;
-    struct Walk {
-      int l, base;
-    };
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.KhT) + (size_t)wn * KGn * 256, 0, KGn * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.KxT) + (size_t)et * KGn * 256, 0, KGn * 1024, 0x00020000);
+    auto kld = [&](int kg) -> f32x4 { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, lg * 16, kg * 1024, 0)); };
+    auto xld = [&](int kg) -> f32x4 { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, lg * 16, kg * 1024, 0)); };
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xacc[r] = 0.0f;
     if (t > 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) dh[r] = 0.0f;
-      const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.KhT) + (size_t)wn * KGn * 256, 0, KGn * 1024, 0x00020000);
-      auto kld = [&](int kg) -> f32x4 { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, lg * 16, kg * 1024, 0)); };
-      // 4 gates x KGl live k-groups (NL = 4 KGl is a multiple of PF), division-free walk, fixed order for every tile
-      constexpr int PF = 4;
-      f32x4 bq[PF], aq[2];
-      const int NL = 4 * KGl;
-      auto adv = [&](Walk &w) {
-        const int l1 = w.l + 1;
-        const bool wrap = l1 == KGl;
-        const int b1 = w.base + KGg;
-        w.base = wrap ? (b1 == 4 * KGg ? 0 : b1) : w.base;
-        w.l = wrap ? 0 : l1;
-      };
-      Walk wb{0, 0}, wa{0, 0};
-#pragma unroll
-      for (int p = 0; p < PF; ++p) {
-        bq[p] = kld(wb.base + wb.l);
-        adv(wb);
-      }
-      aq[0] = *reinterpret_cast<const f32x4 *>(la);
-      adv(wa);
-      __builtin_amdgcn_s_setprio(1);
-      for (int kg = 0; kg < NL; kg += PF) {
+    }
+    // (the last step, t = 0, still runs the loops for its dX partial; its dh is not used)
+    // PF = k-groups of weights in flight per ring (L2).  A wave whose SIMD partner is in another phase has only its own ring to
+    // cover the L2 latency: 4 groups (1 k cycles of MFMAs) were not enough -- the wave that lost the arbitration while both
+    // were in the loop then finished its remainder at half rate.  8 where the group counts allow it.
+    auto mfma_loops = [&](auto pf_tag, bool dxl) {
+      constexpr int PF = decltype(pf_tag)::value;
+      f32x4 bq[PF], xb[PF], aq[2];
+      Walk wb{0, g0}, wa{0, g0}, xw{0, g0};
+      if (dxl) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-          aq[(p + 1) & 1] = *reinterpret_cast<const f32x4 *>(la + (wa.base + wa.l) * 256);  // (wraps to group 0 past the end: unused)
+          bq[p] = kld(wb.base + wb.l);
+          adv(wb);
+          __builtin_amdgcn_sched_barrier(0);
+#if B2_INTERLEAVE
+          xb[p] = xld(xw.base + xw.l);
+          adv(xw);
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+#if !B2_INTERLEAVE
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+          xb[p] = xld(xw.base + xw.l);
+          adv(xw);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+      } else {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+          bq[p] = kld(wb.base + wb.l);
+          adv(wb);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      aq[0] = *reinterpret_cast<const f32x4 *>(la + (wa.base + wa.l) * 256);
+      adv(wa);
+      __builtin_amdgcn_s_setprio(1);
+      int kg = 0;
+      if (dxl) {
+        for (; kg < NA; kg += PF) {
+#pragma unroll
+          for (int p = 0; p < PF; ++p) {
+            aq[(p + 1) & 1] = *reinterpret_cast<const f32x4 *>(la + (wa.base + wa.l) * 256);
+            adv(wa);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              dh = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[p][e], aq[p & 1][e], dh, 0, 0, 0);
+              xacc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[p & 1][e], xb[p][e], xacc, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            bq[p] = kld(wb.base + wb.l);
+            adv(wb);
+            xb[p] = xld(xw.base + xw.l);  // (past the own gates the ring walks on into valid, unused fragments)
+            adv(xw);
+          }
+        }
+      }
+      for (; kg < NL; kg += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+          aq[(p + 1) & 1] = *reinterpret_cast<const f32x4 *>(la + (wa.base + wa.l) * 256);  // (wraps past the end: unused)
           adv(wa);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -222,57 +276,24 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd2_kernel(LstmBwd2Args a) {
         }
       }
       __builtin_amdgcn_s_setprio(0);
-    }
-    B2_CLK(2)
-
-    // ---- dX_t[b][e] = sum_n dG[b][n] Kx[e][n]: this wave's e-tile over its gates' live k-groups (A = the LDS tile: lane =
-    // column e, register = row, the layout the scatter wants)
+    };
+    if (fused) {
+      mfma_loops(std::integral_constant<int, B2_PFV>{}, elive);
+    } else {
+      mfma_loops(std::integral_constant<int, 4>{}, false);
+      if (elive) {  // plain dX loop for the odd shapes (no operand ring: rare, small cells)
+        Walk w{0, g0};
+        for (int i = 0; i < NA; ++i) {
+          const f32x4 av = *reinterpret_cast<const f32x4 *>(la + (w.base + w.l) * 256);
+          const f32x4 bv = xld(w.base + w.l);
+          adv(w);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) xacc[r] = 0.0f;
-    if (elive) {
-      const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.KxT) + (size_t)et * KGn * 256, 0, KGn * 1024, 0x00020000);
-      auto xld = [&](int kg) -> f32x4 { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, lg * 16, kg * 1024, 0)); };
-      constexpr int PX = 4;
-      f32x4 xb[PX], xa[2];
-      const int NX = GPQ * KGl;  // k-groups of this range
-      const int g0 = kq * GPQ * KGg;
-      auto advx = [&](Walk &w) {  // within the range: GPQ gates x KGl groups, wraps to its start
-        const int l1 = w.l + 1;
-        const bool wrap = l1 == KGl;
-        const int b1 = w.base + KGg;
-        w.base = wrap ? (b1 == g0 + GPQ * KGg ? g0 : b1) : w.base;
-        w.l = wrap ? 0 : l1;
-      };
-      Walk xwb{0, g0}, xwa{0, g0};
-#pragma unroll
-      for (int p = 0; p < PX; ++p) {
-        xb[p] = xld(xwb.base + xwb.l);
-        advx(xwb);
-      }
-      xa[0] = *reinterpret_cast<const f32x4 *>(la + (xwa.base + xwa.l) * 256);
-      advx(xwa);
-      for (int i0 = 0; i0 < NX; i0 += PX) {
-#pragma unroll
-        for (int p = 0; p < PX; ++p) {
-          xa[(p + 1) & 1] = *reinterpret_cast<const f32x4 *>(la + (xwa.base + xwa.l) * 256);
-          advx(xwa);
-          __builtin_amdgcn_sched_barrier(0);
-          if (i0 + p < NX) {  // (wave-uniform; NX is a multiple of PX except for tiny cells)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) xacc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[p & 1][e], xb[p][e], xacc, 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          xb[p] = xld(xwb.base + xwb.l);
-          advx(xwb);
+          for (int e = 0; e < 4; ++e) xacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], xacc, 0, 0, 0);
         }
       }
-      if (kq > 0) {
-        float *xp = xpart + ((size_t)((kq - 1) * 2 + et) * 16) * 64 + lane;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xp[r * 64] = xacc[r];
-      }
     }
-
+    B2_CLK(2)
+    if (scatter_now) dx_store(t + 1, xprev);
     B2_CLK(3)
     // ---- refill the tape registers for step t-1 (c_{t-1} is already here: it was this step's c_prev); unconditional (the
     // last step re-reads step 0 for nothing) so that the old values are not kept alive on a not-taken path
@@ -299,27 +320,80 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd2_kernel(LstmBwd2Args a) {
     B2_CLK(4)
     __syncthreads();
     B2_CLK(5)
-    if (kq == 0 && elive) dx_epilogue(t, xacc);
+    if (elive) {  // this step's partial: parked for the scatter wave (read after the next barrier), or kept
+      if (kq != 1) {
+        float *xp = xpart + ((size_t)((kq > 1 ? kq - 1 : 0) * 2 + et) * 16) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xp[r * 64] = xacc[r];
+      } else {
+        xprev = xacc;
+      }
+    }
     B2_CLK(6)
   }
 #ifdef SSE_BWD_CLOCK
   if (a.clk && tile == 0 && lane == 0)
     for (int i = 0; i < 8; ++i) a.clk[wn * 8 + i] = ck_[i];
 #endif
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) xsq += __shfl_xor(xsq, o);
-  if (lane == 0) a.sq_part[tile * NW + wn] = xsq;
+  __syncthreads();
+  if (scat) dx_store(0, xprev);  // dX of step 0
 }
 
+// ---------------------------------------------------------------------------
+// Scatter-add of the dX rows into the dense embedding gradient (duplicate ids summed, as TF's sparse Adagrad does): one wave
+// per (row, step), lane = column e.  PAD (0) and EOS (1) fill most rows of a left-padded batch: their rows are summed per
+// workgroup in LDS and go to hot_part without atomics (dx_hot_reduce_kernel adds the blocks in fixed order).  sum(dx^2) is
+// taken per OCCURRENCE (tf.global_norm sees the un-deduplicated IndexedSlices.values, sse_model.py:359-362) into sq_part.
+#define DXS_ROWS 16  // (row, step) pairs per 1024-thread workgroup
+__global__ __launch_bounds__(DXS_ROWS * 64) void dx_scatter_kernel(const float *__restrict__ dx, const int32_t *__restrict__ ids, int B,
+                                                                   int Bp, int T, int E, int V, float *__restrict__ d_emb,
+                                                                   float *__restrict__ sq_part, float *__restrict__ hot_part) {
+  __shared__ float hot[2][DXS_ROWS][64], sqs[DXS_ROWS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long item = (long long)blockIdx.x * DXS_ROWS + w;  // = t * Bp + row
+  const int t = (int)(item / Bp), row = (int)(item - (long long)t * Bp);
+  float v = 0.0f;
+  int id = -1;
+  if (t < T && row < B) {
+    id = ids[(size_t)row * T + t];
+    if (id < 0 || id >= V) id = -1;  // flagged by the forward pass
+    if (lane < E) v = dx[(size_t)item * 64 + lane];
+  }
+  if (id < 0) v = 0.0f;
+  hot[0][w][lane] = (id == 0) ? v : 0.0f;
+  hot[1][w][lane] = (id == 1) ? v : 0.0f;
+  float sq = v * v;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  if (lane == 0) sqs[w] = sq;
+  if (id >= 2 && lane < E) atomicAdd(d_emb + (size_t)id * E + lane, v);
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int hid = threadIdx.x >> 6;
+    float h = 0.0f;
+#pragma unroll
+    for (int i = 0; i < DXS_ROWS; ++i) h += hot[hid][i][lane];
+    hot_part[((size_t)blockIdx.x * 2 + hid) * 64 + lane] = h;
+  } else if (threadIdx.x == 128) {
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < DXS_ROWS; ++i) s += sqs[i];
+    sq_part[blockIdx.x] = s;
+  }
+}
+
+int dx_scatter_blocks(int T, int Bp) { return (int)(((long long)T * Bp + DXS_ROWS - 1) / DXS_ROWS); }
+
+
 size_t lstm_bwd2_lds_bytes(int Hp) {
-  const int NW = Hp / 32, KQ = NW / 2;
+  const int KQ = Hp / 64;  // k-ranges of the dX product = NW / 2
   return ((size_t)(Hp / 2) * 256 + (size_t)(KQ - 1) * 2 * 16 * 64) * sizeof(float);
 }
 
 hipError_t launch_lstm_bwd2(const float *tape_g, const float *dh_last, const float *KhT, const float *KxT, float *dg_b,
-                            const int32_t *ids, float *d_emb, float *sq_part, float *hot_part, int T, int NT32, int NT_tape,
-                            int Hp, int H, int B, int E, int V, hipStream_t st) {
-  LstmBwd2Args a{tape_g, dh_last, KhT, KxT, dg_b, ids, d_emb, sq_part, hot_part, T, NT32, NT_tape > 0 ? NT_tape : NT32, H, B, E, V, nullptr};
+                            float *dx, const int32_t *ids, float *d_emb, float *sq_part, float *hot_part, int T, int NT32,
+                            int NT_tape, int Hp, int H, int B, int E, int V, hipStream_t st) {
+  LstmBwd2Args a{tape_g, dh_last, KhT, KxT, dg_b, dx, T, NT32, NT_tape > 0 ? NT_tape : NT32, H, E, nullptr};
 #ifdef SSE_BWD_CLOCK
   static long long *clk_dev = nullptr;
   if (!clk_dev) (void)hipMalloc((void **)&clk_dev, 64 * sizeof(long long));
@@ -336,7 +410,7 @@ hipError_t launch_lstm_bwd2(const float *tape_g, const float *dh_last, const flo
       static int n = 0;
       if (n++ % 8 < 2)
         for (int w = 0; w < 8; w += 1)
-          fprintf(stderr, "[bwd2 clock] wave %d cycles/step: elementwise %lld | barrier1 %lld | gemm %lld | dX %lld | refill-issue %lld | barrier2 %lld | epilogue %lld\n",
+          fprintf(stderr, "[bwd2 clock] wave %d cycles/step: elementwise %lld | barrier1 %lld | gemm+dX %lld | dX store %lld | refill-issue %lld | barrier2 %lld | park %lld\n",
                   w, v[w * 8 + 0] / T, v[w * 8 + 1] / T, v[w * 8 + 2] / T, v[w * 8 + 3] / T, v[w * 8 + 4] / T, v[w * 8 + 5] / T, v[w * 8 + 6] / T);
     }
   } report{clk_dev, st, T};
@@ -350,5 +424,10 @@ hipError_t launch_lstm_bwd2(const float *tape_g, const float *dh_last, const flo
     hipLaunchKernelGGL(kern, dim3(NT32), dim3(threads), lds, st, a);
     return hipGetLastError();
   };
-  return Hp == 128 ? go(lstm_bwd2_kernel<4>, 256) : go(lstm_bwd2_kernel<8>, 512);
+  hipError_t e = Hp == 128 ? go(lstm_bwd2_kernel<4>, 256) : go(lstm_bwd2_kernel<8>, 512);
+  if (e != hipSuccess) return e;
+  const int Bp = NT32 * 32;
+  hipLaunchKernelGGL(dx_scatter_kernel, dim3(dx_scatter_blocks(T, Bp)), dim3(DXS_ROWS * 64), 0, st, dx, ids, B, Bp, T, E, V, d_emb, sq_part,
+                     hot_part);
+  return hipGetLastError();
 }

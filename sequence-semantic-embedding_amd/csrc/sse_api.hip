@@ -2084,7 +2084,8 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   // partial sums of dx^2 per side: one per (tile, wave) when dX comes out of the split-operand BPTT kernel, one per
   // (step, tile) from dx_kernel (+ one per target row in source-encoder-only mode)
   int sq_off[3] = {0, 0, 0};
-  for (int s = 0; s < nside; ++s) sq_off[s + 1] = sq_off[s] + ((bwd_x3[s] || bwd2) ? NT32 * (h->enc[s].Hp / 32) : T * NT32);
+  for (int s = 0; s < nside; ++s)
+    sq_off[s + 1] = sq_off[s] + (bwd2 ? dx_scatter_blocks(T, NT32 * 32) : bwd_x3[s] ? NT32 * (h->enc[s].Hp / 32) : T * NT32);
   const int n_sq = sq_off[nside] + (table_tgt ? B : 0);
   if (reserve(h, ts.sq_part, (size_t)n_sq * sizeof(float))) return 1;
   if (table_tgt) {
@@ -2106,7 +2107,8 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
     if (!shared || s == 0) HIPCHECK(h, hipStreamWaitEvent(bs, ts.ev_fork, 0));
     if (reserve(h, ts.dh_last[s], (size_t)Bp * Hp * sizeof(float))) return 1;
     if (!bwd_x3[s] && !bwd2 && reserve(h, ts.dg_a[s], (size_t)T * NT32 * KGn * 256 * sizeof(float))) return 1;
-    if (reserve(h, ts.hot_part[s], (size_t)T * NT32 * 2 * 2 * 64 * sizeof(float))) return 1;
+    if (reserve(h, ts.hot_part[s], (size_t)std::max(T * NT32 * 2, dx_scatter_blocks(T, NT32 * 32)) * 2 * 64 * sizeof(float))) return 1;
+    if (bwd2 && reserve(h, ts.dg_a[s], (size_t)T * NT32 * 32 * 64 * sizeof(float))) return 1;  // (second generation: the dX rows)
     BwdDxArgs bdx{ts.KxT16[s], (const int32_t *)ts.ids[s].p, emb.grad, (float *)ts.sq_part.p + sq_off[s], (float *)ts.hot_part[s].p,
                   B, E, V};
     if (reserve(h, ts.dg_b[s], (size_t)RG * NTn * 256 * sizeof(float))) return 1;
@@ -2117,12 +2119,13 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
                                 S, h->vars[e.proj].grad, (float *)ts.dh_last[s].p, (float *)ts.dm_part[s].p, bs));
     if (bwd2) {
       HIPCHECK(h, launch_lstm_bwd2((const float *)ts.tape_g[s].p, (const float *)ts.dh_last[s].p, ts.KhT[s], ts.KxT[s],
-                                   (float *)ts.dg_b[s].p, (const int32_t *)ts.ids[s].p, emb.grad, (float *)ts.sq_part.p + sq_off[s],
-                                   (float *)ts.hot_part[s].p, T, NT32, half ? NT_half : NT32, Hp, e.H, B, E, V, bs));
+                                   (float *)ts.dg_b[s].p, (float *)ts.dg_a[s].p, (const int32_t *)ts.ids[s].p, emb.grad,
+                                   (float *)ts.sq_part.p + sq_off[s], (float *)ts.hot_part[s].p, T, NT32, half ? NT_half : NT32, Hp,
+                                   e.H, B, E, V, bs));
       const int acc2 = (shared && s == 1) ? 1 : 0;
       HIPCHECK(h, launch_dk((const float *)ts.tape_a[s].p, (const float *)ts.dg_b[s].p, (float *)ts.dk_part[s].p, RGa, KT, NTn, SL,
                             E, e.H, Hp, acc2, h->vars[e.kernel].grad, half ? NT_half * 4 : 0, bs, h->vars[e.bias].grad));
-      HIPCHECK(h, launch_dx_hot_reduce((const float *)ts.hot_part[s].p, T * NT32, E, V, emb.grad, bs));
+      HIPCHECK(h, launch_dx_hot_reduce((const float *)ts.hot_part[s].p, dx_scatter_blocks(T, NT32 * 32), E, V, emb.grad, bs));
       if (!shared || s == 1) {
         HIPCHECK(h, hipEventRecord(ts.ev_join[s], bs));
         HIPCHECK(h, hipStreamWaitEvent(st, ts.ev_join[s], 0));

@@ -34,11 +34,13 @@ int dk_slices(int RG);
 hipError_t launch_dk(const float *tape_a, const float *dg_b, float *part, int RG, int KT, int NTn, int SL, int E, int H,
                      int Hp, int accumulate, float *dK, int pair_rg /* 0: dg_b has RG r-groups */, hipStream_t st,
                      float *db = nullptr /* non-null (E < 64): d(bias) from row E of the partials (A-tape with the constant-1 column) */);
-// fp32 BPTT, second generation (lstm_bwd2.hip): tape_g in the lane = sequence layout (LstmFwdArgs::tape_swap), dX formed
-// inside the kernel (hot rows to hot_part: launch_dx_hot_reduce afterwards; sq_part[NT32 * Hp/32]), dg_b for launch_dk,
-// no bias partials (launch_dk's db)
+// fp32 BPTT, second generation (lstm_bwd2.hip): tape_g in the lane = sequence layout (LstmFwdArgs::tape_swap); dX formed
+// inside the kernel, written as rows to dx [T][NT32*32][64] and scatter-added by dx_scatter_kernel (same launcher):
+// sq_part / hot_part hold dx_scatter_blocks(T, NT32*32) entries / [..][2][64] floats (launch_dx_hot_reduce(.., that many
+// blocks, ..) afterwards); dg_b for launch_dk; no bias partials (launch_dk's db)
+int dx_scatter_blocks(int T, int Bp);
 hipError_t launch_lstm_bwd2(const float *tape_g, const float *dh_last, const float *KhT, const float *KxT, float *dg_b,
-                            const int32_t *ids, float *d_emb, float *sq_part, float *hot_part, int T, int NT32,
+                            float *dx, const int32_t *ids, float *d_emb, float *sq_part, float *hot_part, int T, int NT32,
                             int NT_tape /* 0: NT32 */, int Hp, int H, int B, int E, int V, hipStream_t st);
 hipError_t launch_dk_x3(const void *tape_a, const void *dg_b, float *part, int G, int KT, int NTn, int SL, int E, int H,
                         int Hp, int accumulate, float *dK, int pair_g, hipStream_t st);
