@@ -59,7 +59,9 @@ struct LstmBwd2Args {
 #define BWD2_NT 2  // cache policy of the tape loads: nt (streamed once)
 #endif
 
-template <int NW>
+// LIN: every hidden unit is live (H == Hp): the live k-groups are 0 .. 4 KGg - 1 and the walk is one masked increment (the
+// general (gate base, group in gate) walk costs ~7 scalar instructions per step and walk: 6 % of the kernel at H = 256).
+template <int NW, bool LIN>
 __global__ __launch_bounds__(NW * 64) void lstm_bwd2_kernel(LstmBwd2Args a) {
   extern __shared__ __attribute__((aligned(16))) float dgs[];  // [KGn][256] dG tile, frag32(rows = b, red = n); then the dX partials
   constexpr int Hp = 32 * NW, KGn = Hp / 2, KGg = Hp / 8, NTn = Hp / 8;
@@ -133,6 +135,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd2_kernel(LstmBwd2Args a) {
     int l, base;
   };
   auto adv = [&](Walk &w) {
+    if constexpr (LIN) {
+      w.base = (w.base + 1) & (4 * KGg - 1);  // (l stays 0)
+      return;
+    }
     const int l1 = w.l + 1;
     const bool wrap = l1 == KGl;
     const int b1 = w.base + KGg;
@@ -175,7 +181,11 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd2_kernel(LstmBwd2Args a) {
           *reinterpret_cast<f32x4 *>(ls + (size_t)(g * KGg + q4) * 256) = g4[g];  // n = g Hp + 32 wn + 8 q4 + 4 half + e
           f32x4 tr = g4[g];
           sse_quad_transpose(tr, lane);  // -> rows (b & ~3) .. +3 of column n = g Hp + 32 wn + 8 q4 + 4 half + (b & 3)
+#ifndef B2_NOSTORE  // (measurement builds: what the dG stream costs the loops behind it)
           *reinterpret_cast<f32x4 *>(gb + (size_t)(g * (Hp / 32)) * 256 + q4 * 32) = tr;
+#else
+          if (a.H < 0) *reinterpret_cast<f32x4 *>(gb + (size_t)(g * (Hp / 32)) * 256 + q4 * 32) = tr;
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);  // bound the interleaving to one quarter (register pressure)
       }
@@ -424,7 +434,9 @@ hipError_t launch_lstm_bwd2(const float *tape_g, const float *dh_last, const flo
     hipLaunchKernelGGL(kern, dim3(NT32), dim3(threads), lds, st, a);
     return hipGetLastError();
   };
-  hipError_t e = Hp == 128 ? go(lstm_bwd2_kernel<4>, 256) : go(lstm_bwd2_kernel<8>, 512);
+  const bool lin = H == Hp;
+  hipError_t e = Hp == 128 ? (lin ? go(lstm_bwd2_kernel<4, true>, 256) : go(lstm_bwd2_kernel<4, false>, 256))
+                           : (lin ? go(lstm_bwd2_kernel<8, true>, 512) : go(lstm_bwd2_kernel<8, false>, 512));
   if (e != hipSuccess) return e;
   const int Bp = NT32 * 32;
   hipLaunchKernelGGL(dx_scatter_kernel, dim3(dx_scatter_blocks(T, Bp)), dim3(DXS_ROWS * 64), 0, st, dx, ids, B, Bp, T, E, V, d_emb, sq_part,

@@ -1884,7 +1884,10 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   // step needs the projections, Kh^T / Kx^T in split form and -- below -- the split kernel matrix and embedding table;
   // the fp32 fragment copies wait for the next encode or fp32 step: 7 fewer launches on the critical path of a step)
   if (all_x3 ? ensure_proj_packed(h, st) : ensure_packed(h, st)) return 1;
-  if (ts.packed_dirty || (!all_x3 && ts.fp32_dirty)) {
+  bool any_bwd_x3 = false;
+  for (int s = 0; s < nside; ++s) any_bwd_x3 = any_bwd_x3 || bwd_x3[s];
+  // (the split Kh^T / Kx^T copies are only rebuilt by steps that run the split-operand BPTT: a pure fp32 step leaves them stale)
+  if ((any_bwd_x3 && ts.packed_dirty) || (!all_x3 && ts.fp32_dirty)) {
     for (int s = 0; s < nside; ++s) {
       Encoder &e = h->enc[s];
       if (e.shares_lstm_with >= 0) {
@@ -1894,7 +1897,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
         ts.KxT16[s] = ts.KxT16[e.shares_lstm_with];
         continue;
       }
-      if (ts.packed_dirty) {
+      if (any_bwd_x3 && ts.packed_dirty) {
         if (!ts.KhT16[s]) HIPCHECK(h, hipMalloc((void **)&ts.KhT16[s], kT16_elems(e.Hp) * sizeof(unsigned short)));
         HIPCHECK(h, launch_pack_kT16(h->vars[e.kernel].dev, E, e.H, e.Hp, ts.KhT16[s], st));
         if (!ts.KxT16[s]) HIPCHECK(h, hipMalloc((void **)&ts.KxT16[s], kxT16_elems(e.Hp) * sizeof(unsigned short)));
@@ -1908,7 +1911,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
       }
     }
     if (!all_x3) ts.fp32_dirty = false;
-    ts.packed_dirty = false;
+    if (any_bwd_x3) ts.packed_dirty = false;
   }
   if (E > 64) return fail(h, "train step: embedding_size %d > 64 not supported yet", E);
   for (int s = 0; s < nside; ++s)
