@@ -14,6 +14,7 @@
 //   dg_b    the same values as frag32(rows = n, red = r): B operand of
 //           dK = A^T . dG
 #include <cstdio>
+#include <cstdlib>
 
 #include "train.h"
 
@@ -930,6 +931,235 @@ __global__ __launch_bounds__(512) void dk_gemm_kernel(DkArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// dk_gemm_kernel with TWO r-groups per barrier: four LDS stages (two in use, two being filled), the operands of a pair of
+// r-groups requested one pair ahead.  Half the barriers: after every barrier the matrix pipe waits for the first A fragment
+// to come back from LDS and for the slowest of the 8 waves (clock64: ~8 % of the kernel with one r-group per barrier).
+template <int KT, bool PAIR>
+__global__ __launch_bounds__(512) void dk_gemm2_kernel(DkArgs a) {
+  __shared__ __attribute__((aligned(16))) float stage[4][KT][256];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t live_k = a.live_k;
+  int ngrp, slice;
+  dk_block_map(ngrp, slice);
+  const int nt = min(ngrp * 8 + w, a.NTn - 1);
+  const bool live = ngrp * 8 + w < a.NTn;
+  const int per = ((a.RG + a.SL - 1) / a.SL + 1) & ~1;  // even (see dk_gemm_kernel): every slice is a whole number of pairs
+  const int rg0 = slice * per, rg1 = min(a.RG, rg0 + per);
+  f32x16 acc[KT];
+#pragma unroll
+  for (int i = 0; i < KT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  const float *pa = a.tape_a + lane * 4;
+  const float *pb = a.dg_b + (size_t)nt * 256 + lane * 4;
+  const int pair_rg = a.pair_rg;
+  auto gload_b = [&](int rg) -> f32x4 {
+    if constexpr (!PAIR) return *reinterpret_cast<const f32x4 *>(pb + (size_t)rg * a.NTn * 256);
+    const int t = rg / pair_rg, d1 = rg + t * pair_rg;
+    const f32x4 u = *reinterpret_cast<const f32x4 *>(pb + (size_t)d1 * a.NTn * 256);
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(pb + (size_t)(d1 + pair_rg) * a.NTn * 256);
+    return u + v;
+  };
+  constexpr bool TWO = KT > 8;
+  const bool second = TWO && (8 + w < KT);
+  struct Set {
+    f32x4 s0[2], s1[2], b[2];
+  };
+  auto gload = [&](int rg, Set &x) {  // operands of r-groups rg, rg + 1 (rg even relative to rg0; rg + 1 < rg1 by construction)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (w < KT) x.s0[j] = *reinterpret_cast<const f32x4 *>(pa + ((size_t)(rg + j) * KT + w) * 256);
+      if (second) x.s1[j] = *reinterpret_cast<const f32x4 *>(pa + ((size_t)(rg + j) * KT + 8 + w) * 256);
+      x.b[j] = gload_b(rg + j);
+    }
+  };
+  auto stash = [&](int buf, const Set &x) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (w < KT) *reinterpret_cast<f32x4 *>(&stage[buf * 2 + j][w][lane * 4]) = x.s0[j];
+      if (second) *reinterpret_cast<f32x4 *>(&stage[buf * 2 + j][8 + w][lane * 4]) = x.s1[j];
+    }
+  };
+  auto compute = [&](int st, const f32x4 &bc) {
+    const float *sa = &stage[st][0][lane * 4];
+    f32x4 ax = *reinterpret_cast<const f32x4 *>(sa), ay;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < KT; i += 2) {
+      if (i + 1 < KT) ay = *reinterpret_cast<const f32x4 *>(sa + (i + 1) * 256);
+      __builtin_amdgcn_sched_barrier(0);
+      if ((live_k >> i) & 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bc[e], acc[i], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 2 < KT) ax = *reinterpret_cast<const f32x4 *>(sa + (i + 2) * 256);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 1 < KT && ((live_k >> (i + 1)) & 1)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[e], bc[e], acc[i + 1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  if (rg0 < rg1) {  // (rg1 - rg0 is even: `per` and RG are)
+    auto clampr = [&](int rg) { return rg < rg1 ? rg : rg1 - 2; };
+    Set x, y;
+    f32x4 bc[2];
+    x.s1[0] = x.s1[1] = y.s1[0] = y.s1[1] = f32x4{0, 0, 0, 0};
+    gload(rg0, x);
+    stash(0, x);
+    bc[0] = x.b[0];
+    bc[1] = x.b[1];
+    gload(clampr(rg0 + 2), x);
+    gload(clampr(rg0 + 4), y);
+    __syncthreads();
+    for (int rg = rg0; rg < rg1; rg += 4) {
+      // even pair: stages 0, 1 hold r-groups rg, rg + 1; set X holds rg + 2, rg + 3 (to stages 2, 3), then refetches rg + 6, rg + 7
+      compute(0, bc[0]);
+      compute(1, bc[1]);
+      if (rg + 2 < rg1) stash(1, x);
+      bc[0] = x.b[0];
+      bc[1] = x.b[1];
+      gload(clampr(rg + 6), x);
+      __syncthreads();
+      if (rg + 2 >= rg1) break;
+      // odd pair: stages 2, 3 hold rg + 2, rg + 3; set Y holds rg + 4, rg + 5 (to stages 0, 1), then refetches rg + 8, rg + 9
+      compute(2, bc[0]);
+      compute(3, bc[1]);
+      if (rg + 4 < rg1) stash(0, y);
+      bc[0] = y.b[0];
+      bc[1] = y.b[1];
+      gload(clampr(rg + 8), y);
+      __syncthreads();
+    }
+  }
+  if (!live) return;
+  const int ldn = a.NTn * 32;
+  float *out = a.part + (size_t)slice * KT * 32 * ldn;
+#pragma unroll
+  for (int i = 0; i < KT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(size_t)(i * 32 + mfma_row(r, lane)) * ldn + nt * 32 + (lane & 31)] = acc[i][r];
+}
+
+// ---------------------------------------------------------------------------
+// dK partials, third structure: the A-tape blocks go global -> LDS by LDS-DMA (global_load_lds_dwordx4: a frag32 block IS the
+// lane-linear 1 KiB image the DMA writes), so the stage costs no registers and no ds_write pass and can be G = 4 r-groups
+// deep: ONE barrier per 4 r-groups (160 MFMAs per wave).  Two halves of the stage alternate; the DMA of the next set and
+// the next set's dG fragments (registers) are issued right after the barrier and waited for (vmcnt(0), ~20 k cycles later)
+// in front of the next one.  Raw s_barrier: __syncthreads() would drain the DMA queue at once (cdna_hip_programming.md).
+// Measured at 8192 x 32 rows, H = 256: one r-group per barrier 1.54 ms, two 1.43 ms, this kernel: see profiles/r04_notes.txt.
+template <int KT, bool PAIR>
+__global__ __launch_bounds__(512) void dk_gemm3_kernel(DkArgs a) {
+  constexpr int G = 4;
+  // [2][G][KT][256] floats, dynamic: the only writer of this array is the DMA engine, and a static __shared__ array without a
+  // visible store let the compiler fold every read of it (and with them the whole GEMM) to undef
+  extern __shared__ __attribute__((aligned(16))) float dk_stage[];
+  auto stg = [&](int buf, int g, int kt) -> float * { return dk_stage + (size_t)((buf * G + g) * KT + kt) * 256; };
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t live_k = a.live_k;
+  int ngrp, slice;
+  dk_block_map(ngrp, slice);
+  const int nt = min(ngrp * 8 + w, a.NTn - 1);
+  const bool live = ngrp * 8 + w < a.NTn;
+  const int per = ((a.RG + a.SL - 1) / a.SL + 1) & ~1;
+  const int rg0 = slice * per, rg1 = min(a.RG, rg0 + per);
+  f32x16 acc[KT];
+#pragma unroll
+  for (int i = 0; i < KT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  const float *pa = a.tape_a + lane * 4;
+  const float *pb = a.dg_b + (size_t)nt * 256 + lane * 4;
+  const int pair_rg = a.pair_rg;
+  auto gload_b = [&](int rg) -> f32x4 {
+    if constexpr (!PAIR) return *reinterpret_cast<const f32x4 *>(pb + (size_t)rg * a.NTn * 256);
+    const int t = rg / pair_rg, d1 = rg + t * pair_rg;
+    const f32x4 u = *reinterpret_cast<const f32x4 *>(pb + (size_t)d1 * a.NTn * 256);
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(pb + (size_t)(d1 + pair_rg) * a.NTn * 256);
+    return u + v;
+  };
+  // the G * KT blocks of a set, dealt to the 8 waves (5 each at KT = 10, 3 at KT = 6); r-groups past the slice are clamped
+  // (their products are skipped below)
+  constexpr int NB = G * KT, PER_W = (NB + 7) / 8;
+  auto dma = [&](int buf, int rg) {
+#pragma unroll
+    for (int j = 0; j < PER_W; ++j) {
+      const int blk = w + 8 * j;
+      if (blk < NB) {
+        const int g = blk / KT, kt = blk - g * KT;
+        const int rgc = min(rg + g, rg1 - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pa + ((size_t)rgc * KT + kt) * 256),
+                                         (__attribute__((address_space(3))) void *)stg(buf, g, kt), 16, 0, 0);
+      }
+    }
+  };
+  auto compute = [&](int buf, int g, const f32x4 &bc) {
+    const float *sa = stg(buf, g, 0) + lane * 4;
+    f32x4 ax = *reinterpret_cast<const f32x4 *>(sa), ay;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < KT; i += 2) {
+      if (i + 1 < KT) ay = *reinterpret_cast<const f32x4 *>(sa + (i + 1) * 256);
+      __builtin_amdgcn_sched_barrier(0);
+      if ((live_k >> i) & 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[e], bc[e], acc[i], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 2 < KT) ax = *reinterpret_cast<const f32x4 *>(sa + (i + 2) * 256);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 1 < KT && ((live_k >> (i + 1)) & 1)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[e], bc[e], acc[i + 1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // every wave waits for ITS loads (the DMA pieces it issued and its dG fragments), then the barrier publishes the stage.
+  // The fragments pass through the asm as outputs: the compiler then treats them as ready and puts no wait of its own in
+  // front of their first use (with a DMA in flight that wait would be vmcnt(0) at the top of the compute phase)
+  auto land_and_sync = [&](f32x4 (&bn)[G]) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3])::"memory");
+  };
+  if (rg0 < rg1) {
+    f32x4 bc[G], bn[G];
+    auto clampr = [&](int rg) { return rg < rg1 ? rg : rg1 - 1; };
+#pragma unroll
+    for (int g = 0; g < G; ++g) bn[g] = gload_b(clampr(rg0 + g));
+    dma(0, rg0);
+    land_and_sync(bn);
+    int buf = 0;
+    for (int rg = rg0; rg < rg1; rg += G) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) bc[g] = bn[g];
+      if (rg + G < rg1) {  // next set: dG fragments first (plain loads), then the DMA pieces into the other half of the stage
+#pragma unroll
+        for (int g = 0; g < G; ++g) bn[g] = gload_b(clampr(rg + G + g));
+        dma(buf ^ 1, rg + G);
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        if (rg + g < rg1) compute(buf, g, bc[g]);
+      land_and_sync(bn);
+      buf ^= 1;
+    }
+  }
+  if (!live) return;
+  const int ldn = a.NTn * 32;
+  float *out = a.part + (size_t)slice * KT * 32 * ldn;
+#pragma unroll
+  for (int i = 0; i < KT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(size_t)(i * 32 + mfma_row(r, lane)) * ldn + nt * 32 + (lane & 31)] = acc[i][r];
+}
+
+// ---------------------------------------------------------------------------
 // The same dK partials on the bf16 matrix pipe with split operands (see sse_kernels.h): tape_a and dG arrive as hi / lo
 // frag16 blocks (written that way by the forward and BPTT kernels: 16 reduction rows per block, same bytes as fp32), a
 // product costs three v_mfma_f32_32x32x16_bf16 (32 cycles each, 16 r) instead of eight v_mfma_f32_32x32x2_f32 (64 cycles).
@@ -1536,11 +1766,31 @@ hipError_t launch_dk(const float *tape_a, const float *dg_b, float *part, int RG
   }
   DkArgs a{tape_a, dg_b, part, RG, KT, NTn, SL, live, pair_rg};
   const dim3 grid((NTn + 7) / 8, SL);
-  if (KT == 10 && pair_rg) hipLaunchKernelGGL((dk_gemm_kernel<10, true>), grid, dim3(512), 0, st, a);
-  else if (KT == 10) hipLaunchKernelGGL((dk_gemm_kernel<10, false>), grid, dim3(512), 0, st, a);
-  else if (KT == 6 && pair_rg) hipLaunchKernelGGL((dk_gemm_kernel<6, true>), grid, dim3(512), 0, st, a);
-  else if (KT == 6) hipLaunchKernelGGL((dk_gemm_kernel<6, false>), grid, dim3(512), 0, st, a);
-  else return hipErrorInvalidValue;
+  static const bool one = getenv("SSE_DK_ONE") != nullptr;  // measurement aid: one r-group per barrier (the round-1 kernel)
+  if (one) {
+    if (KT == 10 && pair_rg) hipLaunchKernelGGL((dk_gemm_kernel<10, true>), grid, dim3(512), 0, st, a);
+    else if (KT == 10) hipLaunchKernelGGL((dk_gemm_kernel<10, false>), grid, dim3(512), 0, st, a);
+    else if (KT == 6 && pair_rg) hipLaunchKernelGGL((dk_gemm_kernel<6, true>), grid, dim3(512), 0, st, a);
+    else if (KT == 6) hipLaunchKernelGGL((dk_gemm_kernel<6, false>), grid, dim3(512), 0, st, a);
+    else return hipErrorInvalidValue;
+  } else if (!pair_rg && getenv("SSE_DK_TWO") == nullptr) {  // (pairs: the two-r-group kernel measured 0.76 against 0.78 ms)
+    const int lds3 = 2 * 4 * KT * 1024;
+    auto go3 = [&](auto kern) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+      hipLaunchKernelGGL(kern, grid, dim3(512), lds3, st, a);
+    };
+    if (KT == 10 && pair_rg) go3(dk_gemm3_kernel<10, true>);
+    else if (KT == 10) go3(dk_gemm3_kernel<10, false>);
+    else if (KT == 6 && pair_rg) go3(dk_gemm3_kernel<6, true>);
+    else if (KT == 6) go3(dk_gemm3_kernel<6, false>);
+    else return hipErrorInvalidValue;
+  } else {
+    if (KT == 10 && pair_rg) hipLaunchKernelGGL((dk_gemm2_kernel<10, true>), grid, dim3(512), 0, st, a);
+    else if (KT == 10) hipLaunchKernelGGL((dk_gemm2_kernel<10, false>), grid, dim3(512), 0, st, a);
+    else if (KT == 6 && pair_rg) hipLaunchKernelGGL((dk_gemm2_kernel<6, true>), grid, dim3(512), 0, st, a);
+    else if (KT == 6) hipLaunchKernelGGL((dk_gemm2_kernel<6, false>), grid, dim3(512), 0, st, a);
+    else return hipErrorInvalidValue;
+  }
   hipLaunchKernelGGL(dk_reduce_kernel, dim3(((E + H + (db ? 1 : 0)) * 4 * H + 255) / 256), dim3(256), 0, st, part, SL, KT, NTn, E, H, Hp,
                      accumulate, dK, db);
   return hipGetLastError();
