@@ -97,6 +97,36 @@ def _cpu_lstm(batch, seed=0):
     return run, (p, cfg, ids)
 
 
+def busy_of(*prefixes):
+    """PMC MFMA-busy shares (profiles/pmc_summary.json) of the kernels whose names start with one of the prefixes."""
+    b = PMC.get("mfma_busy", {})
+    return {k: v for k, v in b.items() if k.startswith(tuple(prefixes))} or None
+
+
+def usable_cores():
+    """Hardware threads this process may actually use: os.cpu_count() capped by the scheduler affinity and by the cgroup CPU
+    quota (a container on a 256-thread host is often limited to a few cores: replicas beyond the quota only thrash)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def cpu_replica_worker(batch, threads, t_start, budget_s):
     """One of the R CPU replicas of cpu_baseline (python bench.py --cpu-worker ...): `threads` torch threads, `batch`
     rows per call, timed from the common wall-clock instant t_start for budget_s seconds; prints 'rows seconds'."""
@@ -123,7 +153,8 @@ def cpu_baseline(batch=1024, budget_s=12.0):
     import numpy as np
     import torch
     from oracle import sse_oracle as O
-    cores = os.cpu_count() or 1
+    host_threads = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     run, (p, cfg, ids) = _cpu_lstm(batch)
     rng = np.random.RandomState(0)
@@ -196,7 +227,7 @@ def cpu_baseline(batch=1024, budget_s=12.0):
     best = max(single, agg_rate)
     return {"value": round(best, 1), "unit": "seqs/s",
             "cores": (R - late) * thr if agg_rate >= single else (best_threads if th_rate >= np_rate else cores),
-            "host_cores": cores,
+            "host_cores": host_threads, "usable_cores": cores,
             "kind": "port",
             "sample": "LSTM source encoder fwd (T=32,E=50,H=S=256): %d replicas (processes) x %d torch threads, %d rows per call "
                       "each (the GPU step's 16384 rows spread over the host), common %.0f s window: %.0f seq/s aggregate; one "
@@ -281,19 +312,18 @@ def cnn_leg(sse_amd, torch, np, dev, rows=16384, train_iters=5):
     ms16 = _events_ms(h, lambda: h.encode_dev(0, ids.data_ptr(), rows, CNN_T, True, enc.data_ptr()), 10)
     cos = torch.sum(enc[:2048] * ref, dim=1).min().item()
     h.set_option("cnn_bf16", 0)
-    busy = PMC.get("mfma_busy", {})
     tf32 = rows * CNN_FLOP_PER_SEQ / (ms32 * 1e-3) / 1e12
     tf16 = rows * CNN_FLOP_PER_SEQ / (ms16 * 1e-3) / 1e12
     leg["encode_fp32"] = {"encode_ms": ms32, "seqs_per_s": rows / (ms32 * 1e-3),
                           "roofline": {"kernel": "conv_pool_kernel + proj_norm_kernel", "bound": "mfma", "unit": "TFLOP/s",
                                        "achieved": tf32, "peak": PEAK_F32_MFMA_TFLOPS, "frac": tf32 / PEAK_F32_MFMA_TFLOPS,
-                                       "mfma_busy": busy.get("conv_pool_kernel")}}
+                                       "mfma_busy": busy_of("conv_pool_kernel")}}
     leg["encode_bf16"] = {"encode_ms": ms16, "seqs_per_s": rows / (ms16 * 1e-3), "min_cosine_vs_fp32_encode": cos,
                           "arithmetic": "embeddings / filters rounded to bf16, v_mfma_f32_32x32x16_bf16, fp32 accumulate; bias, ReLU, "
                                         "max-pool, projection, l2-normalise in fp32",
                           "roofline": {"kernel": "conv_pool_bf16_kernel + proj_norm_kernel", "bound": "mfma", "unit": "TFLOP/s",
                                        "achieved": tf16, "peak": 2500.0, "frac": tf16 / 2500.0,
-                                       "mfma_busy": busy.get("conv_pool_bf16_kernel")}}
+                                       "mfma_busy": busy_of("conv_pool_bf16_kernel")}}
     rng = np.random.RandomState(3)
     leg["train"] = {}
     for bf in (0, 1):
@@ -671,7 +701,6 @@ def main():
         dxf = 2 * Bt * T * 2 * 4 * H * E
         dkf = (Bt + Bt // 2) * T * 2 * (E + H) * 4 * H
         executed = float(fwd + rec + dxf + dkf)
-        busy = PMC.get("mfma_busy", {})
         training = {"pair_rows_per_s": Bt * world / tdt, "ms_per_step": tdt * 1e3, "pair_rows_per_gpu": Bt,
                     "ms_per_step_split_bf16_opt_in": xdt_train * 1e3,
                     "collective": ("rccl all_reduce of one flat %.1f MB gradient buffer" % (trainer.arena.numel() * 4 / 1e6))
@@ -688,7 +717,7 @@ def main():
                                  "frac": executed / tdt / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                  "executed_mfma_flop_per_step": executed,
                                  "note": "whole step over the fp32 MFMA flops it executes (with pair de-duplication)",
-                                 "mfma_busy": {k: busy.get(k) for k in busy if k.startswith(("lstm_bwd_kernel", "dk_gemm_kernel", "lstm_fwd_kernel<2, 2, 1, true"))}}}
+                                 "mfma_busy": busy_of("lstm_bwd", "dk_gemm", "lstm_fwd_kernel<2, 2, 1, true", "lstm_fwd_kernel<1, 1, 1, true")}}
 
     # ---- secondary legs on their own models: the reference's recipe shapes, and the text-CNN of configs[4]
     shapes_leg = reference_shapes_leg(sse_amd, torch, dev) if (rank == 0 and not args.no_shapes_leg) else None
@@ -712,7 +741,7 @@ def main():
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_unit": "bytes/launch (PMC: (2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate rocprofv3 "
                                                              "passes of this command; null when the kernel sources changed since)",
-                         "mfma_busy": PMC.get("mfma_busy", {}).get("lstm_fwd_kernel<2, 2, 1, false, true, false>"),
+                         "mfma_busy": (busy_of("lstm_fwd_kernel<2, 2, 1, false, true") or {None: None}).popitem()[1],
                          "pmc_source": PMC.get("source", PMC.get("stale")),
                          "avg_kernel_ms": enc_ms_avg,
                          "algorithmic_flop_per_launch": B * FLOP_PER_SEQ},

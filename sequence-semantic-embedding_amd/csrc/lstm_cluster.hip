@@ -526,6 +526,16 @@ hipError_t launch_lstm_cluster(const LstmClusterArgs &a_in, hipStream_t stream) 
   if (e != hipSuccess) return e;
   // 8 XCDs x 32 slots: cluster c = xcd + 8 * (slot / 16); with at most 8 clusters only the first 16 slots are launched
   const int grid = a.NCL <= 8 ? 8 * LC_NWG : 16 * LC_NWG;
+  // COOPERATIVE launch: the workgroups of a cluster hand h_t to each other every step, so all of them must be resident at
+  // once; hipLaunchCooperativeKernel makes the runtime guarantee that (the grid fits the device by construction: at most
+  // one workgroup per CU is asked for) instead of leaving it to the dispatcher's mood on a busy device.  The bounded spin
+  // with its give-up flag stays as a belt.  (A runtime without cooperative launches falls back to the plain launch.)
+  {
+    void *args[] = {(void *)&a};
+    hipError_t ce = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(lstm_cluster_kernel), dim3(grid), dim3(LC_NT), args, (unsigned)lds, stream);
+    if (ce == hipSuccess) return hipGetLastError();
+    (void)hipGetLastError();  // not supported / too large for this device: plain launch
+  }
   hipLaunchKernelGGL(lstm_cluster_kernel, dim3(grid), dim3(LC_NT), lds, stream, a);
   return hipGetLastError();
 }

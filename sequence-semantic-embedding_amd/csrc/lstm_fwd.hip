@@ -39,6 +39,21 @@
 #define LSTM_THREADS 512
 #define LSTM_BM 64
 
+#ifdef SSE_FWD_CLOCK  // measurement builds (tools/): cycles per phase of a step, summed over the steps, workgroup 0
+#include <cstdio>
+__device__ long long g_fwd_clk[8 * 8];
+#define FW_CLK_DECL long long ck_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ck_t = clock64();
+#define FW_CLK(i)                   \
+  {                                 \
+    const long long n_ = clock64(); \
+    ck_[i] += n_ - ck_t;            \
+    ck_t = n_;                      \
+  }
+#else
+#define FW_CLK_DECL
+#define FW_CLK(i)
+#endif
+
 // LDS: xbuf[XD ? 2 : 1][RT][KGx][256] + hbuf[2 bufs][RT][KGh][256] + red[256 floats].
 // h is double-buffered (step t reads buffer t&1, writes (t+1)&1: one barrier per
 // step); x is double-buffered too when it fits in the 160 KiB (XD).
@@ -65,65 +80,61 @@ __device__ __forceinline__ f32x4 wload(__amdgpu_buffer_rsrc_t r, int voff, int s
 // One GEMM pass of a wave: two gate tiles (B operands at byte offsets soff and soff+1024 of
 // the packed kernel, k-group stride 4096 B) times MT row tiles, over k-groups [0, kend).
 // A fragments: LIN -> x and h parts are contiguous in LDS (xa[m] + kg*256); otherwise x tile
-// for kg < KGx, h tile after.  Hand software-pipelined with two named operand sets (no
-// register copies): the operands of k-group kg+1 are in flight while kg's 8*MT MFMAs issue.
+// for kg < KGx, h tile after.  Operands travel through a ring of R k-groups (weights from L2, A fragments from LDS), issued in
+// consumption order so that every wait is a counted vmcnt: the operands of k-groups kg+1 .. kg+R-1 are in flight while kg's
+// 8*MT MFMAs issue.  (Rounds 1-3: two named sets = one group ahead.  Enough while both waves of a SIMD are in a GEMM pass --
+// the partner's MFMAs double the cover -- but a wave that runs its pass while the partner is in its gate epilogue or waits at
+// the barrier had 8*MT*64 cycles to hide an L2 round trip: clock64 showed such passes at 73 % of the matrix rate at MT = 1.)
+// The accumulation order is k-group by k-group as before: results are bit-identical.
 template <int MT, bool LIN, bool SWAP>
 __device__ __forceinline__ void gemm_pass(__amdgpu_buffer_rsrc_t wr, int voff, int soff, const float *const (&xa)[MT],
                                           const float *const (&ha)[MT], int KGx, int kend, f32x16 (&acc)[MT][2]) {
+  constexpr int R = MT == 1 ? 4 : 3;
   auto a_frag = [&](int m, int kg) -> f32x4 {
     if constexpr (LIN) return *reinterpret_cast<const f32x4 *>(xa[m] + kg * 256);
     return *reinterpret_cast<const f32x4 *>(kg < KGx ? xa[m] + kg * 256 : ha[m] + (kg - KGx) * 256);
   };
-  f32x4 p0 = wload(wr, voff, soff), p1 = wload(wr, voff + 1024, soff);
-  f32x4 q0, q1, a0[MT], a1[MT];
+  f32x4 p0[R], p1[R], af[R][MT];
+  const int klast = kend - 1;
 #pragma unroll
-  for (int m = 0; m < MT; ++m) a0[m] = a_frag(m, 0);
+  for (int s = 0; s < R; ++s) {
+    const int kg = s < kend ? s : klast;  // (shorter passes: harmless reloads of the last group)
+    p0[s] = wload(wr, voff, soff + kg * 4096);
+    p1[s] = wload(wr, voff + 1024, soff + kg * 4096);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) af[s][m] = a_frag(m, kg);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  auto mfmas = [&](int s) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        acc[m][0] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(p0[s][e], af[s][m][e], acc[m][0], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][m][e], p0[s][e], acc[m][0], 0, 0, 0);
+        acc[m][1] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(p1[s][e], af[s][m][e], acc[m][1], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][m][e], p1[s][e], acc[m][1], 0, 0, 0);
+      }
+  };
   __builtin_amdgcn_s_setprio(1);  // the MFMA stream outranks the partner wave's epilogue VALU
   int kg = 0;
-  for (; kg + 1 < kend; kg += 2) {
-    q0 = wload(wr, voff, soff + (kg + 1) * 4096);
-    q1 = wload(wr, voff + 1024, soff + (kg + 1) * 4096);
+  for (; kg + R <= kend; kg += R) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) a1[m] = a_frag(m, kg + 1);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < R; ++s) {
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(s);
+      __builtin_amdgcn_sched_barrier(0);
+      const int kn = (kg + s + R < kend) ? kg + s + R : klast;  // clamped: harmless reload past the end
+      p0[s] = wload(wr, voff, soff + kn * 4096);
+      p1[s] = wload(wr, voff + 1024, soff + kn * 4096);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        acc[m][0] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(p0[e], a0[m][e], acc[m][0], 0, 0, 0)
-                         : __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][e], p0[e], acc[m][0], 0, 0, 0);
-        acc[m][1] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(p1[e], a0[m][e], acc[m][1], 0, 0, 0)
-                         : __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][e], p1[e], acc[m][1], 0, 0, 0);
-      }
-    __builtin_amdgcn_sched_barrier(0);
-    const int k2 = (kg + 2 < kend) ? kg + 2 : kg;  // clamped: harmless reload on the last pair
-    p0 = wload(wr, voff, soff + k2 * 4096);
-    p1 = wload(wr, voff + 1024, soff + k2 * 4096);
-#pragma unroll
-    for (int m = 0; m < MT; ++m) a0[m] = a_frag(m, k2);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        acc[m][0] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(q0[e], a1[m][e], acc[m][0], 0, 0, 0)
-                         : __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m][e], q0[e], acc[m][0], 0, 0, 0);
-        acc[m][1] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(q1[e], a1[m][e], acc[m][1], 0, 0, 0)
-                         : __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m][e], q1[e], acc[m][1], 0, 0, 0);
-      }
-    __builtin_amdgcn_sched_barrier(0);
+      for (int m = 0; m < MT; ++m) af[s][m] = a_frag(m, kn);
+    }
   }
-  if (kg < kend) {  // odd k-group count: operands of the last group are already loaded
+  // the last kend % R groups: their operands are stages 0 .. already loaded
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        acc[m][0] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(p0[e], a0[m][e], acc[m][0], 0, 0, 0)
-                         : __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][e], p0[e], acc[m][0], 0, 0, 0);
-        acc[m][1] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(p1[e], a0[m][e], acc[m][1], 0, 0, 0)
-                         : __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m][e], p1[e], acc[m][1], 0, 0, 0);
-      }
-  }
+  for (int s = 0; s < R - 1; ++s)
+    if (kg + s < kend) mfmas(s);
   __builtin_amdgcn_s_setprio(0);
 }
 
@@ -321,7 +332,9 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       const_cast<float *>(a.Wp), 0, (KGh / 4) * KG * 4096, 0x00020000);
   const int wvoff = lane * 16;
 
+  FW_CLK_DECL
   for (int t = t0; t < T; ++t) {
+    FW_CLK(0)
     // prefetch the embedding rows of step t+1 into registers (one k-group per
     // thread covers E <= 8*TPR; wider embeddings are completed at the store)
     const bool have_next = (t + 1) < T;
@@ -436,7 +449,9 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
           g[m][1][r] = 0.0f;
         }
       }
+      FW_CLK(1)
       if (do_a) gemm_pass<MT, LIN, SWAP>(wr, wvoff, wsoff, xa, ha, KGx, kend, g);
+      FW_CLK(2)
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         if (!do_a) break;
@@ -496,10 +511,13 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
           g[m][0][r] = 0.0f;
           g[m][1][r] = 0.0f;
         }
+      FW_CLK(3)
       if (do_b) gemm_pass<MT, LIN, SWAP>(wr, wvoff, wsoff + 2048, xa, ha, KGx, kend, g);
+      FW_CLK(4)
       if (do_b && !do_a) {  // split3: the i,j pass of this (block, row tile) comes from the partner wave
         while (pass_flag[fidx] < t + 1) __builtin_amdgcn_s_sleep(2);
       }
+      FW_CLK(5)
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         if (!do_b) break;
@@ -574,10 +592,12 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       }
     }
 
+    FW_CLK(6)
     // end of step: with a double-buffered x tile x_{t+1} is already in place; with a single
     // buffer it must wait until every wave finished step t
     if (XD) {
       __syncthreads();  // h_t complete and visible; h_{t-1} / x_t no longer needed
+      FW_CLK(7)
     } else {
       __syncthreads();
       if (have_next) {
@@ -592,6 +612,10 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
     }
   }
 
+#ifdef SSE_FWD_CLOCK
+  if (blockIdx.x == 0 && lane == 0)
+    for (int i = 0; i < 8; ++i) g_fwd_clk[w * 8 + i] = ck_[i];
+#endif
   if constexpr (TRAIN) {
     // h_T, row-major [Bp][Hp], for dM = h_T^T . d(out)
     const int Hp = KGh * 8;
@@ -689,6 +713,20 @@ static hipError_t launch_one(const LstmFwdArgs &a, size_t lds, hipStream_t strea
   if (e != hipSuccess) return e;
   const dim3 grid(a.NT32 > 0 ? a.NT32 / RT : (a.B + RT * 32 - 1) / (RT * 32)), block(LSTM_THREADS);
   hipLaunchKernelGGL((lstm_fwd_kernel<RT, MT, UBW, TRAIN, LIN, SPL, TSW>), grid, block, lds, stream, a);
+#ifdef SSE_FWD_CLOCK
+  {
+    static int n = 0;
+    if (a.B >= 1024 && n++ % 16 == 4) {
+      long long v[64];
+      (void)hipStreamSynchronize(stream);
+      (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_fwd_clk), sizeof v);
+      for (int w = 0; w < 8; ++w)
+        fprintf(stderr, "[fwd clock <%d,%d,%d> B=%d H=%d] wave %d cycles/step: prefetch %lld | setup %lld | passA gemm %lld | epiA+x %lld | passB gemm %lld | flag wait %lld | epiB %lld | barrier %lld\n",
+                RT, MT, UBW, a.B, a.H, w, v[w * 8 + 0] / a.T, v[w * 8 + 1] / a.T, v[w * 8 + 2] / a.T, v[w * 8 + 3] / a.T, v[w * 8 + 4] / a.T, v[w * 8 + 5] / a.T,
+                v[w * 8 + 6] / a.T, v[w * 8 + 7] / a.T);
+    }
+  }
+#endif
   return hipGetLastError();
 }
 

@@ -382,6 +382,16 @@ hipError_t launch_lstm_persist(const LstmPersistArgs &a_in, hipStream_t stream) 
   const size_t lds = lp_lds_bytes(a.E, a.H, a.S, a.NWG);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
+  // COOPERATIVE launch: the workgroups of a cluster hand h_t to each other every step, so all of them must be resident at
+  // once; hipLaunchCooperativeKernel makes the runtime guarantee that (the grid fits the device by construction: at most
+  // one workgroup per CU is asked for) instead of leaving it to the dispatcher's mood on a busy device.  The bounded spin
+  // with its give-up flag stays as a belt.  (A runtime without cooperative launches falls back to the plain launch.)
+  {
+    void *args[] = {(void *)&a};
+    hipError_t ce = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(lstm_persist_kernel), dim3(8 * a.NWG), dim3(LP_NT), args, (unsigned)lds, stream);
+    if (ce == hipSuccess) return hipGetLastError();
+    (void)hipGetLastError();  // not supported / too large for this device: plain launch
+  }
   hipLaunchKernelGGL(lstm_persist_kernel, dim3(8 * a.NWG), dim3(LP_NT), lds, stream, a);
   return hipGetLastError();
 }

@@ -119,7 +119,7 @@ struct sse_handle {
   int lstm_cluster_rows = 1024; // option "lstm_cluster_rows": batches above lstm_persist_rows up to this many rows (<= 1024) take the MFMA cluster kernel
   uint32_t cluster_epoch = 0;   // tag epoch of that kernel's exchange buffers
   int lstm_cluster_chunks = 3;  // option "lstm_cluster_chunks": batches of up to this many times lstm_cluster_rows go through that kernel in launches of lstm_cluster_rows
-  int cluster_backoff = 16;     // option "lstm_cluster_backoff": after a cluster-kernel launch gave up (a workgroup not resident in 10 ms: the device is shared), this many following eligible calls go straight to the kernels that need no co-residency
+  int cluster_backoff = 0;      // option "lstm_cluster_backoff" (default 0 since the cluster kernels are launched cooperatively: co-residency is the runtime's promise, a give-up is a fault, not a mood of a busy device): after a cluster-kernel launch gave up, this many following eligible calls go straight to the kernels that need no co-residency
   int cluster_skip[2] = {0, 0}; // calls still to skip: [0] single-query kernel (lstm_persist), [1] mid-batch kernel (lstm_cluster)
   int lstm_cluster_wt = 0;      // option "lstm_cluster_write_through": force the any-placement publish path (tests)
   int lstm_cluster_drop = 0;    // option "lstm_cluster_drop_wg": one workgroup of the cluster kernel exits at once (tests)

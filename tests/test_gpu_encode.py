@@ -370,8 +370,8 @@ def test_cluster_kernel_miss_falls_back_to_the_few_sequences_kernel():
         m.handle.encode_score_topk(0, bad, False, 7)
     again_s, again_i = m.handle.encode_score_topk(0, ids, False, 7)
     assert np.array_equal(again_i, want_i) and np.array_equal(again_s, want_s)
-    # back-off (the default, 16 calls): after a launch that gave up the following calls do not try the cluster kernel --
-    # a time-out costs 10 ms, a busy device would charge it to every query -- and then it is tried again
+    # back-off (option, off by default since the cluster kernels are launched cooperatively): after a launch that gave up
+    # the following calls do not try the cluster kernel -- a time-out costs 10 ms -- and then it is tried again
     m.handle.set_option("lstm_cluster_backoff", 3)
     m.handle.set_option("lstm_persist_inject_miss", 1)
     assert np.array_equal(m.encode_source(ids), want)
@@ -382,7 +382,7 @@ def test_cluster_kernel_miss_falls_back_to_the_few_sequences_kernel():
     assert np.array_equal(m.encode_source(ids), want)           # tried again (and "misses" again)
     assert m.handle.get_counter("lstm_persist_fallbacks") == 4
     m.handle.set_option("lstm_persist_inject_miss", 0)
-    m.handle.set_option("lstm_cluster_backoff", 16)
+    m.handle.set_option("lstm_cluster_backoff", 0)
 
 
 @pytest.mark.parametrize("H,S", [(40, 16), (100, 64), (72, 24)])
@@ -406,7 +406,7 @@ def test_cluster_kernel_with_workgroups_that_own_no_hidden_unit(H, S):
 def test_four_serving_handles_from_threads_while_a_fifth_trains():
     """sse_serving.py creates one handle per route: four handles issue single-query encode + score calls (the cluster
     kernel: 16 - 32 co-resident workgroups each) from four threads while a fifth handle runs train steps.  Every answer
-    equals the quiet-machine answer; a cluster miss, if the scheduler produces one, is absorbed by the fallback."""
+    equals the quiet-machine answer, and (cooperative launches) none of them needed the fallback."""
     import threading
     params = model_params("dual-encoder", 400, 50, 96, 96, 64, 16)
     rng = np.random.RandomState(9)
@@ -451,6 +451,9 @@ def test_four_serving_handles_from_threads_while_a_fifth_trains():
     stop.set()
     tt.join(60)
     assert not errs, errs
+    # the cluster kernels are launched cooperatively (hipLaunchCooperativeKernel): their workgroups are co-resident by the
+    # runtime's promise, so no query of the four busy handles had to fall back to the few-sequences kernel
+    assert sum(m.handle.get_counter("lstm_persist_fallbacks") for m in servers) == 0
 
 
 @pytest.mark.parametrize("mode,V,E,Hs,Ht,S,T", [
