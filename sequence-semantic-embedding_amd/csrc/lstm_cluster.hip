@@ -36,6 +36,8 @@
 // lstm_persist.hip (tests/test_gpu_encode.py), and the pad-prefix table of lstm_small.hip serves the exact left-PAD skip.
 // All 16 workgroups of a cluster must be resident together (one per CU: the kernel uses 158 of 160 KiB of LDS); clusters are
 // dealt to the XCDs (blockIdx % 8), two per XCD at most: 16 clusters = 1024 sequences fill the chip.
+#include <cstdlib>
+
 #include "sse_kernels.h"
 
 #define LC_NWG 16
@@ -530,7 +532,9 @@ hipError_t launch_lstm_cluster(const LstmClusterArgs &a_in, hipStream_t stream) 
   // once; hipLaunchCooperativeKernel makes the runtime guarantee that (the grid fits the device by construction: at most
   // one workgroup per CU is asked for) instead of leaving it to the dispatcher's mood on a busy device.  The bounded spin
   // with its give-up flag stays as a belt.  (A runtime without cooperative launches falls back to the plain launch.)
-  {
+  // Measured cost: +20 us per launch (single query 0.122 -> 0.142 ms); option lstm_cluster_coop = 0 takes the plain launch.
+  static const bool no_coop = getenv("SSE_NO_COOP") != nullptr;  // measurement aid: plain launches
+  if (!no_coop && !a.plain_launch) {
     void *args[] = {(void *)&a};
     hipError_t ce = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(lstm_cluster_kernel), dim3(grid), dim3(LC_NT), args, (unsigned)lds, stream);
     if (ce == hipSuccess) return hipGetLastError();

@@ -41,7 +41,7 @@
 
 #ifdef SSE_FWD_CLOCK  // measurement builds (tools/): cycles per phase of a step, summed over the steps, workgroup 0
 #include <cstdio>
-__device__ long long g_fwd_clk[8 * 8];
+__device__ long long g_fwd_clk[16 * 8];
 #define FW_CLK_DECL long long ck_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ck_t = clock64();
 #define FW_CLK(i)                   \
   {                                 \
@@ -86,10 +86,10 @@ __device__ __forceinline__ f32x4 wload(__amdgpu_buffer_rsrc_t r, int voff, int s
 // the partner's MFMAs double the cover -- but a wave that runs its pass while the partner is in its gate epilogue or waits at
 // the barrier had 8*MT*64 cycles to hide an L2 round trip: clock64 showed such passes at 73 % of the matrix rate at MT = 1.)
 // The accumulation order is k-group by k-group as before: results are bit-identical.
-template <int MT, bool LIN, bool SWAP>
+// kbeg: first k-group.
+template <int MT, bool LIN, bool SWAP, int R = (MT == 1 ? 4 : 3), bool PRIO = true>
 __device__ __forceinline__ void gemm_pass(__amdgpu_buffer_rsrc_t wr, int voff, int soff, const float *const (&xa)[MT],
-                                          const float *const (&ha)[MT], int KGx, int kend, f32x16 (&acc)[MT][2]) {
-  constexpr int R = MT == 1 ? 4 : 3;
+                                          const float *const (&ha)[MT], int KGx, int kend, f32x16 (&acc)[MT][2], int kbeg = 0) {
   auto a_frag = [&](int m, int kg) -> f32x4 {
     if constexpr (LIN) return *reinterpret_cast<const f32x4 *>(xa[m] + kg * 256);
     return *reinterpret_cast<const f32x4 *>(kg < KGx ? xa[m] + kg * 256 : ha[m] + (kg - KGx) * 256);
@@ -98,7 +98,7 @@ __device__ __forceinline__ void gemm_pass(__amdgpu_buffer_rsrc_t wr, int voff, i
   const int klast = kend - 1;
 #pragma unroll
   for (int s = 0; s < R; ++s) {
-    const int kg = s < kend ? s : klast;  // (shorter passes: harmless reloads of the last group)
+    const int kg = kbeg + s < kend ? kbeg + s : klast;  // (shorter passes: harmless reloads of the last group)
     p0[s] = wload(wr, voff, soff + kg * 4096);
     p1[s] = wload(wr, voff + 1024, soff + kg * 4096);
 #pragma unroll
@@ -116,8 +116,8 @@ __device__ __forceinline__ void gemm_pass(__amdgpu_buffer_rsrc_t wr, int voff, i
                          : __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][m][e], p1[s][e], acc[m][1], 0, 0, 0);
       }
   };
-  __builtin_amdgcn_s_setprio(1);  // the MFMA stream outranks the partner wave's epilogue VALU
-  int kg = 0;
+  if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);  // the MFMA stream outranks the partner wave's epilogue VALU
+  int kg = kbeg;
   for (; kg + R <= kend; kg += R) {
 #pragma unroll
     for (int s = 0; s < R; ++s) {
@@ -135,7 +135,7 @@ __device__ __forceinline__ void gemm_pass(__amdgpu_buffer_rsrc_t wr, int voff, i
 #pragma unroll
   for (int s = 0; s < R - 1; ++s)
     if (kg + s < kend) mfmas(s);
-  __builtin_amdgcn_s_setprio(0);
+  if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
 // Kernel configurations (RT = 32-row tiles per workgroup, MT = row tiles per wave, UBW = unit
@@ -148,9 +148,10 @@ __device__ __forceinline__ void gemm_pass(__amdgpu_buffer_rsrc_t wr, int voff, i
 template <int RT, int MT, int UBW, bool TRAIN, bool LIN, bool SPL = false, bool TSW = false>
 __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   static_assert(!TSW || TRAIN, "TSW is the training forward in the inference orientation");
+  constexpr int NTHR = LSTM_THREADS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int ROWS = RT * 32;                 // sequences per workgroup
-  constexpr int TPR = LSTM_THREADS / ROWS;      // threads per sequence row in the x gather
+  constexpr int TPR = NTHR / ROWS;              // threads per sequence row in the x gather
   constexpr int NWR = 8 / RT;                   // waves sharing one row tile (projection tail)
   // weights as the MFMA A operand (see the file header).  TSW: the training forward in that orientation too -- the h_t /
   // parked-product stores are conflict-free 16-byte pieces instead of 8-way conflicting dword scatters, the gate tape is
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   float *red = smem + (size_t)(LIN ? 2 * RT * KG : RT * KGx + 2 * RT * KGh) * 256;  // [ROWS][NWR] (>= 8 floats)
   const int b0 = blockIdx.x * ROWS;
   volatile int *pass_flag = reinterpret_cast<volatile int *>(red + 16);  // split3: [row tile] = steps whose i,j pass is parked
-  if (tid < 4) pass_flag[tid] = 0;
+  if (tid < 8) pass_flag[tid] = 0;
 
   // --- x gather assignment: TPR threads per sequence row, 8 floats (one k-group) each.  Consecutive lanes take
   // consecutive ROWS of the same k-group, so a 16-byte x_store of 8 adjacent lanes covers 128 contiguous bytes
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
     if (lane == 0) red[w] = __int_as_float(lead);
     __syncthreads();
     lead = T;
-    for (int i = 0; i < LSTM_THREADS / 64; ++i) lead = min(lead, __float_as_int(red[i]));
+    for (int i = 0; i < NTHR / 64; ++i) lead = min(lead, __float_as_int(red[i]));
     t0 = min(lead, T - 1);  // every real sequence ends in EOS, but stay safe: at least one step
     __syncthreads();
   }
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       }
     }
     const int Hp = KGh * 8;
-    for (int i = tid; i < RT * KGh * 256; i += LSTM_THREADS) {  // all row tiles of buffer t0 & 1
+    for (int i = tid; i < RT * KGh * 256; i += NTHR) {  // all row tiles of buffer t0 & 1
       const int mt = i / (KGh * 256), e = i % (KGh * 256);
       const int un = (e >> 8) * 8 + ((e >> 7) & 1) * 4 + (e & 3);  // k index of element e of a frag32 row tile
       hptr(t0 & 1, mt)[e] = (t0 > 0) ? a.pad_h[(size_t)t0 * Hp + un] : 0.0f;
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
         // split bf16 operands for the dK GEMM on the bf16 matrix pipe: per 16-row group and k'-tile a hi and a lo frag16
         // block; lane (k' & 31, half) owns rows 16 j + 8 half .. + 7 of the tile
         unsigned short *ta = reinterpret_cast<unsigned short *>(a.tape_a);
-        for (int i = tid; i < nk * (ROWS / 8); i += LSTM_THREADS) {
+        for (int i = tid; i < nk * (ROWS / 8); i += NTHR) {
           const int kp = i % nk, o = i / nk;  // o: rows 8*o .. 8*o+7 of the workgroup
           const int mt = o >> 2, oc = o & 3;
           float v8[8];
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
           *reinterpret_cast<sse_u32x4 *>(dst + 512) = lo;
         }
       } else {
-        for (int i = tid; i < nk * (ROWS / 4); i += LSTM_THREADS) {
+        for (int i = tid; i < nk * (ROWS / 4); i += NTHR) {
           const int kp = i % nk, b4 = i / nk;  // b4: rows 4*b4 .. 4*b4+3 of the tile
           const int mt = b4 >> 3, bl = (b4 & 7) * 4;
           const f32x4 v = {a_elem(mt, kp, bl), a_elem(mt, kp, bl + 1), a_elem(mt, kp, bl + 2), a_elem(mt, kp, bl + 3)};
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   if constexpr (TRAIN) {
     // h_T, row-major [Bp][Hp], for dM = h_T^T . d(out)
     const int Hp = KGh * 8;
-    for (int i = tid; i < ROWS * Hp; i += LSTM_THREADS) {
+    for (int i = tid; i < ROWS * Hp; i += NTHR) {
       const int un = i % Hp, b = i / Hp;
       a.h_last[(size_t)(b0 + b) * Hp + un] =
           hptr(T & 1, b >> 5)[(size_t)(un >> 3) * 256 + ((((un >> 2) & 1) * 32 + (b & 31)) << 2) + (un & 3)];
@@ -629,6 +630,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   // --- projection  out = h_T . M   (+ optional l2_normalize): NWR waves per row tile,
   // wave -> row tile wm, N tiles nt = wn, wn + NWR, ...
   const int wn = w % NWR, wm = w / NWR;
+  constexpr bool pwave = true;
   constexpr int PT = 16 / NWR;  // up to Sp = 512
   const float *hp = hptr(T & 1, wm) + lane * 4;  // h_T
   f32x16 pacc[PT];
@@ -640,7 +642,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
     const int nt = wn + NWR * i;
 #pragma unroll
     for (int r = 0; r < 16; ++r) pacc[i][r] = 0.0f;
-    if (nt < a.NTS) {
+    if (nt < a.NTS && pwave) {
       const float *mp = a.Mp + (size_t)nt * KGh * 256 + lane * 4;
       // two named operand sets (as in gemm_pass): M fragments come from L2, keep the next one in flight
       f32x4 ax = *reinterpret_cast<const f32x4 *>(hp), bx = *reinterpret_cast<const f32x4 *>(mp), ay, by;
@@ -696,7 +698,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   for (int i = 0; i < PT; ++i) {
     const int nt = wn + NWR * i;
     const int col = nt * 32 + (lane & 31);
-    if (nt < a.NTS && col < a.S) {
+    if (nt < a.NTS && col < a.S && pwave) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = b0 + wm * 32 + mfma_row(r, lane);
@@ -717,7 +719,7 @@ static hipError_t launch_one(const LstmFwdArgs &a, size_t lds, hipStream_t strea
   {
     static int n = 0;
     if (a.B >= 1024 && n++ % 16 == 4) {
-      long long v[64];
+      long long v[128];
       (void)hipStreamSynchronize(stream);
       (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_fwd_clk), sizeof v);
       for (int w = 0; w < 8; ++w)

@@ -179,8 +179,8 @@ hipError_t launch_l2_normalize(const float *x, float *out, int64_t rows, int col
 // k-row E (the first padding row of the x part, Ep > E always) carries the BIAS: the padded embedding table
 // holds a constant 1.0 in column E, so the gate GEMM adds it -- forget_bias = 1.0 folded into the f block
 // (BasicLSTMCell adds it at run time, it is not stored in the variable).
-__global__ void pack_lstm_kernel_k(const float *__restrict__ K, const float *__restrict__ b, int E, int H, int Ep,
-                                   int Hp, int UB, int64_t total4, f32x4 *__restrict__ out) {
+__device__ __forceinline__ void pack_lstm_body(const float *__restrict__ K, const float *__restrict__ b, int E, int H, int Ep,
+                                               int Hp, int64_t total4, f32x4 *__restrict__ out) {
   const int KG = (Ep + Hp) / 8;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -209,12 +209,16 @@ __global__ void pack_lstm_kernel_k(const float *__restrict__ K, const float *__r
     }
     out[i] = v;
   }
+}
+__global__ void pack_lstm_kernel_k(const float *__restrict__ K, const float *__restrict__ b, int E, int H, int Ep,
+                                   int Hp, int UB, int64_t total4, f32x4 *__restrict__ out) {
+  pack_lstm_body(K, b, E, H, Ep, Hp, total4, out);
   (void)UB;
 }
 
 // X[K][N] row-major -> frag32 with rows = n (columns of X), k = rows of X, zero padded to KGp groups
-__global__ void pack_kn_kernel_k(const float *__restrict__ X, int K, int N, int KGp, int64_t total4,
-                                 f32x4 *__restrict__ out) {
+__device__ __forceinline__ void pack_kn_body(const float *__restrict__ X, int K, int N, int KGp, int64_t total4,
+                                             f32x4 *__restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int l = (int)(i & 63);
@@ -234,14 +238,22 @@ __global__ void pack_kn_kernel_k(const float *__restrict__ X, int K, int N, int 
   }
 }
 
+__global__ void pack_kn_kernel_k(const float *__restrict__ X, int K, int N, int KGp, int64_t total4,
+                                 f32x4 *__restrict__ out) {
+  pack_kn_body(X, K, N, KGp, total4, out);
+}
+
 // rows [R][C] -> [R][Cp] zero padded; one_col >= 0: that padding column holds 1.0 (the LSTM bias rides on it)
-__global__ void pad_rows_kernel_k(const float *__restrict__ in, int64_t R, int C, int Cp, int one_col, float *__restrict__ out) {
+__device__ __forceinline__ void pad_rows_body(const float *__restrict__ in, int64_t R, int C, int Cp, int one_col, float *__restrict__ out) {
   const int64_t total = R * Cp;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % Cp);
     const int64_t r = i / Cp;
     out[i] = (c < C) ? in[r * C + c] : (c == one_col ? 1.0f : 0.0f);
   }
+}
+__global__ void pad_rows_kernel_k(const float *__restrict__ in, int64_t R, int C, int Cp, int one_col, float *__restrict__ out) {
+  pad_rows_body(in, R, C, Cp, one_col, out);
 }
 
 static inline int grid_for(int64_t n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
@@ -304,8 +316,8 @@ hipError_t launch_fill(float *p, int64_t n, float v, hipStream_t stream) {
 // Transposed slices of the LSTM kernel for the backward GEMMs:
 // out = frag32(rows = i in [0, RT*32), red = n in [0, 4*Hp)),
 // value = K[row0 + i][g*H + unit] for i < nrows, unit < H, with n = g*Hp + unit (gate-major, padded)
-__global__ void pack_kT_kernel_k(const float *__restrict__ K, int row0, int nrows, int H, int Hp, int64_t total4,
-                                 f32x4 *__restrict__ out) {
+__device__ __forceinline__ void pack_kT_body(const float *__restrict__ K, int row0, int nrows, int H, int Hp, int64_t total4,
+                                             f32x4 *__restrict__ out) {
   const int KGn = Hp / 2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -325,6 +337,50 @@ __global__ void pack_kT_kernel_k(const float *__restrict__ K, int row0, int nrow
     }
     out[i] = v;
   }
+}
+
+__global__ void pack_kT_kernel_k(const float *__restrict__ K, int row0, int nrows, int H, int Hp, int64_t total4,
+                                 f32x4 *__restrict__ out) {
+  pack_kT_body(K, row0, nrows, H, Hp, total4, out);
+}
+
+// Every layout a train step derives from the variables in ONE launch (a step used to end in 9 - 13 pack launches of 2 - 8 us
+// with ~5 us between them: 0.1 ms on the critical path between the optimizer and the next forward).  All workgroups walk all
+// jobs grid-stride; the jobs are independent.
+__global__ __launch_bounds__(256) void pack_multi_kernel(PackJobs jobs) {
+  for (int j = 0; j < jobs.n; ++j) {
+    const PackJob &q = jobs.job[j];
+    switch (q.type) {
+      case PACK_JOB_PAD_ROWS: pad_rows_body(q.a, q.total, q.i0, q.i1, q.i2, q.out); break;
+      case PACK_JOB_LSTM: pack_lstm_body(q.a, q.b, q.i0, q.i1, q.i2, q.i3, q.total, reinterpret_cast<f32x4 *>(q.out)); break;
+      case PACK_JOB_KN: pack_kn_body(q.a, q.i0, q.i1, q.i2, q.total, reinterpret_cast<f32x4 *>(q.out)); break;
+      case PACK_JOB_KT: pack_kT_body(q.a, q.i0, q.i1, q.i2, q.i3, q.total, reinterpret_cast<f32x4 *>(q.out)); break;
+      default: break;
+    }
+  }
+}
+
+void pack_job_pad_rows(PackJobs &js, const float *in, int64_t R, int C, int Cp, int one_col, float *out) {
+  js.job[js.n++] = PackJob{PACK_JOB_PAD_ROWS, in, nullptr, out, R, C, Cp, one_col, 0};
+}
+void pack_job_lstm(PackJobs &js, const float *K, const float *b, int E, int H, int Ep, int Hp, float *Wp) {
+  js.job[js.n++] = PackJob{PACK_JOB_LSTM, K, b, Wp, (int64_t)(Hp / 32) * ((Ep + Hp) / 8) * 4 * 64, E, H, Ep, Hp};
+}
+void pack_job_kn(PackJobs &js, const float *X, int K, int N, int KGp, float *out) {
+  js.job[js.n++] = PackJob{PACK_JOB_KN, X, nullptr, out, (int64_t)((N + 31) / 32) * KGp * 64, K, N, KGp, 0};
+}
+void pack_job_kT(PackJobs &js, const float *K, int row0, int nrows, int RT, int H, int Hp, float *out) {
+  js.job[js.n++] = PackJob{PACK_JOB_KT, K, nullptr, out, (int64_t)RT * (Hp / 2) * 64, row0, nrows, H, Hp};
+}
+hipError_t launch_pack_multi(const PackJobs &js, hipStream_t stream) {
+  if (js.n == 0) return hipSuccess;
+  int64_t mx = 0;
+  for (int j = 0; j < js.n; ++j) {
+    const int64_t items = js.job[j].type == PACK_JOB_PAD_ROWS ? js.job[j].total * js.job[j].i1 : js.job[j].total;
+    mx = items > mx ? items : mx;
+  }
+  hipLaunchKernelGGL(pack_multi_kernel, dim3(grid_for(mx) < 2048 ? grid_for(mx) : 2048), dim3(256), 0, stream, js);
+  return hipGetLastError();
 }
 
 hipError_t launch_pack_kT(const float *K, int row0, int nrows, int RT, int H, int Hp, float *out, hipStream_t stream) {

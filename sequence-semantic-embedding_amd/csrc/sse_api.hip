@@ -121,6 +121,7 @@ struct sse_handle {
   int lstm_cluster_chunks = 3;  // option "lstm_cluster_chunks": batches of up to this many times lstm_cluster_rows go through that kernel in launches of lstm_cluster_rows
   int cluster_backoff = 0;      // option "lstm_cluster_backoff" (default 0 since the cluster kernels are launched cooperatively: co-residency is the runtime's promise, a give-up is a fault, not a mood of a busy device): after a cluster-kernel launch gave up, this many following eligible calls go straight to the kernels that need no co-residency
   int cluster_skip[2] = {0, 0}; // calls still to skip: [0] single-query kernel (lstm_persist), [1] mid-batch kernel (lstm_cluster)
+  int lstm_cluster_coop = 1;    // option "lstm_cluster_coop" (default 1): the cluster kernels are launched with hipLaunchCooperativeKernel (co-residency guaranteed by the runtime; +20 us per launch measured); 0 = plain launches
   int lstm_cluster_wt = 0;      // option "lstm_cluster_write_through": force the any-placement publish path (tests)
   int lstm_cluster_drop = 0;    // option "lstm_cluster_drop_wg": one workgroup of the cluster kernel exits at once (tests)
   int lstm_small_rows = 1024; // option "lstm_small_rows": batches up to this many rows take the few-sequences LSTM kernel
@@ -335,6 +336,53 @@ int ensure_packed(sse_handle *h, hipStream_t st) {
   }
   h->packed_dirty = false;
   h->mp_fresh = true;
+  return 0;
+}
+
+// The layouts a pure fp32 LSTM train step reads -- padded embedding table, packed kernels and projections (what ensure_packed
+// builds for the LSTM modes) and the fp32 Kh^T / Kx^T fragment copies of the BPTT kernel -- in ONE launch (launch_pack_multi).
+int pack_train_fp32(sse_handle *h, TrainState &ts, int nside, hipStream_t st) {
+  const sse_config &c = h->cfg;
+  PackJobs js;
+  if (h->packed_dirty) {
+    const int Ep = emb_cols(c);
+    h->emb16_valid = false;
+    if (!h->emb_pad) HIPCHECK(h, hipMalloc((void **)&h->emb_pad, (size_t)c.vocab_size * Ep * sizeof(float)));
+    pack_job_pad_rows(js, h->vars[0].dev, c.vocab_size, c.embedding_size, Ep, c.embedding_size, h->emb_pad);
+    for (int s = 0; s < 2; ++s) {
+      Encoder &e = h->enc[s];
+      if (e.H <= 0 || e.kernel < 0) continue;
+      e.pad_valid = e.pad_valid_small = e.waug_valid = e.wc_valid = e.x3_valid = e.pad_valid_x3 = false;
+      const int KG = e.KGx + e.KGh;
+      if (e.shares_lstm_with < 0) {
+        if (!e.Wp) HIPCHECK(h, hipMalloc((void **)&e.Wp, (size_t)(e.Hp / 32) * KG * 4 * 256 * sizeof(float)));
+        pack_job_lstm(js, h->vars[e.kernel].dev, h->vars[e.bias].dev, c.embedding_size, e.H, e.Ep, e.Hp, e.Wp);
+      } else {
+        e.Wp = h->enc[e.shares_lstm_with].Wp;
+      }
+      const int NTS = (c.encoding_size + 31) / 32;
+      if (!e.Mp) HIPCHECK(h, hipMalloc((void **)&e.Mp, (size_t)NTS * e.KGh * 256 * sizeof(float)));
+      pack_job_kn(js, h->vars[e.proj].dev, e.H, c.encoding_size, e.KGh, e.Mp);
+    }
+  }
+  if (ts.fp32_dirty) {
+    for (int s = 0; s < nside; ++s) {
+      Encoder &e = h->enc[s];
+      if (e.shares_lstm_with >= 0) {
+        ts.KhT[s] = ts.KhT[e.shares_lstm_with];
+        ts.KxT[s] = ts.KxT[e.shares_lstm_with];
+        continue;
+      }
+      if (!ts.KhT[s]) HIPCHECK(h, hipMalloc((void **)&ts.KhT[s], (size_t)(e.Hp / 32) * (e.Hp / 2) * 256 * sizeof(float)));
+      if (!ts.KxT[s]) HIPCHECK(h, hipMalloc((void **)&ts.KxT[s], (size_t)2 * (e.Hp / 2) * 256 * sizeof(float)));
+      pack_job_kT(js, h->vars[e.kernel].dev, c.embedding_size, e.H, e.Hp / 32, e.H, e.Hp, ts.KhT[s]);
+      pack_job_kT(js, h->vars[e.kernel].dev, 0, c.embedding_size, 2, e.H, e.Hp, ts.KxT[s]);
+    }
+  }
+  HIPCHECK(h, launch_pack_multi(js, st));
+  h->packed_dirty = false;
+  h->mp_fresh = true;
+  ts.fp32_dirty = false;
   return 0;
 }
 
@@ -575,6 +623,7 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
       }
       pa.epoch = ++h->persist_epoch;
       pa.write_through = h->lstm_cluster_wt;
+      pa.plain_launch = h->lstm_cluster_coop ? 0 : 1;
       pa.hx = (unsigned long long *)h->s_persist.p;
       pa.rawx = pa.hx + nhx;
       HIPCHECK(h, launch_lstm_persist(pa, st));
@@ -633,6 +682,7 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
         h->cluster_epoch = 0;
       }
       ca.write_through = h->lstm_cluster_wt;
+      ca.plain_launch = h->lstm_cluster_coop ? 0 : 1;
       ca.drop_wg = h->lstm_cluster_drop;
       ca.hx = (unsigned long long *)h->s_cluster.p;
       ca.sx = ca.hx + nhx;
@@ -1555,6 +1605,10 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value) {
     h->lstm_cluster_drop = value != 0;
     return 0;
   }
+  if (strcmp(name, "lstm_cluster_coop") == 0) {
+    h->lstm_cluster_coop = value != 0;
+    return 0;
+  }
   if (strcmp(name, "lstm_cluster_write_through") == 0) {
     h->lstm_cluster_wt = value != 0;
     return 0;
@@ -1883,7 +1937,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   // layouts derived from the variables, rebuilt after every update: only the ones this step's kernels read (an all-split
   // step needs the projections, Kh^T / Kx^T in split form and -- below -- the split kernel matrix and embedding table;
   // the fp32 fragment copies wait for the next encode or fp32 step: 7 fewer launches on the critical path of a step)
-  if (all_x3 ? ensure_proj_packed(h, st) : ensure_packed(h, st)) return 1;
+  if (bwd2 ? pack_train_fp32(h, ts, nside, st) : all_x3 ? ensure_proj_packed(h, st) : ensure_packed(h, st)) return 1;
   bool any_bwd_x3 = false;
   for (int s = 0; s < nside; ++s) any_bwd_x3 = any_bwd_x3 || bwd_x3[s];
   // (the split Kh^T / Kx^T copies are only rebuilt by steps that run the split-operand BPTT: a pure fp32 step leaves them stale)

@@ -208,6 +208,7 @@ struct LstmPersistArgs {
   int32_t NWG = 0;              // set by the launcher
   int32_t map_mode = 0;         // 0: cluster = blockIdx % 8 (one XCD per cluster); 1: consecutive blocks (measurement aid)
   int32_t write_through = 0;    // 1: always publish h with write-through stores (the any-placement path)
+  int32_t plain_launch = 0;     // 1: hipLaunchKernelGGL instead of the cooperative launch (option lstm_cluster_coop = 0)
 };
 int lstm_persist_nwg(int E, int H, int S);   // workgroups per cluster, 0: shape not supported
 int lstm_persist_max_rows();
@@ -233,6 +234,7 @@ struct LstmClusterArgs {
   uint32_t epoch = 0;                // 1 .. 2^20-1, different for every launch on the same exchange buffers
   int32_t NCL = 0;                   // set by the launcher
   int32_t write_through = 0;         // 1: always publish h with write-through stores (the any-placement path; tests)
+  int32_t plain_launch = 0;          // 1: hipLaunchKernelGGL instead of the cooperative launch (option lstm_cluster_coop = 0)
   int32_t drop_wg = 0;               // 1: the last workgroup of cluster 0 exits at once (tests of the give-up path)
 };
 int lstm_cluster_ok(int E, int H, int S);
@@ -344,6 +346,25 @@ hipError_t launch_l2_normalize(const float *x, float *out, int64_t rows, int col
 
 hipError_t launch_pack_lstm(const float *K, const float *b, int E, int H, int Ep, int Hp, int UB, float *Wp,
                             hipStream_t stream);
+// several re-layouts in one launch (the train step's: padded embedding table, packed kernels / projections, Kh^T / Kx^T)
+enum { PACK_JOB_PAD_ROWS = 1, PACK_JOB_LSTM = 2, PACK_JOB_KN = 3, PACK_JOB_KT = 4 };
+struct PackJob {
+  int32_t type;
+  const float *a, *b;
+  float *out;
+  int64_t total;  // PAD_ROWS: rows; the others: float4 items
+  int32_t i0, i1, i2, i3;
+};
+#define SSE_MAX_PACK_JOBS 12
+struct PackJobs {
+  PackJob job[SSE_MAX_PACK_JOBS];
+  int32_t n = 0;
+};
+void pack_job_pad_rows(PackJobs &js, const float *in, int64_t R, int C, int Cp, int one_col, float *out);
+void pack_job_lstm(PackJobs &js, const float *K, const float *b, int E, int H, int Ep, int Hp, float *Wp);
+void pack_job_kn(PackJobs &js, const float *X, int K, int N, int KGp, float *out);
+void pack_job_kT(PackJobs &js, const float *K, int row0, int nrows, int RT, int H, int Hp, float *out);
+hipError_t launch_pack_multi(const PackJobs &js, hipStream_t stream);
 hipError_t launch_pack_kn(const float *X, int K, int N, int KGp, float *out, hipStream_t stream);
 hipError_t launch_pad_rows(const float *in, int64_t R, int C, int Cp, int one_col, float *out, hipStream_t stream);
 hipError_t launch_row_norm2_max(const float *x, int64_t rows, int cols, float *out_bits, hipStream_t stream);

@@ -21,6 +21,9 @@ CASES = [
     ("source-encoder-only", 64, 8, 32, 32, 16, 5, 3),
     ("dual-encoder", 200, 50, 512, 300, 128, 12, 45),      # cell sizes up to 512 (32-row tiles, 2 unit blocks per wave)
     ("dual-encoder", 500, 50, 256, 256, 256, 32, 9000),    # > 8192 rows: 64-row tiles; below: 32-row tiles
+    ("dual-encoder", 300, 50, 96, 80, 64, 12, 9000),       # reference default cell size at 64-row tiles: three live unit blocks, block 2 split by pass
+    ("shared-encoder", 300, 40, 72, 72, 50, 9, 8300),      # three live unit blocks with a partial last one
+    ("dual-encoder", 200, 40, 64, 40, 50, 10, 8500),        # H <= 64 at 64-row tiles: two live unit blocks
 ]
 
 
@@ -654,3 +657,26 @@ def test_single_query_with_odd_pad_prefix_never_gives_up():
         m.handle.set_option("lstm_persist_rows", 32)
         m.handle.set_option("lstm_cluster_rows", 1024)
     assert m.handle.get_counter("lstm_persist_fallbacks") == before
+
+
+@pytest.mark.parametrize("H", [96, 64, 40, 72])
+def test_small_cells_at_64_row_tiles_are_bit_identical_to_the_other_kernels(H):
+    """H <= 96 at 64-row tiles (batches above 8192 rows): two or three live unit blocks, the third split by pass over two
+    waves.  A row's result must not change a bit: against the few-sequences kernel (what every encoder kernel is
+    bit-identical to), rows taken from everywhere in a 9,000-row batch, with and without the left-pad prefix skip."""
+    params = model_params("dual-encoder", 400, 50, H, H, 64, 20)
+    m, p = make_pair(params, seed=19)
+    rng = np.random.RandomState(23)
+    ids = random_ids(rng, 9000, 20, 400, pad_frac=0.6)
+    for pad_skip in (1, 0):
+        m.handle.set_option("pad_skip", pad_skip)
+        big = m.encode_source(ids)
+        assert np.abs(big[:300] - O.encode(p, params, "src", ids[:300])).max() <= TOL
+        pick = np.concatenate([np.arange(0, 40), np.arange(4480, 4520), np.arange(8960, 9000)])
+        m.handle.set_option("lstm_persist_rows", 0)
+        m.handle.set_option("lstm_cluster_rows", 0)
+        small = m.encode_source(ids[pick])                   # 120 rows: the few-sequences kernel
+        m.handle.set_option("lstm_persist_rows", 32)
+        m.handle.set_option("lstm_cluster_rows", 1024)
+        assert np.array_equal(big[pick], small)
+    m.handle.set_option("pad_skip", 1)
