@@ -274,7 +274,41 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   // stage the query block (already fragment-packed, [query tile][k-group][1 KiB]) into LDS as [k-group][query tile]:
   // the NQ fragments of one k-group are 1 KiB apart and consecutive k-groups NQ KiB, so every read in the unrolled
   // k-loop is ONE base register + an immediate offset (with [q][kg] the NQ*KG addresses each took a VGPR)
-  {
+  if (NQ == 1 && a.q_rows != nullptr) {
+    // latency path: fragments straight from the row-major fp32 queries (same values as launch_pack_rows /
+    // launch_pack_rows_bf16 produce: lane (half, row) owns 4 / 8 consecutive k, bf16 rounded to nearest even)
+    f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
+    const int Sd = a.S;
+    for (int i = tid; i < KG * 64; i += SC_THREADS) {
+      const int kg = i >> 6, l = i & 63, row = qb * 32 + (l & 31);
+      f32x4 v = {0, 0, 0, 0};
+      if (row < Qeff) {
+        if constexpr (BF) {
+          const int k0 = kg * 16 + (l >> 5) * 8;
+          const float *src = a.q_rows + (size_t)row * Sd + k0;
+          unsigned wd[4] = {0, 0, 0, 0};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            unsigned b = 0;
+            if (k0 + j < Sd) {
+              unsigned u = __float_as_uint(src[j]);
+              u += 0x7FFFu + ((u >> 16) & 1u);
+              b = u >> 16;
+            }
+            wd[j >> 1] |= b << ((j & 1) * 16);
+          }
+          v = __builtin_bit_cast(f32x4, u32x4{wd[0], wd[1], wd[2], wd[3]});
+        } else {
+          const int k0 = kg * 8 + (l >> 5) * 4;
+          const float *src = a.q_rows + (size_t)row * Sd + k0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k0 + e < Sd) v[e] = src[e];
+        }
+      }
+      dst[i] = v;
+    }
+  } else {
     const f32x4 *src = reinterpret_cast<const f32x4 *>(a.qp) + (size_t)qb * NQ * KG * 64;
     f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
     const int valid = min(NQ, (Qeff + 31) / 32 - qb * NQ) * KG * 64;
@@ -764,6 +798,7 @@ hipError_t launch_score_topk(const ScoreArgs &a_in, hipStream_t stream) {
   }
 #endif
   if (a.KC != SC_KC) return hipErrorInvalidValue;
+  if (a.q_rows && (a.NQ != 1 || a.S < 1)) return hipErrorInvalidValue;
   if (a.NSPLIT > 8 && (a.NSPLIT & 7)) return hipErrorInvalidValue;
   if (a.NSPLIT < 8 && (8 % a.NSPLIT)) return hipErrorInvalidValue;
   if (a.COLLECT) {  // collect pass: fp32 scores only (the thresholds are fp32 bounds)
@@ -787,29 +822,53 @@ hipError_t launch_score_topk(const ScoreArgs &a_in, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------
-// exact float64 score of query row q against index row n (frag32-packed f32 rows
-// or row-major f64 rows), computed by one wave; result valid in every lane.
-__device__ __forceinline__ double wave_exact_dot(const float *qrow, const float *idxp, const double *idx64,
-                                                 int64_t n, int S, int KG, int lane) {
-  double acc = 0.0;
+// exact float64 scores of query row q against NB index rows n[0..NB) (frag32-packed f32 rows or row-major f64 rows),
+// computed by one wave; results valid in every lane.  The rows' loads are independent and in flight together (a window of
+// ~12 candidates re-scored one row at a time was a chain of 12 HBM round trips); every row's sum is formed in exactly the
+// order of the single-row form below, which is this template with NB = 1: all passes produce bit-identical scores.
+template <int NB>
+__device__ __forceinline__ void wave_exact_dot_n(const float *qrow, const float *idxp, const double *idx64, const int64_t (&n)[NB],
+                                                 int S, int KG, int lane, double (&out)[NB]) {
+  double acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) acc[b] = 0.0;
   if (idx64) {
-    const double *row = idx64 + (size_t)n * S;
-    for (int d = lane; d < S; d += 64) acc += (double)qrow[d] * row[d];
+    for (int d = lane; d < S; d += 64) {
+      double rv[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) rv[b] = idx64[(size_t)n[b] * S + d];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[b] += (double)qrow[d] * rv[b];
+    }
   } else {
-    const float *blk = idxp + (size_t)(n >> 5) * KG * 256;
-    const int r = (int)(n & 31);
     for (int j = lane; j < KG * 2; j += 64) {  // j = kg*2 + half -> 4 consecutive dims
       const int kg = j >> 1, half = j & 1;
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(blk + kg * 256 + (half * 32 + r) * 4);
+      f32x4 v[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        v[b] = *reinterpret_cast<const f32x4 *>(idxp + (size_t)(n[b] >> 5) * KG * 256 + kg * 256 + (half * 32 + (int)(n[b] & 31)) * 4);
       const int d0 = kg * 8 + half * 4;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (d0 + e < S) acc += (double)qrow[d0 + e] * (double)v[e];
+        if (d0 + e < S) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) acc[b] += (double)qrow[d0 + e] * (double)v[b][e];
+        }
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  return acc;
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] += __shfl_xor(acc[b], o);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) out[b] = acc[b];
+}
+__device__ __forceinline__ double wave_exact_dot(const float *qrow, const float *idxp, const double *idx64,
+                                                 int64_t n, int S, int KG, int lane) {
+  const int64_t nn[1] = {n};
+  double out[1];
+  wave_exact_dot_n<1>(qrow, idxp, idx64, nn, S, KG, lane, out);
+  return out[0];
 }
 
 __device__ __forceinline__ bool before(double sa, int64_t ia, double sb, int64_t ib) {
@@ -822,7 +881,7 @@ __device__ __forceinline__ bool before(double sa, int64_t ia, double sb, int64_t
 #define RS_MAXNC 4096  // candidates per query the re-scoring pass accepts
 __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
   __shared__ int s_cnt;
-  __shared__ int s_win[RS_MAXWIN];
+  __shared__ int s_wid[RS_MAXWIN];
   __shared__ double s_ex[RS_MAXWIN];
   __shared__ float s_m[RS_THREADS / 64];
   __shared__ double s_qn[RS_THREADS / 64];
@@ -835,6 +894,22 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
   const float *qrow = a.q + (size_t)q * a.S;
   const int KG = (a.S + 7) / 8;
 
+  // this thread's candidates (c = tid, tid + 256, ...) and split bounds into registers: every global read of the pass
+  // that does not depend on another one is issued here, in front of the first wait (a single query's call is a chain of
+  // dependent round trips: each one removed is ~2 us of a ~0.15 ms call)
+  constexpr int PER = RS_MAXNC / RS_THREADS;
+  float rs[PER];
+  int ri[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int c = tid + j * RS_THREADS;
+    ri[j] = (c < a.NC) ? pi[c] : -1;
+    rs[j] = (c < a.NC) ? ps[c] : NEG_INF;
+  }
+  // M = largest per-split bound (rows outside the candidates score <= M)
+  float mmax = NEG_INF;
+  for (int c = tid; c < a.NC / SC_KC; c += RS_THREADS) mmax = fmaxf(mmax, a.part_bnd[(size_t)q * (a.NC / SC_KC) + c]);
+
   // |q| for the fp32 error bound eps_q = eps * |q|
   {
     double v = 0.0;
@@ -843,21 +918,26 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     if (lane == 0) s_qn[w] = v;
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mmax = fmaxf(mmax, __shfl_xor(mmax, o));
+  if (lane == 0) s_m[w] = mmax;
   if (tid == 0) s_cnt = 0;
+
+  // k-th largest fp32 candidate: stage one sortable 64-bit key per candidate in LDS
+  // (monotone score bits << 32 | inverted row id, 0 = empty slot)
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int c = tid + j * RS_THREADS;
+    if (c < a.NC) {
+      unsigned u = __float_as_uint(rs[j]);
+      u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+      s_key[c] = (ri[j] < 0) ? 0ull : (((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)ri[j]));
+    }
+  }
   __syncthreads();
   const float qnorm = (float)sqrt(s_qn[0] + s_qn[1] + s_qn[2] + s_qn[3]);
   const float eps_q = a.eps * qnorm;
-
-  // k-th largest fp32 candidate: stage one sortable 64-bit key per candidate in LDS
-  // (monotone score bits << 32 | inverted row id, 0 = empty slot), then every thread
-  // ranks its candidates by counting larger keys (LDS broadcast reads).
-  for (int c = tid; c < a.NC; c += RS_THREADS) {
-    const int id = pi[c];
-    unsigned u = __float_as_uint(ps[c]);
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    s_key[c] = (id < 0) ? 0ull : (((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)id));
-  }
-  __syncthreads();
+  mmax = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
   // k-th largest key: every slot of KC candidates is a sorted list (descending), so k rounds of "largest list head
   // wins and advances" find it -- O(k * slots / 256) instead of ranking all NC candidates against each other
   // (NC = 4096 for a single query over 256 index splits: that ranking was a third of the whole pass).
@@ -868,7 +948,7 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
     const unsigned long long key = (tid < a.NC) ? s_key[tid] : 0ull;
     int rank = 0;
     for (int j = 0; j < a.NC; ++j) rank += (s_key[j] > key) ? 1 : 0;
-    float mine = (key != 0ull && rank == a.k - 1) ? ps[tid] : NEG_INF;
+    float mine = (key != 0ull && rank == a.k - 1) ? rs[0] : NEG_INF;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mine = fmaxf(mine, __shfl_xor(mine, o));
     __shared__ float s_thr[RS_THREADS / 64];
@@ -876,12 +956,14 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
     __syncthreads();
     kth = fmaxf(fmaxf(s_thr[0], s_thr[1]), fmaxf(s_thr[2], s_thr[3]));
   } else {
-    __shared__ unsigned long long s_best[RS_THREADS / 64];
+    // every wave plays the tournament over ITS slots on its own (shuffles, no barrier), k rounds; the k winners of the
+    // four waves meet in LDS and are ranked against each other once: the k-th largest of those is the k-th largest of all
+    __shared__ unsigned long long s_best[(RS_THREADS / 64) * SC_KC];
     const int nslots = a.NC / SC_KC;
-    int head[RS_MAXNC / SC_KC / RS_THREADS];   // this thread's slots: tid, tid + 256, ...
+    // slots of this thread: w * 64 + lane + j * 256 -- consecutive slots per wave; any partition works
+    int head[RS_MAXNC / SC_KC / RS_THREADS];
 #pragma unroll
     for (int j = 0; j < RS_MAXNC / SC_KC / RS_THREADS; ++j) head[j] = 0;
-    unsigned long long kkey = 0ull;
     for (int it = 0; it < a.k; ++it) {
       unsigned long long best = 0ull;
 #pragma unroll
@@ -892,24 +974,35 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
           best = key > best ? key : best;
         }
       }
+      unsigned long long win = best;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(best, o);
-        best = other > best ? other : best;
+        const unsigned long long other = __shfl_xor(win, o);
+        win = other > win ? other : win;
       }
-      if (lane == 0) s_best[w] = best;
-      __syncthreads();
-      unsigned long long win = s_best[0];
-#pragma unroll
-      for (int i = 1; i < RS_THREADS / 64; ++i) win = s_best[i] > win ? s_best[i] : win;
-      __syncthreads();
-      kkey = win;
-      if (win == 0ull) break;                  // fewer than k candidates
+      if (lane == 0) s_best[w * SC_KC + it] = win;
+      if (win == 0ull) {  // this wave's slots are exhausted (wave-uniform)
+        for (int r = it + 1; r < a.k; ++r)
+          if (lane == 0) s_best[w * SC_KC + r] = 0ull;
+        break;
+      }
 #pragma unroll
       for (int j = 0; j < RS_MAXNC / SC_KC / RS_THREADS; ++j) {  // keys are unique (row id): exactly one head matches
         const int slot = tid + j * RS_THREADS;
         if (slot < nslots && head[j] < SC_KC && s_key[slot * SC_KC + head[j]] == win) ++head[j];
       }
+    }
+    __syncthreads();
+    // rank the 4 * k wave winners (<= 64 keys, one per lane of every wave -- all waves compute the same)
+    const int nk = (RS_THREADS / 64) * a.k;
+    const unsigned long long key = (lane < nk) ? s_best[(lane / a.k) * SC_KC + lane % a.k] : 0ull;
+    int rank = 0;
+    for (int j = 0; j < nk; ++j) rank += (__shfl(key, j) > key) ? 1 : 0;
+    unsigned long long kkey = (key != 0ull && rank == a.k - 1) ? key : 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long other = __shfl_xor(kkey, o);
+      kkey = other > kkey ? other : kkey;
     }
     if (kkey != 0ull) {  // decode the score bits of the k-th key
       unsigned u = (unsigned)(kkey >> 32);
@@ -919,30 +1012,30 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
   }
 
   // window: candidates whose fp32 score is within 2*eps of the k-th (the only ones
-  // that can be in the exact top-k); M = largest per-split bound (rows outside the candidates score <= M)
-  float mmax = NEG_INF;
-  for (int c = tid; c < a.NC; c += RS_THREADS) {
-    const int id = pi[c];
-    if (id < 0) continue;
-    const float s = ps[c];
-    if (s >= kth - 2.0f * eps_q) {
+  // that can be in the exact top-k)
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    if (ri[j] >= 0 && rs[j] >= kth - 2.0f * eps_q) {
       const int p = atomicAdd(&s_cnt, 1);
-      if (p < RS_MAXWIN) s_win[p] = c;
+      if (p < RS_MAXWIN) s_wid[p] = ri[j];
     }
   }
-  for (int c = tid; c < a.NC / SC_KC; c += RS_THREADS) mmax = fmaxf(mmax, a.part_bnd[(size_t)q * (a.NC / SC_KC) + c]);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mmax = fmaxf(mmax, __shfl_xor(mmax, o));
-  if (lane == 0) s_m[w] = mmax;
   __syncthreads();
-  mmax = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
   const int nwin_all = s_cnt;
   const int nwin = min(nwin_all, RS_MAXWIN);
 
-  // exact float64 re-score of the window, one wave per candidate
-  for (int i = w; i < nwin; i += RS_THREADS / 64) {
-    const double ex = wave_exact_dot(qrow, a.idx32, a.idx64, pi[s_win[i]], a.S, KG, lane);
-    if (lane == 0) s_ex[i] = ex;
+  // exact float64 re-score of the window: a wave takes 4 candidates at a time
+  for (int i0 = w * 4; i0 < nwin; i0 += (RS_THREADS / 64) * 4) {
+    int64_t n[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) n[c] = s_wid[min(i0 + c, nwin - 1)];
+    double ex[4];
+    wave_exact_dot_n<4>(qrow, a.idx32, a.idx64, n, a.S, KG, lane, ex);
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (i0 + c < nwin) s_ex[i0 + c] = ex[c];
+    }
   }
   __syncthreads();
 
@@ -950,15 +1043,20 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
   double theta = -__builtin_inf();
   for (int i = tid; i < nwin; i += RS_THREADS) {
     const double s = s_ex[i];
-    const int64_t id = pi[s_win[i]];
+    const int64_t id = s_wid[i];
     int rank = 0;
-    for (int j = 0; j < nwin; ++j) rank += before(s_ex[j], (int64_t)pi[s_win[j]], s, id);
+    for (int j = 0; j < nwin; ++j) rank += before(s_ex[j], (int64_t)s_wid[j], s, id);
     if (rank < a.k) {
       a.out_scores[(size_t)qo * a.k + rank] = s;
       a.out_ids[(size_t)qo * a.k + rank] = a.id_base + id;
+      if (a.host_flag) {
+        a.host_scores[(size_t)qo * a.k + rank] = s;
+        a.host_ids[(size_t)qo * a.k + rank] = a.id_base + id;
+      }
     }
     if (rank == a.k - 1) theta = s;
   }
+  if (a.host_flag) __threadfence_system();  // this thread's mirror stores are out before the barriers in front of the flag
   // certificate: every row outside the candidate set has fp32 score <= mmax, hence
   // exact score <= mmax + eps_q; it cannot displace the exact k-th if that is < theta.
   {
@@ -975,6 +1073,15 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
       // t = exact score of the k-th best candidate (-inf with fewer than k): a lower bound of the true k-th best, so
       // every exact top-k row has fp32 score >= t - eps32*|q| (the collect pass gathers exactly those)
       if (a.col_thr) a.col_thr[qo] = ok ? __builtin_inff() : __double2float_rd(t - (double)(a.eps32 * qnorm));
+      if (a.col_slot) {
+        a.col_slot[qo] = ok ? -1 : qo;
+        a.col_cnt[qo] = 0;
+      }
+      if (a.host_flag) {
+        a.host_cert[qo] = ok ? 1 : 0;
+        if (qo == 0 && a.host_err) *a.host_err = a.err_in ? *a.err_in : 0;
+        __hip_atomic_store(a.host_flag + qo, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }
@@ -1017,12 +1124,22 @@ __global__ __launch_bounds__(256) void rescore_small_kernel(RescoreArgs a) {
   for (int o = 32; o > 0; o >>= 1) mmax = fmaxf(mmax, __shfl_xor(mmax, o));
   const unsigned long long wmask = __ballot(in_win);
   const int nwin = __popcll(wmask);
-  // exact float64 scores of the window members, one at a time with the whole wave
+  // exact float64 scores of the window members, four at a time with the whole wave (their row loads in flight together)
   double ex = -__builtin_inf();
-  for (unsigned long long m = wmask; m; m &= m - 1) {
-    const int src = __ffsll((long long)m) - 1;
-    const double v = wave_exact_dot(qrow, a.idx32, a.idx64, __shfl(id, src), a.S, KG, lane);
-    if (lane == src) ex = v;
+  for (unsigned long long m = wmask; m;) {
+    int src[4];
+    int64_t n[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      src[c] = m ? __ffsll((long long)m) - 1 : -1;
+      m &= m - 1;  // (0 stays 0)
+      n[c] = __shfl(id, src[c] < 0 ? src[0] : src[c]);
+    }
+    double v[4];
+    wave_exact_dot_n<4>(qrow, a.idx32, a.idx64, n, a.S, KG, lane, v);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (lane == src[c]) ex = v[c];
   }
   // exact rank inside the window (score descending, then lower row id)
   int r2 = 0;
@@ -1033,14 +1150,28 @@ __global__ __launch_bounds__(256) void rescore_small_kernel(RescoreArgs a) {
   if (in_win && r2 < a.k) {
     a.out_scores[(size_t)qo * a.k + r2] = ex;
     a.out_ids[(size_t)qo * a.k + r2] = a.id_base + id;
+    if (a.host_flag) {
+      a.host_scores[(size_t)qo * a.k + r2] = ex;
+      a.host_ids[(size_t)qo * a.k + r2] = a.id_base + id;
+    }
   }
   double theta = (in_win && r2 == a.k - 1) ? ex : -__builtin_inf();
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) theta = fmax(theta, __shfl_xor(theta, o));
+  if (a.host_flag) __threadfence_system();
   if (lane == 0) {
     const bool ok = (nwin >= a.k) && ((double)mmax + (double)eps_q < theta);
     a.cert[qo] = ok ? 1 : 0;
     if (a.col_thr) a.col_thr[qo] = ok ? __builtin_inff() : __double2float_rd(theta - (double)(a.eps32 * qnorm));
+    if (a.col_slot) {
+      a.col_slot[qo] = ok ? -1 : qo;
+      a.col_cnt[qo] = 0;
+    }
+    if (a.host_flag) {
+      a.host_cert[qo] = ok ? 1 : 0;
+      if (qo == 0 && a.host_err) *a.host_err = a.err_in ? *a.err_in : 0;
+      __hip_atomic_store(a.host_flag + qo, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 

@@ -162,6 +162,7 @@ struct sse_handle {
   int32_t *pin_small = nullptr;  // 64 pinned host words: error flag / loss read-backs (a pageable target makes the copy a blocking one)
   void *pin = nullptr;  // pinned host staging of the host-buffer scoring entry points: [scores | ids | certificates]
   size_t pin_cap = 0;
+  int32_t score_seq = 0;  // call number the re-scoring pass stores into the pinned completion flags (ScoreMirror)
   DevBuf s_pb, s_cthr, s_cslot, s_ccnt, s_cbuf;  // per-split bounds; collect path: thresholds, slots, counters, row buffers
   const int32_t *cur_row_map = nullptr;  // set by sse_encode around its launch
   // training
@@ -981,9 +982,18 @@ static int score_select_locked(sse_handle *h, const float *q, int Q, int k, doub
 // with the results say so -- SCORE_REST = second chance / collect / select / brute force: the common call saves five to nine
 // empty launches (~4.5 us each: a third of a single-query call, profiles/r02z_demo_kernel_stats.csv).
 enum { SCORE_ALL = 0, SCORE_FIRST = 1, SCORE_REST = 2 };
+// Host mirror of a SCORE_FIRST call of few queries (see RescoreArgs): pinned, device-visible host pointers the re-scoring pass
+// stores results, certificates, the error flag of the encoder in front of it and -- last, released at system scope -- one
+// completion word per query through.  The host polls the words: no read-back copies, no stream synchronisation.
+struct ScoreMirror {
+  double *scores;
+  int64_t *ids;
+  int32_t *cert, *err, *flag;
+  int32_t seq;
+};
 // *split (out, may be null): 1 when the call has a FIRST / REST split (k <= 16), 0 when SCORE_FIRST did everything
 int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s, int64_t *out_i, hipStream_t st,
-                     int phase = SCORE_ALL, int *split = nullptr) {
+                     int phase = SCORE_ALL, int *split = nullptr, const ScoreMirror *mirror = nullptr) {
   if (split) *split = 0;
   if (!h->idxp) return fail(h, "no index uploaded");
   if (Q < 0) return fail(h, "bad Q");
@@ -1040,11 +1050,17 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   if (reserve_collect(h, Q, POOL)) return 1;
   if (split) *split = 1;
   const bool first = phase != SCORE_REST, rest = phase != SCORE_FIRST;
-  if (first) {
+  // <= 32 queries (the latency path): the sweeps build their query fragments from the rows themselves -- no pack launch
+  const bool rows_direct = NQ == 1;
+  if (first && !rows_direct) {
     if (bf) HIPCHECK(h, launch_pack_rows_bf16(q, Q, S, h->s_qp.p, st));
     else HIPCHECK(h, launch_pack_rows(q, Q, S, (float *)h->s_qp.p, st));
   }
   ScoreArgs a;
+  if (rows_direct) {
+    a.q_rows = q;
+    a.S = S;
+  }
   a.BF = bf ? 1 : 0;
   a.idxp = bf ? (const float *)h->idxp16 : h->idxp;
   a.qp = (const float *)h->s_qp.p;
@@ -1081,12 +1097,33 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   r.eps = eps32;
   r.eps32 = eps32;
   r.col_thr = (float *)h->s_cthr.p;
+  // every query has a collect slot of its own (the usual call): the re-scoring pass hands them out (slot = query for an
+  // uncertified one) and zeroes their counters -- no memset / launch_assign_slots between the passes
+  const bool own_slots = Q <= POOL;
+  if (own_slots) {
+    r.col_slot = (int32_t *)h->s_cslot.p;
+    r.col_cnt = (int32_t *)h->s_ccnt.p;
+  }
   // bf16 operands: |q^.t^ - q.t| <= ((1+u)^2 - 1) sum|q_i t_i| <= (2^-8 + 2^-18) |q||t|, u = 2^-9 (round to nearest)
   if (bf) r.eps += (float)(1.02 * (1.0 / 256.0 + 1.0 / 262144.0) * h->idx_norm_max);
-  if (first) HIPCHECK(h, launch_rescore(r, st));
+  if (first) {
+    RescoreArgs rf = r;
+    if (mirror) {
+      rf.host_scores = mirror->scores;
+      rf.host_ids = mirror->ids;
+      rf.host_cert = mirror->cert;
+      rf.host_err = mirror->err;
+      rf.host_flag = mirror->flag;
+      rf.err_in = h->err_flag;
+      rf.seq = mirror->seq;
+    }
+    HIPCHECK(h, launch_rescore(rf, st));
+  }
   if (!rest) return 0;
   const float *qp32 = (const float *)h->s_qp.p;  // fp32 query fragments for the collect sweep
-  if (bf) {
+  // (<= 32 queries skip the second chance: for one query block it is the same fp32 sweep of the whole index as the collect
+  // pass, which is final)
+  if (bf && Q > 32) {
     // Second chance, entirely on the device (the call stays asynchronous): queries whose bf16-candidate result missed
     // its certificate (top scores packed closer than the bf16 bound) are swept again with fp32 candidates -- the same
     // kernels, where a workgroup whose whole query block is certified returns at once and a certified query is left
@@ -1099,11 +1136,12 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
     // Q; workgroups past the set return at once)
     int32_t *qmap = (int32_t *)h->s_qmap.p, *qcount = qmap + Q;
     HIPCHECK(h, launch_compact_uncert(q, r.cert, Q, S, qmap, qcount, (float *)h->s_qc.p, st));
-    HIPCHECK(h, launch_pack_rows((const float *)h->s_qc.p, Q, S, (float *)h->s_qp32.p, st));
+    if (!rows_direct) HIPCHECK(h, launch_pack_rows((const float *)h->s_qc.p, Q, S, (float *)h->s_qp32.p, st));
     ScoreArgs a2 = a;
     a2.BF = 0;
     a2.idxp = h->idxp;
     a2.qp = (const float *)h->s_qp32.p;
+    if (rows_direct) a2.q_rows = (const float *)h->s_qc.p;
     a2.KG = KG;
     a2.q_count = qcount;
     a2.NSPLIT = nsplit2;
@@ -1116,7 +1154,7 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
     r2.q_count = qcount;
     HIPCHECK(h, launch_rescore(r2, st));
     // fp32 fragments of ALL queries for the collect sweep below
-    HIPCHECK(h, launch_pack_rows(q, Q, S, (float *)h->s_qp32.p, st));
+    if (!rows_direct) HIPCHECK(h, launch_pack_rows(q, Q, S, (float *)h->s_qp32.p, st));
     qp32 = (const float *)h->s_qp32.p;
   }
   // What is still uncertified has its k-th score tied with (or within the fp32 bound of) rows outside the candidate
@@ -1124,8 +1162,10 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   // score reaches (exact k-th of the candidates) - bound is gathered by a grid-wide sweep and sorted in float64:
   // provably the exact top-k, at the cost of one more fp32 sweep for the query blocks concerned.  Launched
   // unconditionally (no host sync); with everything certified all workgroups return at once.
-  HIPCHECK(h, hipMemsetAsync(h->s_ccnt.p, 0, (size_t)(POOL + 1) * sizeof(int32_t), st));
-  HIPCHECK(h, launch_assign_slots(r.cert, Q, POOL, (int32_t *)h->s_cslot.p, (int32_t *)h->s_ccnt.p + POOL, st));
+  if (!own_slots) {
+    HIPCHECK(h, hipMemsetAsync(h->s_ccnt.p, 0, (size_t)(POOL + 1) * sizeof(int32_t), st));
+    HIPCHECK(h, launch_assign_slots(r.cert, Q, POOL, (int32_t *)h->s_cslot.p, (int32_t *)h->s_ccnt.p + POOL, st));
+  }
   ScoreArgs c = a;
   c.BF = 0;
   c.idxp = h->idxp;
@@ -1339,8 +1379,9 @@ static int ensure_pin(sse_handle *h, size_t need) {
   if (h->pin) HIPCHECK(h, hipHostFree(h->pin));
   h->pin = nullptr;
   h->pin_cap = 0;
-  HIPCHECK(h, hipHostMalloc(&h->pin, need + need / 2 + 4096, hipHostMallocDefault));
+  HIPCHECK(h, hipHostMalloc(&h->pin, need + need / 2 + 4096, hipHostMallocCoherent));  // (the device stores into it: ScoreMirror)
   h->pin_cap = need + need / 2 + 4096;
+  memset(h->pin, 0, h->pin_cap);  // (the completion words of ScoreMirror must not hold a call number by accident)
   return 0;
 }
 
@@ -1445,16 +1486,54 @@ static int score_to_host_locked(sse_handle *h, const float *q_dev, int Q, int k,
   hipStream_t st = nullptr;
   if (reserve(h, h->s_os, (size_t)Q * k * sizeof(double))) return 1;
   if (reserve(h, h->s_oi, (size_t)Q * k * sizeof(int64_t))) return 1;
-  const size_t nb = (size_t)Q * k * 8, need = 2 * nb + (size_t)Q * sizeof(int32_t) + sizeof(int32_t);
+  // pinned block: [scores | ids | certificates | error flag | completion words]
+  const size_t nb = (size_t)Q * k * 8, need = 2 * nb + (size_t)(2 * Q + 1) * sizeof(int32_t);
   if (ensure_pin(h, need)) return 1;
   char *pin = (char *)h->pin;
+  int32_t *cert = (int32_t *)(pin + 2 * nb), *flag = cert + Q, *done = flag + 1;
   int split = 0;
-  if (score_dev_locked(h, q_dev, Q, k, (double *)h->s_os.p, (int64_t *)h->s_oi.p, st, SCORE_FIRST, &split)) return 1;
-  for (int pass = 0; pass < 2; ++pass) {
+  // few queries (the demo / web call): the re-scoring pass stores its results through the pinned pointers itself and the
+  // host polls the completion words -- three read-back copies and the stream synchronisation were ~40 us of a 0.19 ms call
+  const bool use_mirror = Q <= 64 && k <= 16;
+  ScoreMirror hm{(double *)pin, (int64_t *)(pin + nb), cert, flag, done, 0};
+  if (use_mirror) {
+    h->score_seq = (h->score_seq == INT32_MAX) ? 1 : h->score_seq + 1;
+    hm.seq = h->score_seq;
+  }
+  if (score_dev_locked(h, q_dev, Q, k, (double *)h->s_os.p, (int64_t *)h->s_oi.p, st, SCORE_FIRST, &split, use_mirror ? &hm : nullptr))
+    return 1;
+  int pass = 0;
+  if (use_mirror && split) {
+    const auto t0 = std::chrono::steady_clock::now();
+    bool synced = false;
+    for (;;) {
+      bool all = true;
+      for (int i = 0; i < Q && all; ++i) all = __atomic_load_n(done + i, __ATOMIC_ACQUIRE) == hm.seq;
+      if (all) break;
+      if (synced) return fail(h, "the re-scoring pass did not report completion");
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(3)) {
+        HIPCHECK(h, hipStreamSynchronize(st));  // (a launch that failed shows up here)
+        synced = true;
+      }
+    }
+    if (err_bits) {
+      *err_bits = *flag;
+      if (*flag) return 0;  // the queries were not what the caller meant: it looks at the flag first
+    }
+    bool open_q = false;
+    for (int i = 0; i < Q && !open_q; ++i) open_q = cert[i] == 0;
+    if (open_q) {
+      // rare: ties / near-ties at the k-th score, or scores packed closer than the bf16 bound
+      if (score_dev_locked(h, q_dev, Q, k, (double *)h->s_os.p, (int64_t *)h->s_oi.p, st, SCORE_REST)) return 1;
+      pass = 1;
+    } else {
+      pass = 2;
+    }
+  }
+  for (; pass < 2; ++pass) {
     HIPCHECK(h, hipMemcpyAsync(pin, h->s_os.p, nb, hipMemcpyDeviceToHost, st));
     HIPCHECK(h, hipMemcpyAsync(pin + nb, h->s_oi.p, nb, hipMemcpyDeviceToHost, st));
-    if (split && pass == 0) HIPCHECK(h, hipMemcpyAsync(pin + 2 * nb, h->s_cert.p, (size_t)Q * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    int32_t *flag = (int32_t *)(pin + 2 * nb + (size_t)Q * sizeof(int32_t));
+    if (split && pass == 0) HIPCHECK(h, hipMemcpyAsync(cert, h->s_cert.p, (size_t)Q * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     if (err_bits && pass == 0) HIPCHECK(h, hipMemcpyAsync(flag, h->err_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHECK(h, sync_stream(st));
     if (err_bits && pass == 0) {
@@ -1463,7 +1542,6 @@ static int score_to_host_locked(sse_handle *h, const float *q_dev, int Q, int k,
     }
     bool open_q = false;
     if (split && pass == 0) {
-      const int32_t *cert = (const int32_t *)(pin + 2 * nb);
       for (int i = 0; i < Q && !open_q; ++i) open_q = cert[i] == 0;
     }
     if (!open_q) break;

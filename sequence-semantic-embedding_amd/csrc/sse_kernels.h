@@ -267,6 +267,11 @@ struct ScoreArgs {
   int32_t *col_buf = nullptr;         // [slots][col_cap] local row numbers
   int32_t col_cap = 0;
   int32_t dbg = 0;  // builds with -DSSE_SCORE_MEASURE only (env SSE_SCORE_DBG): bit 0 = skip the top-k epilogue of the sweep
+  // NQ == 1 (<= 32 queries, the latency path): the workgroups build their query fragments from the row-major fp32 queries
+  // themselves (q_rows [Q][S]; fp32 or rounded to bf16 exactly as launch_pack_rows / launch_pack_rows_bf16 would) -- qp is
+  // not read and the pack launch in front of the sweep goes away
+  const float *q_rows = nullptr;
+  int32_t S = 0;
 };
 hipError_t launch_score_topk(const ScoreArgs &a, hipStream_t stream);
 // query tiles per workgroup (4 / 2 / 1) whose LDS query block fits for index dimension S in every variant of a call
@@ -306,6 +311,18 @@ struct RescoreArgs {
   // candidates) - eps32 * |q| rounded down: no exact top-k row has a smaller fp32 score
   float *col_thr = nullptr;
   float eps32 = 0.0f;      // fp32 bound used for col_thr (eps may be the wider bf16 one)
+  // optional (calls of <= the collect pool's queries): every query owns collect slot `query`; the pass writes
+  // col_slot[query] = certified ? -1 : query and zeroes col_cnt[query], which replaces launch_assign_slots + a memset
+  int32_t *col_slot = nullptr, *col_cnt = nullptr;
+  // optional host mirror (few queries, host-buffer entry points): scores / ids / certificates are ALSO stored through
+  // these device-visible pinned host pointers, then -- after a system-scope fence -- host_flag[query] = seq.  The host
+  // polls the flags instead of queueing three read-back copies and waiting for the stream.  host_err (query 0 only)
+  // receives *err_in, the encoder's error flag of the same call.
+  double *host_scores = nullptr;
+  int64_t *host_ids = nullptr;
+  int32_t *host_cert = nullptr, *host_flag = nullptr, *host_err = nullptr;
+  const int32_t *err_in = nullptr;
+  int32_t seq = 0;
 };
 hipError_t launch_rescore(const RescoreArgs &a, hipStream_t stream);
 

@@ -329,6 +329,48 @@ def test_bf16_candidates_second_chance_on_densely_packed_scores():
     assert 3 <= n <= 30, n                                   # the crowded queries took it; the ordinary ones did not
 
 
+@pytest.mark.parametrize("Q", [1, 5, 32])
+def test_few_queries_with_crowded_scores_take_the_collect_pass(Q):
+    """<= 32 queries build their fragments inside the sweep (no pack launch) and skip the fp32 second chance: a query whose
+    top scores sit closer than the bf16 bound goes straight to the collect pass (one fp32 sweep, final).  Host entry point:
+    results come back through the pinned mirror of the re-scoring pass, call after call (completion words carry the call
+    number), with certified and uncertified queries in one call."""
+    rng = np.random.RandomState(40 + Q)
+    S, N = 64, 40000
+    t = _unit(rng, N, S).astype(np.float64)
+    q = _unit(rng, Q, S)
+    rows = rng.choice(N, 400, replace=False)
+    base = q[0].astype(np.float64)
+    base /= np.linalg.norm(base)
+    for j, r in enumerate(rows):
+        u = rng.standard_normal(S)
+        u -= u.dot(base) * base
+        u /= np.linalg.norm(u)
+        c = 1.0 - 2e-5 * j
+        t[r] = c * base + np.sqrt(1.0 - c * c) * u
+    h = _scorer_bf16()
+    h.index_upload(t)
+    want = O.topk(O.scores_f64(q, t), 10)
+    for _ in range(3):
+        sc, ids = h.score_topk(q, 10)
+        assert np.array_equal(ids, want[1]) and np.abs(sc - want[0]).max() < 1e-12
+    assert h.get_counter("score_bf16_second_chance_queries") == 0
+    assert 3 <= h.get_counter("score_collect_queries") <= 3 * Q
+    assert h.get_counter("score_bruteforce_queries") == 0
+    # fewer queries in the next call: words of the earlier, larger call must not be taken for this one's
+    sc, ids = h.score_topk(q[Q - 1:], 10)
+    assert np.array_equal(ids, want[1][Q - 1:]) and np.abs(sc - want[0][Q - 1:]).max() < 1e-12
+    # and the device entry point (every stage queued, no host check in between)
+    import torch
+    dev = torch.device("cuda:0")
+    qd = torch.from_numpy(q).to(dev)
+    out_s = torch.empty((Q, 10), dtype=torch.float64, device=dev)
+    out_i = torch.empty((Q, 10), dtype=torch.int64, device=dev)
+    h.score_topk_dev(qd.data_ptr(), Q, 10, out_s.data_ptr(), out_i.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(out_i.cpu().numpy(), want[1]) and np.abs(out_s.cpu().numpy() - want[0]).max() < 1e-12
+
+
 # --------------------------------------------------------------------------
 # index dimensions beyond one 128-query LDS block: the sweep runs with 64-query blocks (296 < S <= 616; BASELINE
 # configs[4] has S = 512) or 32-query blocks (S <= 1024).  The reference scores any S with one np.dot
