@@ -20,6 +20,25 @@
 
 #define SC_THREADS 512
 #define SC_KC 16
+#ifndef SC_PRIO_K  // wave priority inside the k-loop / in the top-k epilogue
+#define SC_PRIO_K 1
+#define SC_PRIO_E 0
+#endif
+
+#ifdef SSE_SCORE_CLOCK  // measurement builds (tools/): cycles per phase of a wave tile, summed over the sweep, workgroup 0
+#include <cstdio>
+__device__ long long g_score_clk[8 * 8];
+#define SC_CLK_DECL long long ck_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ck_t = clock64();
+#define SC_CLK(i)                   \
+  {                                 \
+    const long long n_ = clock64(); \
+    ck_[i] += n_ - ck_t;            \
+    ck_t = n_;                      \
+  }
+#else
+#define SC_CLK_DECL
+#define SC_CLK(i)
+#endif
 #define NEG_INF (-__builtin_inff())
 
 // ---------------------------------------------------------------------------
@@ -129,15 +148,22 @@ __device__ __forceinline__ void drain_parked(float (&ls)[KL], int (&li)[KL], int
 //   pass certifies against that bound, so 8-entry lane lists cost no exactness: when one of them overflows with rows
 //   that mattered (probability ~1e-6 per query on unordered data) the certificate fails and the query is recomputed.
 //   (Round 1 kept 16 sorted entries per lane: 128 list registers at NQ = 4 and ~250 instructions per insertion round.)
-// Insertion: one ballot per accumulator register against the threshold; a register some lane beats it with is inserted
-//   with selects (lanes that do not take keep their list) -- ~50 instructions per hit instead of an
-//   extract-max / find-index / insert-16 round.
+// Epilogue of a wave tile (per query tile: 16 accumulator registers x 64 lanes against the lanes' thresholds).  It is an
+//   instruction-count problem: beside the partner wave's MFMA stream an epilogue instruction costs ~12 cycles, and the
+//   partner's k-loop (64 MFMAs) is all there is to hide it behind (clock64 table: profiles/r04_notes.txt).  So: the lane's
+//   threshold lives in a register (shared part re-read every 4th tile); the maxima of the four register groups and of the
+//   tile are 9 v_max3_f32; one compare + branch when nothing beats the threshold (60 % of the query tiles).  Otherwise
+//   the groups, then the registers of a group with a hit, are tested -- the no-hit case falls through, a hit runs out of
+//   line (~6 hits per wave tile in ~1.6 of the 4 query tiles).
 // Deferred insertion (DEFER = the bf16 variants, whose query block leaves LDS room): a hit is almost always ONE lane's,
 //   yet a select-based insertion makes all 64 lanes execute ~75 instructions.  Instead the lane parks (score, row) in
-//   its own 4-entry LDS slot row (one exec-masked ds_write_b64, ~12 instructions per hit) and keeps only its best
-//   score current (that is what the shared threshold is made of); the parked entries are inserted 64 lanes in
-//   parallel when some lane's row is full (about once per 100 wave tiles) and before the final merge.  Parked
-//   entries enter the lists in row order, exactly as they would have; bounds and candidates are unchanged.
+//   its own 4-entry LDS slot row (one exec-masked ds_write_b64) and keeps only its best score current (that is what the
+//   shared threshold is made of); the parked entries are inserted 64 lanes in parallel when some lane's row has filled
+//   up (about every 20th tile of a query tile) and before the final merge; takers that found their row full (start of a
+//   sweep, rows sorted by score) are inserted directly right after that.  Entries enter the lists in row order, exactly as
+//   they would have; bounds and candidates are unchanged.  The fp32 variants insert with selects (list_insert): their
+//   MFMAs are 4x longer per tile and hide it.
+// Tiles are dealt dynamically (LDS counter) and the threshold fold is spread over the waves: see the tile loop.
 // The accumulators start from the MFMA's zero C operand (first k-group), not from 16 moves per query tile.
 // BF: the candidate pass runs on v_mfma_f32_32x32x16_bf16 -- index and queries are bf16 copies in the same 1-KiB
 // block / 16-byte-per-lane fragment scheme (a block now holds 32 rows x 16 k, a.KG counts 16-k groups), ONE MFMA per
@@ -344,7 +370,9 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   // that).  Every list keeps its current best in mx_s[q-tile][list][query] (monotone, plain stores); wave 0 folds the minimum
   // into thr_s every few tiles.  Racy reads only see older, smaller -- still valid -- values.  Rows below it can never
   // reach the merged top-16, so every lane may use it as its threshold: the 16 lists of a query share their progress.
-  int *thr_s = reinterpret_cast<int *>(smem + (size_t)a.thr_off);
+  // (16 words in front of them: the workgroup's tile counter, see the tile loop)
+  int *tile_ctr = reinterpret_cast<int *>(smem + (size_t)a.thr_off);
+  int *thr_s = tile_ctr + 16;
   auto enc = [](float f) -> int { const int i = __float_as_int(f); return i >= 0 ? i : (i ^ 0x7FFFFFFF); };
   auto dec = [](int i) -> float { return __int_as_float(i >= 0 ? i : (i ^ 0x7FFFFFFF)); };
   float *mx_s = reinterpret_cast<float *>(thr_s + NQ * 32);  // [NQ][16 lists][32 queries]: lanes of a store / of the fold
@@ -353,6 +381,7 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
     for (int i = tid; i < NQ * 32; i += SC_THREADS) thr_s[i] = enc(NEG_INF);
     for (int i = tid; i < NQ * 32 * 16; i += SC_THREADS) mx_s[i] = NEG_INF;
   }
+  if (tid == 0) *tile_ctr = SC_THREADS / 64;  // tiles 0 .. 7 of the split are the waves' first ones
   __syncthreads();
   // DEFER: parked hits [wave][q-tile][entry][lane] (score, row), this lane's fill count and best score per query tile
   f32x2 *pend_s = reinterpret_cast<f32x2 *>(mx_s + NQ * 32 * 16) + (size_t)w * NQ * SC_PEND * 64 + lane;
@@ -389,10 +418,14 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
     }
   };
 
+  // Tiles are handed out dynamically: a wave takes the split's next tile from an LDS counter (one tile ahead: the tile after
+  // the one it works on is known when it starts -- the index ring below runs into it).  With the tiles dealt round-robin
+  // the two waves of a SIMD did not finish together: the older one wins the matrix pipe whenever both want it and was done
+  // ~12 % before its partner, which then ran alone (instrumented build: 5.7 k against 6.5 k cycles per tile).  A wave's
+  // tiles still ascend, so a lane's rows still ascend (equal scores keep the earlier row).
   // Index fragments: a ring of RING k-groups per wave in registers, running ACROSS tile boundaries (the slot used for
-  // k-group kg is refilled with k-group kg + RING of the same tile, or the head of this wave's next tile), all through
-  // one buffer descriptor per tile (base = this tile, spanning the wave's next tile 8 tiles on: offsets stay far below
-  // the 4 GiB descriptor range for any index size; per-lane offset is the constant 16*lane).  RING k-groups in
+  // k-group kg is refilled with k-group kg + RING of the same tile, or the head of this wave's next tile), through one
+  // buffer descriptor for the tile and one for the next (per-lane offset: the constant 16*lane).  RING k-groups in
   // flight cover an HBM miss at either matrix rate: fp32 16 MFMAs (1 k cycles) per k-group, bf16 4 MFMAs (128 cycles).
   // Needs KG % RING == 0 (RINGED, chosen by the launcher); other shapes (small encodings) use the two-set pipelined
   // loop below.  A template parameter, not a run-time branch: with both loops in one kernel the compiler's wait-count
@@ -408,29 +441,48 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
     for (int d = 0; d < RING; ++d)
       ring[d] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, voff, d * 1024, 0));
   }
+  auto grab_tile = [&]() -> int {  // lane 0's value counts: t0 + readfirstlane() where it is needed (not here: no wait here)
+    int got = 0;
+    if (lane == 0) got = atomicAdd(tile_ctr, 1);
+    return got;
+  };
 
-  for (int tile = tile0; tile < t1; tile += WSTEP) {
+  float thr_r[NQ];  // this lane's insertion thresholds (see the epilogue)
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) thr_r[q] = NEG_INF;
+  SC_CLK_DECL
+  int nxt = (tile0 < t1) ? t0 + __builtin_amdgcn_readfirstlane(grab_tile()) : t1;
+  int it = 0;  // this wave's tile count
+  int after = 0;
+  for (int tile = tile0; tile < t1; tile = nxt, nxt = t0 + __builtin_amdgcn_readfirstlane(after), ++it) {
+    SC_CLK(0)
+    after = grab_tile();  // (needed at the end of this tile only: the LDS round trip hides)
     const int utile = __builtin_amdgcn_readfirstlane(tile);
-    const int span = min(a.NT - utile, WSTEP + 1);
+    const bool more = nxt < t1;  // this wave has a next tile
     const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.idxp) + (size_t)utile * KG * 256, 0, span * KG * 1024, 0x00020000);
+        const_cast<float *>(a.idxp) + (size_t)utile * KG * 256, 0, KG * 1024, 0x00020000);
+    // the next tile (the ring's refills of the last RING k-groups; without one: this tile again, never used)
+    const __amdgpu_buffer_rsrc_t nr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.idxp) + (size_t)(more ? nxt : utile) * KG * 256, 0, KG * 1024, 0x00020000);
     auto iload = [&](int off_kg) -> f32x4 {
       return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ir, voff, off_kg * 1024, 0));
     };
     f32x16 acc[NQ];
 
     if constexpr (RINGED) {
-      const bool more = tile + WSTEP < t1;  // this wave has a next tile
       f32x4 bq[NQ], bqn[NQ];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) bq[q] = *reinterpret_cast<const f32x4 *>(qs + q * 256);
-      __builtin_amdgcn_s_setprio(1);
+      __builtin_amdgcn_s_setprio(SC_PRIO_K);
       auto ring_block = [&](int kg0, auto zero_tag) {
-        const float *qcur = qs + (size_t)kg0 * NQ * 256;                               // query fragments of k-group kg0
-        const float *qnext = (kg0 + RING < KG) ? qcur + RING * NQ * 256 : qs;          // ... of the next block (or the next tile's first)
+        // the tile's last RING k-groups: the refills are the next tile's first RING (one descriptor select per block)
+        const bool last = kg0 + RING >= KG;
+        const __amdgpu_buffer_rsrc_t rr = last ? nr : ir;
+        const int rbase_kg = last ? 0 : kg0 + RING;
+        const float *qcur = qs + (size_t)kg0 * NQ * 256;            // query fragments of k-group kg0
+        const float *qnext = last ? qs : qcur + RING * NQ * 256;  // ... of the next block (or the next tile's first)
 #pragma unroll
         for (int d = 0; d < RING; ++d) {
-          const int kg = kg0 + d;
           // next k-group's query fragments (LDS) first, then this k-group's MFMAs, then the refill of the slot
 #pragma unroll
           for (int q = 0; q < NQ; ++q)
@@ -440,9 +492,7 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
           else mma(acc, ring[d], bq, TagA{});
           __builtin_amdgcn_sched_barrier(0);
           // refill the slot with the fragment RING k-groups on: same tile, or the head of this wave's next tile
-          const int kn = kg + RING;
-          const int off = (kn < KG) ? kn : (more ? WSTEP * KG + (kn - KG) : kg);
-          ring[d] = iload(off);
+          ring[d] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, voff, (rbase_kg + d) * 1024, 0));
 #pragma unroll
           for (int q = 0; q < NQ; ++q) bq[q] = bqn[q];
         }
@@ -457,7 +507,7 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
       f32x4 bx[NQ], by[NQ];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) bx[q] = *reinterpret_cast<const f32x4 *>(qs + q * 256);
-      __builtin_amdgcn_s_setprio(1);
+      __builtin_amdgcn_s_setprio(SC_PRIO_K);
       int kg = 0;
       if (KG >= 2) {  // first pair: starts the accumulators from zero
         ay = iload(1);
@@ -494,7 +544,8 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
         mma(acc, ax, bx, TagZ{});
       }
     }
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(SC_PRIO_E);
+    SC_CLK(1)
 
     const int nrow0 = tile * 32;
     if constexpr (COLLECT) {
@@ -517,22 +568,30 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
     } else {
       // fused top-k: lane owns query column (lane & 31) of each q-tile and sees 16 index rows per n-tile
       const bool tail = (tile == tail_tile);  // only the last tile of the index can have rows >= N (zero padding)
-      if (w == 0 && (((tile - t0) / WSTEP) & 3) == 3 && lane < 32) {
-#pragma nounroll
-        for (int q = 0; q < NQ; ++q) {  // rolled on purpose: runs once per 4 tiles, must not cost registers
-          const float *mp = mx_s + q * 16 * 32 + lane;
-          float f = mp[0];
-#pragma nounroll
-          for (int j = 1; j < 16; ++j) f = fminf(f, mp[j * 32]);
-          if (f > NEG_INF) atomicMax(&thr_s[q * 32 + lane], enc(f));
-        }
+      // threshold fold, spread over the waves: wave w folds query tile w % NQ every fourth tile of its own (the two waves
+      // of a query tile two tiles apart), all 64 lanes: lane (half, query) takes the minimum over 8 of the 16 list bests,
+      // four LDS reads in flight at a time, the halves meet through one shuffle.  (One wave folding everything -- 64
+      // dependent LDS round trips every fourth tile -- cost that wave 1.8 k cycles per tile: with the static tile
+      // assignment it finished ~10 % after the others.)
+      if (((it + 2 * (w / NQ)) & 3) == 1) {
+        const int fq = w % NQ;
+        const float *mp = mx_s + (fq * 16 + (lane >> 5) * 8) * 32 + (lane & 31);
+        float f = fminf(fminf(mp[0], mp[32]), fminf(mp[64], mp[96]));
+        f = fminf(f, fminf(fminf(mp[128], mp[160]), fminf(mp[192], mp[224])));
+        f = fminf(f, __shfl_xor(f, 32));
+        if (lane < 32 && f > NEG_INF) atomicMax(&thr_s[fq * 32 + lane], enc(f));
       }
       const int rbase = nrow0 + 4 * (lane >> 5);  // row of accumulator register r: rbase + (r & 3) + 8 * (r >> 2)
-      // the NQ shared thresholds up front: one LDS round trip per wave tile instead of one exposed in front of every
-      // query tile's compare
-      int thr_i[NQ];
+      // This lane's thresholds live in registers (thr_r: the larger of its list's last entry and the shared threshold);
+      // the shared part is re-read every fourth tile only -- thresholds only rise, an older one is a valid, lower one.
+      // The epilogue is an instruction-count problem: beside the partner wave's MFMA stream a wave issues ~5 instructions
+      // per 32-cycle MFMA, so every instruction here is ~6 - 8 cycles of a phase that the partner's k-loop (64 MFMAs)
+      // has to cover (tools: -DSSE_SCORE_CLOCK).
+      if ((it & 3) == 0) {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) thr_i[q] = thr_s[q * 32 + (lane & 31)];
+        for (int q = 0; q < NQ; ++q) thr_r[q] = fmaxf(thr_r[q], dec(thr_s[q * 32 + (lane & 31)]));
+      }
+      SC_CLK(2)
 #ifdef SSE_SCORE_MEASURE  // measurement builds only (tools/): k-loop without the top-k epilogue, results are garbage
       if (a.dbg & 1) continue;
 #endif
@@ -548,71 +607,110 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[q][r] = (nb + (r & 3) + 8 * (r >> 2) >= nlim) ? NEG_INF : acc[q][r];
         }
-        float m = NEG_INF;
+        // maxima of the four register groups (rows 0-3, 8-11, 16-19, 24-27 of this lane's half), then of the tile: ten
+        // instructions when nothing beats the threshold.  (Written as chains from a constant so that every step becomes
+        // one v_max3_f32 on the raw MFMA results: pairwise fmaxf() makes the compiler quiet both inputs first.)
+        float gm[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[q][r]);
-        float thr = fmaxf(ls[q][KL - 1], dec(thr_i[q]));
-        if (__any(m > thr)) {
-          // rare (about two hits per wave tile): per register one ballot; a register some lane takes is inserted
-          // with selects.  Registers ascend with the row number, '>' keeps the earlier row on equal scores.
+        for (int g4 = 0; g4 < 4; ++g4) {
+          gm[g4] = fmaxf(fmaxf(NEG_INF, acc[q][4 * g4]), acc[q][4 * g4 + 1]);
+          gm[g4] = fmaxf(fmaxf(gm[g4], acc[q][4 * g4 + 2]), acc[q][4 * g4 + 3]);
+        }
+        const float m = fmaxf(fmaxf(fmaxf(gm[0], gm[1]), gm[2]), gm[3]);
+        SC_CLK(5)
+        if (__ballot(m > thr_r[q]) != 0ull) {
+#ifdef SSE_SCORE_CLOCK
+          ck_[7] += 1;
+#endif
+          asm volatile("");
+#ifdef SSE_SCORE_MEASURE
+          if (a.dbg & 2) continue;
+#endif
+          // (~6 hits per wave tile, in ~1.6 of its 4 query tiles.)  Registers ascend with the row number, '>' keeps the
+          // earlier row on equal scores.
+          float thr = thr_r[q];
+          int rb = rbase;
+          asm volatile("" : "+v"(rb));  // (keeps the 16 row numbers from being formed in front of the branch, on every tile)
           if constexpr (DEFER) {
-            // takers of this lane (upper bound: the threshold only rises); if they do not fit its row, everybody
-            // inserts what is parked first; more takers than a whole row (start of a sweep, rows sorted by score) are
-            // inserted directly
-            int nt = 0;
+            // every taker with room in its parked row parks; a lane whose row is full skips (the rows are looked at below)
+            const int pc0 = pcnt[q];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) nt += (acc[q][r] > thr) ? 1 : 0;
-            bool direct = false;
-            if (__ballot(pcnt[q] + nt > SC_PEND) != 0ull) {
-              asm volatile("");
-              drain_parked<KL>(ls[q], li[q], pcnt[q], pend_s + q * SC_PEND * 64);
-              thr = fmaxf(thr, ls[q][KL - 1]);
-              direct = __ballot(nt > SC_PEND) != 0ull;
-            }
-            if (direct) {
-              asm volatile("");
+            for (int g4 = 0; g4 < 4; ++g4) {
+              if (__builtin_expect(__ballot(gm[g4] > thr) == 0ull, 1)) continue;  // (the usual case falls through)
+              asm volatile("");  // keep it a branch
 #pragma unroll
-              for (int r = 0; r < 16; ++r) {
+              for (int r = 4 * g4; r < 4 * g4 + 4; ++r) {
                 const bool take = acc[q][r] > thr;
-                if (__ballot(take) != 0ull) {
-                  asm volatile("");
-                  list_insert<KL>(ls[q], li[q], acc[q][r], rbase + (r & 3) + 8 * (r >> 2), take);
-                  thr = fmaxf(thr, ls[q][KL - 1]);
-                  lbest[q] = fmaxf(lbest[q], ls[q][0]);
+                if (__builtin_expect(__ballot(take) == 0ull, 1)) continue;
+                asm volatile("");
+#ifdef SSE_SCORE_MEASURE
+                if (a.dbg & 4) continue;
+#endif
+                if (take && pcnt[q] < SC_PEND) {
+                  pend_s[(q * SC_PEND + pcnt[q]) * 64] = f32x2{acc[q][r], __int_as_float(rb + (r & 3) + 8 * (r >> 2))};
+                  pcnt[q] += 1;
+                  lbest[q] = fmaxf(fmaxf(lbest[q], NEG_INF), acc[q][r]);
                 }
               }
-            } else {
+            }
+            if (__builtin_expect(__ballot(pcnt[q] >= SC_PEND) != 0ull, 0)) {
+              // some parked row is full now (about every 20th tile of a query tile; at the start of a sweep, or over rows
+              // sorted by score, with takers left over): everybody inserts what is parked; then the takers that did not fit
+              // -- a lane's takers beyond the `quota` it parked just now, counted against the threshold they were parked
+              // under -- go into the lists directly.  Every entry once, in row order.
+              asm volatile("");
+              const int quota = pcnt[q] - pc0;
+              const float thr0 = thr;
+              drain_parked<KL>(ls[q], li[q], pcnt[q], pend_s + q * SC_PEND * 64);
+              thr = fmaxf(thr, ls[q][KL - 1]);
+              int seen = 0;
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
-                const bool take = acc[q][r] > thr;
-                if (__ballot(take) != 0ull) {
-                  asm volatile("");  // keep it a branch (see above)
-                  if (take) {
-                    pend_s[(q * SC_PEND + pcnt[q]) * 64] = f32x2{acc[q][r], __int_as_float(rbase + (r & 3) + 8 * (r >> 2))};
-                    pcnt[q] += 1;
-                    lbest[q] = fmaxf(lbest[q], acc[q][r]);
-                  }
+                const bool tk = acc[q][r] > thr0;
+                seen += tk ? 1 : 0;
+                const bool ins = tk && seen > quota && acc[q][r] > thr;
+                if (__ballot(ins) != 0ull) {
+                  asm volatile("");
+                  list_insert<KL>(ls[q], li[q], acc[q][r], rb + (r & 3) + 8 * (r >> 2), ins);
+                  thr = fmaxf(thr, ls[q][KL - 1]);
+                  lbest[q] = fmaxf(lbest[q], ls[q][0]);
                 }
               }
             }
           } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const bool take = acc[q][r] > thr;
-              if (__ballot(take) != 0ull) {
-                asm volatile("");  // keep it a branch (see above)
-                list_insert<KL>(ls[q], li[q], acc[q][r], rbase + (r & 3) + 8 * (r >> 2), take);
+            for (int g4 = 0; g4 < 4; ++g4) {
+              if (__builtin_expect(__ballot(gm[g4] > thr) == 0ull, 1)) continue;  // (the usual case falls through)
+              asm volatile("");  // keep it a branch
+#pragma unroll
+              for (int r = 4 * g4; r < 4 * g4 + 4; ++r) {
+                const bool take = acc[q][r] > thr;
+                if (__builtin_expect(__ballot(take) == 0ull, 1)) continue;
+                asm volatile("");
+                list_insert<KL>(ls[q], li[q], acc[q][r], rb + (r & 3) + 8 * (r >> 2), take);
                 thr = fmaxf(thr, ls[q][KL - 1]);
               }
             }
           }
+          thr_r[q] = thr;
           // publish this list's best
+#ifdef SSE_SCORE_MEASURE
+          if (!(a.dbg & 8))
+#endif
           mx_s[(q * 16 + w * 2 + (lane >> 5)) * 32 + (lane & 31)] = DEFER ? lbest[q] : ls[q][0];
+          SC_CLK(6)
         }
       }
     }
   }
   if constexpr (COLLECT) return;
+#ifdef SSE_SCORE_CLOCK
+  SC_CLK(3)
+  if (blockIdx.x == 0 && lane == 0 && NQ == 4) {
+    ck_[4] = it;
+    for (int i = 0; i < 8; ++i) g_score_clk[w * 8 + i] = ck_[i];
+  }
+#endif
   if constexpr (DEFER) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) drain_parked<KL>(ls[q], li[q], pcnt[q], pend_s + q * SC_PEND * 64);
@@ -627,7 +725,7 @@ static size_t score_lds_layout(int NQ, int KG, bool BF, bool COLLECT, int32_t *t
   const size_t merge_lds = (size_t)(SC_THREADS / 128) * NQ * (SC_KC * 2 + 1) * 32 * 4;  // (score, id) planes + bounds
   if (!COLLECT && merge_lds > lds) lds = merge_lds;
   if (thr_off) *thr_off = (int32_t)(lds / sizeof(float));  // shared thresholds live behind the query block / merge scratch
-  lds += (size_t)NQ * 32 * sizeof(int) + (size_t)NQ * 32 * 16 * sizeof(float);  // thresholds + per-list best entries
+  lds += 64 + (size_t)NQ * 32 * sizeof(int) + (size_t)NQ * 32 * 16 * sizeof(float);  // tile counter, thresholds + per-list best entries
   if (BF && !COLLECT) lds += (size_t)(SC_THREADS / 64) * NQ * SC_PEND * 64 * 8;  // parked hits (deferred insertion)
   return lds;
 }
@@ -665,6 +763,22 @@ static hipError_t launch_score_ringed(const ScoreArgs &a_in, hipStream_t stream)
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((score_topk_kernel<NQ, BF, COLLECT, RINGED>), dim3(grid), dim3(SC_THREADS), lds, stream, a);
+#ifdef SSE_SCORE_CLOCK
+  if (NQ == 4 && !COLLECT) {
+    static int n = 0;
+    if (n++ % 8 == 3) {
+      long long v[64];
+      (void)hipStreamSynchronize(stream);
+      (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_score_clk), sizeof v);
+      for (int w = 0; w < 8; ++w) {
+        const double t = (double)(v[w * 8 + 4] > 0 ? v[w * 8 + 4] : 1);
+        fprintf(stderr, "[score clock <%d,%d> KG=%d] wave %d: %lld tiles, cycles per tile: loop top %.0f | k-loop %.0f | fold + thresholds %.0f | compares %.0f | hit paths %.0f (%.2f query tiles with hits per wave tile) | sum %.0f\n",
+                NQ, (int)BF, a.KG, w, v[w * 8 + 4], v[w * 8 + 0] / t, v[w * 8 + 1] / t, v[w * 8 + 2] / t, v[w * 8 + 5] / t, v[w * 8 + 6] / t, v[w * 8 + 7] / t,
+                (v[w * 8 + 0] + v[w * 8 + 1] + v[w * 8 + 2] + v[w * 8 + 5] + v[w * 8 + 6]) / t);
+      }
+    }
+  }
+#endif
   return hipGetLastError();
 }
 

@@ -30,7 +30,7 @@ for name, opts in (("bf16", dict(score_bf16=1)), ("fp32", dict(score_bf16=0))):
     i = torch.empty((Q, 10), dtype=torch.int64, device=dev)
     h.score_topk_dev(q.data_ptr(), Q, 10, s.data_ptr(), i.data_ptr())
     torch.cuda.synchronize()
-    n = 5 if name != "fp32" else 2
+    n = int(os.environ.get("SSE_BENCH_PASSES", 5)) if name != "fp32" else 2
     t0 = time.perf_counter()
     for _ in range(n):
         h.score_topk_dev(q.data_ptr(), Q, 10, s.data_ptr(), i.data_ptr())
