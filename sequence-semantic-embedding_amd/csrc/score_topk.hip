@@ -379,18 +379,20 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
                                                                // hit 32 different banks ([query][list] was a 16-way conflict)
   if constexpr (!COLLECT) {
     for (int i = tid; i < NQ * 32; i += SC_THREADS) thr_s[i] = enc(NEG_INF);
-    for (int i = tid; i < NQ * 32 * 16; i += SC_THREADS) mx_s[i] = NEG_INF;
+    for (int i = tid; i < 2 * NQ * 32 * 16; i += SC_THREADS) mx_s[i] = NEG_INF;  // (both planes: bests and second bests)
   }
   if (tid == 0) *tile_ctr = SC_THREADS / 64;  // tiles 0 .. 7 of the split are the waves' first ones
   __syncthreads();
   // DEFER: parked hits [wave][q-tile][entry][lane] (score, row), this lane's fill count and best score per query tile
-  f32x2 *pend_s = reinterpret_cast<f32x2 *>(mx_s + NQ * 32 * 16) + (size_t)w * NQ * SC_PEND * 64 + lane;
+  float *mx2_s = mx_s + NQ * 32 * 16;  // the lists' second-best entries, same layout (the tight threshold below)
+  f32x2 *pend_s = reinterpret_cast<f32x2 *>(mx2_s + NQ * 32 * 16) + (size_t)w * NQ * SC_PEND * 64 + lane;
   int pcnt[NQ];
-  float lbest[NQ];
+  float lbest[NQ], lbest2[NQ];  // best and second-best score among the rows this lane took (two distinct rows)
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     pcnt[q] = 0;
     lbest[q] = NEG_INF;
+    lbest2[q] = NEG_INF;
   }
 
   const int tps = (a.NT + a.NSPLIT - 1) / a.NSPLIT;  // n-tiles per split
@@ -457,6 +459,33 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   for (int tile = tile0; tile < t1; tile = nxt, nxt = t0 + __builtin_amdgcn_readfirstlane(after), ++it) {
     SC_CLK(0)
     after = grab_tile();  // (needed at the end of this tile only: the LDS round trip hides)
+    if constexpr (!COLLECT) {
+      // Tight threshold: the 16th largest of the 32 values {best, second best of the 16 lists} of a query is a lower bound
+      // of the workgroup's 16th best score too (two distinct rows per list) and -- unlike the minimum of the 16 bests,
+      // which sits near the 54th best -- nearly always IS it: a third of the hits.  It costs a 32-value sort per query (two
+      // queries at a time across the wave, shuffles), so it runs on a doubling schedule: wave w for query tile w % NQ
+      // at its tile counts 4, 8, 16, ... (the second wave of a query tile at 6, 12, 24, ...).  Here, in front of the k-loop:
+      // the accumulators are dead, registers are free.
+      const int itq = (w / NQ) & 1 ? it / 3 : it;
+      if (it >= 4 && (itq & (itq - 1)) == 0 && ((w / NQ) & 1 ? itq * 3 == it : true)) {
+        const int fq = w % NQ, j = lane & 31;
+        const float *plane = (j < 16 ? mx_s : mx2_s) + (fq * 16 + (j & 15)) * 32 + (lane >> 5);
+#pragma nounroll
+        for (int x0 = 0; x0 < 32; x0 += 2) {
+          float v = plane[x0];  // value j of query x0 + (lane >> 5)
+          // bitonic sort, descending, across the 32 lanes of a half
+#pragma unroll
+          for (int k = 2; k <= 32; k <<= 1)
+#pragma unroll
+            for (int jj = k >> 1; jj > 0; jj >>= 1) {
+              const float o = __shfl_xor(v, jj);
+              const bool keep_max = ((j & jj) == 0) == ((j & k) == 0 || k == 32);
+              v = keep_max ? fmaxf(v, o) : fminf(v, o);
+            }
+          if (j == 15 && v > NEG_INF) atomicMax(&thr_s[fq * 32 + x0 + (lane >> 5)], enc(v));
+        }
+      }
+    }
     const int utile = __builtin_amdgcn_readfirstlane(tile);
     const bool more = nxt < t1;  // this wave has a next tile
     const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(
@@ -649,6 +678,7 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
                 if (take && pcnt[q] < SC_PEND) {
                   pend_s[(q * SC_PEND + pcnt[q]) * 64] = f32x2{acc[q][r], __int_as_float(rb + (r & 3) + 8 * (r >> 2))};
                   pcnt[q] += 1;
+                  lbest2[q] = fmaxf(lbest2[q], fminf(fminf(lbest[q], -NEG_INF), acc[q][r]));
                   lbest[q] = fmaxf(fmaxf(lbest[q], NEG_INF), acc[q][r]);
                 }
               }
@@ -673,7 +703,8 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
                   asm volatile("");
                   list_insert<KL>(ls[q], li[q], acc[q][r], rb + (r & 3) + 8 * (r >> 2), ins);
                   thr = fmaxf(thr, ls[q][KL - 1]);
-                  lbest[q] = fmaxf(lbest[q], ls[q][0]);
+                  lbest[q] = fmaxf(lbest[q], ls[q][0]);  // (after the drain the list's first two ARE the lane's best two rows)
+                  lbest2[q] = fmaxf(lbest2[q], ls[q][1]);
                 }
               }
             }
@@ -698,6 +729,7 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
           if (!(a.dbg & 8))
 #endif
           mx_s[(q * 16 + w * 2 + (lane >> 5)) * 32 + (lane & 31)] = DEFER ? lbest[q] : ls[q][0];
+          mx2_s[(q * 16 + w * 2 + (lane >> 5)) * 32 + (lane & 31)] = DEFER ? lbest2[q] : ls[q][1];
           SC_CLK(6)
         }
       }
@@ -725,7 +757,7 @@ static size_t score_lds_layout(int NQ, int KG, bool BF, bool COLLECT, int32_t *t
   const size_t merge_lds = (size_t)(SC_THREADS / 128) * NQ * (SC_KC * 2 + 1) * 32 * 4;  // (score, id) planes + bounds
   if (!COLLECT && merge_lds > lds) lds = merge_lds;
   if (thr_off) *thr_off = (int32_t)(lds / sizeof(float));  // shared thresholds live behind the query block / merge scratch
-  lds += 64 + (size_t)NQ * 32 * sizeof(int) + (size_t)NQ * 32 * 16 * sizeof(float);  // tile counter, thresholds + per-list best entries
+  lds += 64 + (size_t)NQ * 32 * sizeof(int) + 2 * (size_t)NQ * 32 * 16 * sizeof(float);  // tile counter, thresholds + per-list best and second-best entries
   if (BF && !COLLECT) lds += (size_t)(SC_THREADS / 64) * NQ * SC_PEND * 64 * 8;  // parked hits (deferred insertion)
   return lds;
 }
