@@ -606,7 +606,11 @@ def main():
                    "roofline": {"kernel": "score_topk_kernel<4,true,false,true>", "bound": "mfma", "unit": "TFLOP/s",
                                 "achieved": 2.0 * S * Q * Ns / sdt / 1e12, "peak": 2500.0, "frac": 2.0 * S * Q * Ns / sdt / 1e12 / 2500.0,
                                 "note": "whole pass (bf16 sweep + float64 re-scoring + second-chance / collect launches) over the "
-                                        "sweep's algorithmic flops; the chip clocks ~1.7 GHz under this load",
+                                        "sweep's algorithmic flops; peak = the 2.5 PF datasheet figure; a register-only "
+                                        "v_mfma_f32_32x32x16_bf16 loop on random data sustains 1.70 PF on this part at "
+                                        "1.71 GHz (tools/mfma_peak_bf16.hip, profiles/r04_notes.txt)",
+                                "sustained_mfma_tflops_measured": 1700.0,
+                                "frac_of_sustained": 2.0 * S * Q * Ns / sdt / 1e12 / 1700.0,
                                 "mfma_busy": PMC.get("mfma_busy", {}).get("score_topk_kernel<4, true, false, true>")}}
 
     # ---- secondary leg: the demo / web path (sse_demo.py:112-134, webserver.py:124-161): ONE query, token ids in ->
@@ -719,12 +723,12 @@ def main():
                                   "(recurrence + dX) and weight-gradient GEMMs on v_mfma_f32_32x32x2_f32; projections, loss, clip and "
                                   "Adagrad in fp32.  ms_per_step_split_bf16_opt_in = options train_fwd_x3 / train_bwd_x3 / train_dk_x3 "
                                   "= 1 (three bf16 MFMAs on hi + lo split operands per product, ~4e-6 relative)",
-                    "roofline": {"kernel": "whole step: lstm_fwd_kernel<TRAIN> x2, lstm_bwd_kernel x2, dk_gemm_kernel x2", "bound": "mfma",
+                    "roofline": {"kernel": "whole step: lstm_fwd_kernel<TRAIN, tape_swap> x2, lstm_bwd2_kernel x2 (+ dx_scatter), dk_gemm3 / dk_gemm2 (paired side)", "bound": "mfma",
                                  "unit": "TFLOP/s", "achieved": executed / tdt / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
                                  "frac": executed / tdt / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                  "executed_mfma_flop_per_step": executed,
                                  "note": "whole step over the fp32 MFMA flops it executes (with pair de-duplication)",
-                                 "mfma_busy": busy_of("lstm_bwd", "dk_gemm", "lstm_fwd_kernel<2, 2, 1, true", "lstm_fwd_kernel<1, 1, 1, true")}}
+                                 "mfma_busy": busy_of("lstm_bwd", "void lstm_bwd", "dk_gemm", "void dk_gemm", "lstm_fwd_kernel<2, 2, 1, true", "void lstm_fwd_kernel<2, 2, 1, true", "lstm_fwd_kernel<1, 1, 1, true", "void lstm_fwd_kernel<1, 1, 1, true")}}
 
     # ---- secondary legs on their own models: the reference's recipe shapes, and the text-CNN of configs[4]
     shapes_leg = reference_shapes_leg(sse_amd, torch, dev) if (rank == 0 and not args.no_shapes_leg) else None

@@ -20,7 +20,19 @@ pmc() {  # name, counters, command...
   name=$1; ctr=$2; shift 2
   ( cd /tmp && timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$out/${name}_pmc_$(echo $ctr | tr ' ' '_' | cut -c1-24)" -o p -- "$@" > /dev/null 2>&1 )
 }
-if [ -n "${QUICK:-}" ]; then
+if [ -n "${R4:-}" ]; then
+  # round-4 set: what changed this round -- the fp32 training kernels (times, MFMA-busy, FETCH / WRITE), the single-query
+  # call, the bf16 sweep, the recipe shapes
+  SSE_TRAIN_SERIAL=1 run train python "$root/tools/bench_train.py" 8192
+  SSE_TRAIN_SERIAL=1 pmc train "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" python "$root/tools/bench_train.py" 8192
+  SSE_TRAIN_SERIAL=1 pmc train FETCH_SIZE python "$root/tools/bench_train.py" 8192
+  SSE_TRAIN_SERIAL=1 pmc train WRITE_SIZE python "$root/tools/bench_train.py" 8192
+  run train_default python "$root/tools/bench_train_default.py"
+  run latency python "$root/tools/bench_latency.py"
+  run score env SSE_BENCH_PASSES=10 python "$root/tools/bench_score.py"
+  pmc score "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" env SSE_BENCH_PASSES=4 python "$root/tools/bench_score.py"
+  run shapes python "$root/tools/bench_shapes.py"
+elif [ -n "${QUICK:-}" ]; then
   # round-3 set (GPU-minutes were short): the kernels that changed this round, one plain + one --stats run each, and the
   # MFMA-busy pass of the training step
   run demo python "$root/tools/bench_demo_query.py" 2500000

@@ -60,7 +60,8 @@ def main():
         open(os.path.join(dst, "%s_hbm_pmc.txt" % tag), "w").write("\n".join(out) + "\n")
     print("\n".join(out[-40:]))
     # MFMA-busy share of the training kernels: (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs) per dispatch
-    for d in sorted(glob.glob(os.path.join(src, "train_pmc_SQ_VALU*"))):
+    for d in sorted(glob.glob(os.path.join(src, "*_pmc_SQ_VALU*"))):
+        tool = os.path.basename(d).split("_pmc_")[0]
         f = os.path.join(d, "p_counter_collection.csv")
         if not os.path.exists(f):
             continue
@@ -74,7 +75,7 @@ def main():
                 dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
             elif r["Counter_Name"] == "GRBM_GUI_ACTIVE":
                 gui[key].append(float(r["Counter_Value"]))
-        lines = ["# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- SSE_TRAIN_SERIAL=1 python tools/bench_train.py 8192",
+        lines = ["# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- the '%s' command of tools/collect_profiles_extra.sh" % tool,
                  "# MFMA-busy = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs), averaged over the dispatches of a (kernel, grid)"]
         for key in sorted(busy, key=lambda k: -sum(dur[k])):
             if key not in gui or sum(dur[key]) / len(dur[key]) < 20000:
@@ -83,7 +84,7 @@ def main():
             g = sum(gui[key]) / len(gui[key]) / 8.0
             lines.append("%-60s grid=%-9s n=%-3d MFMA-busy %.3f  (avg dispatch %.3f ms)"
                          % (key[0], key[1], len(busy[key]), b / g if g else 0.0, sum(dur[key]) / len(dur[key]) / 1e6))
-        open(os.path.join(dst, "%s_train_pmc.txt" % tag), "w").write("\n".join(lines) + "\n")
+        open(os.path.join(dst, "%s_%s_pmc.txt" % (tag, tool)), "w").write("\n".join(lines) + "\n")
         print("\n".join(lines))
 
 
