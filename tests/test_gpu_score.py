@@ -249,7 +249,8 @@ def _scorer_bf16(S=8):
 
 
 @pytest.mark.parametrize("Q,N,S", [(300, 9000, 64), (129, 8192, 256), (600, 32060, 64), (200, 10000, 50), (4000, 70000, 256),
-                                   (1, 8200, 32), (1, 200000, 256), (7, 150000, 256), (32, 9000, 64), (3, 300000, 64)])
+                                   (1, 8200, 32), (1, 200000, 256), (7, 150000, 256), (32, 9000, 64), (3, 300000, 64),
+                                   (129, 9000, 128), (5, 20000, 128), (700, 40000, 384)])  # (128: one ring block per tile)
 def test_bf16_candidate_pass_keeps_results_exact(Q, N, S):
     rng = np.random.RandomState(Q + N)
     q, t = _unit(rng, Q, S), _unit(rng, N, S)
