@@ -46,3 +46,27 @@ def test_tracked_summary_matches_the_tree():
         return
     d = json.load(open(path))
     assert "csrc_sha" in d and isinstance(d.get("mfma_busy", {}), dict)
+
+
+def test_usable_cores_respects_affinity_and_quota():
+    """The CPU baseline sizes its replicas by the cores the process may USE (the driver's container gets 16 of 256 hardware
+    threads through a cgroup quota: replicas beyond it only thrash)."""
+    n = bench.usable_cores()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    if hasattr(os, "sched_getaffinity"):
+        assert n <= len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            assert n <= max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        pass
+
+
+def test_busy_of_selects_kernels_by_name_prefix(monkeypatch):
+    monkeypatch.setattr(bench, "PMC", {"mfma_busy": {"lstm_bwd2_kernel<8, true>": 0.77, "dk_gemm3_kernel<10, false>": 0.85,
+                                                     "score_topk_kernel<4, true, false, true>": 0.69}})
+    assert bench.busy_of("lstm_bwd", "dk_gemm") == {"lstm_bwd2_kernel<8, true>": 0.77, "dk_gemm3_kernel<10, false>": 0.85}
+    assert bench.busy_of("cnn_") is None
+    monkeypatch.setattr(bench, "PMC", {"stale": "sources changed"})
+    assert bench.busy_of("lstm_bwd") is None
