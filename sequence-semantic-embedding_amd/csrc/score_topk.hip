@@ -1024,6 +1024,73 @@ __device__ __forceinline__ double wave_exact_dot(const float *qrow, const float 
   return out[0];
 }
 
+// The same NB sums with the cross-lane reduction PACKED: the first log2(NB) butterfly steps (xor 32, 16, ...) also halve
+// the number of values a lane carries -- a lane keeps the half its lane bit selects and adds what its partner sends of it --
+// so NB values cost (NB - 1) + (6 - log2 NB) shuffles instead of 6 NB.  Every partial sum is the one the plain xor butterfly
+// (32, 16, 8, 4, 2, 1) forms, from the same two operands (IEEE addition commutes): the totals are bit-identical to
+// wave_exact_dot's.  Returns the total of value packed_value_of_lane<NB>(lane) (all lanes of that value agree).
+template <int NB>
+__device__ __forceinline__ int packed_value_of_lane(int lane) {
+  int v = 0;
+#pragma unroll
+  for (int cnt = NB, bit = 5; cnt > 1; cnt >>= 1, --bit) v = v * 2 + ((lane >> bit) & 1);
+  return v;
+}
+template <int NB>
+__device__ __forceinline__ int packed_lane_of_value(int v) {  // the first lane that ends up with value v
+  int lane = 0;
+#pragma unroll
+  for (int cnt = NB, bit = 5; cnt > 1; cnt >>= 1, --bit) lane |= ((v / (cnt / 2)) & 1) << bit;
+  return lane;
+}
+template <int NB>
+__device__ __forceinline__ double wave_exact_dot_packed(const float *qrow, const float *idxp, const double *idx64, const int64_t (&n)[NB],
+                                                        int S, int KG, int lane, const float *idx_rm = nullptr) {
+  static_assert(NB == 2 || NB == 4 || NB == 8, "power of two");
+  double acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) acc[b] = 0.0;
+  if (idx64) {
+    for (int d = lane; d < S; d += 64) {
+      double rv[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) rv[b] = idx64[(size_t)n[b] * S + d];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[b] += (double)qrow[d] * rv[b];
+    }
+  } else {
+    for (int j = lane; j < KG * 2; j += 64) {  // j = kg*2 + half -> 4 consecutive dims
+      const int kg = j >> 1, half = j & 1;
+      f32x4 v[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        v[b] = idx_rm ? *reinterpret_cast<const f32x4 *>(idx_rm + (size_t)n[b] * S + j * 4)  // (dimensions 4j .. 4j+3 either way)
+                      : *reinterpret_cast<const f32x4 *>(idxp + (size_t)(n[b] >> 5) * KG * 256 + kg * 256 + (half * 32 + (int)(n[b] & 31)) * 4);
+      const int d0 = kg * 8 + half * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (d0 + e < S) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) acc[b] += (double)qrow[d0 + e] * (double)v[b][e];
+        }
+    }
+  }
+  int m = 32;
+#pragma unroll
+  for (int cnt = NB; cnt > 1; cnt >>= 1, m >>= 1) {
+    const bool up = (lane & m) != 0;
+#pragma unroll
+    for (int i = 0; i < cnt / 2; ++i) {
+      const double send = up ? acc[i] : acc[i + cnt / 2];
+      const double keep = up ? acc[i + cnt / 2] : acc[i];
+      acc[i] = keep + __shfl_xor(send, m);
+    }
+  }
+#pragma unroll
+  for (; m > 0; m >>= 1) acc[0] += __shfl_xor(acc[0], m);
+  return acc[0];
+}
+
 __device__ __forceinline__ bool before(double sa, int64_t ia, double sb, int64_t ib) {
   return (sa > sb) || (sa == sb && ia < ib);  // score descending, then lower row id
 }
@@ -1182,13 +1249,9 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
     int64_t n[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) n[c] = s_wid[min(i0 + c, nwin - 1)];
-    double ex[4];
-    wave_exact_dot_n<4>(qrow, a.idx32, a.idx64, n, a.S, KG, lane, ex);
-    if (lane == 0) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (i0 + c < nwin) s_ex[i0 + c] = ex[c];
-    }
+    const double tot = wave_exact_dot_packed<4>(qrow, a.idx32, a.idx64, n, a.S, KG, lane, a.idx_rm);
+    const int c = packed_value_of_lane<4>(lane);
+    if ((lane & 15) == 0 && i0 + c < nwin) s_ex[i0 + c] = tot;
   }
   __syncthreads();
 
@@ -1240,9 +1303,20 @@ __global__ __launch_bounds__(RS_THREADS) void rescore_kernel(RescoreArgs a) {
 }
 
 // Same pass for NC <= 64 candidates per query (many-queries launches: 16 per index split, <= 4 splits), one WAVE per
-// query and everything in registers -- no LDS, no barriers: lane c owns candidate c; ranks by shuffling every key past
-// every lane; the float64 dots use the same wave_exact_dot as above (bit-identical scores).  A workgroup per query
-// cost 0.10 ms per 16384 queries, mostly idle threads and barriers.
+// query and everything in registers -- no LDS arrays, no barriers: lane c owns candidate c.  Round 4 (16384 queries x 571
+// targets, the evaluator's shape, spent 76 us here = 3 % of the headline step): wave-uniform lane indices are read with
+// v_readlane instead of shuffles (the rank loops, the k-th candidate, the bounds, theta); the window members are moved to
+// lanes 0 .. nwin-1 with one ds_permute; their float64 dots are formed RS_NB rows at a time with the packed reduction
+// (wave_exact_dot_packed: 7 shuffles per 4 rows instead of 24) and land in the members' lanes with one more shuffle.
+// The float64 scores are bit-identical to wave_exact_dot's (same sums, same order).
+#ifndef RS_NB
+#define RS_NB 4  // rows per float64 dot batch of rescore_small_kernel (8: 130 registers, half the occupancy)
+#endif
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __global__ __launch_bounds__(256) void rescore_small_kernel(RescoreArgs a) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1251,67 +1325,83 @@ __global__ __launch_bounds__(256) void rescore_small_kernel(RescoreArgs a) {
   const int qo = a.qmap ? a.qmap[q] : q;
   const float *qrow = a.q + (size_t)q * a.S;
   const int KG = (a.S + 7) / 8;
+#ifdef SSE_SCORE_CLOCK
+  long long rk_[6] = {0, 0, 0, 0, 0, 0}, rk_t = clock64();
+#define RS_CLK(i) { const long long n_ = clock64(); rk_[i] += n_ - rk_t; rk_t = n_; }
+#else
+#define RS_CLK(i)
+#endif
+  // candidates and bounds first: their loads are in flight under the norm
+  const bool have = lane < a.NC;
+  const int id = have ? a.part_ids[(size_t)q * a.NC + lane] : -1;
+  const float sc = have ? a.part_scores[(size_t)q * a.NC + lane] : NEG_INF;
+  const float bnd = (lane < a.NC / SC_KC) ? a.part_bnd[(size_t)q * (a.NC / SC_KC) + lane] : NEG_INF;
   double qn = 0.0;
   for (int d = lane; d < a.S; d += 64) qn += (double)qrow[d] * qrow[d];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
   const float qnorm = (float)sqrt(qn);
   const float eps_q = a.eps * qnorm;
+  RS_CLK(0)
 
-  const bool have = lane < a.NC;
-  const int id = have ? a.part_ids[(size_t)q * a.NC + lane] : -1;
-  const float sc = have ? a.part_scores[(size_t)q * a.NC + lane] : NEG_INF;
   unsigned u = __float_as_uint(sc);
   u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
   const unsigned long long key = (id < 0) ? 0ull : (((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)id));
+  const int key_lo = (int)(unsigned)key, key_hi = (int)(unsigned)(key >> 32);
   int rank = 0;
-  for (int j = 0; j < a.NC; ++j) rank += (__shfl(key, j) > key) ? 1 : 0;
-  // fp32 score of the k-th best candidate
-  float kth = (key != 0ull && rank == a.k - 1) ? sc : NEG_INF;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) kth = fmaxf(kth, __shfl_xor(kth, o));
+  for (int j = 0; j < a.NC; ++j) {
+    const unsigned long long kj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(key_hi, j) << 32) |
+                                  (unsigned long long)(unsigned)__builtin_amdgcn_readlane(key_lo, j);
+    rank += (kj > key) ? 1 : 0;
+  }
+  // fp32 score of the k-th best candidate (keys are unique: one lane at most holds rank k - 1)
+  const unsigned long long kmask = __ballot(key != 0ull && rank == a.k - 1);
+  const float kth = kmask ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), __ffsll((long long)kmask) - 1)) : NEG_INF;
   // window: candidates within 2*eps of the k-th; M: largest per-split bound (rows outside the candidates score <= M)
   const bool in_win = (id >= 0) && (sc >= kth - 2.0f * eps_q);
-  float mmax = (lane < a.NC / SC_KC) ? a.part_bnd[(size_t)q * (a.NC / SC_KC) + lane] : NEG_INF;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mmax = fmaxf(mmax, __shfl_xor(mmax, o));
+  float mmax = NEG_INF;
+  for (int j = 0; j < a.NC / SC_KC; ++j) mmax = fmaxf(mmax, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bnd), j)));
   const unsigned long long wmask = __ballot(in_win);
   const int nwin = __popcll(wmask);
-  // exact float64 scores of the window members, four at a time with the whole wave (their row loads in flight together)
-  double ex = -__builtin_inf();
-  for (unsigned long long m = wmask; m;) {
-    int src[4];
-    int64_t n[4];
+  // the window members to lanes 0 .. nwin-1, in candidate order
+  const int mi = __popcll(wmask & ((1ull << lane) - 1ull));
+  const int idm = __builtin_amdgcn_ds_permute((in_win ? mi : 63) * 4, id);  // (lane 63 is a member's only with all 64 in the window)
+  RS_CLK(1)
+  // exact float64 scores, RS_NB members at a time (padding: member 0 again)
+  double exm = -__builtin_inf();
+  for (int m0 = 0; m0 < nwin; m0 += RS_NB) {
+    int64_t n[RS_NB];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      src[c] = m ? __ffsll((long long)m) - 1 : -1;
-      m &= m - 1;  // (0 stays 0)
-      n[c] = __shfl(id, src[c] < 0 ? src[0] : src[c]);
-    }
-    double v[4];
-    wave_exact_dot_n<4>(qrow, a.idx32, a.idx64, n, a.S, KG, lane, v);
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (lane == src[c]) ex = v[c];
+    for (int c = 0; c < RS_NB; ++c) n[c] = __builtin_amdgcn_readlane(idm, (m0 + c < nwin) ? m0 + c : 0);
+    const double tot = wave_exact_dot_packed<RS_NB>(qrow, a.idx32, a.idx64, n, a.S, KG, lane, a.idx_rm);
+    const int want = lane - m0;  // this lane's member of the batch
+    const double got = __shfl(tot, packed_lane_of_value<RS_NB>(want & (RS_NB - 1)));
+    if (want >= 0 && want < RS_NB && lane < nwin) exm = got;
   }
+  RS_CLK(2)
   // exact rank inside the window (score descending, then lower row id)
   int r2 = 0;
-  for (unsigned long long m = wmask; m; m &= m - 1) {
-    const int src = __ffsll((long long)m) - 1;
-    r2 += before(__shfl(ex, src), (int64_t)__shfl(id, src), ex, (int64_t)id) ? 1 : 0;
-  }
-  if (in_win && r2 < a.k) {
-    a.out_scores[(size_t)qo * a.k + r2] = ex;
-    a.out_ids[(size_t)qo * a.k + r2] = a.id_base + id;
+  for (int j = 0; j < nwin; ++j)
+    r2 += before(readlane_f64(exm, j), (int64_t)__builtin_amdgcn_readlane(idm, j), exm, (int64_t)idm) ? 1 : 0;
+  const bool member = lane < nwin;
+  if (member && r2 < a.k) {
+    a.out_scores[(size_t)qo * a.k + r2] = exm;
+    a.out_ids[(size_t)qo * a.k + r2] = a.id_base + idm;
     if (a.host_flag) {
-      a.host_scores[(size_t)qo * a.k + r2] = ex;
-      a.host_ids[(size_t)qo * a.k + r2] = a.id_base + id;
+      a.host_scores[(size_t)qo * a.k + r2] = exm;
+      a.host_ids[(size_t)qo * a.k + r2] = a.id_base + idm;
     }
   }
-  double theta = (in_win && r2 == a.k - 1) ? ex : -__builtin_inf();
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) theta = fmax(theta, __shfl_xor(theta, o));
+  const unsigned long long tmask = __ballot(member && r2 == a.k - 1);
+  const double theta = tmask ? readlane_f64(exm, __ffsll((long long)tmask) - 1) : -__builtin_inf();
   if (a.host_flag) __threadfence_system();
+  RS_CLK(3)
+#ifdef SSE_SCORE_CLOCK
+  if (q == a.Q / 2 && lane == 0) {
+    rk_[4] = nwin;
+    for (int i = 0; i < 6; ++i) g_score_clk[i] = rk_[i];
+  }
+#endif
   if (lane == 0) {
     const bool ok = (nwin >= a.k) && ((double)mmax + (double)eps_q < theta);
     a.cert[qo] = ok ? 1 : 0;
@@ -1332,6 +1422,18 @@ hipError_t launch_rescore(const RescoreArgs &a, hipStream_t stream) {
   if (a.NC > RS_MAXNC) return hipErrorInvalidValue;
   if (a.NC <= 64) {
     hipLaunchKernelGGL(rescore_small_kernel, dim3((a.Q + 3) / 4), dim3(256), 0, stream, a);
+#ifdef SSE_SCORE_CLOCK
+    if (a.Q >= 8192) {
+      static int n = 0;
+      if (n++ % 8 == 3) {
+        long long v[8];
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_score_clk), sizeof v);
+        fprintf(stderr, "[rescore_small clock Q=%d NC=%d] cycles: query norm %lld | candidates, rank, k-th, window %lld | float64 dots %lld (window of %lld) | exact rank + outputs %lld\n",
+                a.Q, a.NC, v[0], v[1], v[2], v[4], v[3]);
+      }
+    }
+#endif
     return hipGetLastError();
   }
   hipLaunchKernelGGL(rescore_kernel, dim3(a.Q), dim3(RS_THREADS), (size_t)a.NC * sizeof(unsigned long long), stream, a);

@@ -323,6 +323,10 @@ struct RescoreArgs {
   int32_t *host_cert = nullptr, *host_flag = nullptr, *host_err = nullptr;
   const int32_t *err_in = nullptr;
   int32_t seq = 0;
+  // optional row-major f32 copy of the index [N][S] (S % 4 == 0; kept for small indexes): the float64 re-scoring gathers a
+  // row from 8 cache lines instead of the 64 the fragment order spreads it over.  A lane reads the same four dimensions
+  // either way, so the sums -- and the float64 scores -- are bit-identical.
+  const float *idx_rm = nullptr;
 };
 hipError_t launch_rescore(const RescoreArgs &a, hipStream_t stream);
 
