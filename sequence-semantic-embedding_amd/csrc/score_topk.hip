@@ -300,13 +300,14 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   // stage the query block (already fragment-packed, [query tile][k-group][1 KiB]) into LDS as [k-group][query tile]:
   // the NQ fragments of one k-group are 1 KiB apart and consecutive k-groups NQ KiB, so every read in the unrolled
   // k-loop is ONE base register + an immediate offset (with [q][kg] the NQ*KG addresses each took a VGPR)
-  if (NQ == 1 && a.q_rows != nullptr) {
-    // latency path: fragments straight from the row-major fp32 queries (same values as launch_pack_rows /
-    // launch_pack_rows_bf16 produce: lane (half, row) owns 4 / 8 consecutive k, bf16 rounded to nearest even)
+  if ((NQ == 1 || COLLECT) && a.q_rows != nullptr) {
+    // latency path (and every collect sweep): fragments straight from the row-major fp32 queries (same values as
+    // launch_pack_rows / launch_pack_rows_bf16 produce: lane (half, row) owns 4 / 8 consecutive k, bf16 rounded to nearest
+    // even); LDS order [k-group][query tile]
     f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
     const int Sd = a.S;
-    for (int i = tid; i < KG * 64; i += SC_THREADS) {
-      const int kg = i >> 6, l = i & 63, row = qb * 32 + (l & 31);
+    for (int i = tid; i < NQ * KG * 64; i += SC_THREADS) {
+      const int kg = (i >> 6) / NQ, l = i & 63, row = (qb * NQ + (i >> 6) % NQ) * 32 + (l & 31);
       f32x4 v = {0, 0, 0, 0};
       if (row < Qeff) {
         if constexpr (BF) {
@@ -942,6 +943,227 @@ hipError_t launch_frag32_to_bf16(const float *idxp, int64_t NT, int KG, void *ou
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Small-index scorer (see SmallIndexArgs).  16384 queries x 571 targets -- the scoring half of the headline step, the
+// evaluator's shape (sse_evaluator.py:104-112) -- took 110 us in the list sweep (+ 7 us of packing) for ~30 us of fp32 MFMA
+// work: 18 index tiles are 9 tiles on the 8 waves of a workgroup, and every cold tile pays ~50 k cycles of select-insertions
+// into empty lists.  Here a 4-wave workgroup owns 32 queries, holds their fragments in REGISTERS (32 k-groups x 4), forms all
+// N scores into an LDS tile [32 queries][NP] (74 KiB at 571 rows: two workgroups per CU, one's selection under the other's
+// MFMAs) and selects per query.
+// Selection (a wave: four queries side by side): a lane holds rows lane, lane + 64, ... of a query's score row.  The 16th
+// best score is found by bisection on the scores' order-preserving integer keys -- count(score >= T) is J compares + ballot
+// population counts, on the scalar unit -- between the smallest and the largest of the lanes' maxima, stopping as soon as a
+// threshold has exactly 16 rows above it (else it ends on the 16th best itself, ties included); the winners are moved to
+// lanes 0 .. n-1 with ds_permute, ranked against each other (score descending, lower row first) and written in order.
+// (A first version -- per-lane sorted lists and 16 rounds of a wave-wide arg-max -- cost ~1300 VALU instructions per query,
+// as much as the list sweep's insertions: 110 us.  profiles/r04_notes.txt)
+__device__ __forceinline__ int si_key(float f) {  // signed-integer order == float order
+  const int i = __float_as_int(f);
+  return i >= 0 ? i : (i ^ 0x7FFFFFFF);
+}
+__device__ __forceinline__ float si_val(int k) { return __int_as_float(k >= 0 ? k : (k ^ 0x7FFFFFFF)); }
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_f(float x) {  // lanes the row mask leaves out (or without a source lane) see their own value
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, ROWMASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_max_f(float x) {  // row_ror 8 / 4 / 2 / 1, row_bcast15 / 31: lane 63 holds the result
+  x = fmaxf(x, dpp_f<0x128, 0xF>(x));
+  x = fmaxf(x, dpp_f<0x124, 0xF>(x));
+  x = fmaxf(x, dpp_f<0x122, 0xF>(x));
+  x = fmaxf(x, dpp_f<0x121, 0xF>(x));
+  x = fmaxf(x, dpp_f<0x142, 0xA>(x));
+  x = fmaxf(x, dpp_f<0x143, 0xC>(x));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+template <int JMAX>  // score registers per lane this instance holds (J <= JMAX)
+__device__ __forceinline__ void si_select4(const SmallIndexArgs &a, const float *sc, int NP, int NT, int qt, int q0, int lane) {
+  constexpr int QW = 4;
+  const int J = (NT * 32 + 63) / 64;  // score registers per lane (uniform, <= 16)
+  float v[QW][JMAX];
+#pragma unroll
+  for (int j = 0; j < JMAX; ++j) {
+    const int row = lane + 64 * j;
+#pragma unroll
+    for (int c = 0; c < QW; ++c) v[c][j] = (j < J && row < NT * 32) ? sc[(q0 + c) * NP + row] : NEG_INF;
+  }
+  // bisection bounds: count(>= smallest lane maximum) >= 64 >= 16 rows (or everything, when some lane holds no row: -inf);
+  // count(> largest) = 0
+  int lok[QW], hik[QW];
+  bool done[QW];
+#pragma unroll
+  for (int c = 0; c < QW; ++c) {
+    float lm = NEG_INF;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) lm = fmaxf(lm, v[c][j]);
+    const float hi = wave_max_f(lm), lo = -wave_max_f(-lm);
+    lok[c] = si_key(lo);
+    hik[c] = si_key(hi) + 1;  // (exclusive; scores are finite, no overflow)
+    done[c] = (unsigned)hik[c] - (unsigned)lok[c] <= 1u;
+  }
+  for (;;) {
+    bool all_done = true;
+#pragma unroll
+    for (int c = 0; c < QW; ++c) {
+      if (!done[c]) {  // (wave-uniform)
+        const int mid = lok[c] + (int)(((unsigned)hik[c] - (unsigned)lok[c]) >> 1);
+        const float T = si_val(mid);
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j)
+          if (j < J) cnt += __popcll(__ballot(v[c][j] >= T));
+        lok[c] = (cnt >= SC_KC) ? mid : lok[c];
+        hik[c] = (cnt >= SC_KC) ? hik[c] : mid;
+        done[c] = cnt == SC_KC || (unsigned)hik[c] - (unsigned)lok[c] <= 1u;
+        all_done = all_done && done[c];
+      }
+    }
+    if (all_done) break;
+  }
+#pragma unroll
+  for (int c = 0; c < QW; ++c) {
+    const int query = qt * 32 + q0 + c;
+    if (query < a.Q) {  // (uniform)
+      const float T = si_val(lok[c]);
+      // the winners (>= T, masked rows left out) to lanes 0 .. n-1, in row order; non-winners push to lane 63 (unused)
+      float cs = NEG_INF;
+      int cr = -1, base = 0;
+#pragma unroll
+      for (int j = 0; j < JMAX; ++j) {
+        const bool take = (j < J) & (v[c][j] >= T) & (v[c][j] > NEG_INF);
+        const unsigned long long mask = __ballot(take);
+        const int n = __popcll(mask);
+        if (n != 0) {  // (uniform)
+          const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+          const int dst = (take && slot < 63) ? slot : 63;
+          const int gs = __builtin_amdgcn_ds_permute(dst * 4, __float_as_int(v[c][j]));
+          const int gr = __builtin_amdgcn_ds_permute(dst * 4, lane + 64 * j);
+          if (lane >= base && lane < base + n && lane < 63) {
+            cs = __int_as_float(gs);
+            cr = gr;
+          }
+          base += n;
+        }
+      }
+      const int nw = base < 63 ? base : 63;  // (more than 63 rows tied into the selection: the bound says so below)
+      int rank = 0;
+      for (int l = 0; l < nw; ++l) {
+        const float os = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), l));
+        const int orow = __builtin_amdgcn_readlane(cr, l);
+        rank += ((os > cs) | ((os == cs) & (orow < cr))) ? 1 : 0;
+      }
+      const bool mine = lane < nw;
+      if (mine && rank < SC_KC) {
+        a.part_scores[(size_t)query * SC_KC + rank] = cs;
+        a.part_ids[(size_t)query * SC_KC + rank] = cr;
+      }
+      if (lane >= nw && lane < SC_KC) {  // fewer than 16 rows in the index: empty slots
+        a.part_scores[(size_t)query * SC_KC + lane] = NEG_INF;
+        a.part_ids[(size_t)query * SC_KC + lane] = -1;
+      }
+      const unsigned long long m16 = __ballot(mine && rank == SC_KC - 1);
+      const float last = m16 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), __ffsll((long long)m16) - 1)) : NEG_INF;
+      if (lane == 0) a.part_bnd[query] = (base > 63) ? __builtin_inff() : last;
+    }
+  }
+}
+
+template <int KGC>
+__global__ __launch_bounds__(256) void score_small_index_kernel(SmallIndexArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float si_sc[];  // scores [32 queries][NP]
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NT = a.NT, NP = NT * 32 + 1;  // odd row stride: the 32 queries of a store hit 32 banks
+  const int qt = blockIdx.x;
+  float *sc = si_sc;
+  SC_CLK_DECL
+  // this lane's query fragments (lane (half, query): 4 consecutive k per k-group), straight from the fp32 rows
+  f32x4 b[KGC];
+  {
+    const int row = qt * 32 + (lane & 31), kb = (lane >> 5) * 4;
+    const float *src = a.q_rows + (size_t)(row < a.Q ? row : 0) * a.S + kb;
+    const bool vec = (a.S & 3) == 0 && (reinterpret_cast<uintptr_t>(a.q_rows) & 15) == 0 && KGC * 8 <= a.S;  // (uniform)
+#pragma unroll
+    for (int kg = 0; kg < KGC; ++kg) {
+      f32x4 v = {0, 0, 0, 0};
+      if (vec) {
+        v = *reinterpret_cast<const f32x4 *>(src + kg * 8);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (kg * 8 + kb + e < a.S) v[e] = src[kg * 8 + e];
+      }
+      if (row >= a.Q) v = f32x4{0, 0, 0, 0};
+      b[kg] = v;
+    }
+  }
+  SC_CLK(0)
+  // all N scores of the 32 queries: wave w takes tiles w, w + 4, ...; index fragments from L2 four k-groups ahead (pinned:
+  // the compiler otherwise sinks the refills behind the block and waits for them at once); a lane ends up with query
+  // (lane & 31) and 16 rows of the tile, as in the list sweep
+  for (int t = w; t < NT; t += 4) {
+    const f32x4 *ap = reinterpret_cast<const f32x4 *>(a.idxp) + (size_t)t * KGC * 64 + lane;
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 ar[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) ar[d] = ap[(d < KGC ? d : 0) * 64];
+#pragma unroll
+    for (int kg = 0; kg < KGC; ++kg) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[kg & 3][e], b[kg][e], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ar[kg & 3] = ap[(kg + 4 < KGC ? kg + 4 : kg) * 64];  // (the last ones re-read themselves: never used)
+    }
+    const int rb = t * 32 + 4 * (lane >> 5);
+    float *col = sc + (lane & 31) * NP;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rb + (r & 3) + 8 * (r >> 2);
+      col[row] = (row < a.N) ? acc[r] : NEG_INF;  // (the zero padding of the last tile)
+    }
+  }
+  SC_CLK(1)
+  __syncthreads();
+  SC_CLK(2)
+  if (NT * 32 <= 640) {  // (571 rows: 9 registers per lane and query instead of 16)
+    si_select4<10>(a, sc, NP, NT, qt, w * 8, lane);
+    SC_CLK(3)
+    si_select4<10>(a, sc, NP, NT, qt, w * 8 + 4, lane);
+    SC_CLK(4)
+#ifdef SSE_SCORE_CLOCK
+    if (blockIdx.x == gridDim.x / 2 && lane == 0)
+      for (int i = 0; i < 8; ++i) g_score_clk[w * 8 + i] = ck_[i];
+#endif
+  } else {
+    si_select4<16>(a, sc, NP, NT, qt, w * 8, lane);
+    si_select4<16>(a, sc, NP, NT, qt, w * 8 + 4, lane);
+  }
+}
+bool score_small_index_applies(int Q, int KG, int64_t NT) {
+  // many queries only: a single query's workgroup would walk all tiles alone (0.09 ms against 0.05 for the list sweep)
+  return Q >= 1024 && KG == 32 && NT * 32 <= 1024 && (size_t)32 * (NT * 32 + 1) * sizeof(float) <= (size_t)80 * 1024;
+}
+hipError_t launch_score_small_index(const SmallIndexArgs &a, hipStream_t stream) {
+  if (!score_small_index_applies(a.Q, a.KG, a.NT)) return hipErrorInvalidValue;
+  const size_t lds = (size_t)32 * (a.NT * 32 + 1) * sizeof(float);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(score_small_index_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(score_small_index_kernel<32>, dim3((a.Q + 31) / 32), dim3(256), lds, stream, a);
+#ifdef SSE_SCORE_CLOCK
+  if (a.Q >= 8192) {
+    static int n = 0;
+    if (n++ % 8 == 3) {
+      long long v[64];
+      (void)hipStreamSynchronize(stream);
+      (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_score_clk), sizeof v);
+      for (int w = 0; w < 4; w += 3)
+        fprintf(stderr, "[small index clock Q=%d NT=%d] wave %d cycles: query fragments %lld | scores (MFMA + LDS stores) %lld | barrier %lld | selection, first four queries %lld | second four %lld\n",
+                a.Q, a.NT, w, v[w * 8 + 0], v[w * 8 + 1], v[w * 8 + 2], v[w * 8 + 3], v[w * 8 + 4]);
+    }
+  }
+#endif
+  return hipGetLastError();
+}
+
 hipError_t launch_score_topk(const ScoreArgs &a_in, hipStream_t stream) {
   ScoreArgs a = a_in;
 #ifdef SSE_SCORE_MEASURE
@@ -951,7 +1173,7 @@ hipError_t launch_score_topk(const ScoreArgs &a_in, hipStream_t stream) {
   }
 #endif
   if (a.KC != SC_KC) return hipErrorInvalidValue;
-  if (a.q_rows && (a.NQ != 1 || a.S < 1)) return hipErrorInvalidValue;
+  if (a.q_rows && ((a.NQ != 1 && !a.COLLECT) || a.S < 1)) return hipErrorInvalidValue;
   if (a.NSPLIT > 8 && (a.NSPLIT & 7)) return hipErrorInvalidValue;
   if (a.NSPLIT < 8 && (8 % a.NSPLIT)) return hipErrorInvalidValue;
   if (a.COLLECT) {  // collect pass: fp32 scores only (the thresholds are fp32 bounds)

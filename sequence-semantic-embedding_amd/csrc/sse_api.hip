@@ -125,6 +125,7 @@ struct sse_handle {
   int lstm_cluster_wt = 0;      // option "lstm_cluster_write_through": force the any-placement publish path (tests)
   int lstm_cluster_drop = 0;    // option "lstm_cluster_drop_wg": one workgroup of the cluster kernel exits at once (tests)
   int lstm_small_rows = 1024; // option "lstm_small_rows": batches up to this many rows take the few-sequences LSTM kernel
+  bool score_small_index = true;  // option "score_small_index": many queries against <= 1024 rows skip the list sweep (launch_score_small_index)
   bool score_bf16 = true;    // option "score_bf16" (default on): candidate pass on the bf16 matrix pipe; results stay exact
   void *idxp16 = nullptr;    // bf16 fragment copy of the index (built on demand)
   size_t idxp16_cap = 0;
@@ -1036,7 +1037,10 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   // takes its parallelism from the index instead -- at least 32 splits -- or three workgroups would walk 1.25 M rows alone
   int nsplit2 = nsplit;
   while (nsplit2 < 32 && NT / (nsplit2 * 2 * 2) >= 16) nsplit2 *= 2;
-  const int NC = nsplit * 16, NCmax = std::max(nsplit, nsplit2) * 16;
+  // many queries against a small index (the evaluator's 16384 x 571): one launch forms all N scores per query and selects the
+  // 16 best exactly (launch_score_small_index) instead of the list sweep
+  const bool small_idx = h->score_small_index && !bf && score_small_index_applies(Q, KG, NT);
+  const int NC = small_idx ? 16 : nsplit * 16, NCmax = std::max(nsplit, nsplit2) * 16;
   const int KG16 = (S + 15) / 16;
   if (bf && !h->idxp16_valid) {
     const size_t need = (size_t)NT * KG16 * 1024;
@@ -1063,7 +1067,7 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   const bool first = phase != SCORE_REST, rest = phase != SCORE_FIRST;
   // <= 32 queries (the latency path): the sweeps build their query fragments from the rows themselves -- no pack launch
   const bool rows_direct = NQ == 1;
-  if (first && !rows_direct) {
+  if (first && !rows_direct && !small_idx) {
     if (bf) HIPCHECK(h, launch_pack_rows_bf16(q, Q, S, h->s_qp.p, st));
     else HIPCHECK(h, launch_pack_rows(q, Q, S, (float *)h->s_qp.p, st));
   }
@@ -1086,7 +1090,14 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   a.NSPLIT = nsplit;
   a.KC = 16;
   a.NQ = NQ;
-  if (first) HIPCHECK(h, launch_score_topk(a, st));
+  if (first) {
+    if (small_idx) {
+      SmallIndexArgs si{q, h->idxp, a.part_scores, a.part_ids, a.part_bnd, h->idx_N, Q, S, KG, (int)NT};
+      HIPCHECK(h, launch_score_small_index(si, st));
+    } else {
+      HIPCHECK(h, launch_score_topk(a, st));
+    }
+  }
   RescoreArgs r;
   r.q = q;
   r.idx32 = h->idxp;
@@ -1165,9 +1176,7 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
     r2.qmap = qmap;
     r2.q_count = qcount;
     HIPCHECK(h, launch_rescore(r2, st));
-    // fp32 fragments of ALL queries for the collect sweep below
-    if (!rows_direct) HIPCHECK(h, launch_pack_rows(q, Q, S, (float *)h->s_qp32.p, st));
-    qp32 = (const float *)h->s_qp32.p;
+    qp32 = (const float *)h->s_qp32.p;  // (unused by the collect sweep: it reads the rows)
   }
   // What is still uncertified has its k-th score tied with (or within the fp32 bound of) rows outside the candidate
   // lists -- e.g. an index holding many exact duplicates of a query's best rows.  Collect path: every row whose fp32
@@ -1182,6 +1191,8 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   c.BF = 0;
   c.idxp = h->idxp;
   c.qp = qp32;
+  c.q_rows = q;  // (the collect sweep builds its fp32 fragments from the rows: nothing packed for it)
+  c.S = S;
   c.KG = KG;
   c.COLLECT = 1;
   c.col_thr = (const float *)h->s_cthr.p;
@@ -1618,6 +1629,10 @@ int sse_get_counter(sse_handle *h, const char *name, int64_t *value) {
 int sse_set_option(sse_handle *h, const char *name, int32_t value) {
   if (!h || !name) return 1;
   std::lock_guard<std::mutex> lk(h->mu);
+  if (strcmp(name, "score_small_index") == 0) {
+    h->score_small_index = value != 0;
+    return 0;
+  }
   if (strcmp(name, "score_bf16") == 0) {
     h->score_bf16 = value != 0;
     return 0;

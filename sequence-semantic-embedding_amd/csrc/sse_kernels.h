@@ -267,7 +267,7 @@ struct ScoreArgs {
   int32_t *col_buf = nullptr;         // [slots][col_cap] local row numbers
   int32_t col_cap = 0;
   int32_t dbg = 0;  // builds with -DSSE_SCORE_MEASURE only (env SSE_SCORE_DBG): bit 0 = skip the top-k epilogue of the sweep
-  // NQ == 1 (<= 32 queries, the latency path): the workgroups build their query fragments from the row-major fp32 queries
+  // NQ == 1 (<= 32 queries, the latency path) and every COLLECT sweep: the workgroups build their query fragments from the row-major fp32 queries
   // themselves (q_rows [Q][S]; fp32 or rounded to bf16 exactly as launch_pack_rows / launch_pack_rows_bf16 would) -- qp is
   // not read and the pack launch in front of the sweep goes away
   const float *q_rows = nullptr;
@@ -329,6 +329,24 @@ struct RescoreArgs {
   const float *idx_rm = nullptr;
 };
 hipError_t launch_rescore(const RescoreArgs &a, hipStream_t stream);
+
+// Small indexes under MANY queries (the evaluator's shape: 16384 x 571 x 256, the scoring half of the headline step): no
+// lists, no splits -- a workgroup of 32 queries forms ALL N <= 1024 fp32 scores on the matrix pipe into an LDS tile and then
+// selects each query's 16 best (score descending, lower row first) exactly, by a threshold search; part_* in the layout of
+// launch_score_topk with ONE split (NC = 16), so launch_rescore follows unchanged.  part_bnd[q] = the 16th best (every
+// other row scores <= that), +inf when more than 63 rows tie into the selection (the certificate then fails: next stage).
+// Index dimensions 249 .. 256 only (KG == 32: the query fragments live in registers).
+struct SmallIndexArgs {
+  const float *q_rows;   // [Q][S] fp32 row-major
+  const float *idxp;     // frag32 index [NT][KG][256]
+  float *part_scores;    // [Q][16]
+  int32_t *part_ids;     // [Q][16]
+  float *part_bnd;       // [Q]
+  int64_t N;
+  int32_t Q, S, KG, NT;
+};
+bool score_small_index_applies(int Q, int KG, int64_t NT);
+hipError_t launch_score_small_index(const SmallIndexArgs &a, hipStream_t stream);
 
 // uncertified queries (cert[q] == 0) get collect-buffer slots 0, 1, ... (col_slot[q]; -1 when certified or the pool
 // of `slots` is exhausted); *counter must be zero on entry

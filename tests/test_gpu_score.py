@@ -372,6 +372,40 @@ def test_few_queries_with_crowded_scores_take_the_collect_pass(Q):
     assert np.array_equal(out_i.cpu().numpy(), want[1]) and np.abs(out_s.cpu().numpy() - want[0]).max() < 1e-12
 
 
+@pytest.mark.parametrize("Q,N,S", [(1024, 571, 256), (1100, 1, 256), (2000, 15, 250), (1500, 16, 256), (1030, 17, 249), (1300, 1024, 256),
+                                   (1056, 993, 253), (4000, 640, 256), (1025, 641, 256)])
+def test_small_index_path_equals_the_list_sweep(Q, N, S):
+    """Many queries (>= 1024) against <= 1024 rows at the default encoding size are scored by one launch that forms all N
+    scores per query and selects the 16 best by a threshold search (option score_small_index, default on): ids and float64
+    scores equal the list sweep's (option off) and the oracle's -- with ties, more exact copies of a query's best row than
+    the 16 candidates hold (collect pass), fewer rows than candidates, partial query tiles, un-normalised queries."""
+    rng = np.random.RandomState(Q * 7 + N + S)
+    q, t = _unit(rng, Q, S), _unit(rng, N, S)
+    if N > 40:
+        t[N - 1] = t[3]                                      # exact ties: the lower row first
+        t[N // 2] = t[3]
+        q[0] = t[3]
+        for r in rng.choice(N, 30, replace=False):           # 30 exact copies of query 1's best row: more than 16 candidates tie
+            t[r] = t[7]
+        q[1] = t[7]
+    if N > 200:
+        for r in rng.choice(N, 100, replace=False):          # and 100 copies: more winners than the selection's 63 lanes
+            t[r] = t[11]
+        q[2] = t[11]
+    q[Q - 1] *= 23.0                                         # sse_demo.py:123 scores with the un-normalised encoding
+    h = _scorer()
+    h.index_upload(t)
+    k = min(10, N)
+    sc, ids = h.score_topk(q, k)
+    h.set_option("score_small_index", 0)
+    sc0, ids0 = h.score_topk(q, k)
+    assert np.array_equal(ids, ids0) and np.array_equal(sc, sc0)
+    sub = np.concatenate([np.arange(40), np.arange(Q - 40, Q)])
+    wsc, wids = O.topk(O.scores_f64(q[sub], t.astype(np.float64)), k)
+    assert np.array_equal(ids[sub], wids)
+    assert np.abs(sc[sub] - wsc).max() < 1e-9
+
+
 # --------------------------------------------------------------------------
 # index dimensions beyond one 128-query LDS block: the sweep runs with 64-query blocks (296 < S <= 616; BASELINE
 # configs[4] has S = 512) or 32-query blocks (S <= 1024).  The reference scores any S with one np.dot
