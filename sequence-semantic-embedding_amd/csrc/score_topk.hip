@@ -950,11 +950,9 @@ hipError_t launch_frag32_to_bf16(const float *idxp, int64_t NT, int KG, void *ou
 // into empty lists.  Here a 4-wave workgroup owns 32 queries, holds their fragments in REGISTERS (32 k-groups x 4), forms all
 // N scores into an LDS tile [32 queries][NP] (74 KiB at 571 rows: two workgroups per CU, one's selection under the other's
 // MFMAs) and selects per query.
-// Selection (a wave: four queries side by side): a lane holds rows lane, lane + 64, ... of a query's score row.  The 16th
-// best score is found by bisection on the scores' order-preserving integer keys -- count(score >= T) is J compares + ballot
-// population counts, on the scalar unit -- between the smallest and the largest of the lanes' maxima, stopping as soon as a
-// threshold has exactly 16 rows above it (else it ends on the 16th best itself, ties included); the winners are moved to
-// lanes 0 .. n-1 with ds_permute, ranked against each other (score descending, lower row first) and written in order.
+// Selection (a wave: four queries side by side): a lane holds rows lane, lane + 64, ... of a query's score row; the rows that
+// reach a threshold 16 .. 24 of the 64 lanes' maxima reach (>= 16 rows, ~25 as a rule) are moved to lanes 0 .. n-1 with ds_permute,
+// ranked against each other (score descending, lower row first) and the best 16 written in order.
 // (A first version -- per-lane sorted lists and 16 rounds of a wave-wide arg-max -- cost ~1300 VALU instructions per query,
 // as much as the list sweep's insertions: 110 us.  profiles/r04_notes.txt)
 __device__ __forceinline__ int si_key(float f) {  // signed-integer order == float order
@@ -976,7 +974,14 @@ __device__ __forceinline__ float wave_max_f(float x) {  // row_ror 8 / 4 / 2 / 1
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
 template <int JMAX>  // score registers per lane this instance holds (J <= JMAX)
-__device__ __forceinline__ void si_select4(const SmallIndexArgs &a, const float *sc, int NP, int NT, int qt, int q0, int lane) {
+#ifdef SSE_SCORE_CLOCK
+#define SI_CLK_PARAMS , long long (&ck_)[8], long long &ck_t
+#define SI_CLK_ARGS , ck_, ck_t
+#else
+#define SI_CLK_PARAMS
+#define SI_CLK_ARGS
+#endif
+__device__ __forceinline__ void si_select4(const SmallIndexArgs &a, const float *sc, int NP, int NT, int qt, int q0, int lane SI_CLK_PARAMS) {
   constexpr int QW = 4;
   const int J = (NT * 32 + 63) / 64;  // score registers per lane (uniform, <= 16)
   float v[QW][JMAX];
@@ -986,39 +991,43 @@ __device__ __forceinline__ void si_select4(const SmallIndexArgs &a, const float 
 #pragma unroll
     for (int c = 0; c < QW; ++c) v[c][j] = (j < J && row < NT * 32) ? sc[(q0 + c) * NP + row] : NEG_INF;
   }
-  // bisection bounds: count(>= smallest lane maximum) >= 64 >= 16 rows (or everything, when some lane holds no row: -inf);
-  // count(> largest) = 0
+  // Threshold: ANY value that 16 .. 24 of the 64 lanes' maxima reach.  That many lanes hold a row >= it, so it is a lower bound
+  // of the 16th best score, and a tight one (the best 16 rows sit in ~14 different lanes): ~20 - 30 rows reach it, and they
+  // are ranked exactly below.  Found by bisection on the order-preserving integer keys between the smallest and the largest
+  // lane maximum, ONE compare + ballot count per step, ~6 steps.  (Bisecting on all rows for the exact 16th best -- nine
+  // compares and a DPP sum per step -- and bisecting on the lane maxima to convergence, 32 steps, were each half of the
+  // selection.)  Fewer than 16 lanes with a row (N < 16): it ends on -inf, every row is taken.
   int lok[QW], hik[QW];
+  float lm[QW];
   bool done[QW];
 #pragma unroll
   for (int c = 0; c < QW; ++c) {
-    float lm = NEG_INF;
+    float m = NEG_INF;
 #pragma unroll
-    for (int j = 0; j < JMAX; ++j) lm = fmaxf(lm, v[c][j]);
-    const float hi = wave_max_f(lm), lo = -wave_max_f(-lm);
-    lok[c] = si_key(lo);
-    hik[c] = si_key(hi) + 1;  // (exclusive; scores are finite, no overflow)
-    done[c] = (unsigned)hik[c] - (unsigned)lok[c] <= 1u;
+    for (int j = 0; j < JMAX; ++j) m = fmaxf(m, v[c][j]);
+    lm[c] = m;
+    lok[c] = si_key(-wave_max_f(-m));    // the smallest lane maximum: all 64 reach it
+    hik[c] = si_key(wave_max_f(m)) + 1;  // nothing reaches this (exclusive; scores are finite: no overflow)
+    done[c] = false;
   }
+  SC_CLK(5)
   for (;;) {
     bool all_done = true;
 #pragma unroll
     for (int c = 0; c < QW; ++c) {
-      if (!done[c]) {  // (wave-uniform)
-        const int mid = lok[c] + (int)(((unsigned)hik[c] - (unsigned)lok[c]) >> 1);
-        const float T = si_val(mid);
-        int cnt = 0;
-#pragma unroll
-        for (int j = 0; j < JMAX; ++j)
-          if (j < J) cnt += __popcll(__ballot(v[c][j] >= T));
-        lok[c] = (cnt >= SC_KC) ? mid : lok[c];
-        hik[c] = (cnt >= SC_KC) ? hik[c] : mid;
-        done[c] = cnt == SC_KC || (unsigned)hik[c] - (unsigned)lok[c] <= 1u;
-        all_done = all_done && done[c];
-      }
+      const unsigned width = (unsigned)hik[c] - (unsigned)lok[c];
+      const int mid = lok[c] + (int)(width >> 1);
+      const int cnt = __popcll(__ballot(lm[c] >= si_val(mid)));
+      const bool open = !done[c] && width > 1u;
+      const bool ge = cnt >= SC_KC;
+      lok[c] = (open && ge) ? mid : lok[c];
+      hik[c] = (open && !ge) ? mid : hik[c];
+      done[c] = !open || (ge && cnt <= 24);
+      all_done = all_done && done[c];
     }
     if (all_done) break;
   }
+  SC_CLK(6)
 #pragma unroll
   for (int c = 0; c < QW; ++c) {
     const int query = qt * 32 + q0 + c;
@@ -1032,17 +1041,15 @@ __device__ __forceinline__ void si_select4(const SmallIndexArgs &a, const float 
         const bool take = (j < J) & (v[c][j] >= T) & (v[c][j] > NEG_INF);
         const unsigned long long mask = __ballot(take);
         const int n = __popcll(mask);
-        if (n != 0) {  // (uniform)
-          const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-          const int dst = (take && slot < 63) ? slot : 63;
-          const int gs = __builtin_amdgcn_ds_permute(dst * 4, __float_as_int(v[c][j]));
-          const int gr = __builtin_amdgcn_ds_permute(dst * 4, lane + 64 * j);
-          if (lane >= base && lane < base + n && lane < 63) {
-            cs = __int_as_float(gs);
-            cr = gr;
-          }
-          base += n;
-        }
+        // (no branch on n: the nine pushes and their waits then batch; with no taker nobody receives)
+        const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        const int dst = (take && slot < 63) ? slot : 63;
+        const int gs = __builtin_amdgcn_ds_permute(dst * 4, __float_as_int(v[c][j]));
+        const int gr = __builtin_amdgcn_ds_permute(dst * 4, lane + 64 * j);
+        const bool recv = (lane >= base) & (lane < base + n) & (lane < 63);
+        cs = recv ? __int_as_float(gs) : cs;
+        cr = recv ? gr : cr;
+        base += n;
       }
       const int nw = base < 63 ? base : 63;  // (more than 63 rows tied into the selection: the bound says so below)
       int rank = 0;
@@ -1125,17 +1132,17 @@ __global__ __launch_bounds__(256) void score_small_index_kernel(SmallIndexArgs a
   __syncthreads();
   SC_CLK(2)
   if (NT * 32 <= 640) {  // (571 rows: 9 registers per lane and query instead of 16)
-    si_select4<10>(a, sc, NP, NT, qt, w * 8, lane);
+    si_select4<10>(a, sc, NP, NT, qt, w * 8, lane SI_CLK_ARGS);
     SC_CLK(3)
-    si_select4<10>(a, sc, NP, NT, qt, w * 8 + 4, lane);
+    si_select4<10>(a, sc, NP, NT, qt, w * 8 + 4, lane SI_CLK_ARGS);
     SC_CLK(4)
 #ifdef SSE_SCORE_CLOCK
     if (blockIdx.x == gridDim.x / 2 && lane == 0)
       for (int i = 0; i < 8; ++i) g_score_clk[w * 8 + i] = ck_[i];
 #endif
   } else {
-    si_select4<16>(a, sc, NP, NT, qt, w * 8, lane);
-    si_select4<16>(a, sc, NP, NT, qt, w * 8 + 4, lane);
+    si_select4<16>(a, sc, NP, NT, qt, w * 8, lane SI_CLK_ARGS);
+    si_select4<16>(a, sc, NP, NT, qt, w * 8 + 4, lane SI_CLK_ARGS);
   }
 }
 bool score_small_index_applies(int Q, int KG, int64_t NT) {
@@ -1156,8 +1163,8 @@ hipError_t launch_score_small_index(const SmallIndexArgs &a, hipStream_t stream)
       (void)hipStreamSynchronize(stream);
       (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_score_clk), sizeof v);
       for (int w = 0; w < 4; w += 3)
-        fprintf(stderr, "[small index clock Q=%d NT=%d] wave %d cycles: query fragments %lld | scores (MFMA + LDS stores) %lld | barrier %lld | selection, first four queries %lld | second four %lld\n",
-                a.Q, a.NT, w, v[w * 8 + 0], v[w * 8 + 1], v[w * 8 + 2], v[w * 8 + 3], v[w * 8 + 4]);
+        fprintf(stderr, "[small index clock Q=%d NT=%d] wave %d cycles: query fragments %lld | scores (MFMA + LDS stores) %lld | barrier %lld | selection: loads + bounds %lld | bisection %lld | winners + rank + stores %lld (both batches)\n",
+                a.Q, a.NT, w, v[w * 8 + 0], v[w * 8 + 1], v[w * 8 + 2], v[w * 8 + 5], v[w * 8 + 6], v[w * 8 + 3] + v[w * 8 + 4]);
     }
   }
 #endif
