@@ -6,7 +6,7 @@ import csv
 import os
 import sys
 
-OURS = ("lstm_fwd", "lstm_bwd", "dk_x3", "dx_scatter", "emb_grad", "dx_hot", "compact_uncert", "gather_query", "multi_kernel", "proj_bwd_dm_mfma", "score_topk", "rescore", "exact_topk", "pack_", "merge_topk", "row_norm2", "pad_rows",
+OURS = ("score_small_index", "lstm_fwd", "lstm_bwd", "dk_x3", "dx_scatter", "emb_grad", "dx_hot", "compact_uncert", "gather_query", "multi_kernel", "proj_bwd_dm_mfma", "score_topk", "rescore", "exact_topk", "pack_", "merge_topk", "row_norm2", "pad_rows",
         "l2_normalize", "conv_pool", "proj_norm", "dk_gemm", "dx_kernel", "loss_", "adagrad", "sumsq", "clip_scale",
         "proj_bwd", "db_reduce", "dk_reduce")
 
@@ -31,7 +31,7 @@ def main():
         agg = collections.defaultdict(list)
         dur = collections.defaultdict(list)
         for r in csv.DictReader(open(os.path.join(d, "p_counter_collection.csv"))):
-            if any(k in r["Kernel_Name"] for k in ("lstm_fwd", "lstm_bwd", "dk_x3", "dk_gemm", "dx_scatter", "conv_pool", "score_topk", "rescore_kernel")):
+            if any(k in r["Kernel_Name"] for k in ("lstm_fwd", "lstm_bwd", "dk_x3", "dk_gemm", "dx_scatter", "conv_pool", "score_topk", "score_small_index", "rescore_kernel")):
                 key = (r["Kernel_Name"].split("(")[0][:64], r["Grid_Size"])
                 agg[key + (r["Counter_Name"],)].append(float(r["Counter_Value"]))
                 dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
