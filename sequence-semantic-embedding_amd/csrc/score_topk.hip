@@ -1147,14 +1147,24 @@ __global__ __launch_bounds__(256) void score_small_index_kernel(SmallIndexArgs a
 }
 bool score_small_index_applies(int Q, int KG, int64_t NT) {
   // many queries only: a single query's workgroup would walk all tiles alone (0.09 ms against 0.05 for the list sweep)
-  return Q >= 1024 && KG == 32 && NT * 32 <= 1024 && (size_t)32 * (NT * 32 + 1) * sizeof(float) <= (size_t)80 * 1024;
+  // index dimensions 249 .. 256 (configs[1]), 57 .. 64 (the reference's default encoding_size, sse_train.py:67), 49 .. 56 (its
+  // crosslingual recipe, makefile:42): the k-groups are a template parameter (query fragments in registers)
+  return Q >= 1024 && (KG == 32 || KG == 8 || KG == 7) && NT * 32 <= 1024 && (size_t)32 * (NT * 32 + 1) * sizeof(float) <= (size_t)80 * 1024;
 }
 hipError_t launch_score_small_index(const SmallIndexArgs &a, hipStream_t stream) {
   if (!score_small_index_applies(a.Q, a.KG, a.NT)) return hipErrorInvalidValue;
   const size_t lds = (size_t)32 * (a.NT * 32 + 1) * sizeof(float);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(score_small_index_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(score_small_index_kernel<32>, dim3((a.Q + 31) / 32), dim3(256), lds, stream, a);
+  const dim3 grid((a.Q + 31) / 32), block(256);
+  auto go = [&](auto kernel) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, a);
+    return hipGetLastError();
+  };
+  if (a.KG == 8) return go(score_small_index_kernel<8>);
+  if (a.KG == 7) return go(score_small_index_kernel<7>);
+  const hipError_t e32 = go(score_small_index_kernel<32>);
+  if (e32 != hipSuccess) return e32;
 #ifdef SSE_SCORE_CLOCK
   if (a.Q >= 8192) {
     static int n = 0;

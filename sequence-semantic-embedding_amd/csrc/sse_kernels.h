@@ -335,7 +335,7 @@ hipError_t launch_rescore(const RescoreArgs &a, hipStream_t stream);
 // selects each query's 16 best (score descending, lower row first) exactly, by a threshold search; part_* in the layout of
 // launch_score_topk with ONE split (NC = 16), so launch_rescore follows unchanged.  part_bnd[q] = the 16th best (every
 // other row scores <= that), +inf when more than 63 rows tie into the selection (the certificate then fails: next stage).
-// Index dimensions 249 .. 256 only (KG == 32: the query fragments live in registers).
+// Index dimensions 249 .. 256, 57 .. 64 and 49 .. 56 (the k-groups are a template parameter: the query fragments live in registers).
 struct SmallIndexArgs {
   const float *q_rows;   // [Q][S] fp32 row-major
   const float *idxp;     // frag32 index [NT][KG][256]

@@ -373,7 +373,8 @@ def test_few_queries_with_crowded_scores_take_the_collect_pass(Q):
 
 
 @pytest.mark.parametrize("Q,N,S", [(1024, 571, 256), (1100, 1, 256), (2000, 15, 250), (1500, 16, 256), (1030, 17, 249), (1300, 1024, 256),
-                                   (1056, 993, 253), (4000, 640, 256), (1025, 641, 256)])
+                                   (1056, 993, 253), (4000, 640, 256), (1025, 641, 256), (1100, 571, 64), (3000, 1000, 57),
+                                   (1300, 300, 50), (1024, 33, 49), (1500, 571, 56), (1200, 571, 48), (1200, 571, 65)])
 def test_small_index_path_equals_the_list_sweep(Q, N, S):
     """Many queries (>= 1024) against <= 1024 rows at the default encoding size are scored by one launch that forms all N
     scores per query and selects the 16 best by a threshold search (option score_small_index, default on): ids and float64
