@@ -118,7 +118,13 @@ int sse_encode_dev(sse_handle *h, int side, const int32_t *ids_dev, int32_t B, i
  * embeddings and filters rounded to bf16 (fp32 masters, fp32 accumulation, fp32 bias/ReLU/pool/projection) on the bf16
  * matrix pipe -- the reference has no reduced-precision behaviour; BASELINE configs[4] names bf16.
  * "train_serial" (default 0): run both encoders of a train step on one stream (profiling aid:
- * isolated kernel durations; same results). */
+ * isolated kernel durations; same results).
+ * "score_small_index" (default 1): >= 1024 queries against <= 1024 index rows (index dimensions 249 .. 256, 57 .. 64,
+ * 49 .. 56: the evaluator's shape, sse_evaluator.py:104-112) are scored by one launch that forms all N scores per query and
+ * selects the 16 best exactly, instead of the list sweep; identical results.  "lstm_cluster_coop" (default 1): the cluster
+ * encoder kernels are launched cooperatively (co-residency guaranteed by the runtime; ~20 us per call on ROCm 7.2; 0 =
+ * plain launch, the give-up / fall-back path alone).  "train_gen1" (default 0): the first-generation fp32 training
+ * kernels instead of the round-4 ones (A/B and test aid; same results to fp32 summation order). */
 int sse_set_option(sse_handle *h, const char *name, int32_t value);
 /* Diagnostic counters (cumulative).  "score_bf16_second_chance_queries": queries whose bf16-candidate result missed
  * its certificate and were re-run with fp32 candidates.  "score_collect_queries": queries served by the collect path
