@@ -400,7 +400,6 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   const int t0 = split * tps, t1 = min(a.NT, t0 + tps);
   const float *qs = smem + lane * 4;
   const int voff = lane * 16;
-  constexpr int WSTEP = SC_THREADS / 64;
 
   // k-group product: acc (+)= A fragment x the NQ query fragments; ZERO: the accumulators start from the MFMA's
   // inline-constant C operand
