@@ -123,7 +123,9 @@ int sse_encode_dev(sse_handle *h, int side, const int32_t *ids_dev, int32_t B, i
  * 49 .. 56: the evaluator's shape, sse_evaluator.py:104-112) are scored by one launch that forms all N scores per query and
  * selects the 16 best exactly, instead of the list sweep; identical results.  "lstm_cluster_coop" (default 1): the cluster
  * encoder kernels are launched cooperatively (co-residency guaranteed by the runtime; ~20 us per call on ROCm 7.2; 0 =
- * plain launch, the give-up / fall-back path alone).  "train_gen1" (default 0): the first-generation fp32 training
+ * plain launch, the give-up / fall-back path alone).  "lstm_cluster_backoff" (default -1 = automatic): eligible calls that go
+ * straight to the kernels needing no co-residency after a cluster launch gave up (a give-up costs 10 ms); automatic arms 16
+ * calls once a give-up was observed (another process on the device, or a refused cooperative launch).  "train_gen1" (default 0): the first-generation fp32 training
  * kernels instead of the round-4 ones (A/B and test aid; same results to fp32 summation order). */
 int sse_set_option(sse_handle *h, const char *name, int32_t value);
 /* Diagnostic counters (cumulative).  "score_bf16_second_chance_queries": queries whose bf16-candidate result missed
@@ -131,7 +133,8 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value);
  * (k > 16, or a k-th score tied with rows outside the candidate lists: one more grid-wide sweep gathers every row that
  * can be in the exact top-k).  "score_bruteforce_queries": queries that fell through to the one-workgroup-per-query
  * float64 sweep (k > 1024, or more than 4096 rows within the fp32 bound of the k-th score).
- * "lstm_persist_fallbacks": host-buffer encodes re-run on the few-sequences kernel (see option lstm_persist_rows). */
+ * "lstm_persist_fallbacks": host-buffer encodes re-run on the few-sequences kernel (see option lstm_persist_rows).
+ * "lstm_coop_refused" (process-wide): cooperative launches the runtime refused -- the plain launch was taken instead. */
 int sse_get_counter(sse_handle *h, const char *name, int64_t *value);
 
 /* tf.nn.l2_normalize(x, dim=-1) on device rows (sse_model.py:282-283). */

@@ -538,7 +538,8 @@ hipError_t launch_lstm_cluster(const LstmClusterArgs &a_in, hipStream_t stream) 
     void *args[] = {(void *)&a};
     hipError_t ce = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(lstm_cluster_kernel), dim3(grid), dim3(LC_NT), args, (unsigned)lds, stream);
     if (ce == hipSuccess) return hipGetLastError();
-    (void)hipGetLastError();  // not supported / too large for this device: plain launch
+    (void)hipGetLastError();  // not supported / too large for this device: plain launch, and say so (counter lstm_coop_refused)
+    lstm_note_coop_refused();
   }
   hipLaunchKernelGGL(lstm_cluster_kernel, dim3(grid), dim3(LC_NT), lds, stream, a);
   return hipGetLastError();

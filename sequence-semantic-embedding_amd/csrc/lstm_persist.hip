@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "sse_kernels.h"
+#include <atomic>
 
 #define LP_RB 4      // sequences per cluster
 #define LP_NT 256    // threads per workgroup: wave g computes gate g of (sequence, unit) = lane
@@ -375,6 +376,10 @@ int lstm_persist_max_steps() { return 4094; }
 
 // a.epoch must differ from the epoch of every earlier launch that used the same exchange buffers (20 bits; the buffers
 // start zeroed and epoch 0 is never used)
+static std::atomic<long long> g_coop_refused{0};
+void lstm_note_coop_refused() { g_coop_refused.fetch_add(1, std::memory_order_relaxed); }
+long long lstm_coop_refused() { return g_coop_refused.load(std::memory_order_relaxed); }
+
 hipError_t launch_lstm_persist(const LstmPersistArgs &a_in, hipStream_t stream) {
   LstmPersistArgs a = a_in;
   a.NWG = lstm_persist_nwg(a.E, a.H, a.S);
@@ -394,7 +399,8 @@ hipError_t launch_lstm_persist(const LstmPersistArgs &a_in, hipStream_t stream) 
     void *args[] = {(void *)&a};
     hipError_t ce = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(lstm_persist_kernel), dim3(8 * a.NWG), dim3(LP_NT), args, (unsigned)lds, stream);
     if (ce == hipSuccess) return hipGetLastError();
-    (void)hipGetLastError();  // not supported / too large for this device: plain launch
+    (void)hipGetLastError();  // not supported / too large for this device: plain launch, and say so (counter lstm_coop_refused)
+    lstm_note_coop_refused();
   }
   hipLaunchKernelGGL(lstm_persist_kernel, dim3(8 * a.NWG), dim3(LP_NT), lds, stream, a);
   return hipGetLastError();

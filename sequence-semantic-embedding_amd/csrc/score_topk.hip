@@ -1148,7 +1148,7 @@ bool score_small_index_applies(int Q, int KG, int64_t NT) {
   // many queries only: a single query's workgroup would walk all tiles alone (0.09 ms against 0.05 for the list sweep)
   // index dimensions 249 .. 256 (configs[1]), 57 .. 64 (the reference's default encoding_size, sse_train.py:67), 49 .. 56 (its
   // crosslingual recipe, makefile:42): the k-groups are a template parameter (query fragments in registers)
-  return Q >= 1024 && (KG == 32 || KG == 8 || KG == 7) && NT * 32 <= 1024 && (size_t)32 * (NT * 32 + 1) * sizeof(float) <= (size_t)80 * 1024;
+  return Q >= 1024 && (KG == 32 || KG == 8 || KG == 7) && NT * 32 <= 1024 && (size_t)32 * (NT * 32 + 1) * sizeof(float) <= (size_t)144 * 1024;  // (1024 rows: 128.1 KiB of the CU's 160 KiB -> one workgroup per CU; up to 608 rows two fit)
 }
 hipError_t launch_score_small_index(const SmallIndexArgs &a, hipStream_t stream) {
   if (!score_small_index_applies(a.Q, a.KG, a.NT)) return hipErrorInvalidValue;

@@ -119,7 +119,7 @@ struct sse_handle {
   int lstm_cluster_rows = 1024; // option "lstm_cluster_rows": batches above lstm_persist_rows up to this many rows (<= 1024) take the MFMA cluster kernel
   uint32_t cluster_epoch = 0;   // tag epoch of that kernel's exchange buffers
   int lstm_cluster_chunks = 3;  // option "lstm_cluster_chunks": batches of up to this many times lstm_cluster_rows go through that kernel in launches of lstm_cluster_rows
-  int cluster_backoff = 0;      // option "lstm_cluster_backoff" (default 0 since the cluster kernels are launched cooperatively: co-residency is the runtime's promise, a give-up is a fault, not a mood of a busy device): after a cluster-kernel launch gave up, this many following eligible calls go straight to the kernels that need no co-residency
+  int cluster_backoff = -1;     // option "lstm_cluster_backoff": after a cluster-kernel launch gave up, this many following eligible calls go straight to the kernels that need no co-residency.  -1 (default) = automatic: no back-off is ARMED until a give-up has been observed (cooperative launches make co-residency the runtime's promise), but an observed give-up -- another process on the device, or a cooperative launch the runtime refused (counter lstm_coop_refused) -- arms 16 calls, so a busy device pays the 10 ms give-up once in 17 calls, not on every call
   int cluster_skip[2] = {0, 0}; // calls still to skip: [0] single-query kernel (lstm_persist), [1] mid-batch kernel (lstm_cluster)
   int lstm_cluster_coop = 1;    // option "lstm_cluster_coop" (default 1): the cluster kernels are launched with hipLaunchCooperativeKernel (co-residency guaranteed by the runtime; +20 us per launch measured); 0 = plain launches
   int lstm_cluster_wt = 0;      // option "lstm_cluster_write_through": force the any-placement publish path (tests)
@@ -1414,7 +1414,7 @@ static int ensure_pin(sse_handle *h, size_t need) {
 // Nothing was written that the other kernels do not overwrite; results are bit-identical.
 static int encode_fallback_locked(sse_handle *h, int side, int32_t B, int32_t T, int32_t normalize, hipStream_t st) {
   h->persist_fallbacks += 1;
-  h->cluster_skip[B <= 32 ? 0 : 1] = h->cluster_backoff;  // a time-out costs 10 ms: do not pay it on every call of a busy device
+  h->cluster_skip[B <= 32 ? 0 : 1] = h->cluster_backoff >= 0 ? h->cluster_backoff : 16;  // a time-out costs 10 ms: do not pay it on every call of a busy device
   const int keep = h->lstm_persist_rows, keep_c = h->lstm_cluster_rows;
   h->lstm_persist_rows = 0;
   h->lstm_cluster_rows = 0;
@@ -1522,6 +1522,12 @@ static int score_to_host_locked(sse_handle *h, const float *q_dev, int Q, int k,
   if (use_mirror) {
     h->score_seq = (h->score_seq == INT32_MAX) ? 1 : h->score_seq + 1;
     hm.seq = h->score_seq;
+    // The completion words move inside the pinned block with (Q, k), and the block is shared with earlier calls of other
+    // shapes (scores, int64 ids, certificates) and with sse_encode's read-back: a stale word could equal this call's
+    // sequence number.  Nothing of this handle is in flight here (the previous call returned after its last poll / sync),
+    // so the host clears them before the launch.
+    for (int i = 0; i < Q; ++i) __atomic_store_n(done + i, 0, __ATOMIC_RELAXED);
+    __atomic_store_n(flag, 0, __ATOMIC_RELEASE);
   }
   if (score_dev_locked(h, q_dev, Q, k, (double *)h->s_os.p, (int64_t *)h->s_oi.p, st, SCORE_FIRST, &split, use_mirror ? &hm : nullptr))
     return 1;
@@ -1611,6 +1617,10 @@ int sse_get_counter(sse_handle *h, const char *name, int64_t *value) {
     *value = h->persist_fallbacks;
     return 0;
   }
+  if (strcmp(name, "lstm_coop_refused") == 0) {  // process-wide: cooperative launches refused by the runtime (plain launch taken)
+    *value = (int64_t)lstm_coop_refused();
+    return 0;
+  }
   static const char *const names[3] = {"score_bf16_second_chance_queries", "score_collect_queries", "score_bruteforce_queries"};
   for (int i = 0; i < 3; ++i) {
     if (strcmp(name, names[i]) != 0) continue;
@@ -1696,7 +1706,7 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value) {
     return 0;
   }
   if (strcmp(name, "lstm_cluster_backoff") == 0) {
-    if (value < 0) return fail(h, "lstm_cluster_backoff must be >= 0");
+    if (value < -1) return fail(h, "lstm_cluster_backoff must be >= 0 (or -1: automatic)");
     h->cluster_backoff = (int)value;
     h->cluster_skip[0] = h->cluster_skip[1] = 0;
     return 0;
@@ -2075,6 +2085,16 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   if (E > 64) return fail(h, "train step: embedding_size %d > 64 not supported yet", E);
   for (int s = 0; s < nside; ++s)
     if (h->enc[s].Hp > 256) return fail(h, "train step: LSTM cell size %d > 256 not supported yet (inference only)", h->enc[s].H);
+  for (int s = 0; s < nside; ++s) {
+    // the BPTT kernels address the gate tape [T][rows/32][Hp/32][5][1024] floats through 32-bit offsets (both generations)
+    const size_t tape_bytes = (size_t)T * NT32 * (h->enc[s].Hp / 32) * 5 * 1024 * sizeof(float);
+    if (tape_bytes >= ((size_t)1 << 31))
+      return fail(h, "train step: batch x T x H too large -- %d rows x %d steps x cell size %d need a %.2f GiB gate tape per encoder, "
+                     "the limit is 2 GiB (<= %lld rows at this T and cell size): use a smaller batch, or sse_train_grads per micro-batch with "
+                     "rows_global = the whole batch and the gradient arenas summed before sse_train_apply (the data-parallel recipe)",
+                  B, T, h->enc[s].H, (double)tape_bytes / (double)((size_t)1 << 30),
+                  (long long)(((((size_t)1 << 31) - 1) / ((size_t)T * (h->enc[s].Hp / 32) * 5 * 1024 * sizeof(float))) * 32 / 64 * 64));
+  }
 
   // ---- inputs
   // Paired batch (data.py:95-115 builds every batch this way: source row 2i and 2i+1 are the same sequence, once with

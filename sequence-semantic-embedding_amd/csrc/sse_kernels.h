@@ -216,6 +216,10 @@ int lstm_persist_max_steps();
 size_t lstm_persist_hx_words(int H);
 size_t lstm_persist_raw_words(int S);
 hipError_t launch_lstm_persist(const LstmPersistArgs &a, hipStream_t stream);
+// cooperative launches the runtime REFUSED (the launchers then took the plain launch, whose co-residency nobody promises):
+// process-wide count, surfaced as counter "lstm_coop_refused"
+void lstm_note_coop_refused();
+long long lstm_coop_refused();
 
 // mid-size batches (33 .. 1024 sequences) with the hidden units of a 64-row tile spread over a cluster of 16 workgroups that
 // keep their weight fragments in LDS and exchange h_t every step -- lstm_persist.hip's layout on MFMA (lstm_cluster.hip)

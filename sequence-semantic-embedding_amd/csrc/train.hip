@@ -1773,15 +1773,13 @@ hipError_t launch_dk(const float *tape_a, const float *dg_b, float *part, int RG
     else if (KT == 6 && pair_rg) hipLaunchKernelGGL((dk_gemm_kernel<6, true>), grid, dim3(512), 0, st, a);
     else if (KT == 6) hipLaunchKernelGGL((dk_gemm_kernel<6, false>), grid, dim3(512), 0, st, a);
     else return hipErrorInvalidValue;
-  } else if (!pair_rg && getenv("SSE_DK_TWO") == nullptr) {  // (pairs: the two-r-group kernel measured 0.76 against 0.78 ms)
+  } else if (static const bool two = getenv("SSE_DK_TWO") != nullptr; !pair_rg && !two) {  // (pairs: the two-r-group kernel measured 0.76 against 0.78 ms)
     const int lds3 = 2 * 4 * KT * 1024;
     auto go3 = [&](auto kern) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
       hipLaunchKernelGGL(kern, grid, dim3(512), lds3, st, a);
     };
-    if (KT == 10 && pair_rg) go3(dk_gemm3_kernel<10, true>);
-    else if (KT == 10) go3(dk_gemm3_kernel<10, false>);
-    else if (KT == 6 && pair_rg) go3(dk_gemm3_kernel<6, true>);
+    if (KT == 10) go3(dk_gemm3_kernel<10, false>);  // (no pairs in this branch: the PAIR = true bodies are not instantiated)
     else if (KT == 6) go3(dk_gemm3_kernel<6, false>);
     else return hipErrorInvalidValue;
   } else {
@@ -1912,7 +1910,11 @@ __global__ __launch_bounds__(256) void emb_grad_pack_kernel(const float *__restr
 // order, after the block has been zeroed: the same sums in the same order on every rank.
 __global__ __launch_bounds__(256) void emb_grad_unpack_kernel(const float *__restrict__ packed, int V, int E, int cap, float *__restrict__ g,
                                                               int32_t *err) {
-  const int count = min(reinterpret_cast<const int32_t *>(packed)[0], cap);
+  const int sent = reinterpret_cast<const int32_t *>(packed)[0];
+  // a peer whose pack overflowed (count > cap) raised bit 8 on ITS err word only and cancels its own update: raise it here
+  // too, so every rank cancels the step together instead of applying a truncated gradient and drifting apart
+  if ((sent > cap || sent < 0) && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err, 8);
+  const int count = sent < 0 ? 0 : min(sent, cap);
   const int cap4 = (cap + 3) & ~3;
   const int64_t n = (int64_t)count * E;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
