@@ -351,11 +351,232 @@ def cnn_leg(sse_amd, torch, np, dev, rows=16384, train_iters=5):
                 "roofline": {"kernel": "whole step (conv forward with arg-max tape, projection fwd/bwd, gather/scatter conv "
                                        "backward, clip, Adagrad)", "bound": "mfma", "unit": "TFLOP/s",
                              "achieved": executed / d / 1e12, "peak": peak, "frac": executed / d / 1e12 / peak,
-                             "note": "GEMM-shaped flops of the step over its wall time; the backward of a max-pooled convolution "
-                                     "is latency-bound gather / scatter work, not matrix work"}}
+                             "mfma_busy": busy_of("conv_pool", "cnn_d", "cnn_bwd", "proj_norm", "proj_bwd"),
+                             "note": "GEMM-shaped flops of the step over its wall time"}}
     h.set_option("cnn_bf16", 0)
+    leg["hbm_bytes_per_launch_from_profiles"] = PMC.get("cnn_hbm_bytes_per_launch")
     h.close()
     return leg
+
+
+
+def _oracle_encode_chunk(job):
+    """Worker of oracle_encode_parallel (spawned process: numpy only, no HIP)."""
+    p, cfg, side, ids = job
+    from oracle import sse_oracle as O
+    return O.encode(p, cfg, side, ids)
+
+
+def oracle_encode_parallel(p, cfg, side, ids, procs):
+    """The CPU oracle's encode over row chunks in `procs` spawned processes (rows are independent; the checker of
+    realdata_leg would otherwise spend ~20 s single-threaded in numpy's elementwise gate arithmetic for 32,060 rows)."""
+    import multiprocessing as mp
+    import numpy as np
+    procs = max(1, min(procs, 16, (len(ids) + 511) // 512))
+    if procs == 1:
+        return _oracle_encode_chunk((p, cfg, side, ids))
+    chunks = np.array_split(ids, procs)
+    env_keep = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+    for k in env_keep:
+        os.environ[k] = "1"                                 # one BLAS thread per worker: the workers are the parallelism
+    try:
+        with mp.get_context("spawn").Pool(procs) as pool:
+            outs = pool.map(_oracle_encode_chunk, [(p, cfg, side, c) for c in chunks])
+    finally:
+        for k, v in env_keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return np.concatenate(outs, axis=0)
+
+
+def realdata_leg(sse_amd, torch, np, dev, check_queries=2048):
+    """BASELINE configs[2] on the REAL rawdata-crosslingual token rows the reference's own prepare_raw_data
+    produced (tests/golden/crosslingual_full_ids.npz; makefile:42 T = 50; BASELINE: dual-encoder H = S = 256, E = 50):
+    index build = encode ALL 32,060 targets (sse_index.py:66-92), evaluation = encode ALL 16,491 queries and rank each
+    against the whole index, top-10 (sse_evaluator.py:103-113).  Rows are left-padded (mean 8.5 / 3.0 real tokens of 50):
+    timed with the exact left-PAD prefix skip (library default) and without it; roofline fractions over the DENSE
+    algorithmic flops (all T steps, what the reference executes) and over the NON-PAD steps only.  Parity inside the leg:
+    top-1 ids of `check_queries` queries against the CPU oracle run on the same weights (oracle encodings of all targets
+    and of the sampled queries, float64 scores), and the opt-in lstm_x3 path's top-1 against the exact fp32 path on ALL
+    queries."""
+    path = os.path.join(ROOT, "tests", "golden", "crosslingual_full_ids.npz")
+    if not os.path.exists(path):
+        return {"skipped": "tests/golden/crosslingual_full_ids.npz not found"}
+    z = np.load(path)
+    src_np, tgt_np = z["src_ids"].astype(np.int32), z["tgt_ids"].astype(np.int32)
+    V3, T3, E3, H3, S3 = int(z["vocab_size"]), int(src_np.shape[1]), 50, 256, 256
+    params = dict(forward_only=True, network_mode="dual-encoder", predict_nbest=10, max_seq_length=T3, vocab_size=V3,
+                  embedding_size=E3, encoding_size=S3, src_cell_size=H3, tgt_cell_size=H3, learning_rate=0.9,
+                  learning_rate_decay_factor=0.99, targetSpaceSize=len(tgt_np))
+    m = sse_amd.SSEModel(params, device=dev.index)
+    m.init_variables(seed=0)
+    h = m.handle
+    NT_, NQ_ = len(tgt_np), len(src_np)
+    tgt_d, src_d = torch.from_numpy(tgt_np).to(dev), torch.from_numpy(src_np).to(dev)
+    tgt_e = torch.empty((NT_, S3), dtype=torch.float32, device=dev)
+    src_e = torch.empty((NQ_, S3), dtype=torch.float32, device=dev)
+    top_s = torch.empty((NQ_, 10), dtype=torch.float64, device=dev)
+    top_i = torch.empty((NQ_, 10), dtype=torch.int64, device=dev)
+    flop_step = 8 * H3 * (E3 + H3)
+    dense_flop = T3 * flop_step + 2 * H3 * S3
+    nonpad_t, nonpad_q = float((tgt_np != 0).sum(1).mean()), float((src_np != 0).sum(1).mean())
+    # pad_skip sorts nothing on the device entry point: a 64-row tile starts at the smallest leading-PAD count of ITS rows.
+    # The host-buffer entry point (sse_encode, what sse_index / Evaluator call) counting-sorts the rows by pad count first.
+    leg = {"config": "configs[2]: rawdata-crosslingual real token rows, dual-encoder H=S=%d E=%d T=%d V=%d; %d targets, %d queries"
+                     % (H3, E3, T3, V3, NT_, NQ_),
+           "mean_non_pad_tokens": {"targets": nonpad_t, "queries": nonpad_q},
+           "weights": "random-init (reference initialisers, seed 0)", "arithmetic": "exact fp32 (v_mfma_f32_32x32x2_f32)"}
+
+    def enc_dev(side, ids_d, n, out):
+        return lambda: h.encode_dev(side, ids_d.data_ptr(), n, T3, True, out.data_ptr())
+
+    def roof(n, ms, nonpad):
+        tf = n * dense_flop / (ms * 1e-3) / 1e12
+        tf_np = n * (nonpad * flop_step + 2 * H3 * S3) / (ms * 1e-3) / 1e12
+        return {"kernel": "lstm_fwd_kernel", "bound": "mfma", "unit": "TFLOP/s", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS,
+                "frac": tf / PEAK_F32_MFMA_TFLOPS, "basis": "dense algorithmic flops: all T steps, as the reference executes them",
+                "achieved_non_pad_steps_only": tf_np, "frac_non_pad_steps_only": tf_np / PEAK_F32_MFMA_TFLOPS}
+
+    for skip in (0, 1):
+        h.set_option("pad_skip", skip)
+        ms_t = _events_ms(h, enc_dev(1, tgt_d, NT_, tgt_e), 5, warm=2)
+        ms_q = _events_ms(h, enc_dev(0, src_d, NQ_, src_e), 5, warm=2)
+        # host buffers in and out (PCIe-inclusive; rows counting-sorted by pad count inside the call when pad_skip = 1)
+        m.encode_target(tgt_np[:4096])
+        t0 = time.perf_counter()
+        m.encode_target(tgt_np)
+        host_t = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        m.encode_source(src_np)
+        host_q = time.perf_counter() - t0
+        leg["pad_skip_%d" % skip] = {
+            "index_build": {"encode_ms": ms_t, "seqs_per_s": NT_ / (ms_t * 1e-3), "roofline": roof(NT_, ms_t, nonpad_t),
+                            "host_buffers_ms": host_t * 1e3, "host_buffers_seqs_per_s": NT_ / host_t},
+            "query_encode": {"encode_ms": ms_q, "seqs_per_s": NQ_ / (ms_q * 1e-3), "roofline": roof(NQ_, ms_q, nonpad_q),
+                             "host_buffers_ms": host_q * 1e3, "host_buffers_seqs_per_s": NQ_ / host_q}}
+    # ranking: all queries against the whole index (resident, float32 rows as the device produced them)
+    h.index_set_dev(tgt_e.data_ptr(), NT_, S3)
+    ms_s = _events_ms(h, lambda: h.score_topk_dev(src_e.data_ptr(), NQ_, 10, top_s.data_ptr(), top_i.data_ptr()), 5, warm=2)
+    leg["score"] = {"queries": NQ_, "index_rows": NT_, "k": 10, "ms_per_pass": ms_s, "scores_per_s": NQ_ * NT_ / (ms_s * 1e-3),
+                    "roofline": {"kernel": "score_topk_kernel (bf16 candidates) + float64 re-scoring", "bound": "mfma", "unit": "TFLOP/s",
+                                 "achieved": 2.0 * S3 * NQ_ * NT_ / (ms_s * 1e-3) / 1e12, "peak": 2500.0,
+                                 "frac": 2.0 * S3 * NQ_ * NT_ / (ms_s * 1e-3) / 1e12 / 2500.0}}
+    best = leg["pad_skip_1"]
+    whole = best["index_build"]["encode_ms"] + best["query_encode"]["encode_ms"] + ms_s
+    leg["whole_job_ms"] = whole
+    leg["whole_job"] = "index build + query encode + ranking, device-resident inputs, pad_skip = 1: %.2f ms for %d + %d sequences and %.3g scores" \
+                       % (whole, NT_, NQ_, float(NQ_) * NT_)
+    exact_i = top_i[:, 0].clone()
+    # the opt-in split-bf16 encoder on the same data: top-1 of ALL queries against the exact fp32 path
+    h.set_option("lstm_x3", 1)
+    tgt_x = torch.empty_like(tgt_e)
+    src_x = torch.empty_like(src_e)
+    ms_tx = _events_ms(h, enc_dev(1, tgt_d, NT_, tgt_x), 3, warm=1)
+    ms_qx = _events_ms(h, enc_dev(0, src_d, NQ_, src_x), 3, warm=1)
+    h.index_set_dev(tgt_x.data_ptr(), NT_, S3)
+    xs = torch.empty_like(top_s)
+    xi = torch.empty_like(top_i)
+    h.score_topk_dev(src_x.data_ptr(), NQ_, 10, xs.data_ptr(), xi.data_ptr())
+    h.synchronize()
+    margin = (top_s[:, 0] - top_s[:, 1])
+    same = (xi[:, 0] == exact_i)
+    leg["lstm_x3"] = {"index_build_ms": ms_tx, "query_encode_ms": ms_qx,
+                      "top1_equal_to_exact_fp32_path": int(same.sum().item()), "queries": NQ_,
+                      "max_abs_encoding_diff": float(max((tgt_x - tgt_e).abs().max().item(), (src_x - src_e).abs().max().item())),
+                      "max_top2_margin_among_flips": float(margin[~same].max().item()) if int((~same).sum().item()) else 0.0,
+                      "note": "opt-in (option lstm_x3): three bf16 MFMAs on hi + lo split fp32 operands per product; flips can only "
+                              "happen where the exact path's own top-2 margin is below the encoding difference"}
+    h.set_option("lstm_x3", 0)
+    h.index_set_dev(tgt_e.data_ptr(), NT_, S3)
+    # parity against the CPU oracle on the same weights: its encodings of ALL targets and of a query sample
+    from oracle import sse_oracle as O
+    p = {k: v for k, v in m.get_variables().items()}
+    nq = min(check_queries, NQ_)
+    pick = np.linspace(0, NQ_ - 1, nq).astype(np.int64)
+    t0 = time.perf_counter()
+    procs = usable_cores()
+    want_t = oracle_encode_parallel(p, params, "tgt", tgt_np, procs)
+    want_q = oracle_encode_parallel(p, params, "src", src_np[pick], procs)
+    wsc, wids = O.topk_fast(O.scores_f64(want_q, want_t.astype(np.float64)), 2)
+    pick_d = torch.from_numpy(pick).to(dev)
+    got_i = exact_i[pick_d].cpu().numpy()
+    clear = (wsc[:, 0] - wsc[:, 1]) > 2e-6
+    leg["parity_vs_oracle"] = {"queries_checked": int(nq), "index_rows": NT_,
+                               "top1_equal": int(np.sum(got_i == wids[:, 0])),
+                               "top1_equal_where_oracle_margin_gt_2e-6": "%d of %d" % (int(np.sum(got_i[clear] == wids[clear, 0])), int(clear.sum())),
+                               "max_abs_encoding_err_targets": float(np.abs(tgt_e.cpu().numpy() - want_t).max()),
+                               "max_abs_encoding_err_queries": float(np.abs(src_e[pick_d].cpu().numpy() - want_q).max()),
+                               "oracle_seconds": time.perf_counter() - t0, "oracle_processes": procs}
+    h.close()
+    return leg
+
+
+def config_sweep_leg(sse_amd, torch, dev, h_main, full_c4=True):
+    """SURVEY 8d C2 batch sweep (both encoders of the configs[1] model, B in {1, 64, 1024, 16384, 131072}, device-resident
+    dense ids) and configs[3] in full: 100,000 queries x 10,000,000 targets, k = 10, as 8 LOGICAL shards of 1.25 M rows
+    scored one after the other on this GPU (id_base = shard offset) + the k-way merge the RCCL all-gather feeds; top-1
+    checked against planted targets (normalize(q + 0.1 noise) at row j of shard j % 8)."""
+    h = h_main
+    out = {"c2_batch_sweep": [], "timing": "HIP events on the library's stream around n back-to-back calls"}
+    for B in (1, 64, 1024, 16384, 131072):
+        g = torch.Generator(device=dev).manual_seed(31 + B)
+        ids = torch.randint(2, V, (B, T), generator=g, device=dev, dtype=torch.int32)
+        ids[:, -1] = 1
+        enc = torch.empty((B, S), dtype=torch.float32, device=dev)
+        row = {"B": B}
+        for side, name in ((0, "src"), (1, "tgt")):
+            n = 100 if B <= 1024 else 10 if B <= 16384 else 3
+            ms = _events_ms(h, lambda: h.encode_dev(side, ids.data_ptr(), B, T, True, enc.data_ptr()), n, warm=2)
+            tf = B * FLOP_PER_SEQ / (ms * 1e-3) / 1e12
+            row[name] = {"ms_per_call": ms, "seqs_per_s": B / (ms * 1e-3), "tflops": tf, "frac_of_f32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS}
+        out["c2_batch_sweep"].append(row)
+        del ids, enc
+    if full_c4:
+        Q, NS, P, k = 100000, 1250000, 8, 10
+        gq = torch.Generator(device=dev).manual_seed(2)
+        q = torch.nn.functional.normalize(torch.randn((Q, S), generator=gq, device=dev), dim=1)
+        noise = torch.randn((Q, S), generator=gq, device=dev)
+        all_s = torch.empty((P, Q, k), dtype=torch.float64, device=dev)
+        all_i = torch.empty((P, Q, k), dtype=torch.int64, device=dev)
+        jj = torch.arange(Q, device=dev)
+        t_build = t_score = 0.0
+        for p in range(P):
+            g = torch.Generator(device=dev).manual_seed(100 + p)
+            shard = torch.nn.functional.normalize(torch.randn((NS, S), generator=g, device=dev), dim=1)
+            mine = jj[jj % P == p]
+            shard[mine] = torch.nn.functional.normalize(q[mine] + 0.1 * noise[mine], dim=1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            h.index_set_dev(shard.data_ptr(), NS, S, id_base=p * NS)
+            h.synchronize()
+            t1 = time.perf_counter()
+            h.score_topk_dev(q.data_ptr(), Q, k, all_s[p].data_ptr(), all_i[p].data_ptr())
+            h.synchronize()
+            t2 = time.perf_counter()
+            t_build += t1 - t0
+            t_score += t2 - t1
+            del shard
+        out_s = torch.empty((Q, k), dtype=torch.float64, device=dev)
+        out_i = torch.empty((Q, k), dtype=torch.int64, device=dev)
+        t0 = time.perf_counter()
+        h.merge_topk_dev(all_s.data_ptr(), all_i.data_ptr(), P, Q, k, out_s.data_ptr(), out_i.data_ptr())
+        h.synchronize()
+        t_merge = time.perf_counter() - t0
+        tot = t_score + t_merge
+        out["c4_full"] = {"queries": Q, "index_rows": NS * P, "logical_shards": P, "k": k, "S": S,
+                          "score_s": t_score, "merge_s": t_merge, "total_s": tot, "index_layout_build_s": t_build,
+                          "scores_per_s": float(Q) * NS * P / tot,
+                          "planted_top1_acc": float((out_i[:, 0] == (jj % P) * NS + jj).double().mean().item()),
+                          "rows_sorted": bool((out_s[:, :-1] >= out_s[:, 1:]).all().item()),
+                          "roofline": {"kernel": "score_topk_kernel<4,true,false,true> x 8 shards + merge_topk", "bound": "mfma",
+                                       "unit": "TFLOP/s", "achieved": 2.0 * S * Q * NS * P / tot / 1e12, "peak": 2500.0,
+                                       "frac": 2.0 * S * Q * NS * P / tot / 1e12 / 2500.0},
+                          "note": "ONE GPU doing the work of the 8 of configs[3]; on 8 GPUs each rank runs one shard's pass and the "
+                                  "merge consumes the all-gathered lists"}
+        del q, noise, all_s, all_i
+    return out
 
 
 def main():
@@ -375,6 +596,8 @@ def main():
     ap.add_argument("--no-x3-leg", action="store_true")
     ap.add_argument("--no-cnn-leg", action="store_true")
     ap.add_argument("--no-shapes-leg", action="store_true")
+    ap.add_argument("--no-realdata-leg", action="store_true")
+    ap.add_argument("--no-sweep-leg", action="store_true")
     args = ap.parse_args()
 
     global PMC
@@ -733,6 +956,13 @@ def main():
     # ---- secondary legs on their own models: the reference's recipe shapes, and the text-CNN of configs[4]
     shapes_leg = reference_shapes_leg(sse_amd, torch, dev) if (rank == 0 and not args.no_shapes_leg) else None
     cnn = cnn_leg(sse_amd, torch, np, dev) if (rank == 0 and not args.no_cnn_leg) else None
+    realdata = realdata_leg(sse_amd, torch, np, dev) if (rank == 0 and world == 1 and not args.no_realdata_leg) else None
+    sweep = None
+    if rank == 0 and world == 1 and not args.no_sweep_leg:
+        m_sw = sse_amd.SSEModel(params, device=local_rank)      # (the main model's weights were updated by the train leg)
+        m_sw.init_variables(seed=0)
+        sweep = config_sweep_leg(sse_amd, torch, dev, m_sw.handle)
+        m_sw.handle.close()
     barrier()
 
     traffic = PMC.get("lstm_fwd_hbm_bytes_per_launch") if B == 16384 else None   # PMC pass of this same command, same sources
@@ -754,6 +984,10 @@ def main():
                                                              "passes of this command; null when the kernel sources changed since)",
                          "mfma_busy": (busy_of("lstm_fwd_kernel<2, 2, 1, false, true") or {None: None}).popitem()[1],
                          "pmc_source": PMC.get("source", PMC.get("stale")),
+                         "traffic_measured_in_this_run": False,
+                         "pmc_note": "traffic / mfma_busy (here and in every leg) are REPLAYED from the tracked profiles/pmc_summary.json -- the "
+                                     "builder's separate rocprofv3 --pmc passes of this same command, quoted only while the hash of csrc/ "
+                                     "matches -- they are not counted in this run; achieved / avg_kernel_ms ARE measured in this run (HIP events)",
                          "avg_kernel_ms": enc_ms_avg,
                          "algorithmic_flop_per_launch": B * FLOP_PER_SEQ},
         }
@@ -772,6 +1006,10 @@ def main():
             line["encode_leg_reference_shapes"] = shapes_leg
         if cnn is not None:
             line["cnn_leg"] = cnn
+        if realdata is not None:
+            line["realdata_leg"] = realdata
+        if sweep is not None:
+            line["config_sweep"] = sweep
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import sse_oracle as O
-from tests.util import make_pair, model_params
+from tests.util import make_pair, model_params, random_ids
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
@@ -469,3 +469,39 @@ def test_index_dimension_limit_is_loud():
     h = _scorer()
     with pytest.raises(sse_amd.SSEError, match="index dimension"):
         h.index_upload(np.zeros((4, 1025), np.float32))
+
+
+def test_alternating_shapes_share_the_pinned_mirror_block():
+    """The few-queries path stores scores / ids / certificates / completion words through one pinned block whose layout
+    moves with (Q, k), and sse_encode's small read-back uses the same block (a stale word of an earlier,
+    differently shaped call must never be taken for this call's completion word).  One handle, calls of changing shape
+    interleaved with small encodes and a host-buffer encode + score: every result against the float64 oracle."""
+    params = model_params("dual-encoder", 300, 20, 64, 64, 64, 9)
+    m, p = make_pair(params, seed=5)
+    rng = np.random.RandomState(8)
+    t = _unit(rng, 9000, 64)
+    m.handle.index_upload(t)
+    t64 = t.astype(np.float64)
+    shapes = [(1, 10), (64, 16), (3, 5), (1, 1), (7, 16), (64, 1), (2, 10), (33, 7), (1, 16), (64, 16), (5, 3)]
+    for rep in range(3):
+        for Q, k in shapes:
+            q = _unit(rng, Q, 64)
+            sc, ids = m.handle.score_topk(q, k)
+            wsc, wids = O.topk(O.scores_f64(q, t64), k)
+            assert np.array_equal(ids, wids), (rep, Q, k)
+            assert np.abs(sc - wsc).max() < 1e-12
+            n = int(rng.randint(1, 40))
+            tok = random_ids(rng, n, 9, 300)
+            enc = m.encode_source(tok)                                  # <= 64 KiB: the pinned read-back of sse_encode
+            assert np.abs(enc - O.encode(p, params, "src", tok)).max() < 1e-4
+            one = random_ids(rng, 1 + rep, 9, 300)
+            es, ei = m.handle.encode_score_topk(0, one, True, k)
+            w = O.encode(p, params, "src", one)
+            _, wi = O.topk(O.scores_f64(w, t64), k)
+            assert ei.shape == wi.shape
+            margin_ok = True                                             # ids equal unless the oracle's own margin is within the encoder tolerance
+            ws, _ = O.topk(O.scores_f64(w, t64), min(k + 1, 9000))
+            if ws.shape[1] > 1:
+                margin_ok = bool(np.all(np.diff(-ws, axis=1) > 1e-5))
+            if margin_ok:
+                assert np.array_equal(ei, wi), (rep, Q, k)

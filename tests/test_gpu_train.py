@@ -474,3 +474,20 @@ def test_restore_prefers_the_newer_of_npz_and_tf_index(tmp_path):
     os.utime(prefix + ".npz", (time.time() + 10, time.time() + 10))             # now the .npz is the newer one
     m.saver.restore(None, prefix)
     assert m.saver.restored_from.endswith(".npz") and m.handle.global_step == 5
+
+
+def test_tape_size_limit_is_an_explicit_error():
+    """a batch whose gate tape [T][rows/32][Hp/32][5][1024] floats reaches 2 GiB (32-bit offsets in the BPTT
+    kernels) must be refused with a message that names the limit, not with a bare hipErrorInvalidValue."""
+    import sse_amd
+    T, B = 32, 16384                                                      # 32 * 512 * 8 * 5 * 1024 * 4 B = 2.5 GiB per encoder
+    params = model_params("dual-encoder", 400, 50, 256, 256, 256, T)
+    m, _ = make_pair(params, seed=1)
+    rng = np.random.RandomState(0)
+    src, tgt, z = _batch(rng, B, T, 400, pad_frac=0.0)
+    with pytest.raises(sse_amd.SSEError) as e:
+        m.train_step(src, tgt, z)
+    assert "too large" in str(e.value) and "2 GiB" in str(e.value)
+    src, tgt, z = _batch(rng, 256, T, 400)                               # the handle stays usable
+    loss, _ = m.train_step(src, tgt, z)
+    assert np.isfinite(loss)

@@ -1,0 +1,208 @@
+"""Parity on TRAINED weights, and the reference's own acceptance number.
+
+Every other parity test runs on random-init weights.  The reference's only quality gate is the line
+"task specific evaluation: top 1/3/10 accuracies" that sse_train prints per epoch (sse_train.py:223-229), on weights
+that hundreds of Adagrad steps have moved: gates saturate, projections grow, scores crowd together.  Here the HIP train
+step (sse_train_step through the C ABI) and the CPU oracle (O.train_step: KAT-pinned cell / Adagrad / clip,
+tests/test_oracle_tf_kat.py) run the SAME recipe from the SAME initial weights on the SAME batches:
+
+  phase A  free-running: the two loss trajectories, the final variables, and the final top-1/3/10 accuracies (device
+           model evaluated on the device, oracle model by the oracle);
+  phase B  identical trained weights (the oracle's, loaded into the device model): index build + query encode + ranking
+           against the oracle -- encodings within the north-star 1e-3 (observed ~1e-6), ids and float64 scores exact on
+           identical encodings, top-1/3/10 equal, top-1 ids on the device's own encodings equal wherever the oracle's top-2
+           margin exceeds the encoding tolerance -- and ONE more train step at the exact-path tolerance.
+
+Recipes:
+  * `standin`: the seeded stand-in for rawdata-classification (tools/make_standin_dataset.py; 37 classes), dual-encoder
+    with the reference's default sizes (sse_train.py:60-74: E = 50, H = 96, S = 64, batch 32 -> 64 pair rows), T = 24,
+    --learning_rate=0.005.  At the makefile's lr = 0.9 the first Adagrad steps (lr * g / sqrt(0.1 + g^2) ~ 0.9 per weight)
+    throw the model into the all-cosines-zero plateau (loss ln 2) where it sits for thousands of steps -- the oracle shows
+    the same -- so a run that actually LEARNS within a test's time uses the smaller rate: top-1 rises from chance (1/37) to
+    > 0.4.  This is the "trained" case: large accuracy, real margins.
+  * `crosslingual`: makefile:42 verbatim (shared-encoder, E = 40, S = 50, T = 50, H = 96, batch 32, lr = 0.9) on the real
+    token rows of tests/golden/crosslingual_full_ids.npz, 240 steps: the plateau regime -- clipping engaged on most
+    steps, every score of a query within 1e-5 of every other: the near-tie torture case for the ranking path."""
+import importlib.util
+import os
+import time
+
+import numpy as np
+import pytest
+
+from oracle import sse_oracle as O
+from tests.util import LOSS_REL_EXACT
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _batch(rng, src_ids, tgt_ids, positives, bs):
+    """Data.get_train_batch (data.py:95-115): a random contiguous window of positives (cut at the end of the corpus),
+    per source one of its verified targets, then one uniformly drawn target outside its positive set; rows interleaved
+    pos, neg; labels 1, 0."""
+    n = len(src_ids)
+    start = rng.randint(0, n - bs) + bs
+    rows = np.arange(start, min(n, start + bs))
+    s, t, z = [], [], []
+    for r in rows:
+        pos = positives[r]
+        s += [src_ids[r], src_ids[r]]
+        t.append(tgt_ids[pos[rng.randint(len(pos))]])
+        neg = rng.randint(len(tgt_ids))
+        while neg in pos:
+            neg = rng.randint(len(tgt_ids))
+        t.append(tgt_ids[neg])
+        z += [1.0, 0.0]
+    return np.array(s, np.int32), np.array(t, np.int32), np.array(z, np.float32)
+
+
+def _standin_recipe(tmp):
+    from sse_amd import sse_data
+    spec = importlib.util.spec_from_file_location("standin", os.path.join(ROOT, "tools", "make_standin_dataset.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    raw = os.path.join(tmp, "rawdata-classification")
+    mod.write_tar(mod.generate(n_targets=37, n_train=2000, n_eval=300, n_vocab=1000, seed=1), raw)
+    mdir = os.path.join(tmp, "models")
+    os.makedirs(mdir)
+    T = 24
+    data = sse_data.Data(mdir, raw, 2000, T, seed=0, log=lambda *a: None)
+    src, tgt = data.corpus_matrices()
+    row_of = {t: i for i, t in enumerate(data.fullSetTargetIds)}
+    positives = [[row_of[t] for t in v] for _, v in data.rawTrainPosCorpus]
+    ev_src = np.array([tok for tok, _ in data.rawEvalCorpus], np.int32)
+    ev_labels = [[row_of[t] for t in v] for _, v in data.rawEvalCorpus]
+    cfg = dict(forward_only=False, network_mode="dual-encoder", predict_nbest=10, max_seq_length=T, vocab_size=data.vocab_size,
+               embedding_size=50, encoding_size=64, src_cell_size=96, tgt_cell_size=96, learning_rate=0.005,
+               learning_rate_decay_factor=0.99, targetSpaceSize=len(tgt))
+    return dict(cfg=cfg, lr=0.005, steps=1200, src=src, tgt=tgt, positives=positives, ev_src=ev_src, ev_labels=ev_labels,
+                learns=True)
+
+
+def _crosslingual_recipe(tmp):
+    z = np.load(os.path.join(G, "crosslingual_full_ids.npz"))
+    src, tgt = z["src_ids"].astype(np.int32), z["tgt_ids"].astype(np.int32)
+    positives = [[int(v) for v in row if v >= 0] for row in z["labels"]]
+    cfg = dict(forward_only=False, network_mode="shared-encoder", predict_nbest=10, max_seq_length=50, vocab_size=int(z["vocab_size"]),
+               embedding_size=40, encoding_size=50, src_cell_size=96, tgt_cell_size=96, learning_rate=0.9,
+               learning_rate_decay_factor=0.99, targetSpaceSize=len(tgt))
+    pick = np.linspace(0, len(src) - 1, 2000).astype(np.int64)          # Train == Eval in this data set: a 2,000-query sample
+    return dict(cfg=cfg, lr=0.9, steps=240, src=src, tgt=tgt, positives=positives, ev_src=src[pick],
+                ev_labels=[positives[i] for i in pick], learns=False)
+
+
+def _oracle_rank(se, te, k=10, batch=600):
+    sc, ids = [], []
+    t64 = te.astype(np.float64)
+    for b0 in range(0, len(se), batch):                                  # Evaluator-style batches (sse_evaluator.py:104-112)
+        s, i = O.topk_fast(O.scores_f64(se[b0:b0 + batch], t64), k)
+        sc.append(s)
+        ids.append(i)
+    return np.concatenate(sc), np.concatenate(ids)
+
+
+@pytest.mark.parametrize("recipe", ["standin", "crosslingual"])
+def test_training_trajectory_and_trained_weights_parity(recipe, tmp_path, capsys):
+    import sse_amd
+    r = (_standin_recipe if recipe == "standin" else _crosslingual_recipe)(str(tmp_path))
+    cfg, lr, steps = r["cfg"], r["lr"], r["steps"]
+    p = O.init_params(cfg, seed=0)
+    m = sse_amd.SSEModel(cfg)
+    m.set_variables(p)
+    m.handle.learning_rate = lr
+    st = O.new_optimizer_state(p)
+    rng = np.random.RandomState(0)
+    got, want, got_acc, want_acc = [], [], [], []
+    t_dev = t_cpu = 0.0
+    for step in range(steps):
+        s, t, z = _batch(rng, r["src"], r["tgt"], r["positives"], 32)
+        t0 = time.perf_counter()
+        wl, wa = O.train_step(p, st, cfg, s, t, z, lr)
+        t1 = time.perf_counter()
+        gl, ga = m.train_step(s, t, z)
+        t_dev += time.perf_counter() - t1
+        t_cpu += t1 - t0
+        want.append(float(wl))
+        want_acc.append(float(wa))
+        got.append(gl)
+        got_acc.append(ga)
+    got, want = np.array(got), np.array(want)
+    rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
+    dev_vars = m.get_variables(with_slots=True)
+    dv = {k: float(np.abs(dev_vars[k].reshape(w.shape) - w).max()) for k, w in p.items()}
+    ds = {k: float(np.abs(dev_vars[k + "/Adagrad"].reshape(w.shape) - st[k]).max() / max(1.0, float(np.abs(st[k]).max()))) for k, w in p.items()}
+
+    # ---- phase A: the free-running device model, evaluated on the device
+    tgt_dev, src_dev = m.encode_target(r["tgt"]), m.encode_source(r["ev_src"])
+    m.handle.index_upload(tgt_dev.astype(np.float64))
+    _, ids_dev = m.handle.score_topk(src_dev, 10)
+    acc_dev = [O.topk_tight_accuracy(n, r["ev_labels"], ids_dev) for n in (1, 3, 10)]
+    # the oracle-trained model, evaluated by the oracle
+    te, se = O.encode(p, cfg, "tgt", r["tgt"]), O.encode(p, cfg, "src", r["ev_src"])
+    wsc, wids = _oracle_rank(se, te)
+    acc_cpu = [O.topk_tight_accuracy(n, r["ev_labels"], wids) for n in (1, 3, 10)]
+
+    # ---- phase B: identical TRAINED weights
+    m.set_variables(p)
+    for k in p:                                                          # and the oracle's Adagrad slots: the next step must agree too
+        m.handle.set_variable(k + "/Adagrad", st[k])
+    tgt_b, src_b = m.encode_target(r["tgt"]), m.encode_source(r["ev_src"])
+    enc_err = max(float(np.abs(tgt_b - te).max()), float(np.abs(src_b - se).max()))
+    m.handle.index_upload(te.astype(np.float64))                          # identical encodings: ids / scores exact by construction
+    sc_x, ids_x = m.handle.score_topk(se, 10)
+    m.handle.index_upload(tgt_b.astype(np.float64))                       # the device's own encodings
+    sc_o, ids_o = m.handle.score_topk(src_b, 10)
+    margin = wsc[:, 0] - wsc[:, 1]
+    clear = margin > max(1e-5, 20 * enc_err)
+    with capsys.disabled():
+        print("\n[%s] %d steps, %d pair rows/step: device %.1f ms/step, oracle %.1f ms/step" % (recipe, steps, 64, t_dev / steps * 1e3, t_cpu / steps * 1e3))
+        print("[%s] loss first/last device %.5f / %.5f, oracle %.5f / %.5f; max rel loss diff: steps 0-199 %.2e, all %.2e; "
+              "train_acc (mean of the last 100 steps) device %.4f oracle %.4f"
+              % (recipe, got[0], got[-1], want[0], want[-1], rel[:200].max(), rel.max(), np.mean(got_acc[-100:]), np.mean(want_acc[-100:])))
+        print("[%s] free-running final weights: max |device - oracle| per variable %s; Adagrad slots (relative to the slot's max) %s"
+              % (recipe, {k.split("/")[-1] if "/" in k else k: "%.1e" % v for k, v in dv.items()}, "%.1e" % max(ds.values())))
+        print("[%s] top 1/3/10 accuracies: device-trained model on the device %s | oracle-trained model by the oracle %s"
+              % (recipe, ["%.4f" % a for a in acc_dev], ["%.4f" % a for a in acc_cpu]))
+        print("[%s] trained weights, identical on both sides: max |encoding diff| %.2e; top-1 ids equal on the device's own encodings: "
+              "%d of %d (queries whose oracle top-2 margin exceeds %.1e: %d, all equal: %s); median top-2 margin %.2e"
+              % (recipe, enc_err, int(np.sum(ids_o[:, 0] == wids[:, 0])), len(wids), max(1e-5, 20 * enc_err), int(clear.sum()),
+                 bool(np.array_equal(ids_o[clear, 0], wids[clear, 0])), float(np.median(margin))))
+
+    # phase A assertions.  Two fp32 implementations with different summation orders drift apart step by step; the bar
+    # (VERDICT r04): the loss trajectory within 1e-3 relative over the first 200 steps, and the whole run within 1e-2.
+    assert rel[:200].max() < 1e-3, rel[:200].max()
+    assert rel.max() < 1e-2, rel.max()
+    for k, v in dv.items():
+        assert v < 2e-2, (k, v)
+    for a, b in zip(acc_dev, acc_cpu):
+        assert abs(a - b) <= 0.03, (acc_dev, acc_cpu)
+    if r["learns"]:
+        assert acc_cpu[0] > 0.4 and acc_cpu[2] > 0.9, acc_cpu               # chance: 1/37, 10/37
+        assert acc_dev[0] > 0.4 and acc_dev[2] > 0.9, acc_dev
+        assert np.mean(want_acc[-100:]) > 0.5 and np.mean(got_acc[-100:]) > 0.5
+
+    # phase B assertions
+    assert enc_err < 1e-3                                                    # north_star tolerance
+    assert enc_err < 5e-5                                                    # what fp32 actually gives on trained weights
+    assert np.array_equal(ids_x, wids) and np.abs(sc_x - wsc).max() < 1e-12
+    for n in (1, 3, 10):
+        assert O.topk_tight_accuracy(n, r["ev_labels"], ids_x) == O.topk_tight_accuracy(n, r["ev_labels"], wids)
+    assert np.abs(sc_o[:, 0] - wsc[:, 0]).max() < 1e-3
+    assert np.array_equal(ids_o[clear, 0], wids[clear, 0])
+    if r["learns"]:
+        assert clear.mean() > 0.9
+        for n, a in zip((1, 3, 10), acc_cpu):
+            assert abs(O.topk_tight_accuracy(n, r["ev_labels"], ids_o) - a) <= 1.0 / len(wids) + 1e-12
+    # one more train step on the trained weights + trained Adagrad slots, exact-path tolerance
+    s, t, z = _batch(rng, r["src"], r["tgt"], r["positives"], 32)
+    wl, wa = O.train_step(p, st, cfg, s, t, z, lr)
+    gl, ga = m.train_step(s, t, z)
+    assert gl == pytest.approx(float(wl), rel=10 * LOSS_REL_EXACT, abs=1e-6)
+    assert ga == pytest.approx(float(wa), abs=1e-6)
+    v = m.get_variables(with_slots=True)
+    for name, w in p.items():
+        assert np.abs(v[name].reshape(w.shape) - w).max() < 2e-4, name
+        sl = st[name]
+        assert np.abs(v[name + "/Adagrad"].reshape(w.shape) - sl).max() < 2e-4 * max(1.0, float(np.abs(sl).max())), name

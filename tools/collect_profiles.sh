@@ -23,7 +23,7 @@ fi
 for c in "${groups[@]}"; do
     d="$out/pmc_$(echo $c | tr ' ' '_' | cut -c1-40)"
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$d" -o p -- \
-        python "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --score-iters 1 --no-cnn-leg --no-shapes-leg > "$out/log_$(basename $d).txt" 2>&1
+        python "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --score-iters 1 --no-shapes-leg --no-realdata-leg --no-sweep-leg > "$out/log_$(basename $d).txt" 2>&1
 done
 cd "$root"
 find "$out" -name "*.csv" -size +20M -delete

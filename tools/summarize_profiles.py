@@ -7,7 +7,7 @@ import os
 import sys
 
 OURS = ("score_small_index", "lstm_fwd", "lstm_bwd", "dk_x3", "dx_scatter", "emb_grad", "dx_hot", "compact_uncert", "gather_query", "multi_kernel", "proj_bwd_dm_mfma", "score_topk", "rescore", "exact_topk", "pack_", "merge_topk", "row_norm2", "pad_rows",
-        "l2_normalize", "conv_pool", "proj_norm", "dk_gemm", "dx_kernel", "loss_", "adagrad", "sumsq", "clip_scale",
+        "l2_normalize", "conv_pool", "proj_norm", "cnn_d", "cnn_bwd", "dk_gemm", "dx_kernel", "loss_", "adagrad", "sumsq", "clip_scale",
         "proj_bwd", "db_reduce", "dk_reduce")
 
 
@@ -31,7 +31,7 @@ def main():
         agg = collections.defaultdict(list)
         dur = collections.defaultdict(list)
         for r in csv.DictReader(open(os.path.join(d, "p_counter_collection.csv"))):
-            if any(k in r["Kernel_Name"] for k in ("lstm_fwd", "lstm_bwd", "dk_x3", "dk_gemm", "dx_scatter", "conv_pool", "score_topk", "score_small_index", "rescore_kernel")):
+            if any(k in r["Kernel_Name"] for k in ("lstm_fwd", "lstm_bwd", "dk_x3", "dk_gemm", "dx_scatter", "conv_pool", "proj_norm", "cnn_d", "cnn_bwd", "lstm_cluster", "score_topk", "score_small_index", "rescore_kernel")):
                 key = (r["Kernel_Name"].split("(")[0][:64], r["Grid_Size"])
                 agg[key + (r["Counter_Name"],)].append(float(r["Counter_Value"]))
                 dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -47,6 +47,8 @@ def main():
     sys.path.insert(0, os.path.dirname(root))
     import bench
     traffic, busy, gui, q1 = {}, collections.defaultdict(dict), collections.defaultdict(dict), []
+    CNN = ("conv_pool", "proj_norm", "cnn_d", "cnn_bwd")
+    cnn_io = collections.defaultdict(lambda: collections.defaultdict(dict))   # kernel -> counter -> grid -> [values]
     for d in pmc_dirs:
         for r in csv.DictReader(open(os.path.join(d, "p_counter_collection.csv"))):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
@@ -55,6 +57,8 @@ def main():
                 traffic.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
             if "score_topk_kernel<1, true, false" in name and r["Counter_Name"] == "FETCH_SIZE" and float(r["Counter_Value"]) > 1e5:
                 q1.append(float(r["Counter_Value"]))
+            if any(k in name for k in CNN) and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                cnn_io[name][r["Counter_Name"]].setdefault(int(r["Grid_Size"]), []).append(float(r["Counter_Value"]))
             if r["Counter_Name"] in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
                 tgt = busy if r["Counter_Name"].startswith("SQ") else gui
                 tgt[name].setdefault(int(r["Grid_Size"]), []).append(float(r["Counter_Value"]))
@@ -71,8 +75,17 @@ def main():
         if g in gui.get(name, {}):
             b = sum(busy[name][g]) / len(busy[name][g]) / 1024.0
             a = sum(gui[name][g]) / len(gui[name][g]) / 8.0
-            if a > 0 and b / a > 0.005:
+            if a > 0 and (b / a > 0.005 or any(k in name for k in CNN)):   # (the CNN kernels are listed even at 0: "no MFMA" is a finding)
                 summary["mfma_busy"][name] = round(b / a, 4)
+    # configs[4] kernels: HBM bytes per launch of the largest grid = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (same correction)
+    summary["cnn_hbm_bytes_per_launch"] = {}
+    for name, io in cnn_io.items():
+        if "FETCH_SIZE" in io and "WRITE_SIZE" in io:
+            g = max(io["FETCH_SIZE"])
+            if g in io["WRITE_SIZE"]:
+                f = sum(io["FETCH_SIZE"][g]) / len(io["FETCH_SIZE"][g])
+                w_ = sum(io["WRITE_SIZE"][g]) / len(io["WRITE_SIZE"][g])
+                summary["cnn_hbm_bytes_per_launch"][name] = {"grid": g, "fetch_bytes": 2 * f * 1024, "write_bytes": w_ * 1024}
     json.dump(summary, open(os.path.join(root, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
     print("\n".join(out))
 
