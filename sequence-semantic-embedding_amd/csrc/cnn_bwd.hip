@@ -18,6 +18,7 @@
 //   rows_gather / rows_scatter: target-table lookup and its gradient.
 #include "sse_kernels.h"
 #include "train.h"
+#include <cstdlib>
 
 namespace {
 
@@ -47,12 +48,16 @@ __device__ __forceinline__ float bf16_rne(float f) {  // nearest bfloat16 (ties 
   return __uint_as_float(u & 0xFFFF0000u);
 }
 
-template <int FS, int NF>
+// Software pipeline of the per-sequence staging (round 5; the arithmetic and its order are unchanged -- results bit-identical
+// to the round-2 kernel): the gathered embedding values of sequence b+1 and the token ids of sequence b+2 are in flight in
+// registers while sequence b is multiplied out of LDS, so the two dependent global loads (ids -> embedding row) of a
+// sequence no longer sit between two barriers.  0.55 -> 0.1x ms at 8192 sequences (profiles/r05_notes.txt).
+template <int FS, int NF, int RMAX>
 __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
   constexpr int PARTS = 256 / NF;
   constexpr int KMAX = (FS * 64 + PARTS - 1) / PARTS;  // E <= 64
   const int tid = threadIdx.x, f = tid % NF, part = tid / NF;
-  const int T = a.T, E = a.E, K = FS * E, KPT = (K + PARTS - 1) / PARTS, k0 = part * KPT;
+  const int T = a.T, E = a.E, K = FS * E, KPT = (K + PARTS - 1) / PARTS, k0 = part * KPT, TE = T * E;
   const int wi = FS - 2, fo = b_foff[wi] + f;
   const int chunk = blockIdx.x, per = (a.B + a.NCH - 1) / a.NCH;
   const int b_begin = chunk * per, b_end = min(a.B, b_begin + per);
@@ -60,14 +65,32 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
 #pragma unroll
   for (int kk = 0; kk < KMAX; ++kk) acc[kk] = 0.0f;
   float bsum = 0.0f;
-  int buf = 0;
-  for (int b = b_begin; b < b_end; ++b, buf ^= 1) {
-    float *xb = xs + buf * T * E;
-    for (int i = tid; i < T * E; i += 256) {
-      const float x = a.emb[(size_t)a.ids[(size_t)b * T + i / E] * E + i % E];
-      xb[i] = a.bf16 ? bf16_rne(x) : x;
-    }
-    __syncthreads();
+  // this thread's elements of a [T][E] tile: column ce = lane (idle for ce >= E), tokens tq, tq + 4, tq + 8, .. with tq = its
+  // wave -- a wave reads ONE token id per step (uniform: scalar loads, no vector registers) and one embedding row coalesced
+  const int ce = tid & 63, tq = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int idn[RMAX > 0 ? RMAX : 1];   // token ids in flight (wave-uniform)
+  float vn[RMAX > 0 ? RMAX : 1];  // embedding values in flight
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) {
+    idn[r] = 0;
+    vn[r] = 0.0f;
+  }
+  auto load_ids = [&](int b) {
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+      if (tq + 4 * r < T) idn[r] = a.ids[(size_t)b * T + tq + 4 * r];
+  };
+  auto load_vals = [&]() {
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+      if (tq + 4 * r < T && ce < E) vn[r] = a.emb[(size_t)idn[r] * E + ce];
+  };
+  auto store_vals = [&](float *xb) {
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+      if (tq + 4 * r < T && ce < E) xb[(tq + 4 * r) * E + ce] = a.bf16 ? bf16_rne(vn[r]) : vn[r];
+  };
+  auto multiply = [&](const float *xb, int b) {
     float g = a.dfeat[(size_t)b * 576 + fo];
     if (!(a.feat[(size_t)b * 576 + fo] > 0.0f)) g = 0.0f;
     if (g != 0.0f) {
@@ -76,6 +99,39 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
       for (int kk = 0; kk < KMAX; ++kk)
         if (kk < KPT && k0 + kk < K) acc[kk] += g * xw[kk];
       bsum += g;
+    }
+  };
+  if constexpr (RMAX == 0) {
+    // any T (more than 160 tokens: narrow embeddings): the plain staging loop, one sequence between two barriers
+    int buf = 0;
+    for (int b = b_begin; b < b_end; ++b, buf ^= 1) {
+      float *xb = xs + buf * TE;
+      for (int i = tid; i < TE; i += 256) {
+        const float x = a.emb[(size_t)a.ids[(size_t)b * T + i / E] * E + i % E];
+        xb[i] = a.bf16 ? bf16_rne(x) : x;
+      }
+      __syncthreads();
+      multiply(xb, b);
+    }
+  } else {
+    if (b_begin < b_end) {
+      load_ids(b_begin);
+      load_vals();
+      store_vals(xs);
+      if (b_begin + 1 < b_end) {
+        load_ids(b_begin + 1);
+        load_vals();
+      }
+      if (b_begin + 2 < b_end) load_ids(b_begin + 2);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int b = b_begin; b < b_end; ++b, buf ^= 1) {
+      multiply(xs + buf * TE, b);
+      if (b + 1 < b_end) store_vals(xs + (buf ^ 1) * TE);  // (that buffer was last read before the previous barrier)
+      if (b + 2 < b_end) load_vals();                       // ids of b+2 arrived during this iteration
+      if (b + 3 < b_end) load_ids(b + 3);
+      __syncthreads();
     }
   }
   float *out = a.dw_part[wi] + (size_t)chunk * K * NF;
@@ -86,29 +142,43 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
 }
 
 // (the four bodies are inlined: as calls they took the argument block through scratch and spilled around the call)
-__global__ __launch_bounds__(256) void cnn_dw_kernel(CnnBwdArgs a) {
+template <int RMAX>
+__global__ __launch_bounds__(256, 2) void cnn_dw_kernel(CnnBwdArgs a) {
   extern __shared__ float xs[];  // [2][T*E]
   switch (blockIdx.y) {
-    case 0: dw_body<2, 256>(a, xs); break;
-    case 1: dw_body<3, 128>(a, xs); break;
-    case 2: dw_body<4, 128>(a, xs); break;
-    default: dw_body<5, 64>(a, xs); break;
+    case 0: dw_body<2, 256, RMAX>(a, xs); break;
+    case 1: dw_body<3, 128, RMAX>(a, xs); break;
+    case 2: dw_body<4, 128, RMAX>(a, xs); break;
+    default: dw_body<5, 64, RMAX>(a, xs); break;
   }
 }
 
-__global__ void chunk_reduce_kernel(const float *part, int nch, int n, float *out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float acc = 0.0f;
-  for (int c = 0; c < nch; ++c) acc += part[(size_t)c * n + i];
-  out[i] = acc;
-}
-
-__global__ void strided_reduce_kernel(const float *part, int nch, int stride, int n, float *out) {
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+// dW (four widths) and db from the chunk partials in ONE launch (round 5: eight launches before, four of them single
+// workgroups): thread i sums its element over the chunks in chunk order -- the order of the kernels it replaces.
+struct CnnReduceArgs {
+  const float *dw_part[4];
+  float *dW[4];
+  const float *db_part;
+  float *db[4];
+  int32_t n[4], nch;
+};
+__global__ void cnn_reduce_kernel(CnnReduceArgs a) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (i < a.n[w]) {
+      float acc = 0.0f;
+      for (int c = 0; c < a.nch; ++c) acc += a.dw_part[w][(size_t)c * a.n[w] + i];
+      a.dW[w][i] = acc;
+      return;
+    }
+    i -= a.n[w];
+  }
+  if (i < 576) {
     float acc = 0.0f;
-    for (int c = 0; c < nch; ++c) acc += part[(size_t)c * stride + i];
-    out[i] = acc;
+    for (int c = 0; c < a.nch; ++c) acc += a.db_part[(size_t)c * 576 + i];
+    const int w = i < 256 ? 0 : i < 384 ? 1 : i < 512 ? 2 : 3;
+    a.db[w][i - b_foff[w]] = acc;
   }
 }
 
@@ -241,9 +311,10 @@ hipError_t launch_rows_scatter(const float *d, const int32_t *rows, int B, int S
 
 hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfeat, const float *feat, const int32_t *pos,
                           const float *const W[4], float *const dW[4], float *const db[4], float *dw_part,
-                          float *db_part, float *wt_scratch /* [E*1728] */, float *d_emb, float *sq_part, int B, int T,
-                          int E, int bf16, hipStream_t st) {
-  static const int fs[4] = {2, 3, 4, 5}, nf[4] = {256, 128, 128, 64}, foff[4] = {0, 256, 384, 512};
+                          float *db_part, float *wt_scratch /* [E*1728] */, unsigned short *wct_scratch /* cnn_wct_elems(E) */,
+                          float *d_emb, float *sq_part, int B, int T, int E, int bf16, hipStream_t st) {
+  static const int fs[4] = {2, 3, 4, 5}, nf[4] = {256, 128, 128, 64};
+  if (E > 64) return hipErrorInvalidValue;
   CnnBwdArgs a;
   a.ids = ids;
   a.emb = emb;
@@ -258,24 +329,37 @@ hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfe
   a.E = E;
   a.NCH = cnn_bwd_chunks(B);
   a.bf16 = bf16;
+  // bf16 mode: dX as a dense contraction on the bf16 matrix pipe (cnn_bwd_mfma.hip); fp32 mode (and sequences longer than
+  // its three t tiles): the gather kernel over the transposed filters
+  static const bool no_mfma = getenv("SSE_CNN_DX_GATHER") != nullptr;  // measurement aid: the gather kernel in bf16 mode too
+  const bool dx_mfma = bf16 && wct_scratch && cnn_dx_mfma_ok(T, E) && !no_mfma;
+  CnnReduceArgs ra;
   size_t off = 0, toff = 0;
+  int total = 576;
   for (int i = 0; i < 4; ++i) {
     const int n = fs[i] * E * nf[i];
     a.W[i] = W[i];
     a.Wt[i] = wt_scratch + toff;
-    hipLaunchKernelGGL(transpose_kernel, dim3((n + 255) / 256), dim3(256), 0, st, W[i], fs[i] * E, nf[i], bf16, wt_scratch + toff);
+    if (!dx_mfma)
+      hipLaunchKernelGGL(transpose_kernel, dim3((n + 255) / 256), dim3(256), 0, st, W[i], fs[i] * E, nf[i], bf16, wt_scratch + toff);
     toff += n;
     a.dw_part[i] = dw_part + off;
     off += (size_t)a.NCH * n;
+    ra.dw_part[i] = a.dw_part[i];
+    ra.dW[i] = dW[i];
+    ra.db[i] = db[i];
+    ra.n[i] = n;
+    total += n;
   }
-  hipLaunchKernelGGL(cnn_dw_kernel, dim3(a.NCH, 4), dim3(256), (size_t)2 * T * E * sizeof(float), st, a);
-  for (int i = 0; i < 4; ++i) {
-    const int n = fs[i] * E * nf[i];
-    hipLaunchKernelGGL(chunk_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a.dw_part[i], a.NCH, n, dW[i]);
-  }
-  // db: the four bias vectors are disjoint slices of the 576 features
-  for (int i = 0; i < 4; ++i)
-    hipLaunchKernelGGL(strided_reduce_kernel, dim3(1), dim3(256), 0, st, db_part + foff[i], a.NCH, 576, nf[i], db[i]);
+  ra.db_part = db_part;
+  ra.nch = a.NCH;
+  const size_t lds = (size_t)2 * T * E * sizeof(float);
+  if (T <= 4 * 16) hipLaunchKernelGGL((cnn_dw_kernel<16>), dim3(a.NCH, 4), dim3(256), lds, st, a);
+  else if (T <= 4 * 24) hipLaunchKernelGGL((cnn_dw_kernel<24>), dim3(a.NCH, 4), dim3(256), lds, st, a);
+  else if (T <= 4 * 40) hipLaunchKernelGGL((cnn_dw_kernel<40>), dim3(a.NCH, 4), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((cnn_dw_kernel<0>), dim3(a.NCH, 4), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(cnn_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ra);
+  if (dx_mfma) return launch_cnn_dx_mfma(ids, dfeat, feat, pos, W, wct_scratch, d_emb, sq_part, B, T, E, st);
   hipLaunchKernelGGL(cnn_dx_kernel, dim3(B), dim3(256), (size_t)(T + 1) * sizeof(int), st, a);
   return hipGetLastError();
 }

@@ -68,7 +68,7 @@ struct DevBuf {  // grow-only device scratch; freed with its owner (handle / Tra
 struct TrainState {
   DevBuf ids[2], labels, raw[2], draw[2], tape_g[2], tape_a[2], h_last[2], dh_last[2], dg_a[2], dg_b[2], db_part[2],
       dk_part[2], dm_part[2], sq_part, norm_part, row_loss, row_acc, scal;
-  DevBuf feat_rm, pos, dfeat, dw_part, dbias_part, wt;  // text-CNN training
+  DevBuf feat_rm, pos, dfeat, dw_part, dbias_part, wt, wct;  // text-CNN training
   hipStream_t side[2] = {nullptr, nullptr};  // the two encoders run concurrently (forward and backward)
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   float *KhT[2] = {nullptr, nullptr}, *KxT[2] = {nullptr, nullptr};
@@ -1951,6 +1951,7 @@ static int cnn_train_grads_locked(sse_handle *h, const int32_t *src_ids_host, co
   if (reserve(h, ts.dw_part, cnn_dw_part_floats(E, B) * sizeof(float))) return 1;
   if (reserve(h, ts.dbias_part, (size_t)cnn_bwd_chunks(B) * 576 * sizeof(float))) return 1;
   if (reserve(h, ts.wt, (size_t)E * 1728 * sizeof(float))) return 1;
+  if (reserve(h, ts.wct, cnn_wct_elems(E) * sizeof(unsigned short))) return 1;
   if (reserve(h, ts.dm_part[0], (size_t)proj_bwd_chunks(Bp) * 576 * S * sizeof(float))) return 1;
   if (reserve(h, ts.sq_part, (size_t)2 * B * sizeof(float))) return 1;
   if (reserve(h, ts.row_loss, (size_t)B * sizeof(float))) return 1;
@@ -1992,7 +1993,7 @@ static int cnn_train_grads_locked(sse_handle *h, const int32_t *src_ids_host, co
   float *sq = (float *)ts.sq_part.p;
   HIPCHECK(h, launch_cnn_bwd((const int32_t *)ts.ids[0].p, emb.dev, (const float *)ts.dfeat.p, (const float *)ts.feat_rm.p,
                              (const int32_t *)ts.pos.p, W, dW, db, (float *)ts.dw_part.p, (float *)ts.dbias_part.p,
-                             (float *)ts.wt.p, emb.grad, sq, B, T, E, h->cnn_bf16 ? 1 : 0, st));
+                             (float *)ts.wt.p, (unsigned short *)ts.wct.p, emb.grad, sq, B, T, E, h->cnn_bf16 ? 1 : 0, st));
   HIPCHECK(h, launch_rows_scatter((const float *)ts.draw[1].p, (const int32_t *)ts.ids[1].p, B, S, table.grad, sq + B, st));
   // tail[0]: both lookups are IndexedSlices -> raw slice norms
   HIPCHECK(h, launch_sum(sq, 2 * B, (float)B, tail, st));
