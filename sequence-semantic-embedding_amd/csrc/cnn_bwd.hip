@@ -52,12 +52,14 @@ __device__ __forceinline__ float bf16_rne(float f) {  // nearest bfloat16 (ties 
 // to the round-2 kernel): the gathered embedding values of sequence b+1 and the token ids of sequence b+2 are in flight in
 // registers while sequence b is multiplied out of LDS, so the two dependent global loads (ids -> embedding row) of a
 // sequence no longer sit between two barriers.  0.55 -> 0.1x ms at 8192 sequences (profiles/r05_notes.txt).
+constexpr int DW_THREADS = 512, DW_WAVES = DW_THREADS / 64;
+
 template <int FS, int NF, int RMAX>
 __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
-  constexpr int PARTS = 256 / NF;
-  constexpr int KMAX = (FS * 64 + PARTS - 1) / PARTS;  // E <= 64
+  constexpr int PARTS = DW_THREADS / NF;
+  constexpr int KMAX = ((FS * 64 + PARTS - 1) / PARTS + 3) & ~3;  // E <= 64; a multiple of 4
   const int tid = threadIdx.x, f = tid % NF, part = tid / NF;
-  const int T = a.T, E = a.E, K = FS * E, KPT = (K + PARTS - 1) / PARTS, k0 = part * KPT, TE = T * E;
+  const int T = a.T, E = a.E, K = FS * E, KPT = ((K + PARTS - 1) / PARTS + 3) & ~3, k0 = part * KPT, TE = T * E;  // (k0 % 4 == 0: aligned float2 reads)
   const int wi = FS - 2, fo = b_foff[wi] + f;
   const int chunk = blockIdx.x, per = (a.B + a.NCH - 1) / a.NCH;
   const int b_begin = chunk * per, b_end = min(a.B, b_begin + per);
@@ -65,7 +67,7 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
 #pragma unroll
   for (int kk = 0; kk < KMAX; ++kk) acc[kk] = 0.0f;
   float bsum = 0.0f;
-  // this thread's elements of a [T][E] tile: column ce = lane (idle for ce >= E), tokens tq, tq + 4, tq + 8, .. with tq = its
+  // this thread's elements of a [T][E] tile: column ce = lane (idle for ce >= E), tokens tq, tq + 8, tq + 16, .. with tq = its
   // wave -- a wave reads ONE token id per step (uniform: scalar loads, no vector registers) and one embedding row coalesced
   const int ce = tid & 63, tq = __builtin_amdgcn_readfirstlane(tid >> 6);
   int idn[RMAX > 0 ? RMAX : 1];   // token ids in flight (wave-uniform)
@@ -78,35 +80,59 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
   auto load_ids = [&](int b) {
 #pragma unroll
     for (int r = 0; r < RMAX; ++r)
-      if (tq + 4 * r < T) idn[r] = a.ids[(size_t)b * T + tq + 4 * r];
+      if (tq + DW_WAVES * r < T) idn[r] = a.ids[(size_t)b * T + tq + DW_WAVES * r];
   };
   auto load_vals = [&]() {
 #pragma unroll
     for (int r = 0; r < RMAX; ++r)
-      if (tq + 4 * r < T && ce < E) vn[r] = a.emb[(size_t)idn[r] * E + ce];
+      if (tq + DW_WAVES * r < T && ce < E) vn[r] = a.emb[(size_t)idn[r] * E + ce];
   };
   auto store_vals = [&](float *xb) {
 #pragma unroll
     for (int r = 0; r < RMAX; ++r)
-      if (tq + 4 * r < T && ce < E) xb[(tq + 4 * r) * E + ce] = a.bf16 ? bf16_rne(vn[r]) : vn[r];
+      if (tq + DW_WAVES * r < T && ce < E) xb[(tq + DW_WAVES * r) * E + ce] = a.bf16 ? bf16_rne(vn[r]) : vn[r];
   };
+  // The multiply is branch-free inside: every thread walks all KMAX slots of its k range -- slots past the range read whatever
+  // follows in LDS (the next rows, the other buffer, the KMAX-float pad behind the tiles) into accumulators that are never
+  // stored.  (With a per-slot range test the compiler emitted one ds_read -> wait -> fmac block per slot: 100 serialised LDS
+  // round trips per sequence, 8 us of the 8.5 us an iteration took.)  Even E: the window starts 8-byte aligned -> float2 reads.
+  float g_n = 0.0f, f_n = 0.0f;
+  int p_n = 0;
+  auto fetch_g = [&](int b) {  // the next sequence's gradient / ReLU mask / position: in flight under this one's multiply
+    g_n = a.dfeat[(size_t)b * 576 + fo];
+    f_n = a.feat[(size_t)b * 576 + fo];
+    p_n = a.pos[(size_t)b * 576 + fo];
+  };
+  const bool vec2 = (E & 1) == 0;
   auto multiply = [&](const float *xb, int b) {
-    float g = a.dfeat[(size_t)b * 576 + fo];
-    if (!(a.feat[(size_t)b * 576 + fo] > 0.0f)) g = 0.0f;
+    const float g = (f_n > 0.0f) ? g_n : 0.0f;
+    const int p = p_n;
+    if (b + 1 < b_end) fetch_g(b + 1);
     if (g != 0.0f) {
-      const float *xw = xb + a.pos[(size_t)b * 576 + fo] * E + k0;
+      const float *xw = xb + p * E + k0;
+      if (vec2) {
+        float2 v[KMAX / 2];  // all reads of the window in flight, then the FMAs
 #pragma unroll
-      for (int kk = 0; kk < KMAX; ++kk)
-        if (kk < KPT && k0 + kk < K) acc[kk] += g * xw[kk];
+        for (int i = 0; i < KMAX / 2; ++i) v[i] = *reinterpret_cast<const float2 *>(xw + 2 * i);
+#pragma unroll
+        for (int i = 0; i < KMAX / 2; ++i) {
+          acc[2 * i] += g * v[i].x;
+          acc[2 * i + 1] += g * v[i].y;
+        }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < KMAX; ++kk) acc[kk] += g * xw[kk];
+      }
       bsum += g;
     }
   };
+  if (b_begin < b_end) fetch_g(b_begin);
   if constexpr (RMAX == 0) {
     // any T (more than 160 tokens: narrow embeddings): the plain staging loop, one sequence between two barriers
     int buf = 0;
     for (int b = b_begin; b < b_end; ++b, buf ^= 1) {
       float *xb = xs + buf * TE;
-      for (int i = tid; i < TE; i += 256) {
+      for (int i = tid; i < TE; i += DW_THREADS) {
         const float x = a.emb[(size_t)a.ids[(size_t)b * T + i / E] * E + i % E];
         xb[i] = a.bf16 ? bf16_rne(x) : x;
       }
@@ -143,8 +169,8 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
 
 // (the four bodies are inlined: as calls they took the argument block through scratch and spilled around the call)
 template <int RMAX>
-__global__ __launch_bounds__(256, 2) void cnn_dw_kernel(CnnBwdArgs a) {
-  extern __shared__ float xs[];  // [2][T*E]
+__global__ __launch_bounds__(DW_THREADS) void cnn_dw_kernel(CnnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [2][T*E] + 128 floats of pad (read, never used: see multiply)
   switch (blockIdx.y) {
     case 0: dw_body<2, 256, RMAX>(a, xs); break;
     case 1: dw_body<3, 128, RMAX>(a, xs); break;
@@ -353,11 +379,11 @@ hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfe
   }
   ra.db_part = db_part;
   ra.nch = a.NCH;
-  const size_t lds = (size_t)2 * T * E * sizeof(float);
-  if (T <= 4 * 16) hipLaunchKernelGGL((cnn_dw_kernel<16>), dim3(a.NCH, 4), dim3(256), lds, st, a);
-  else if (T <= 4 * 24) hipLaunchKernelGGL((cnn_dw_kernel<24>), dim3(a.NCH, 4), dim3(256), lds, st, a);
-  else if (T <= 4 * 40) hipLaunchKernelGGL((cnn_dw_kernel<40>), dim3(a.NCH, 4), dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((cnn_dw_kernel<0>), dim3(a.NCH, 4), dim3(256), lds, st, a);
+  const size_t lds = ((size_t)2 * T * E + 128) * sizeof(float);
+  if (T <= DW_WAVES * 8) hipLaunchKernelGGL((cnn_dw_kernel<8>), dim3(a.NCH, 4), dim3(DW_THREADS), lds, st, a);
+  else if (T <= DW_WAVES * 12) hipLaunchKernelGGL((cnn_dw_kernel<12>), dim3(a.NCH, 4), dim3(DW_THREADS), lds, st, a);
+  else if (T <= DW_WAVES * 20) hipLaunchKernelGGL((cnn_dw_kernel<20>), dim3(a.NCH, 4), dim3(DW_THREADS), lds, st, a);
+  else hipLaunchKernelGGL((cnn_dw_kernel<0>), dim3(a.NCH, 4), dim3(DW_THREADS), lds, st, a);
   hipLaunchKernelGGL(cnn_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ra);
   if (dx_mfma) return launch_cnn_dx_mfma(ids, dfeat, feat, pos, W, wct_scratch, d_emb, sq_part, B, T, E, st);
   hipLaunchKernelGGL(cnn_dx_kernel, dim3(B), dim3(256), (size_t)(T + 1) * sizeof(int), st, a);
