@@ -54,12 +54,16 @@ __device__ __forceinline__ float bf16_rne(float f) {  // nearest bfloat16 (ties 
 // sequence no longer sit between two barriers.  0.55 -> 0.1x ms at 8192 sequences (profiles/r05_notes.txt).
 constexpr int DW_THREADS = 512, DW_WAVES = DW_THREADS / 64;
 
-template <int FS, int NF, int RMAX>
+template <int FS, int NF, int RMAX, bool X16>
 __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
   constexpr int PARTS = DW_THREADS / NF;
   constexpr int KMAX = ((FS * 64 + PARTS - 1) / PARTS + 3) & ~3;  // E <= 64; a multiple of 4
   const int tid = threadIdx.x, f = tid % NF, part = tid / NF;
-  const int T = a.T, E = a.E, K = FS * E, KPT = ((K + PARTS - 1) / PARTS + 3) & ~3, k0 = part * KPT, TE = T * E;  // (k0 % 4 == 0: aligned float2 reads)
+  const int T = a.T, E = a.E, K = FS * E, KPT = ((K + PARTS - 1) / PARTS + 3) & ~3, k0 = part * KPT, TE = T * E;  // (k0 % 4 == 0)
+  // X16 (option cnn_bf16, even E): the tile holds the bf16-rounded embeddings AS bf16 -- half the LDS bytes, and a row is E / 2
+  // dwords: 25 for E = 50, an ODD bank stride, where the fp32 rows (50 dwords) put every window start on an even bank and
+  // doubled the conflicts of the 64 lanes' independent window reads.  A dword unpacks into two exact fp32 values.
+  unsigned short *xs16 = reinterpret_cast<unsigned short *>(xs);
   const int wi = FS - 2, fo = b_foff[wi] + f;
   const int chunk = blockIdx.x, per = (a.B + a.NCH - 1) / a.NCH;
   const int b_begin = chunk * per, b_end = min(a.B, b_begin + per);
@@ -87,10 +91,13 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
     for (int r = 0; r < RMAX; ++r)
       if (tq + DW_WAVES * r < T && ce < E) vn[r] = a.emb[(size_t)idn[r] * E + ce];
   };
-  auto store_vals = [&](float *xb) {
+  auto store_vals = [&](int buf) {
 #pragma unroll
     for (int r = 0; r < RMAX; ++r)
-      if (tq + DW_WAVES * r < T && ce < E) xb[(tq + DW_WAVES * r) * E + ce] = a.bf16 ? bf16_rne(vn[r]) : vn[r];
+      if (tq + DW_WAVES * r < T && ce < E) {
+        if constexpr (X16) xs16[buf * TE + (tq + DW_WAVES * r) * E + ce] = (unsigned short)(__float_as_uint(bf16_rne(vn[r])) >> 16);
+        else xs[buf * TE + (tq + DW_WAVES * r) * E + ce] = a.bf16 ? bf16_rne(vn[r]) : vn[r];
+      }
   };
   // The multiply is branch-free inside: every thread walks all KMAX slots of its k range -- slots past the range read whatever
   // follows in LDS (the next rows, the other buffer, the KMAX-float pad behind the tiles) into accumulators that are never
@@ -104,24 +111,36 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
     p_n = a.pos[(size_t)b * 576 + fo];
   };
   const bool vec2 = (E & 1) == 0;
-  auto multiply = [&](const float *xb, int b) {
+  auto multiply = [&](int buf, int b) {
     const float g = (f_n > 0.0f) ? g_n : 0.0f;
     const int p = p_n;
     if (b + 1 < b_end) fetch_g(b + 1);
     if (g != 0.0f) {
-      const float *xw = xb + p * E + k0;
-      if (vec2) {
-        float2 v[KMAX / 2];  // all reads of the window in flight, then the FMAs
+      if constexpr (X16) {
+        const unsigned *xw = reinterpret_cast<const unsigned *>(xs16 + buf * TE + p * E + k0);  // (E even, k0 % 4 == 0: dword aligned)
+        unsigned v[KMAX / 2];  // all reads of the window in flight, then the FMAs
 #pragma unroll
-        for (int i = 0; i < KMAX / 2; ++i) v[i] = *reinterpret_cast<const float2 *>(xw + 2 * i);
+        for (int i = 0; i < KMAX / 2; ++i) v[i] = xw[i];
 #pragma unroll
         for (int i = 0; i < KMAX / 2; ++i) {
-          acc[2 * i] += g * v[i].x;
-          acc[2 * i + 1] += g * v[i].y;
+          acc[2 * i] += g * __uint_as_float(v[i] << 16);
+          acc[2 * i + 1] += g * __uint_as_float(v[i] & 0xFFFF0000u);
         }
       } else {
+        const float *xw = xs + buf * TE + p * E + k0;
+        if (vec2) {
+          float2 v[KMAX / 2];
 #pragma unroll
-        for (int kk = 0; kk < KMAX; ++kk) acc[kk] += g * xw[kk];
+          for (int i = 0; i < KMAX / 2; ++i) v[i] = *reinterpret_cast<const float2 *>(xw + 2 * i);
+#pragma unroll
+          for (int i = 0; i < KMAX / 2; ++i) {
+            acc[2 * i] += g * v[i].x;
+            acc[2 * i + 1] += g * v[i].y;
+          }
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < KMAX; ++kk) acc[kk] += g * xw[kk];
+        }
       }
       bsum += g;
     }
@@ -131,19 +150,19 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
     // any T (more than 160 tokens: narrow embeddings): the plain staging loop, one sequence between two barriers
     int buf = 0;
     for (int b = b_begin; b < b_end; ++b, buf ^= 1) {
-      float *xb = xs + buf * TE;
       for (int i = tid; i < TE; i += DW_THREADS) {
         const float x = a.emb[(size_t)a.ids[(size_t)b * T + i / E] * E + i % E];
-        xb[i] = a.bf16 ? bf16_rne(x) : x;
+        if constexpr (X16) xs16[buf * TE + i] = (unsigned short)(__float_as_uint(bf16_rne(x)) >> 16);
+        else xs[buf * TE + i] = a.bf16 ? bf16_rne(x) : x;
       }
       __syncthreads();
-      multiply(xb, b);
+      multiply(buf, b);
     }
   } else {
     if (b_begin < b_end) {
       load_ids(b_begin);
       load_vals();
-      store_vals(xs);
+      store_vals(0);
       if (b_begin + 1 < b_end) {
         load_ids(b_begin + 1);
         load_vals();
@@ -153,9 +172,9 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
     __syncthreads();
     int buf = 0;
     for (int b = b_begin; b < b_end; ++b, buf ^= 1) {
-      multiply(xs + buf * TE, b);
-      if (b + 1 < b_end) store_vals(xs + (buf ^ 1) * TE);  // (that buffer was last read before the previous barrier)
-      if (b + 2 < b_end) load_vals();                       // ids of b+2 arrived during this iteration
+      multiply(buf, b);
+      if (b + 1 < b_end) store_vals(buf ^ 1);  // (that buffer was last read before the previous barrier)
+      if (b + 2 < b_end) load_vals();           // ids of b+2 arrived during this iteration
       if (b + 3 < b_end) load_ids(b + 3);
       __syncthreads();
     }
@@ -168,14 +187,14 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
 }
 
 // (the four bodies are inlined: as calls they took the argument block through scratch and spilled around the call)
-template <int RMAX>
+template <int RMAX, bool X16>
 __global__ __launch_bounds__(DW_THREADS) void cnn_dw_kernel(CnnBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];  // [2][T*E] + 128 floats of pad (read, never used: see multiply)
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [2][T*E] fp32 (or bf16: X16) + 128 floats of pad (read, never used: see multiply)
   switch (blockIdx.y) {
-    case 0: dw_body<2, 256, RMAX>(a, xs); break;
-    case 1: dw_body<3, 128, RMAX>(a, xs); break;
-    case 2: dw_body<4, 128, RMAX>(a, xs); break;
-    default: dw_body<5, 64, RMAX>(a, xs); break;
+    case 0: dw_body<2, 256, RMAX, X16>(a, xs); break;
+    case 1: dw_body<3, 128, RMAX, X16>(a, xs); break;
+    case 2: dw_body<4, 128, RMAX, X16>(a, xs); break;
+    default: dw_body<5, 64, RMAX, X16>(a, xs); break;
   }
 }
 
@@ -380,10 +399,19 @@ hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfe
   ra.db_part = db_part;
   ra.nch = a.NCH;
   const size_t lds = ((size_t)2 * T * E + 128) * sizeof(float);
-  if (T <= DW_WAVES * 8) hipLaunchKernelGGL((cnn_dw_kernel<8>), dim3(a.NCH, 4), dim3(DW_THREADS), lds, st, a);
-  else if (T <= DW_WAVES * 12) hipLaunchKernelGGL((cnn_dw_kernel<12>), dim3(a.NCH, 4), dim3(DW_THREADS), lds, st, a);
-  else if (T <= DW_WAVES * 20) hipLaunchKernelGGL((cnn_dw_kernel<20>), dim3(a.NCH, 4), dim3(DW_THREADS), lds, st, a);
-  else hipLaunchKernelGGL((cnn_dw_kernel<0>), dim3(a.NCH, 4), dim3(DW_THREADS), lds, st, a);
+  const bool x16 = bf16 && (E & 1) == 0;
+  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(a.NCH, 4), dim3(DW_THREADS), lds, st, a); };
+  if (x16) {
+    if (T <= DW_WAVES * 8) go(cnn_dw_kernel<8, true>);
+    else if (T <= DW_WAVES * 12) go(cnn_dw_kernel<12, true>);
+    else if (T <= DW_WAVES * 20) go(cnn_dw_kernel<20, true>);
+    else go(cnn_dw_kernel<0, true>);
+  } else {
+    if (T <= DW_WAVES * 8) go(cnn_dw_kernel<8, false>);
+    else if (T <= DW_WAVES * 12) go(cnn_dw_kernel<12, false>);
+    else if (T <= DW_WAVES * 20) go(cnn_dw_kernel<20, false>);
+    else go(cnn_dw_kernel<0, false>);
+  }
   hipLaunchKernelGGL(cnn_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ra);
   if (dx_mfma) return launch_cnn_dx_mfma(ids, dfeat, feat, pos, W, wct_scratch, d_emb, sq_part, B, T, E, st);
   hipLaunchKernelGGL(cnn_dx_kernel, dim3(B), dim3(256), (size_t)(T + 1) * sizeof(int), st, a);

@@ -1623,6 +1623,51 @@ hipError_t launch_loss(const float *src_raw, const float *tgt_raw, const float *
   return hipGetLastError();
 }
 
+// dh on the fp32 matrix pipe (round 5; the 64 x 64 LDS-tiled VALU kernel above took 0.12 ms for 8192 x 576 x 512, 40 TFLOP/s):
+// D[b][j] = sum_s d[b][s] * M[j][s] -- both operands are read along s as they lie in memory: lane (row, k half) takes one
+// float4 of its row, s0 + 4 * (k half) .. + 3, and component u of the two halves is the k pair of the u-th
+// v_mfma_f32_32x32x2_f32 (both operands permute s identically).  A wave owns one 32 x 32 tile, a workgroup four j tiles of
+// one b tile (the d fragment is the same for the four waves and comes from L1).  Needs S % 8 == 0 (16-byte aligned rows).
+__global__ __launch_bounds__(256) void proj_bwd_dh_mfma_kernel(const float *__restrict__ d, const float *__restrict__ M, int Bp,
+                                                               int H, int Hp, int S, float *__restrict__ dh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int bt = blockIdx.y, jt = blockIdx.x * 4 + w;
+  if (jt * 32 >= Hp) return;  // (no barriers in this kernel)
+  const int row = lane & 31, kh = lane >> 5;
+  const int b = bt * 32 + row, j = jt * 32 + row;
+  const bool bok = b < Bp, jok = j < H;  // j >= H: weights read as 0 -> dh = 0
+  const float *pa = d + (size_t)(bok ? b : 0) * S + 4 * kh;
+  const float *pb = M + (size_t)(jok ? j : 0) * S + 4 * kh;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  constexpr int U = 4;  // 8 float4 loads in flight
+  int s0 = 0;
+  for (; s0 + 8 * U <= S; s0 += 8 * U) {
+    f32x4 av[U], bv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      av[u] = *reinterpret_cast<const f32x4 *>(pa + s0 + 8 * u);
+      bv[u] = *reinterpret_cast<const f32x4 *>(pb + s0 + 8 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bok ? av[u][e] : 0.0f, jok ? bv[u][e] : 0.0f, acc, 0, 0, 0);
+  }
+  for (; s0 < S; s0 += 8) {
+    const f32x4 av = *reinterpret_cast<const f32x4 *>(pa + s0), bv = *reinterpret_cast<const f32x4 *>(pb + s0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bok ? av[e] : 0.0f, jok ? bv[e] : 0.0f, acc, 0, 0, 0);
+  }
+  const int jc = jt * 32 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int br = bt * 32 + mfma_row(r, lane);
+    if (br < Bp && jc < Hp) dh[(size_t)br * Hp + jc] = acc[r];
+  }
+}
+
 int proj_bwd_chunks(int Bp) { return Bp <= 256 ? 1 : (Bp + 255) / 256 > 32 ? 32 : (Bp + 255) / 256; }
 
 hipError_t launch_proj_bwd(const float *hT, const float *d, const float *M, int Bp, int H, int Hp, int S, float *dM,
@@ -1637,8 +1682,12 @@ hipError_t launch_proj_bwd(const float *hT, const float *d, const float *M, int 
                        hT, d, Bp, H, Hp, S, chunk, nch == 1 ? dM : dm_part);
   if (nch > 1)
     hipLaunchKernelGGL(proj_bwd_dm_reduce_kernel, dim3((H * S + 255) / 256), dim3(256), 0, st, dm_part, nch, H * S, dM);
-  hipLaunchKernelGGL(proj_bwd_dh_kernel, dim3((Hp + PB_TILE - 1) / PB_TILE, (Bp + PB_TILE - 1) / PB_TILE), dim3(256), 0, st, d,
-                     M, Bp, H, Hp, S, dh);
+  static const bool dh_valu = getenv("SSE_PROJ_DH_VALU") != nullptr;  // measurement aid: the LDS-tiled VALU kernel
+  if (S % 8 == 0 && !dh_valu && (reinterpret_cast<uintptr_t>(d) & 15) == 0 && (reinterpret_cast<uintptr_t>(M) & 15) == 0)
+    hipLaunchKernelGGL(proj_bwd_dh_mfma_kernel, dim3((Hp / 32 + 3) / 4, (Bp + 31) / 32), dim3(256), 0, st, d, M, Bp, H, Hp, S, dh);
+  else
+    hipLaunchKernelGGL(proj_bwd_dh_kernel, dim3((Hp + PB_TILE - 1) / PB_TILE, (Bp + PB_TILE - 1) / PB_TILE), dim3(256), 0, st, d,
+                       M, Bp, H, Hp, S, dh);
   return hipGetLastError();
 }
 
