@@ -177,6 +177,27 @@ int sse_merge_topk_strided_dev(sse_handle *h, const double *in_scores_dev, const
                                int64_t shard_stride, int32_t P, int32_t Q, int32_t k, double *out_scores_dev,
                                int64_t *out_ids_dev, void *stream);
 
+/* The exchange step WITHOUT torch: RCCL from the C ABI, so that the reference-side binding of
+ * INTEGRATION.md can shard an index with ctypes alone.  `nccl_comm` is an ncclComm_t of the caller's RCCL (one rank per GPU,
+ * created on the handle's device); the library resolves ncclAllGather in the process image or in librccl.so.1 at first use
+ * (libsse_hip.so itself does not link RCCL).
+ *   sse_allgather_merge_topk_dev  this rank's [Q][k] lists (global row ids) -> ONE ncclAllGather of the packed
+ *       (float64 score bits | int64 ids) words on `stream` -> k-way merge: the unsharded result on every rank;
+ *   sse_score_topk_sharded_dev    sse_score_topk_dev on this rank's shard (rows set with id_base = shard offset) + the above;
+ *   sse_rccl_get_unique_id / sse_rccl_comm_init_rank / sse_rccl_comm_destroy: thin conveniences over ncclGetUniqueId /
+ *       ncclCommInitRank / ncclCommDestroy for hosts without an RCCL binding of their own (id128: the 128-byte ncclUniqueId;
+ *       rank 0 creates it and hands it to the other ranks by whatever channel the host has -- file, socket, MPI).
+ * Replaces nothing in the reference (it has no distributed code); consumes what sse_evaluator.py:110-111 / data_utils.py:263-267
+ * compute per shard. */
+int sse_rccl_get_unique_id(char *id128);
+int sse_rccl_comm_init_rank(sse_handle *h, void **comm, int32_t world, int32_t rank, const char *id128);
+int sse_rccl_comm_destroy(sse_handle *h, void *comm);
+int sse_allgather_merge_topk_dev(sse_handle *h, void *nccl_comm, int32_t world, const double *local_scores_dev,
+                                 const int64_t *local_ids_dev, int32_t Q, int32_t k, double *out_scores_dev,
+                                 int64_t *out_ids_dev, void *stream);
+int sse_score_topk_sharded_dev(sse_handle *h, void *nccl_comm, int32_t world, const float *q_dev, int32_t Q, int32_t k,
+                               double *out_scores_dev, int64_t *out_ids_dev, void *stream);
+
 /* session.run([model.train, model.loss, model.train_acc], feed) --
  * sse_train.py:170-172; loss/acc are evaluated before the update.  labels
  * float32 [B] (sse_model.py:420).  tgt_ids_host is int32 [B,T] token ids in the

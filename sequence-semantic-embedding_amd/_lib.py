@@ -48,6 +48,11 @@ SYMBOLS = {
     "sse_encode_score_topk": (C.c_int, [_P, C.c_int, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "sse_merge_topk_dev": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "sse_merge_topk_strided_dev": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "sse_rccl_get_unique_id": (C.c_int, [_P]),
+    "sse_rccl_comm_init_rank": (C.c_int, [_P, C.POINTER(_P), C.c_int32, C.c_int32, _P]),
+    "sse_rccl_comm_destroy": (C.c_int, [_P, _P]),
+    "sse_allgather_merge_topk_dev": (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "sse_score_topk_sharded_dev": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "sse_train_step": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sse_set_stream": (C.c_int, [_P, _P]),
     "sse_train_grad_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
@@ -253,6 +258,29 @@ class Handle(object):
 
     def merge_topk_dev(self, in_s, in_i, P, Q, k, out_s, out_i, stream=0):
         self.check(self.lib.sse_merge_topk_dev(self._h, in_s, in_i, P, Q, k, out_s, out_i, stream))
+
+    # -- RCCL exchange without torch ------------------------------
+    def rccl_unique_id(self):
+        """A fresh 128-byte ncclUniqueId (rank 0 creates it; the other ranks receive the bytes)."""
+        buf = C.create_string_buffer(128)
+        if self.lib.sse_rccl_get_unique_id(buf) != 0:
+            raise SSEError("RCCL (librccl.so.1) is not loadable in this process")
+        return buf.raw
+
+    def rccl_comm_init_rank(self, world, rank, unique_id):
+        """ncclCommInitRank on the handle's device; returns the communicator as an integer handle (void*)."""
+        comm = _P()
+        self.check(self.lib.sse_rccl_comm_init_rank(self._h, C.byref(comm), int(world), int(rank), C.c_char_p(bytes(unique_id))))
+        return comm.value
+
+    def rccl_comm_destroy(self, comm):
+        self.check(self.lib.sse_rccl_comm_destroy(self._h, comm))
+
+    def allgather_merge_topk_dev(self, comm, world, loc_s, loc_i, Q, k, out_s, out_i, stream=0):
+        self.check(self.lib.sse_allgather_merge_topk_dev(self._h, comm, int(world), loc_s, loc_i, Q, k, out_s, out_i, stream))
+
+    def score_topk_sharded_dev(self, comm, world, q_ptr, Q, k, out_s, out_i, stream=0):
+        self.check(self.lib.sse_score_topk_sharded_dev(self._h, comm, int(world), q_ptr, Q, k, out_s, out_i, stream))
 
     # -- training ------------------------------------------------------------
     @staticmethod

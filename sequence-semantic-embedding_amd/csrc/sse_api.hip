@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -160,6 +161,7 @@ struct sse_handle {
   DevBuf s_ids, s_out, s_q, s_qp, s_ps, s_pi, s_cert, s_os, s_oi, s_tmp, s_tmp2, s_feat, s_zero, s_map;
   DevBuf s_qmap, s_qc;     // fp32 second chance of the bf16 candidate pass: the uncertified queries as a dense set
   DevBuf s_qp32, s_fb_cnt;  // fp32 second chance of the bf16 candidate pass: fp32 query fragments, counter
+  DevBuf s_xchg;     // sse_score_topk_sharded_dev: [local lists | gathered lists] of the RCCL exchange
   DevBuf s_persist;  // lstm_persist.hip: h_t / raw-encoding exchange buffers and arrival counters
   DevBuf s_cluster;  // lstm_cluster.hip: h_t / sum-of-squares exchange buffers
   int32_t *pin_small = nullptr;  // 64 pinned host words: error flag / loss read-backs (a pageable target makes the copy a blocking one)
@@ -1825,6 +1827,127 @@ int sse_merge_topk_strided_dev(sse_handle *h, const double *in_scores_dev, const
 int sse_merge_topk_dev(sse_handle *h, const double *in_scores_dev, const int64_t *in_ids_dev, int32_t P, int32_t Q,
                        int32_t k, double *out_scores_dev, int64_t *out_ids_dev, void *stream) {
   return sse_merge_topk_strided_dev(h, in_scores_dev, in_ids_dev, (int64_t)Q * k, P, Q, k, out_scores_dev, out_ids_dev, stream);
+}
+
+// ---------------------------------------------------------------------------
+// Torch-free exchange step of the row-sharded index (BASELINE configs[3]): RCCL straight from the C ABI.
+// The library does not LINK librccl: the few entry points it needs are looked up at first use -- in the process image first
+// (a host that already loaded RCCL, e.g. through torch, keeps ONE copy), then in librccl.so.1 -- so libsse_hip.so loads on a
+// box without RCCL and every other entry point works there.
+namespace {
+typedef struct { char internal[128]; } sse_nccl_uid;  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
+struct RcclApi {
+  int (*get_unique_id)(sse_nccl_uid *) = nullptr;
+  int (*comm_init_rank)(void **, int, sse_nccl_uid, int) = nullptr;
+  int (*comm_destroy)(void *) = nullptr;
+  int (*all_gather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  const char *(*error_string)(int) = nullptr;
+  const char *why = nullptr;
+};
+const RcclApi *rccl_api_ptr() {
+  static const RcclApi api = [] {
+    RcclApi a;
+    void *lib = nullptr;
+    auto sym = [&](const char *name) -> void * {
+      void *p = dlsym(RTLD_DEFAULT, name);
+      if (!p) {
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (lib) p = dlsym(lib, name);
+      }
+      return p;
+    };
+    a.get_unique_id = reinterpret_cast<int (*)(sse_nccl_uid *)>(sym("ncclGetUniqueId"));
+    a.comm_init_rank = reinterpret_cast<int (*)(void **, int, sse_nccl_uid, int)>(sym("ncclCommInitRank"));
+    a.comm_destroy = reinterpret_cast<int (*)(void *)>(sym("ncclCommDestroy"));
+    a.all_gather = reinterpret_cast<int (*)(const void *, void *, size_t, int, void *, hipStream_t)>(sym("ncclAllGather"));
+    a.error_string = reinterpret_cast<const char *(*)(int)>(sym("ncclGetErrorString"));
+    if (!a.get_unique_id || !a.comm_init_rank || !a.comm_destroy || !a.all_gather) a.why = "RCCL (librccl.so.1) is not loadable in this process";
+    return a;
+  }();
+  return &api;
+}
+constexpr int SSE_NCCL_INT64 = 4;  // ncclInt64 (rccl.h: ncclDataType_t)
+int rccl_fail(sse_handle *h, const char *what, int rc) {
+  const RcclApi &r = *rccl_api_ptr();
+  return fail(h, "%s: RCCL error %d (%s)", what, rc, r.error_string ? r.error_string(rc) : "?");
+}
+}  // namespace
+
+int sse_rccl_get_unique_id(char *id128) {
+  const RcclApi &r = *rccl_api_ptr();
+  if (!id128 || r.why) return 1;
+  sse_nccl_uid u;
+  if (r.get_unique_id(&u) != 0) return 1;
+  memcpy(id128, u.internal, sizeof u.internal);
+  return 0;
+}
+
+int sse_rccl_comm_init_rank(sse_handle *h, void **comm, int32_t world, int32_t rank, const char *id128) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  const RcclApi &r = *rccl_api_ptr();
+  if (r.why) return fail(h, "%s", r.why);
+  if (!comm || !id128 || world < 1 || rank < 0 || rank >= world) return fail(h, "bad arguments to sse_rccl_comm_init_rank");
+  HIPCHECK(h, hipSetDevice(h->cfg.device));  // the communicator binds the calling thread's current device
+  sse_nccl_uid u;
+  memcpy(u.internal, id128, sizeof u.internal);
+  const int rc = r.comm_init_rank(comm, world, u, rank);
+  return rc == 0 ? 0 : rccl_fail(h, "ncclCommInitRank", rc);
+}
+
+int sse_rccl_comm_destroy(sse_handle *h, void *comm) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  const RcclApi &r = *rccl_api_ptr();
+  if (r.why) return fail(h, "%s", r.why);
+  if (!comm) return 0;
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  const int rc = r.comm_destroy(comm);
+  return rc == 0 ? 0 : rccl_fail(h, "ncclCommDestroy", rc);
+}
+
+// gather + merge of lists that are already on the device; the handle mutex is held by the caller
+static int allgather_merge_locked(sse_handle *h, void *comm, int world, const double *loc_s, const int64_t *loc_i, int Q, int k,
+                                  double *out_s, int64_t *out_i, hipStream_t st) {
+  const RcclApi &r = *rccl_api_ptr();
+  if (r.why) return fail(h, "%s", r.why);
+  const size_t n = (size_t)Q * k;  // 64-bit words per list
+  // exchange buffer: [ this rank's (scores | ids) : 2n words ][ gathered, rank-major: world x 2n words ]
+  if (reserve(h, h->s_xchg, (size_t)(world + 1) * 2 * n * 8)) return 1;
+  int64_t *loc = (int64_t *)h->s_xchg.p, *all = loc + 2 * n;
+  HIPCHECK(h, hipMemcpyAsync(loc, loc_s, n * 8, hipMemcpyDeviceToDevice, st));  // (float64 scores travel as their bit patterns)
+  HIPCHECK(h, hipMemcpyAsync(loc + n, loc_i, n * 8, hipMemcpyDeviceToDevice, st));
+  const int rc = r.all_gather(loc, all, 2 * n, SSE_NCCL_INT64, comm, st);  // ONE collective for scores and ids
+  if (rc != 0) return rccl_fail(h, "ncclAllGather", rc);
+  HIPCHECK(h, launch_merge_topk((const double *)all, all + n, (int64_t)(2 * n), world, Q, k, out_s, out_i, st));
+  return 0;
+}
+
+int sse_allgather_merge_topk_dev(sse_handle *h, void *nccl_comm, int32_t world, const double *local_scores_dev,
+                                 const int64_t *local_ids_dev, int32_t Q, int32_t k, double *out_scores_dev, int64_t *out_ids_dev,
+                                 void *stream) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  if (!nccl_comm || world < 1 || Q < 0 || k < 1 || !local_scores_dev || !local_ids_dev || !out_scores_dev || !out_ids_dev)
+    return fail(h, "bad arguments to sse_allgather_merge_topk_dev");
+  if (Q == 0) return 0;
+  return allgather_merge_locked(h, nccl_comm, world, local_scores_dev, local_ids_dev, Q, k, out_scores_dev, out_ids_dev, (hipStream_t)stream);
+}
+
+int sse_score_topk_sharded_dev(sse_handle *h, void *nccl_comm, int32_t world, const float *q_dev, int32_t Q, int32_t k,
+                               double *out_scores_dev, int64_t *out_ids_dev, void *stream) {
+  if (!h) return 1;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHECK(h, hipSetDevice(h->cfg.device));
+  if (!nccl_comm || world < 1 || Q < 0 || k < 1 || !q_dev || !out_scores_dev || !out_ids_dev)
+    return fail(h, "bad arguments to sse_score_topk_sharded_dev");
+  if (Q == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  // this shard's lists go to the out buffers first (global row ids: id_base of sse_index_set_dev), the merged lists overwrite them
+  if (score_dev_locked(h, q_dev, Q, k, out_scores_dev, out_ids_dev, st)) return 1;
+  return allgather_merge_locked(h, nccl_comm, world, out_scores_dev, out_ids_dev, Q, k, out_scores_dev, out_ids_dev, st);
 }
 
 static int64_t grad_arena_count(sse_handle *h) {

@@ -99,6 +99,34 @@ class ShardedIndex(object):
         return fs, fi
 
 
+class RcclShardedIndex(object):
+    """The same sharded index WITHOUT torch.distributed: the exchange is the library's own entry point
+    (sse_score_topk_sharded_dev: shard sweep -> ONE ncclAllGather of the packed lists -> k-way merge, all on one stream)
+    over an RCCL communicator created through the C ABI.  What a reference-side integration that must not import torch
+    uses; the host moves the 128-byte unique id from rank 0 to the other ranks itself."""
+
+    def __init__(self, handle, rank, world, n_total, unique_id):
+        self.handle, self.rank, self.world = handle, int(rank), int(world)
+        self.n_total = int(n_total)
+        self.start, self.end = shard_bounds(n_total, world)[rank]
+        self.comm = handle.rccl_comm_init_rank(world, rank, unique_id)
+
+    def close(self):
+        if self.comm:
+            self.handle.rccl_comm_destroy(self.comm)
+            self.comm = None
+
+    def set_local_rows_ptr(self, rows_ptr, n_rows, S, stream=0):
+        """rows_ptr: device pointer of this rank's [end-start, S] float32 shard."""
+        if n_rows != self.end - self.start:
+            raise ValueError("shard of rank %d must have %d rows, got %d" % (self.rank, self.end - self.start, n_rows))
+        self.handle.index_set_dev(rows_ptr, n_rows, S, id_base=self.start, stream=stream)
+
+    def score_topk_ptr(self, q_ptr, Q, k, out_scores_ptr, out_ids_ptr, stream=0):
+        """q_ptr: device float32 [Q,S] (identical on every rank); out_*: device float64 / int64 [Q,k]: the global top-k."""
+        self.handle.score_topk_sharded_dev(self.comm, self.world, q_ptr, Q, k, out_scores_ptr, out_ids_ptr, stream)
+
+
 def split_rows(n_rows, rank, world):
     """Independent units (sequences to encode): the slice of [0, n_rows) rank handles; no collective."""
     return shard_bounds(n_rows, world)[rank]

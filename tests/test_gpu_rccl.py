@@ -99,3 +99,49 @@ def test_data_parallel_on_a_side_stream_and_sparse_embedding_exchange(nccl_group
     assert auto._use_sparse(8, src[:8], False) == (2 * 8 * 12 < 5000 // 4)
     ma.handle.set_stream(0)
     mb.handle.set_stream(0)
+
+
+def test_torch_free_rccl_exchange_through_the_c_abi():
+    """the exchange step of the sharded index WITHOUT torch.distributed -- an RCCL communicator created
+    through the C ABI (sse_rccl_get_unique_id / sse_rccl_comm_init_rank), then sse_score_topk_sharded_dev (shard sweep ->
+    ncclAllGather of the packed lists -> merge on one stream) and sse_allgather_merge_topk_dev on ready-made lists.  One rank
+    (one GPU here); the multi-rank merge semantics are the gloo tests' (same merge kernel, same packing).  torch only holds
+    the device buffers."""
+    import torch
+    import sse_amd
+    params = model_params("dual-encoder", 50, 8, 16, 16, 32, 4)
+    m, _ = make_pair(params)
+    h = m.handle
+    rng = np.random.RandomState(13)
+    t = rng.standard_normal((7000, 32)).astype(np.float32)
+    q = rng.standard_normal((260, 32)).astype(np.float32)
+    uid = h.rccl_unique_id()
+    assert len(uid) == 128
+    sh = sse_amd.RcclShardedIndex(h, 0, 1, 7000, uid)
+    td, qd = torch.from_numpy(t).cuda(), torch.from_numpy(q).cuda()
+    out_s = torch.empty((260, 10), dtype=torch.float64, device="cuda")
+    out_i = torch.empty((260, 10), dtype=torch.int64, device="cuda")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        sh.set_local_rows_ptr(td.data_ptr(), 7000, 32, stream=st.cuda_stream)
+        sh.score_topk_ptr(qd.data_ptr(), 260, 10, out_s.data_ptr(), out_i.data_ptr(), stream=st.cuda_stream)
+    st.synchronize()
+    wsc, wids = O.topk(O.scores_f64(q, t.astype(np.float64)), 10)
+    assert np.array_equal(out_i.cpu().numpy(), wids)
+    assert np.abs(out_s.cpu().numpy() - wsc).max() < 1e-12
+    # ready-made lists (e.g. of a shard scored earlier): gather + merge only; with one rank the merge of one list is the list
+    ls, li = torch.from_numpy(wsc).cuda(), torch.from_numpy(wids).cuda()
+    o2s, o2i = torch.empty_like(ls), torch.empty_like(li)
+    h.allgather_merge_topk_dev(sh.comm, 1, ls.data_ptr(), li.data_ptr(), 260, 10, o2s.data_ptr(), o2i.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(o2i, li) and torch.equal(o2s, ls)
+    # an id_base: global row ids come back
+    sh2 = sse_amd.RcclShardedIndex(h, 0, 1, 7000, h.rccl_unique_id())
+    h.index_set_dev(td.data_ptr(), 7000, 32, id_base=123456)
+    sh2.score_topk_ptr(qd.data_ptr(), 260, 3, out_s.data_ptr(), out_i.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(out_i.reshape(-1)[:780].cpu().numpy().reshape(260, 3), wids[:, :3] + 123456)   # ([Q][3] packed at the front of the buffer)
+    sh.close()
+    sh2.close()
+    with pytest.raises(sse_amd.SSEError):
+        h.allgather_merge_topk_dev(0, 1, ls.data_ptr(), li.data_ptr(), 260, 10, o2s.data_ptr(), o2i.data_ptr())
