@@ -117,6 +117,7 @@ int sse_encode_dev(sse_handle *h, int side, const int32_t *ids_dev, int32_t B, i
  * "cnn_bf16" (default 0; source_only_cnn only): the convolution of inference encodes AND of the train step reads
  * embeddings and filters rounded to bf16 (fp32 masters, fp32 accumulation, fp32 bias/ReLU/pool/projection) on the bf16
  * matrix pipe -- the reference has no reduced-precision behaviour; BASELINE configs[4] names bf16.
+ * "train_generic" (default 0): run the LSTM train step on the any-shape path whatever the shape (tests, A/B).
  * "train_serial" (default 0): run both encoders of a train step on one stream (profiling aid:
  * isolated kernel durations; same results).
  * "score_small_index" (default 1): >= 1024 queries against <= 1024 index rows (index dimensions 249 .. 256, 57 .. 64,
@@ -204,8 +205,11 @@ int sse_score_topk_sharded_dev(sse_handle *h, void *nccl_comm, int32_t world, co
  * dual- and shared-encoder modes; in source-encoder-only and source_only_cnn
  * (builder-defined training: the reference's loss is ill-shaped for the free
  * target matrix and its CNN graph does not build) it is int32 [B] rows of the
- * free target matrix.  Limits (rejected with an error, never silently): cell size <= 256
- * and embedding_size <= 64 for training, cell size <= 512 for inference. */
+ * free target matrix.  LSTM modes accept ANY cell size / embedding_size / encoding_size (round 5): the fused kernels cover
+ * cell sizes <= 512 (training <= 256), embeddings that fit their LDS tile (training <= 64 columns) and encodings <= 512;
+ * every other shape runs the per-step any-shape path (csrc/lstm_generic.hip: same arithmetic, exact fp32, latency-bound).
+ * Remaining limits (rejected with an error, never silently): source_only_cnn embedding_size <= 64 for training and
+ * T x E within the LDS tile; index dimension <= 1024 for scoring. */
 int sse_train_step(sse_handle *h, const int32_t *src_ids_host, const int32_t *tgt_ids_host,
                    const float *labels_host, int32_t B, int32_t T, float *loss, float *train_acc);
 

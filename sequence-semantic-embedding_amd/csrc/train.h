@@ -73,6 +73,24 @@ int64_t emb_grad_packed_floats(int E, int cap);
 hipError_t launch_emb_grad_pack(const float *g, int V, int E, int cap, float *packed, int32_t *err, hipStream_t st);
 hipError_t launch_emb_grad_unpack(const float *gathered, int world, int V, int E, int cap, float *g, int32_t *err, hipStream_t st);
 
+// LSTM encoder for any shape (lstm_generic.hip): per-step GEMM + gate kernels behind the fused ones
+struct GenLstmDims {
+  int B, Bp, T, E, H, Hq, Kp;  // Bp = rows padded to 32, Hq = cell size padded to 8, Kp = padded width of an A row [x | h | pad]
+};
+GenLstmDims gen_lstm_dims(int B, int T, int E, int H);
+size_t gen_lstm_a_floats(const GenLstmDims &d);
+size_t gen_lstm_tape_floats(const GenLstmDims &d);
+size_t gen_lstm_dg_floats(const GenLstmDims &d);
+size_t gen_lstm_kt_floats(const GenLstmDims &d);
+size_t gen_lstm_dk_part_floats(const GenLstmDims &d);
+hipError_t launch_gen_pack(const float *K, const float *Mv, const GenLstmDims &d, int S, float *KT, float *Kq, float *MT, hipStream_t st);
+hipError_t launch_gen_forward(const int32_t *ids, const float *emb, int V, const float *KT, const float *bias, const GenLstmDims &d,
+                              float *A, float *G, float *c, float *tape, float *h_last, int32_t *err, hipStream_t st);
+hipError_t launch_gen_project(const float *h_last, const float *MT, const GenLstmDims &d, int S, float *raw, hipStream_t st);
+hipError_t launch_gen_backward(const int32_t *ids, const float *Kq, const GenLstmDims &d, const float *A, const float *tape,
+                               const float *dh_last, int ldh_last, float *dG, float *dA, float *dc, float *dk_part, int accumulate,
+                               float *dK, float *db, float *d_emb, float *sq, hipStream_t st);
+
 // text-CNN training path (cnn_bwd.hip)
 int cnn_bwd_chunks(int B);
 size_t cnn_dw_part_floats(int E, int B);
