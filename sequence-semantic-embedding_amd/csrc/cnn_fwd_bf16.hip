@@ -172,6 +172,126 @@ __global__ __launch_bounds__(CB_THREADS) void conv_pool_bf16_kernel(CnnBf16Args 
   }
 }
 
+// ---------------------------------------------------------------------------
+// Projection tail of the bf16 variant on the bf16 matrix pipe (round 5): [B,576] . [576,S] + row l2-normalise with SPLIT
+// operands -- x = hi + lo (bf16 each, x to 2^-17), a*b as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulation: the fp32
+// projection's result to ~4e-6 relative at 1/5 of its matrix-pipe time (proj_norm_kernel: 288 v_mfma_f32_32x32x2_f32 of
+// 64 cycles per 32 x 32 tile; here 108 v_mfma_f32_32x32x16_bf16 of 32).  It was 27 % of the bf16 encode for 5 % of its flops.
+// A = the pooled features as conv_pool_bf16_kernel leaves them (frag32 fp32: k-group of 8 = two float4 per (row, k half));
+// a lane (row, k octet) takes both float4 of ITS octet's group and splits them in registers (v_cvt_pk_bf16_f32).
+// B = the projection matrix as split frag16 blocks [n tile][36 groups of 16][hi | lo][512] (pack_kn_x3_kernel).
+struct ProjX3Args {
+  const float *featp;          // frag32(rows = b, red = feature): [ceil(B/32)][72][256]
+  const unsigned short *Mx3;   // [NTS][36][2][512]
+  float *out;                  // [B][S]
+  int32_t B, S, NTS, normalize;
+};
+
+__global__ __launch_bounds__(256) void proj_norm_x3_kernel(ProjX3Args a) {
+  __shared__ __attribute__((aligned(16))) float red[32 * 4];
+  const int lane = threadIdx.x & 63, wn = threadIdx.x >> 6;
+  const int mt = blockIdx.x;
+  constexpr int PT = 4;   // up to Sp = 512
+  constexpr int KG = 36;  // 576 features / 16
+  const int row = lane & 31, oct = lane >> 5;
+  // this lane's octet of group kg: frag32 block 2*kg + oct, float4 of (k half 0, row) and (k half 1, row)
+  const float *ap = a.featp + (size_t)mt * 72 * 256 + (size_t)oct * 256 + row * 4;
+  f32x16 pacc[PT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pacc[i][r] = 0.0f;
+  const sse_u32x4 *mp = reinterpret_cast<const sse_u32x4 *>(a.Mx3) + lane;
+  for (int kg = 0; kg < KG; ++kg) {
+    const f32x4 lo4 = *reinterpret_cast<const f32x4 *>(ap + (size_t)kg * 512), hi4 = *reinterpret_cast<const f32x4 *>(ap + (size_t)kg * 512 + 128);
+    const float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    sse_u32x4 ah, al;
+    sse_split8(v, ah, al);
+    const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah), a_lo = __builtin_bit_cast(bf16x8, al);
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int nt = wn + 4 * i;
+      if (nt < a.NTS) {
+        const sse_u32x4 *bp = mp + ((size_t)nt * KG + kg) * 128;  // 2 blocks x 64 lanes of 16 bytes
+        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, bp[0]), b_lo = __builtin_bit_cast(bf16x8, bp[64]);
+        pacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, pacc[i], 0, 0, 0);
+        pacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, pacc[i], 0, 0, 0);
+        pacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, pacc[i], 0, 0, 0);
+      }
+    }
+  }
+  float ss[16], scale[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    ss[r] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) ss[r] += pacc[i][r] * pacc[i][r];  // (tiles past NTS hold zeros)
+  }
+  if (a.normalize) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = ss[r];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      v += __shfl_xor(v, 8);
+      v += __shfl_xor(v, 16);
+      if ((lane & 31) == 0) red[mfma_row(r, lane) * 4 + wn] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const f32x4 p = *reinterpret_cast<const f32x4 *>(red + mfma_row(r, lane) * 4);
+      scale[r] = 1.0f / sqrtf(fmaxf((p[0] + p[1]) + (p[2] + p[3]), 1e-12f));
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scale[r] = 1.0f;
+  }
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int nt = wn + 4 * i, col = nt * 32 + (lane & 31);
+    if (nt < a.NTS && col < a.S) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rw = mt * 32 + mfma_row(r, lane);
+        if (rw < a.B) a.out[(size_t)rw * a.S + col] = pacc[i][r] * scale[r];
+      }
+    }
+  }
+}
+
+// M [576][S] (fp32 master) -> split frag16 blocks: (nt, kg) -> [hi 512 | lo 512]; lane l (column nt*32 + (l & 31), k octet l >> 5)
+// owns k = kg*16 + 8*(l >> 5) + i
+__global__ void pack_kn_x3_kernel(const float *__restrict__ Mv, int K, int N, int64_t total, unsigned short *__restrict__ out) {
+  const int KG = K / 16;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int idx = (int)(i & 7), l = (int)((i >> 3) & 63);
+    const int64_t blk = i >> 9;  // (nt * KG + kg)
+    const int kg = (int)(blk % KG), nt = (int)(blk / KG);
+    const int n = nt * 32 + (l & 31), k = kg * 16 + 8 * (l >> 5) + idx;
+    const float x = (n < N && k < K) ? Mv[(size_t)k * N + n] : 0.0f;
+    const unsigned short hi = f32_to_bf16(x);
+    out[blk * 1024 + (size_t)l * 8 + idx] = hi;
+    out[blk * 1024 + 512 + (size_t)l * 8 + idx] = f32_to_bf16(x - __uint_as_float((unsigned)hi << 16));
+  }
+}
+
+size_t cnn_proj_x3_elems(int S) { return (size_t)((S + 31) / 32) * 36 * 1024; }
+
+hipError_t launch_pack_cnn_proj_x3(const float *Mv, int S, unsigned short *Mx3, hipStream_t stream) {
+  const int64_t total = (int64_t)((S + 31) / 32) * 36 * 512;
+  hipLaunchKernelGGL(pack_kn_x3_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, Mv, 576, S, total, Mx3);
+  return hipGetLastError();
+}
+
+hipError_t launch_cnn_proj_x3(const float *featp, const unsigned short *Mx3, float *out, int B, int S, int normalize, hipStream_t stream) {
+  if (S > 512) return hipErrorInvalidValue;
+  ProjX3Args p{featp, Mx3, out, B, S, (S + 31) / 32, normalize};
+  hipLaunchKernelGGL(proj_norm_x3_kernel, dim3((B + 31) / 32), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
 // rows [R][C] fp32 -> [R][Cp] bf16 (zero padded columns)
 __global__ void to_bf16_rows_kernel(const float *__restrict__ in, int64_t R, int C, int Cp, unsigned short *__restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R * Cp; i += (int64_t)gridDim.x * blockDim.x) {

@@ -135,7 +135,7 @@ struct sse_handle {
   bool idxp16_valid = false;
   bool fb_cnt_init = false;
   bool cnn_bf16 = false;     // option "cnn_bf16": source_only_cnn inference with bf16 storage / fp32 accumulation
-  unsigned short *emb_bf16 = nullptr, *cnn_Wc16 = nullptr;
+  unsigned short *emb_bf16 = nullptr, *cnn_Wc16 = nullptr, *cnn_Mx3 = nullptr;
   int lstm_train_rows = 0;   // option "lstm_train_rows": 0 = automatic, 32 / 64 = rows per workgroup of the training forward (Hp = 256)
   // The train step computes in fp32 like the reference (tf.float32 graph, sse_model.py:355-364): the three split-operand
   // options below are OPT-IN (a default narrower than the reference's arithmetic earns no credit).
@@ -341,6 +341,8 @@ int ensure_packed(sse_handle *h, hipStream_t st) {
       if (!h->emb_bf16) HIPCHECK(h, hipMalloc((void **)&h->emb_bf16, (size_t)c.vocab_size * Ep8 * sizeof(unsigned short)));
       if (!h->cnn_Wc16) HIPCHECK(h, hipMalloc((void **)&h->cnn_Wc16, cnn_bf16_packed_weight_elems(Ep8) * sizeof(unsigned short)));
       HIPCHECK(h, launch_cnn_bf16_pack(h->vars[0].dev, c.vocab_size, c.embedding_size, Ep8, h->emb_bf16, W, h->cnn_Wc16, st));
+      if (!h->cnn_Mx3) HIPCHECK(h, hipMalloc((void **)&h->cnn_Mx3, cnn_proj_x3_elems(c.encoding_size) * sizeof(unsigned short)));
+      HIPCHECK(h, launch_pack_cnn_proj_x3(h->vars[h->cnn_M].dev, c.encoding_size, h->cnn_Mx3, st));
     }
     HIPCHECK(h, launch_pack_kn(h->vars[h->cnn_M].dev, 576, c.encoding_size, 72, h->cnn_Mp, st));
   }
@@ -604,7 +606,7 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
         return fail(h, "source_only_cnn (bf16): T*E = %d*%d does not fit the LDS tile of the gfx950 kernel", T, c.embedding_size);
       HIPCHECK(h, launch_cnn_fwd_bf16(ids, h->emb_bf16, h->cnn_Wc16, h->cnn_bias, (float *)h->s_feat.p, h->err_flag, B, T,
                                       c.vocab_size, Ep8, nullptr, nullptr, st));
-      HIPCHECK(h, launch_cnn_proj((const float *)h->s_feat.p, h->cnn_Mp, out, B, c.encoding_size, normalize ? 1 : 0, st));
+      HIPCHECK(h, launch_cnn_proj_x3((const float *)h->s_feat.p, h->cnn_Mx3, out, B, c.encoding_size, normalize ? 1 : 0, st));
       return 0;
     }
     HIPCHECK(h, launch_cnn_fwd(ids, h->emb_pad, h->cnn_Wc, h->cnn_bias, h->cnn_Mp, (float *)h->s_feat.p, out, h->err_flag, B,
@@ -1358,6 +1360,7 @@ void sse_destroy(sse_handle *h) {
   if (h->cnn_Wc) (void)hipFree(h->cnn_Wc);
   if (h->emb_bf16) (void)hipFree(h->emb_bf16);
   if (h->cnn_Wc16) (void)hipFree(h->cnn_Wc16);
+  if (h->cnn_Mx3) (void)hipFree(h->cnn_Mx3);
   if (h->cnn_bias) (void)hipFree(h->cnn_bias);
   if (h->cnn_Mp) (void)hipFree(h->cnn_Mp);
   if (h->train) {
@@ -2124,7 +2127,7 @@ static int cnn_train_grads_locked(sse_handle *h, const int32_t *src_ids_host, co
     // pooling, projection, loss and the optimizer in fp32
     HIPCHECK(h, launch_cnn_fwd_bf16((const int32_t *)ts.ids[0].p, h->emb_bf16, h->cnn_Wc16, h->cnn_bias, (float *)h->s_feat.p,
                                     h->err_flag, B, T, V, Ep8, (float *)ts.feat_rm.p, (int32_t *)ts.pos.p, st));
-    HIPCHECK(h, launch_cnn_proj((const float *)h->s_feat.p, h->cnn_Mp, (float *)ts.raw[0].p, B, S, 0, st));
+    HIPCHECK(h, launch_cnn_proj_x3((const float *)h->s_feat.p, h->cnn_Mx3, (float *)ts.raw[0].p, B, S, 0, st));
   } else {
     HIPCHECK(h, launch_cnn_fwd((const int32_t *)ts.ids[0].p, h->emb_pad, h->cnn_Wc, h->cnn_bias, h->cnn_Mp,
                                (float *)h->s_feat.p, (float *)ts.raw[0].p, h->err_flag, B, T, V, Ep, S, 0,

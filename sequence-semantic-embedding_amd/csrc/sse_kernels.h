@@ -426,6 +426,10 @@ hipError_t launch_cnn_fwd_bf16(const int32_t *ids, const unsigned short *emb_bf1
                                float *featp, int32_t *err, int B, int T, int V, int Ep, float *feat_rm, int32_t *pos,
                                hipStream_t stream);
 hipError_t launch_cnn_proj(const float *featp, const float *Mp, float *out, int B, int S, int normalize, hipStream_t stream);
+// the same tail on split bf16 operands (option cnn_bf16; cnn_fwd_bf16.hip)
+size_t cnn_proj_x3_elems(int S);
+hipError_t launch_pack_cnn_proj_x3(const float *Mv, int S, unsigned short *Mx3, hipStream_t stream);
+hipError_t launch_cnn_proj_x3(const float *featp, const unsigned short *Mx3, float *out, int B, int S, int normalize, hipStream_t stream);
 size_t cnn_lds_bytes(int T, int Ep, int train);
 size_t cnn_packed_weight_floats(int Ep);
 hipError_t launch_pack_conv(const float *const W[4], int E, int Ep, float *out, hipStream_t stream);

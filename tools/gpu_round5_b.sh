@@ -15,4 +15,5 @@ import csv
 rows=list(csv.DictReader(open('gpurun_out/r05b/prof/p_kernel_stats.csv')))
 for r in rows[:22]: print(r['Name'][:90], r['Calls'], r['AverageNs'], r['MinNs'], r['MaxNs'], r['Percentage'])
 PY
+python tools/bench_c3.py 2>&1 | tail -6 | tee $o/c3.txt
 find $o -name "*.csv" -size +5M -delete
