@@ -202,23 +202,52 @@ __global__ __launch_bounds__(256) void proj_norm_x3_kernel(ProjX3Args a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) pacc[i][r] = 0.0f;
   const sse_u32x4 *mp = reinterpret_cast<const sse_u32x4 *>(a.Mx3) + lane;
-  for (int kg = 0; kg < KG; ++kg) {
-    const f32x4 lo4 = *reinterpret_cast<const f32x4 *>(ap + (size_t)kg * 512), hi4 = *reinterpret_cast<const f32x4 *>(ap + (size_t)kg * 512 + 128);
-    const float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+  // two named operand sets: group kg+1's fragments (two float4 of features, eight 16-byte filter fragments) are in flight under
+  // group kg's twelve MFMAs -- without it every group waited out an L2 round trip (36 in a row: 60 us for 11 us of matrix work)
+  auto lda = [&](int kg, f32x4 &x0, f32x4 &x1) {
+    x0 = *reinterpret_cast<const f32x4 *>(ap + (size_t)kg * 512);
+    x1 = *reinterpret_cast<const f32x4 *>(ap + (size_t)kg * 512 + 128);
+  };
+  auto ldb = [&](int kg, sse_u32x4 (&bh)[PT], sse_u32x4 (&bl)[PT]) {
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int nt = wn + 4 * i;
+      const sse_u32x4 *bp = mp + ((size_t)(nt < a.NTS ? nt : 0) * KG + kg) * 128;  // 2 blocks x 64 lanes of 16 bytes
+      bh[i] = bp[0];
+      bl[i] = bp[64];
+    }
+  };
+  auto mma = [&](const f32x4 &x0, const f32x4 &x1, const sse_u32x4 (&bh)[PT], const sse_u32x4 (&bl)[PT]) {
+    const float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
     sse_u32x4 ah, al;
     sse_split8(v, ah, al);
     const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah), a_lo = __builtin_bit_cast(bf16x8, al);
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
-      const int nt = wn + 4 * i;
-      if (nt < a.NTS) {
-        const sse_u32x4 *bp = mp + ((size_t)nt * KG + kg) * 128;  // 2 blocks x 64 lanes of 16 bytes
-        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, bp[0]), b_lo = __builtin_bit_cast(bf16x8, bp[64]);
+      if (wn + 4 * i < a.NTS) {
+        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, bh[i]), b_lo = __builtin_bit_cast(bf16x8, bl[i]);
         pacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, pacc[i], 0, 0, 0);
         pacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, pacc[i], 0, 0, 0);
         pacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, pacc[i], 0, 0, 0);
       }
     }
+  };
+  f32x4 ax0, ax1, ay0, ay1;
+  sse_u32x4 bxh[PT], bxl[PT], byh[PT], byl[PT];
+  lda(0, ax0, ax1);
+  ldb(0, bxh, bxl);
+  for (int kg = 0; kg < KG; kg += 2) {  // KG is even
+    lda(kg + 1, ay0, ay1);
+    ldb(kg + 1, byh, byl);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(ax0, ax1, bxh, bxl);
+    __builtin_amdgcn_sched_barrier(0);
+    const int k2 = (kg + 2 < KG) ? kg + 2 : kg;
+    lda(k2, ax0, ax1);
+    ldb(k2, bxh, bxl);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(ay0, ay1, byh, byl);
+    __builtin_amdgcn_sched_barrier(0);
   }
   float ss[16], scale[16];
 #pragma unroll

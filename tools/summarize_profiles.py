@@ -32,7 +32,7 @@ def main():
         dur = collections.defaultdict(list)
         for r in csv.DictReader(open(os.path.join(d, "p_counter_collection.csv"))):
             if any(k in r["Kernel_Name"] for k in ("lstm_fwd", "lstm_bwd", "dk_x3", "dk_gemm", "dx_scatter", "conv_pool", "proj_norm", "cnn_d", "cnn_bwd", "lstm_cluster", "score_topk", "score_small_index", "rescore_kernel")):
-                key = (r["Kernel_Name"].split("(")[0][:64], r["Grid_Size"])
+                key = (r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:64], r["Grid_Size"])
                 agg[key + (r["Counter_Name"],)].append(float(r["Counter_Value"]))
                 dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         for (k, g, c), v in sorted(agg.items()):
@@ -51,7 +51,7 @@ def main():
     cnn_io = collections.defaultdict(lambda: collections.defaultdict(dict))   # kernel -> counter -> grid -> [values]
     for d in pmc_dirs:
         for r in csv.DictReader(open(os.path.join(d, "p_counter_collection.csv"))):
-            name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
             if ("lstm_fwd_kernel<2, 2, 1, false" in name and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE")
                     and int(r["Grid_Size"]) >= 65536):
                 traffic.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
