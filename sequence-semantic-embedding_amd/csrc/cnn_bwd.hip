@@ -37,7 +37,7 @@ struct CnnBwdArgs {
   float *db_part;       // [NCH][576]
   float *d_emb;         // [V][E] dense embedding gradient (zeroed by the caller)
   float *sq_part;       // [B]
-  int32_t B, T, E, NCH;
+  int32_t B, T, E, NCH, V;  // V: token ids outside [0, V) read row 0 / add nothing (the forward raised the error flag: the update is cancelled)
   int32_t bf16;         // option cnn_bf16: the forward ran on bf16-rounded embeddings / filters; the backward
                         // differentiates THAT function (dW from the rounded windows, dX from the rounded filters)
 };
@@ -84,7 +84,10 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
   auto load_ids = [&](int b) {
 #pragma unroll
     for (int r = 0; r < RMAX; ++r)
-      if (tq + DW_WAVES * r < T) idn[r] = a.ids[(size_t)b * T + tq + DW_WAVES * r];
+      if (tq + DW_WAVES * r < T) {
+        const int id = a.ids[(size_t)b * T + tq + DW_WAVES * r];
+        idn[r] = (id < 0 || id >= a.V) ? 0 : id;
+      }
   };
   auto load_vals = [&]() {
 #pragma unroll
@@ -151,7 +154,9 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
     int buf = 0;
     for (int b = b_begin; b < b_end; ++b, buf ^= 1) {
       for (int i = tid; i < TE; i += DW_THREADS) {
-        const float x = a.emb[(size_t)a.ids[(size_t)b * T + i / E] * E + i % E];
+        int id = a.ids[(size_t)b * T + i / E];
+        if (id < 0 || id >= a.V) id = 0;
+        const float x = a.emb[(size_t)id * E + i % E];
         if constexpr (X16) xs16[buf * TE + i] = (unsigned short)(__float_as_uint(bf16_rne(x)) >> 16);
         else xs[buf * TE + i] = a.bf16 ? bf16_rne(x) : x;
       }
@@ -287,7 +292,8 @@ __global__ __launch_bounds__(256) void cnn_dx_kernel(CnnBwdArgs a) {
       }
     }
     sq += acc * acc;
-    if (acc != 0.0f) atomicAdd(a.d_emb + (size_t)a.ids[(size_t)b * T + t] * E + e, acc);
+    const int id = a.ids[(size_t)b * T + t];
+    if (acc != 0.0f && id >= 0 && id < a.V) atomicAdd(a.d_emb + (size_t)id * E + e, acc);
   }
   red[tid] = sq;
   __syncthreads();
@@ -318,7 +324,7 @@ __global__ void rows_gather_kernel(const float *table, const int32_t *rows, int 
 }
 
 // d_table[rows[b]][:] += d[b][:]; sq[b] = |d[b]|^2 (raw slice norm)
-__global__ void rows_scatter_kernel(const float *d, const int32_t *rows, int B, int S, float *d_table, float *sq) {
+__global__ void rows_scatter_kernel(const float *d, const int32_t *rows, int B, int S, int N, float *d_table, float *sq) {
   const int lane = threadIdx.x & 63, b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (b >= B) return;
   const int r = rows[b];
@@ -326,7 +332,7 @@ __global__ void rows_scatter_kernel(const float *d, const int32_t *rows, int B, 
   for (int s = lane; s < S; s += 64) {
     const float v = d[(size_t)b * S + s];
     acc += v * v;
-    atomicAdd(d_table + (size_t)r * S + s, v);
+    if (r >= 0 && r < N) atomicAdd(d_table + (size_t)r * S + s, v);  // (a row out of range raised the error flag in rows_gather)
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -348,16 +354,16 @@ hipError_t launch_rows_gather(const float *table, const int32_t *rows, int B, in
   return hipGetLastError();
 }
 
-hipError_t launch_rows_scatter(const float *d, const int32_t *rows, int B, int S, float *d_table, float *sq,
+hipError_t launch_rows_scatter(const float *d, const int32_t *rows, int B, int S, int N, float *d_table, float *sq,
                                hipStream_t st) {
-  hipLaunchKernelGGL(rows_scatter_kernel, dim3((B + 3) / 4), dim3(256), 0, st, d, rows, B, S, d_table, sq);
+  hipLaunchKernelGGL(rows_scatter_kernel, dim3((B + 3) / 4), dim3(256), 0, st, d, rows, B, S, N, d_table, sq);
   return hipGetLastError();
 }
 
 hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfeat, const float *feat, const int32_t *pos,
                           const float *const W[4], float *const dW[4], float *const db[4], float *dw_part,
                           float *db_part, float *wt_scratch /* [E*1728] */, unsigned short *wct_scratch /* cnn_wct_elems(E) */,
-                          float *d_emb, float *sq_part, int B, int T, int E, int bf16, hipStream_t st) {
+                          float *d_emb, float *sq_part, int B, int T, int E, int V, int bf16, hipStream_t st) {
   static const int fs[4] = {2, 3, 4, 5}, nf[4] = {256, 128, 128, 64};
   if (E > 64) return hipErrorInvalidValue;
   CnnBwdArgs a;
@@ -373,6 +379,7 @@ hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfe
   a.T = T;
   a.E = E;
   a.NCH = cnn_bwd_chunks(B);
+  a.V = V;
   a.bf16 = bf16;
   // bf16 mode: dX as a dense contraction on the bf16 matrix pipe (cnn_bwd_mfma.hip); fp32 mode (and sequences longer than
   // its three t tiles): the gather kernel over the transposed filters
@@ -413,7 +420,7 @@ hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfe
     else go(cnn_dw_kernel<0, false>);
   }
   hipLaunchKernelGGL(cnn_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ra);
-  if (dx_mfma) return launch_cnn_dx_mfma(ids, dfeat, feat, pos, W, wct_scratch, d_emb, sq_part, B, T, E, st);
+  if (dx_mfma) return launch_cnn_dx_mfma(ids, dfeat, feat, pos, W, wct_scratch, d_emb, sq_part, B, T, E, V, st);
   hipLaunchKernelGGL(cnn_dx_kernel, dim3(B), dim3(256), (size_t)(T + 1) * sizeof(int), st, a);
   return hipGetLastError();
 }

@@ -41,7 +41,7 @@ struct CnnDxArgs {
   const unsigned short *WcT;  // [108][ET][512] bf16 filter fragments in step order (pack_wct_bf16_kernel)
   float *d_emb;               // [V][E] dense embedding gradient (zeroed by the caller)
   float *sq_part;             // [B]
-  int32_t B, T, E;
+  int32_t B, T, E, V;
 };
 
 __device__ __forceinline__ unsigned short dx_bf16(float f) {  // nearest bfloat16, ties to even (finite inputs)
@@ -101,7 +101,10 @@ __global__ __launch_bounds__(DX_WAVES * 64) void cnn_dx_mfma_kernel(CnnDxArgs a)
     s_ghi[w][f] = hi;
     s_glo[w][f] = dx_bf16(g - __uint_as_float((unsigned)hi << 16));
   }
-  for (int t = lane; t < T; t += 64) s_ids[w][t] = (b < a.B) ? a.ids[(size_t)b * T + t] : 0;
+  for (int t = lane; t < T; t += 64) {  // (an id out of range: -1 = add nothing; the forward raised the error flag and the update is cancelled)
+    const int id = (b < a.B) ? a.ids[(size_t)b * T + t] : -1;
+    s_ids[w][t] = (id < 0 || id >= a.V) ? -1 : id;
+  }
   if (tid < CHUNK_VEC) reinterpret_cast<u32x4 *>(s_B[0])[tid] = stage;
   __syncthreads();
   f32x16 acc[TT][ET];
@@ -158,7 +161,10 @@ __global__ __launch_bounds__(DX_WAVES * 64) void cnn_dx_mfma_kernel(CnnDxArgs a)
         const int t = tt * 32 + mfma_row(r, lane), e = et * 32 + (lane & 31);
         const float v = acc[tt][et][r];
         sq += v * v;  // (rows t >= T and columns e >= E are exact zeros: no position matches / zero filter columns)
-        if (v != 0.0f && t < T && e < E && b < a.B) atomicAdd(a.d_emb + (size_t)s_ids[w][t] * E + e, v);
+        if (v != 0.0f && t < T && e < E && b < a.B) {
+          const int id = s_ids[w][t];
+          if (id >= 0) atomicAdd(a.d_emb + (size_t)id * E + e, v);
+        }
       }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
@@ -194,7 +200,7 @@ size_t cnn_wct_elems(int E) { return (size_t)DX_STEPS * ((E + 31) / 32) * 512; }
 
 // dX of the whole batch on the bf16 matrix pipe; wct_scratch: cnn_wct_elems(E) bf16, rebuilt here from the masters
 hipError_t launch_cnn_dx_mfma(const int32_t *ids, const float *dfeat, const float *feat, const int32_t *pos, const float *const W[4],
-                              unsigned short *wct_scratch, float *d_emb, float *sq_part, int B, int T, int E, hipStream_t st) {
+                              unsigned short *wct_scratch, float *d_emb, float *sq_part, int B, int T, int E, int V, hipStream_t st) {
   if (!cnn_dx_mfma_ok(T, E)) return hipErrorInvalidValue;
   const int ET = (E + 31) / 32, TT = (T + 31) / 32;
   WctArgs wa;
@@ -203,7 +209,7 @@ hipError_t launch_cnn_dx_mfma(const int32_t *ids, const float *dfeat, const floa
   wa.E = E;
   wa.ET = ET;
   hipLaunchKernelGGL(pack_wct_bf16_kernel, dim3((int)((cnn_wct_elems(E) + 255) / 256)), dim3(256), 0, st, wa);
-  CnnDxArgs a{ids, dfeat, feat, pos, wct_scratch, d_emb, sq_part, B, T, E};
+  CnnDxArgs a{ids, dfeat, feat, pos, wct_scratch, d_emb, sq_part, B, T, E, V};
   const dim3 grid((B + DX_WAVES - 1) / DX_WAVES), block(DX_WAVES * 64);
 #define DX_GO(tt, et) hipLaunchKernelGGL((cnn_dx_mfma_kernel<tt, et>), grid, block, 0, st, a)
   if (ET == 1) {

@@ -2135,7 +2135,9 @@ static int cnn_train_grads_locked(sse_handle *h, const int32_t *src_ids_host, co
   }
   HIPCHECK(h, launch_rows_gather(table.dev, (const int32_t *)ts.ids[1].p, B, Bp, table.rows, S, (float *)ts.raw[1].p,
                                  h->err_flag, st));
-  if (check_err_flag(h, st)) return 1;  // (never deferred here: the gather / scatter backward below trusts the ids)
+  // (the backward kernels validate every token id / target row themselves: the fused step reads the flag once at its end --
+  // train_apply_locked; a flagged step cancels its own update on the device)
+  if (!ts.defer_err && check_err_flag(h, st)) return 1;
   HIPCHECK(h, launch_loss((const float *)ts.raw[0].p, (const float *)ts.raw[1].p, (const float *)ts.labels.p,
                           (float *)ts.draw[0].p, (float *)ts.draw[1].p, (float *)ts.row_loss.p, (float *)ts.row_acc.p,
                           tail + 1, B, Bp, S, inv_rows, st));
@@ -2155,8 +2157,8 @@ static int cnn_train_grads_locked(sse_handle *h, const int32_t *src_ids_host, co
   float *sq = (float *)ts.sq_part.p;
   HIPCHECK(h, launch_cnn_bwd((const int32_t *)ts.ids[0].p, emb.dev, (const float *)ts.dfeat.p, (const float *)ts.feat_rm.p,
                              (const int32_t *)ts.pos.p, W, dW, db, (float *)ts.dw_part.p, (float *)ts.dbias_part.p,
-                             (float *)ts.wt.p, (unsigned short *)ts.wct.p, emb.grad, sq, B, T, E, h->cnn_bf16 ? 1 : 0, st));
-  HIPCHECK(h, launch_rows_scatter((const float *)ts.draw[1].p, (const int32_t *)ts.ids[1].p, B, S, table.grad, sq + B, st));
+                             (float *)ts.wt.p, (unsigned short *)ts.wct.p, emb.grad, sq, B, T, E, V, h->cnn_bf16 ? 1 : 0, st));
+  HIPCHECK(h, launch_rows_scatter((const float *)ts.draw[1].p, (const int32_t *)ts.ids[1].p, B, S, table.rows, table.grad, sq + B, st));
   // tail[0]: both lookups are IndexedSlices -> raw slice norms
   HIPCHECK(h, launch_sum(sq, 2 * B, (float)B, tail, st));
   ts.grads_ready = true;
@@ -2242,7 +2244,7 @@ static int train_grads_generic_locked(sse_handle *h, const int32_t *src_ids_host
   if (table_tgt) {
     Variable &table = h->vars[h->tgt_table];
     HIPCHECK(h, hipMemsetAsync(table.grad, 0, table.count * sizeof(float), st));
-    HIPCHECK(h, launch_rows_scatter((const float *)ts.draw[1].p, (const int32_t *)ts.ids[1].p, B, S, table.grad,
+    HIPCHECK(h, launch_rows_scatter((const float *)ts.draw[1].p, (const int32_t *)ts.ids[1].p, B, S, table.rows, table.grad,
                                     (float *)ts.sq_part.p + (size_t)nside * T * B, st));
   }
   for (int s = 0; s < nside; ++s) {
@@ -2516,7 +2518,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   // token ids / corpus rows out of range: the sequence-encoder backward kernels validate every id themselves, so the fused
   // step reads the flag once at its end (train_apply_locked; a flagged step cancels its own update on the device) instead
   // of stalling the queue here; the free-target-matrix scatter trusts its rows: checked now
-  if ((!ts.defer_err || table_tgt) && check_err_flag(h, st)) return 1;
+  if (!ts.defer_err && check_err_flag(h, st)) return 1;  // (rows_scatter validates the target rows itself since round 5)
 
   // ---- loss, train accuracy, d(raw encodings)
   if (reserve(h, ts.row_loss, (size_t)B * sizeof(float))) return 1;
@@ -2538,7 +2540,7 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   if (table_tgt) {
     Variable &table = h->vars[h->tgt_table];
     HIPCHECK(h, hipMemsetAsync(table.grad, 0, table.count * sizeof(float), st));
-    HIPCHECK(h, launch_rows_scatter((const float *)ts.draw[1].p, (const int32_t *)ts.ids[1].p, B, S, table.grad,
+    HIPCHECK(h, launch_rows_scatter((const float *)ts.draw[1].p, (const int32_t *)ts.ids[1].p, B, S, table.rows, table.grad,
                                     (float *)ts.sq_part.p + sq_off[1], st));
   }
   HIPCHECK(h, hipEventRecord(ts.ev_fork, st));  // loss + zeroed embedding gradient are ready
