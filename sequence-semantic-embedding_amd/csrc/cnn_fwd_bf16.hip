@@ -71,109 +71,88 @@ __global__ __launch_bounds__(CB_THREADS) void conv_pool_bf16_kernel(CnnBf16Args 
   const int voff = lane * 16;
   const int NSG = NB / CB_SG;
   const int PT = (T + 31) / 32;
-  // work item = (PAIR of 32-filter tiles of one width) x (position tile) x (group of CB_SG sequences): a window fragment read
-  // from LDS feeds TWO MFMAs (round 5; one before: 1 KiB of LDS per MFMA at 16 waves per CU asked for 4x the 128 B/clk the LDS
-  // delivers -- the kernel ran at a quarter of the matrix pipe), a filter fragment CB_SG as before.  Every width has an even
-  // number of tiles (8, 4, 4, 2): 9 pairs.
-  const int n_items = 9 * NSG * PT;
+  const int n_items = 18 * NSG * PT;
   for (;;) {
     int item = 0;
     if (lane == 0) item = atomicAdd(s_next, 1);
     item = __builtin_amdgcn_readfirstlane(item);
     if (item >= n_items) break;
     const int sg = item % NSG, pt = (item / NSG) % PT;
-    int pair = item / (NSG * PT), wi = 3, woff_tiles = 0;  // pair counted from the widest filter down
-    while (pair >= q_nt[wi] / 2) {
-      pair -= q_nt[wi] / 2;
+    int tile = item / (NSG * PT), wi = 3, woff_tiles = 0;  // tile counted from the widest filter down
+    while (tile >= q_nt[wi]) {
+      tile -= q_nt[wi];
       --wi;
     }
-    const int tile = 2 * pair;
     for (int j = 0; j < wi; ++j) woff_tiles += q_nt[j] * ((q_fs[j] * Ep + 15) / 16);
     const int fs = q_fs[wi], KG = (fs * Ep + 15) / 16, P = T - fs + 1;  // a last half group reads 8 bf16 past the window: weights 0
-    const int wsoff = (woff_tiles + tile * KG) * 1024;                  // tile's fragments, then tile + 1's (KG KiB each)
-    float bias[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) bias[u] = a.bias[q_foff[wi] + (tile + u) * 32 + (lane & 31)];
+    const int wsoff = (woff_tiles + tile * KG) * 1024;
+    const float bias = a.bias[q_foff[wi] + tile * 32 + (lane & 31)];
     // lane: position row (lane & 31) of the tile, k half (lane >> 5) -> 8 consecutive bf16
     const unsigned short *xa = xs + (size_t)(sg * CB_SG) * T * Ep + (size_t)(pt * 32 + (lane & 31)) * Ep + (lane >> 5) * 8;
-    f32x16 acc[2][CB_SG];
+    f32x16 acc[CB_SG];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int s = 0; s < CB_SG; ++s)
 #pragma unroll
-      for (int s = 0; s < CB_SG; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[u][s][r] = 0.0f;
-    auto wl = [&](int u, int kg) -> bf16x8 {
-      return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, voff, wsoff + (u * KG + kg) * 1024, 0));
+      for (int r = 0; r < 16; ++r) acc[s][r] = 0.0f;
+    auto wl = [&](int kg) -> bf16x8 {
+      return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, voff, wsoff + kg * 1024, 0));
     };
     auto al = [&](int s, int kg) -> bf16x8 {
       return *reinterpret_cast<const bf16x8 *>(xa + (size_t)s * T * Ep + kg * 16);
     };
-    // two named operand sets: group kg+1's fragments are in flight under group kg's 8 MFMAs
-    bf16x8 bx[2], by[2], ax[CB_SG], ay[CB_SG];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) bx[u] = wl(u, 0);
+    // two named operand sets: group kg+1's fragments are in flight under group kg's 4 MFMAs
+    bf16x8 bx = wl(0), by, ax[CB_SG], ay[CB_SG];
 #pragma unroll
     for (int s = 0; s < CB_SG; ++s) ax[s] = al(s, 0);
     int kg = 0;
     for (; kg + 1 < KG; kg += 2) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) by[u] = wl(u, kg + 1);
+      by = wl(kg + 1);
 #pragma unroll
       for (int s = 0; s < CB_SG; ++s) ay[s] = al(s, kg + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < CB_SG; ++s)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) acc[u][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[s], bx[u], acc[u][s], 0, 0, 0);
+      for (int s = 0; s < CB_SG; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[s], bx, acc[s], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       const int k2 = (kg + 2 < KG) ? kg + 2 : kg;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) bx[u] = wl(u, k2);
+      bx = wl(k2);
 #pragma unroll
       for (int s = 0; s < CB_SG; ++s) ax[s] = al(s, k2);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < CB_SG; ++s)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) acc[u][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ay[s], by[u], acc[u][s], 0, 0, 0);
+      for (int s = 0; s < CB_SG; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ay[s], by, acc[s], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (kg < KG) {
 #pragma unroll
-      for (int s = 0; s < CB_SG; ++s)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) acc[u][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[s], bx[u], acc[u][s], 0, 0, 0);
+      for (int s = 0; s < CB_SG; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[s], bx, acc[s], 0, 0, 0);
     }
     // bias + ReLU + max over this tile's valid positions (row = position, column = filter)
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int s = 0; s < CB_SG; ++s) {
+      if constexpr (TRAIN) {
+        unsigned long long key = 0;  // below every valid position's key
 #pragma unroll
-      for (int s = 0; s < CB_SG; ++s) {
-        if constexpr (TRAIN) {
-          unsigned long long key = 0;  // below every valid position's key
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int p = pt * 32 + mfma_row(r, lane);
-            const float v = fmaxf(acc[u][s][r] + bias[u], 0.0f);
-            const unsigned long long kv = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(~p);
-            if (p < P && kv > key) key = kv;
-          }
-          const unsigned long long other = __shfl_xor(key, 32);
-          if (other > key) key = other;
-          if (lane < 32) atomicMax(&featk[(sg * CB_SG + s) * 576 + q_foff[wi] + (tile + u) * 32 + lane], key);
-        } else {
-          float m = 0.0f;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int p = pt * 32 + mfma_row(r, lane);
-            const float v = fmaxf(acc[u][s][r] + bias[u], 0.0f);
-            m = fmaxf(m, (p < P) ? v : 0.0f);
-          }
-          m = fmaxf(m, __shfl_xor(m, 32));
-          if (lane < 32) atomicMax(&feat[(sg * CB_SG + s) * 576 + q_foff[wi] + (tile + u) * 32 + lane], __float_as_int(m));
+        for (int r = 0; r < 16; ++r) {
+          const int p = pt * 32 + mfma_row(r, lane);
+          const float v = fmaxf(acc[s][r] + bias, 0.0f);
+          const unsigned long long kv = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(~p);
+          if (p < P && kv > key) key = kv;
         }
+        const unsigned long long other = __shfl_xor(key, 32);
+        if (other > key) key = other;
+        if (lane < 32) atomicMax(&featk[(sg * CB_SG + s) * 576 + q_foff[wi] + tile * 32 + lane], key);
+      } else {
+        float m = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int p = pt * 32 + mfma_row(r, lane);
+          const float v = fmaxf(acc[s][r] + bias, 0.0f);
+          m = fmaxf(m, (p < P) ? v : 0.0f);
+        }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        if (lane < 32) atomicMax(&feat[(sg * CB_SG + s) * 576 + q_foff[wi] + tile * 32 + lane], __float_as_int(m));
       }
+    }
   }
   __syncthreads();
   for (int i = tid; i < NB * 576; i += CB_THREADS) {
