@@ -924,7 +924,12 @@ static int choose_nsplit(int NQ, int QB, int64_t NT) {
     };
     int best = nsplit;
     double best_score = eff(nsplit);
-    for (int ns = nsplit * 2, d = 1; ns <= 128 && NT / ns >= 256; ns *= 2, ++d) {
+    // (splits down to 200 n-tiles -- 256 before round 5: the crosslingual index, 1002 tiles x 129 query blocks, stopped at 2 splits = 258
+    // workgroups = one full round + one of 2 workgroups, and its 32 candidates per query left 3,850 of 16,491 crowded random-init
+    // queries to the fp32 second chance: 1.60 ms per pass; 4 splits: 1.17 ms, no second chance; 8 splits 1.18; on well-spread
+    // vectors 0.97 / 1.07 / 1.38 ms -- tools/bench_c3.py, profiles/r05_notes.txt)
+    static const int min_tiles = getenv("SSE_SPLIT_MIN_TILES") ? atoi(getenv("SSE_SPLIT_MIN_TILES")) : 200;  // (env: measurement aid)
+    for (int ns = nsplit * 2, d = 1; ns <= 128 && NT / ns >= min_tiles; ns *= 2, ++d) {
       const double sc = eff(ns) - 0.01 * d;
       if (sc > best_score + 0.01) {
         best = ns;
