@@ -56,21 +56,30 @@ constexpr int DW_THREADS = 512, DW_WAVES = DW_THREADS / 64;
 
 template <int FS, int NF, int RMAX, bool X16>
 __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
-  constexpr int PARTS = DW_THREADS / NF;
-  constexpr int KMAX = ((FS * 64 + PARTS - 1) / PARTS + 3) & ~3;  // E <= 64; a multiple of 4
-  const int tid = threadIdx.x, f = tid % NF, part = tid / NF;
-  const int T = a.T, E = a.E, K = FS * E, KPT = ((K + PARTS - 1) / PARTS + 3) & ~3, k0 = part * KPT, TE = T * E;  // (k0 % 4 == 0)
-  // X16 (option cnn_bf16, even E): the tile holds the bf16-rounded embeddings AS bf16 -- half the LDS bytes, and a row is E / 2
-  // dwords: 25 for E = 50, an ODD bank stride, where the fp32 rows (50 dwords) put every window start on an even bank and
-  // doubled the conflicts of the 64 lanes' independent window reads.  A dword unpacks into two exact fp32 values.
+  // Round 5, second version: LANE = k.  A wave owns FPW = NF / 8 filters; for filter f of sequence b its 64 lanes read 64
+  // CONSECUTIVE elements of the winning window (one conflict-free LDS read per 64 k; g and the position are wave-uniform:
+  // v_readlane) and add g * x into acc[filter][k chunk].  The first version (thread = filter, registers = k) had 64 lanes
+  // reading 64 different rows: bank conflicts set the pace (0.20 - 0.27 ms at 8192 sequences).  Each (k, f) is still summed over
+  // the chunk's sequences in order and the chunks in order: results bit-identical to every earlier version.
+  constexpr int FPW = NF / DW_WAVES;                 // 32, 16, 16, 8
+  constexpr int EPL = X16 ? 2 : 1;                   // elements per lane and read (a dword of the bf16 tile holds two)
+  constexpr int NCK = (FS * 64 + 64 * EPL - 1) / (64 * EPL);  // k chunks of 64 lanes (E <= 64)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int T = a.T, E = a.E, K = FS * E, TE = T * E;
+  // X16 (option cnn_bf16, even E): the tile holds the bf16-rounded embeddings AS bf16 -- half the LDS bytes; a dword unpacks
+  // into two exact fp32 values.
   unsigned short *xs16 = reinterpret_cast<unsigned short *>(xs);
-  const int wi = FS - 2, fo = b_foff[wi] + f;
+  const int wi = FS - 2;
   const int chunk = blockIdx.x, per = (a.B + a.NCH - 1) / a.NCH;
   const int b_begin = chunk * per, b_end = min(a.B, b_begin + per);
-  float acc[KMAX];
+  float acc[FPW][NCK][EPL];
 #pragma unroll
-  for (int kk = 0; kk < KMAX; ++kk) acc[kk] = 0.0f;
-  float bsum = 0.0f;
+  for (int i = 0; i < FPW; ++i)
+#pragma unroll
+    for (int c = 0; c < NCK; ++c)
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) acc[i][c][e] = 0.0f;
+  float bsum = 0.0f;  // lane fl < FPW: d bias of this wave's filter fl
   // this thread's elements of a [T][E] tile: column ce = lane (idle for ce >= E), tokens tq, tq + 8, tq + 16, .. with tq = its
   // wave -- a wave reads ONE token id per step (uniform: scalar loads, no vector registers) and one embedding row coalesced
   const int ce = tid & 63, tq = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,10 +111,11 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
         else xs[buf * TE + (tq + DW_WAVES * r) * E + ce] = a.bf16 ? bf16_rne(vn[r]) : vn[r];
       }
   };
-  // The multiply is branch-free inside: every thread walks all KMAX slots of its k range -- slots past the range read whatever
-  // follows in LDS (the next rows, the other buffer, the KMAX-float pad behind the tiles) into accumulators that are never
-  // stored.  (With a per-slot range test the compiler emitted one ds_read -> wait -> fmac block per slot: 100 serialised LDS
-  // round trips per sequence, 8 us of the 8.5 us an iteration took.)  Even E: the window starts 8-byte aligned -> float2 reads.
+  // (Slots past the window -- k >= K -- read whatever follows in LDS, the next rows / the other buffer / the pad behind the
+  // tiles, into accumulators that are never stored: no per-slot range test, which once made the compiler emit one
+  // ds_read -> s_waitcnt -> v_fmac block PER SLOT.)
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fo = b_foff[wi] + w * FPW + (lane < FPW ? lane : 0);  // lane fl holds filter fl's gradient / position
   float g_n = 0.0f, f_n = 0.0f;
   int p_n = 0;
   auto fetch_g = [&](int b) {  // the next sequence's gradient / ReLU mask / position: in flight under this one's multiply
@@ -113,39 +123,30 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
     f_n = a.feat[(size_t)b * 576 + fo];
     p_n = a.pos[(size_t)b * 576 + fo];
   };
-  const bool vec2 = (E & 1) == 0;
   auto multiply = [&](int buf, int b) {
-    const float g = (f_n > 0.0f) ? g_n : 0.0f;
-    const int p = p_n;
+    const float gl = (f_n > 0.0f && lane < FPW) ? g_n : 0.0f;
+    const int pl = p_n;
     if (b + 1 < b_end) fetch_g(b + 1);
-    if (g != 0.0f) {
-      if constexpr (X16) {
-        const unsigned *xw = reinterpret_cast<const unsigned *>(xs16 + buf * TE + p * E + k0);  // (E even, k0 % 4 == 0: dword aligned)
-        unsigned v[KMAX / 2];  // all reads of the window in flight, then the FMAs
+    bsum += gl;
 #pragma unroll
-        for (int i = 0; i < KMAX / 2; ++i) v[i] = xw[i];
+    for (int i = 0; i < FPW; ++i) {
+      const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gl), i));
+      {  // (no "if (g != 0)": a branch per filter exposes one LDS round trip per filter; a masked filter adds 0 * (finite window data))
+        const int p = __builtin_amdgcn_readlane(pl, i);
+        if constexpr (X16) {
+          const unsigned *xw = reinterpret_cast<const unsigned *>(xs16 + buf * TE + p * E) + lane;  // (E even: dword aligned)
 #pragma unroll
-        for (int i = 0; i < KMAX / 2; ++i) {
-          acc[2 * i] += g * __uint_as_float(v[i] << 16);
-          acc[2 * i + 1] += g * __uint_as_float(v[i] & 0xFFFF0000u);
-        }
-      } else {
-        const float *xw = xs + buf * TE + p * E + k0;
-        if (vec2) {
-          float2 v[KMAX / 2];
-#pragma unroll
-          for (int i = 0; i < KMAX / 2; ++i) v[i] = *reinterpret_cast<const float2 *>(xw + 2 * i);
-#pragma unroll
-          for (int i = 0; i < KMAX / 2; ++i) {
-            acc[2 * i] += g * v[i].x;
-            acc[2 * i + 1] += g * v[i].y;
+          for (int c = 0; c < NCK; ++c) {
+            const unsigned v = xw[c * 64];
+            acc[i][c][0] += g * __uint_as_float(v << 16);
+            acc[i][c][1] += g * __uint_as_float(v & 0xFFFF0000u);
           }
         } else {
+          const float *xw = xs + buf * TE + p * E + lane;
 #pragma unroll
-          for (int kk = 0; kk < KMAX; ++kk) acc[kk] += g * xw[kk];
+          for (int c = 0; c < NCK; ++c) acc[i][c][0] += g * xw[c * 64];
         }
       }
-      bsum += g;
     }
   };
   if (b_begin < b_end) fetch_g(b_begin);
@@ -184,17 +185,26 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
       __syncthreads();
     }
   }
+  // partials [chunk][filter][k] (k contiguous: coalesced stores; cnn_reduce_kernel reads them the same way)
   float *out = a.dw_part[wi] + (size_t)chunk * K * NF;
 #pragma unroll
-  for (int kk = 0; kk < KMAX; ++kk)
-    if (kk < KPT && k0 + kk < K) out[(size_t)(k0 + kk) * NF + f] = acc[kk];
-  if (part == 0) a.db_part[(size_t)chunk * 576 + fo] = bsum;
+  for (int i = 0; i < FPW; ++i) {
+    float *row = out + (size_t)(w * FPW + i) * K;
+#pragma unroll
+    for (int c = 0; c < NCK; ++c)
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        const int k = (c * 64 + lane) * EPL + e;
+        if (k < K) row[k] = acc[i][c][e];
+      }
+  }
+  if (lane < FPW) a.db_part[(size_t)chunk * 576 + b_foff[wi] + w * FPW + lane] = bsum;
 }
 
 // (the four bodies are inlined: as calls they took the argument block through scratch and spilled around the call)
 template <int RMAX, bool X16>
 __global__ __launch_bounds__(DW_THREADS) void cnn_dw_kernel(CnnBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];  // [2][T*E] fp32 (or bf16: X16) + 128 floats of pad (read, never used: see multiply)
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [2][T*E] fp32 (or bf16: X16) + 384 floats of pad (read, never used: see multiply)
   switch (blockIdx.y) {
     case 0: dw_body<2, 256, RMAX, X16>(a, xs); break;
     case 1: dw_body<3, 128, RMAX, X16>(a, xs); break;
@@ -216,10 +226,11 @@ __global__ void cnn_reduce_kernel(CnnReduceArgs a) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
-    if (i < a.n[w]) {
+    if (i < a.n[w]) {  // i = f * K + k in the partials' layout [chunk][filter][k]; dW is [k][filter]
       float acc = 0.0f;
       for (int c = 0; c < a.nch; ++c) acc += a.dw_part[w][(size_t)c * a.n[w] + i];
-      a.dW[w][i] = acc;
+      const int nf = w == 0 ? 256 : w == 3 ? 64 : 128, K = a.n[w] / nf;
+      a.dW[w][(size_t)(i % K) * nf + i / K] = acc;
       return;
     }
     i -= a.n[w];
@@ -405,7 +416,7 @@ hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfe
   }
   ra.db_part = db_part;
   ra.nch = a.NCH;
-  const size_t lds = ((size_t)2 * T * E + 128) * sizeof(float);
+  const size_t lds = ((size_t)2 * T * E + 384) * sizeof(float);  // (pad: a window read runs up to 5 * 64 elements past its start)
   const bool x16 = bf16 && (E & 1) == 0;
   auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(a.NCH, 4), dim3(DW_THREADS), lds, st, a); };
   if (x16) {
