@@ -52,16 +52,16 @@ __device__ __forceinline__ float bf16_rne(float f) {  // nearest bfloat16 (ties 
 // to the round-2 kernel): the gathered embedding values of sequence b+1 and the token ids of sequence b+2 are in flight in
 // registers while sequence b is multiplied out of LDS, so the two dependent global loads (ids -> embedding row) of a
 // sequence no longer sit between two barriers.  0.55 -> 0.1x ms at 8192 sequences (profiles/r05_notes.txt).
-constexpr int DW_THREADS = 512, DW_WAVES = DW_THREADS / 64;
+constexpr int DW_THREADS = 1024, DW_WAVES = DW_THREADS / 64;  // 16 waves: one workgroup per CU, 4 waves per SIMD
 
 template <int FS, int NF, int RMAX, bool X16>
 __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
-  // Round 5, second version: LANE = k.  A wave owns FPW = NF / 8 filters; for filter f of sequence b its 64 lanes read 64
+  // Round 5, second version: LANE = k.  A wave owns FPW = NF / 16 filters; for filter f of sequence b its 64 lanes read 64
   // CONSECUTIVE elements of the winning window (one conflict-free LDS read per 64 k; g and the position are wave-uniform:
   // v_readlane) and add g * x into acc[filter][k chunk].  The first version (thread = filter, registers = k) had 64 lanes
   // reading 64 different rows: bank conflicts set the pace (0.20 - 0.27 ms at 8192 sequences).  Each (k, f) is still summed over
   // the chunk's sequences in order and the chunks in order: results bit-identical to every earlier version.
-  constexpr int FPW = NF / DW_WAVES;                 // 32, 16, 16, 8
+  constexpr int FPW = NF / DW_WAVES;                 // 16, 8, 8, 4
   constexpr int EPL = X16 ? 2 : 1;                   // elements per lane and read (a dword of the bf16 tile holds two)
   constexpr int NCK = (FS * 64 + 64 * EPL - 1) / (64 * EPL);  // k chunks of 64 lanes (E <= 64)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -80,15 +80,20 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
 #pragma unroll
       for (int e = 0; e < EPL; ++e) acc[i][c][e] = 0.0f;
   float bsum = 0.0f;  // lane fl < FPW: d bias of this wave's filter fl
-  // this thread's elements of a [T][E] tile: column ce = lane (idle for ce >= E), tokens tq, tq + 8, tq + 16, .. with tq = its
+  // this thread's elements of a [T][E] tile: column ce = lane (idle for ce >= E), tokens tq, tq + 16, tq + 32, .. with tq = its
   // wave -- a wave reads ONE token id per step (uniform: scalar loads, no vector registers) and one embedding row coalesced
   const int ce = tid & 63, tq = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // pipeline depth (round 5, third version): with 16 waves an iteration's arithmetic is ~0.5 us, well below an HBM / L2 round
+  // trip -- one iteration of lead left every iteration waiting for its loads (2.4 us).  Now: embedding values of b+1 (landed)
+  // and b+2 (in flight), token ids of b+3 (in flight); gradient / mask / position of b+1 and b+2.
   int idn[RMAX > 0 ? RMAX : 1];   // token ids in flight (wave-uniform)
-  float vn[RMAX > 0 ? RMAX : 1];  // embedding values in flight
+  float vn[RMAX > 0 ? RMAX : 1];  // embedding values of the sequence staged next
+  float vm[RMAX > 0 ? RMAX : 1];  // ... and of the one after
 #pragma unroll
   for (int r = 0; r < RMAX; ++r) {
     idn[r] = 0;
     vn[r] = 0.0f;
+    vm[r] = 0.0f;
   }
   auto load_ids = [&](int b) {
 #pragma unroll
@@ -98,10 +103,10 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
         idn[r] = (id < 0 || id >= a.V) ? 0 : id;
       }
   };
-  auto load_vals = [&]() {
+  auto load_vals = [&](float (&dst)[RMAX > 0 ? RMAX : 1]) {
 #pragma unroll
     for (int r = 0; r < RMAX; ++r)
-      if (tq + DW_WAVES * r < T && ce < E) vn[r] = a.emb[(size_t)idn[r] * E + ce];
+      if (tq + DW_WAVES * r < T && ce < E) dst[r] = a.emb[(size_t)idn[r] * E + ce];
   };
   auto store_vals = [&](int buf) {
 #pragma unroll
@@ -116,17 +121,20 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
   // ds_read -> s_waitcnt -> v_fmac block PER SLOT.)
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fo = b_foff[wi] + w * FPW + (lane < FPW ? lane : 0);  // lane fl holds filter fl's gradient / position
-  float g_n = 0.0f, f_n = 0.0f;
-  int p_n = 0;
-  auto fetch_g = [&](int b) {  // the next sequence's gradient / ReLU mask / position: in flight under this one's multiply
-    g_n = a.dfeat[(size_t)b * 576 + fo];
-    f_n = a.feat[(size_t)b * 576 + fo];
-    p_n = a.pos[(size_t)b * 576 + fo];
+  float g_n = 0.0f, f_n = 0.0f, g_m = 0.0f, f_m = 0.0f;  // (_n: the sequence multiplied next; _m: the one after, in flight)
+  int p_n = 0, p_m = 0;
+  auto fetch_g = [&](int b) {
+    g_m = a.dfeat[(size_t)b * 576 + fo];
+    f_m = a.feat[(size_t)b * 576 + fo];
+    p_m = a.pos[(size_t)b * 576 + fo];
   };
   auto multiply = [&](int buf, int b) {
     const float gl = (f_n > 0.0f && lane < FPW) ? g_n : 0.0f;
     const int pl = p_n;
-    if (b + 1 < b_end) fetch_g(b + 1);
+    g_n = g_m;
+    f_n = f_m;
+    p_n = p_m;
+    if (b + 2 < b_end) fetch_g(b + 2);
     bsum += gl;
 #pragma unroll
     for (int i = 0; i < FPW; ++i) {
@@ -149,7 +157,13 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
       }
     }
   };
-  if (b_begin < b_end) fetch_g(b_begin);
+  if (b_begin < b_end) {
+    fetch_g(b_begin);
+    g_n = g_m;
+    f_n = f_m;
+    p_n = p_m;
+    if (b_begin + 1 < b_end) fetch_g(b_begin + 1);
+  }
   if constexpr (RMAX == 0) {
     // any T (more than 160 tokens: narrow embeddings): the plain staging loop, one sequence between two barriers
     int buf = 0;
@@ -167,21 +181,27 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
   } else {
     if (b_begin < b_end) {
       load_ids(b_begin);
-      load_vals();
+      load_vals(vn);
       store_vals(0);
       if (b_begin + 1 < b_end) {
         load_ids(b_begin + 1);
-        load_vals();
+        load_vals(vn);
       }
-      if (b_begin + 2 < b_end) load_ids(b_begin + 2);
+      if (b_begin + 2 < b_end) {
+        load_ids(b_begin + 2);
+        load_vals(vm);
+      }
+      if (b_begin + 3 < b_end) load_ids(b_begin + 3);
     }
     __syncthreads();
     int buf = 0;
     for (int b = b_begin; b < b_end; ++b, buf ^= 1) {
       multiply(buf, b);
-      if (b + 1 < b_end) store_vals(buf ^ 1);  // (that buffer was last read before the previous barrier)
-      if (b + 2 < b_end) load_vals();           // ids of b+2 arrived during this iteration
-      if (b + 3 < b_end) load_ids(b + 3);
+      if (b + 1 < b_end) store_vals(buf ^ 1);  // vn = sequence b+1 (that buffer was last read before the previous barrier)
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) vn[r] = vm[r];  // b+2 moves up
+      if (b + 3 < b_end) load_vals(vm);              // ids of b+3 arrived an iteration ago
+      if (b + 4 < b_end) load_ids(b + 4);
       __syncthreads();
     }
   }
@@ -420,14 +440,14 @@ hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfe
   const bool x16 = bf16 && (E & 1) == 0;
   auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(a.NCH, 4), dim3(DW_THREADS), lds, st, a); };
   if (x16) {
-    if (T <= DW_WAVES * 8) go(cnn_dw_kernel<8, true>);
-    else if (T <= DW_WAVES * 12) go(cnn_dw_kernel<12, true>);
-    else if (T <= DW_WAVES * 20) go(cnn_dw_kernel<20, true>);
+    if (T <= DW_WAVES * 4) go(cnn_dw_kernel<4, true>);
+    else if (T <= DW_WAVES * 6) go(cnn_dw_kernel<6, true>);
+    else if (T <= DW_WAVES * 10) go(cnn_dw_kernel<10, true>);
     else go(cnn_dw_kernel<0, true>);
   } else {
-    if (T <= DW_WAVES * 8) go(cnn_dw_kernel<8, false>);
-    else if (T <= DW_WAVES * 12) go(cnn_dw_kernel<12, false>);
-    else if (T <= DW_WAVES * 20) go(cnn_dw_kernel<20, false>);
+    if (T <= DW_WAVES * 4) go(cnn_dw_kernel<4, false>);
+    else if (T <= DW_WAVES * 6) go(cnn_dw_kernel<6, false>);
+    else if (T <= DW_WAVES * 10) go(cnn_dw_kernel<10, false>);
     else go(cnn_dw_kernel<0, false>);
   }
   hipLaunchKernelGGL(cnn_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ra);
