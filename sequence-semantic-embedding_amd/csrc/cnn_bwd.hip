@@ -52,16 +52,17 @@ __device__ __forceinline__ float bf16_rne(float f) {  // nearest bfloat16 (ties 
 // to the round-2 kernel): the gathered embedding values of sequence b+1 and the token ids of sequence b+2 are in flight in
 // registers while sequence b is multiplied out of LDS, so the two dependent global loads (ids -> embedding row) of a
 // sequence no longer sit between two barriers.  0.55 -> 0.1x ms at 8192 sequences (profiles/r05_notes.txt).
-constexpr int DW_THREADS = 1024, DW_WAVES = DW_THREADS / 64;  // 16 waves: one workgroup per CU, 4 waves per SIMD
+constexpr int DW_THREADS = 512, DW_WAVES = DW_THREADS / 64;
+constexpr int DW_G = 4;  // sequences staged per barrier
 
 template <int FS, int NF, int RMAX, bool X16>
 __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
-  // Round 5, second version: LANE = k.  A wave owns FPW = NF / 16 filters; for filter f of sequence b its 64 lanes read 64
+  // Round 5, second version: LANE = k.  A wave owns FPW = NF / 8 filters; for filter f of sequence b its 64 lanes read 64
   // CONSECUTIVE elements of the winning window (one conflict-free LDS read per 64 k; g and the position are wave-uniform:
   // v_readlane) and add g * x into acc[filter][k chunk].  The first version (thread = filter, registers = k) had 64 lanes
   // reading 64 different rows: bank conflicts set the pace (0.20 - 0.27 ms at 8192 sequences).  Each (k, f) is still summed over
   // the chunk's sequences in order and the chunks in order: results bit-identical to every earlier version.
-  constexpr int FPW = NF / DW_WAVES;                 // 16, 8, 8, 4
+  constexpr int FPW = NF / DW_WAVES;                 // 32, 16, 16, 8
   constexpr int EPL = X16 ? 2 : 1;                   // elements per lane and read (a dword of the bf16 tile holds two)
   constexpr int NCK = (FS * 64 + 64 * EPL - 1) / (64 * EPL);  // k chunks of 64 lanes (E <= 64)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -80,92 +81,45 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
 #pragma unroll
       for (int e = 0; e < EPL; ++e) acc[i][c][e] = 0.0f;
   float bsum = 0.0f;  // lane fl < FPW: d bias of this wave's filter fl
-  // this thread's elements of a [T][E] tile: column ce = lane (idle for ce >= E), tokens tq, tq + 16, tq + 32, .. with tq = its
-  // wave -- a wave reads ONE token id per step (uniform: scalar loads, no vector registers) and one embedding row coalesced
-  const int ce = tid & 63, tq = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // pipeline depth (round 5, third version): with 16 waves an iteration's arithmetic is ~0.5 us, well below an HBM / L2 round
-  // trip -- one iteration of lead left every iteration waiting for its loads (2.4 us).  Now: embedding values of b+1 (landed)
-  // and b+2 (in flight), token ids of b+3 (in flight); gradient / mask / position of b+1 and b+2.
-  int idn[RMAX > 0 ? RMAX : 1];   // token ids in flight (wave-uniform)
-  float vn[RMAX > 0 ? RMAX : 1];  // embedding values of the sequence staged next
-  float vm[RMAX > 0 ? RMAX : 1];  // ... and of the one after
-#pragma unroll
-  for (int r = 0; r < RMAX; ++r) {
-    idn[r] = 0;
-    vn[r] = 0.0f;
-    vm[r] = 0.0f;
-  }
-  auto load_ids = [&](int b) {
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r)
-      if (tq + DW_WAVES * r < T) {
-        const int id = a.ids[(size_t)b * T + tq + DW_WAVES * r];
-        idn[r] = (id < 0 || id >= a.V) ? 0 : id;
-      }
-  };
-  auto load_vals = [&](float (&dst)[RMAX > 0 ? RMAX : 1]) {
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r)
-      if (tq + DW_WAVES * r < T && ce < E) dst[r] = a.emb[(size_t)idn[r] * E + ce];
-  };
-  auto store_vals = [&](int buf) {
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r)
-      if (tq + DW_WAVES * r < T && ce < E) {
-        if constexpr (X16) xs16[buf * TE + (tq + DW_WAVES * r) * E + ce] = (unsigned short)(__float_as_uint(bf16_rne(vn[r])) >> 16);
-        else xs[buf * TE + (tq + DW_WAVES * r) * E + ce] = a.bf16 ? bf16_rne(vn[r]) : vn[r];
-      }
-  };
-  // (Slots past the window -- k >= K -- read whatever follows in LDS, the next rows / the other buffer / the pad behind the
-  // tiles, into accumulators that are never stored: no per-slot range test, which once made the compiler emit one
-  // ds_read -> s_waitcnt -> v_fmac block PER SLOT.)
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fo = b_foff[wi] + w * FPW + (lane < FPW ? lane : 0);  // lane fl holds filter fl's gradient / position
-  float g_n = 0.0f, f_n = 0.0f, g_m = 0.0f, f_m = 0.0f;  // (_n: the sequence multiplied next; _m: the one after, in flight)
-  int p_n = 0, p_m = 0;
-  auto fetch_g = [&](int b) {
-    g_m = a.dfeat[(size_t)b * 576 + fo];
-    f_m = a.feat[(size_t)b * 576 + fo];
-    p_m = a.pos[(size_t)b * 576 + fo];
-  };
-  auto multiply = [&](int buf, int b) {
-    const float gl = (f_n > 0.0f && lane < FPW) ? g_n : 0.0f;
-    const int pl = p_n;
-    g_n = g_m;
-    f_n = f_m;
-    p_n = p_m;
-    if (b + 2 < b_end) fetch_g(b + 2);
+  // Staging, third version.  Ablation of the second (one sequence per barrier, 16 waves; profiles/r05_notes.txt): with the
+  // multiply AND every global load switched off the kernel still took half its time -- the per-sequence barrier and the loop
+  // skeleton, ~1 us per iteration.  Now DW_G = 4 sequences per barrier: the chunk's token ids sit in LDS (staged once,
+  // validated), the next group's embedding values and gradient / mask / position words are loaded at the top of a group step
+  // and stored / taken over at its bottom, four multiplies later.
+  // This thread's elements of a [T][E] tile: column ce = lane (idle for ce >= E), tokens tq, tq + 8, .. with tq = its wave.
+  const int ce = tid & 63, tq = __builtin_amdgcn_readfirstlane(tid >> 6), w = tq;
+  constexpr int RM = RMAX > 0 ? RMAX : 1;
+  int *s_ids = reinterpret_cast<int *>(xs + 2 * DW_G * TE + 384);  // [per][T] (RMAX > 0 only)
+  const int fo = b_foff[wi] + w * FPW + (lane < FPW ? lane : 0);    // lane fl holds filter fl's gradient / position
+  // (Slots past the window -- k >= K -- read whatever follows in LDS, the next rows / tiles / the pad behind them, into
+  // accumulators that are never stored: no per-slot range test, which once made the compiler emit one ds_read -> s_waitcnt ->
+  // v_fmac block PER SLOT.  No "if (g != 0)" either: a branch per filter exposes one LDS round trip per filter; a masked filter
+  // adds 0 * (finite window data).)
+  auto multiply = [&](int tile, float g_l, float f_l, int pl) {
+    const float gl = (f_l > 0.0f && lane < FPW) ? g_l : 0.0f;
     bsum += gl;
 #pragma unroll
     for (int i = 0; i < FPW; ++i) {
       const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gl), i));
-      {  // (no "if (g != 0)": a branch per filter exposes one LDS round trip per filter; a masked filter adds 0 * (finite window data))
-        const int p = __builtin_amdgcn_readlane(pl, i);
-        if constexpr (X16) {
-          const unsigned *xw = reinterpret_cast<const unsigned *>(xs16 + buf * TE + p * E) + lane;  // (E even: dword aligned)
+      const int p = __builtin_amdgcn_readlane(pl, i);
+      if constexpr (X16) {
+        const unsigned *xw = reinterpret_cast<const unsigned *>(xs16 + tile * TE + p * E) + lane;  // (E even: dword aligned)
 #pragma unroll
-          for (int c = 0; c < NCK; ++c) {
-            const unsigned v = xw[c * 64];
-            acc[i][c][0] += g * __uint_as_float(v << 16);
-            acc[i][c][1] += g * __uint_as_float(v & 0xFFFF0000u);
-          }
-        } else {
-          const float *xw = xs + buf * TE + p * E + lane;
-#pragma unroll
-          for (int c = 0; c < NCK; ++c) acc[i][c][0] += g * xw[c * 64];
+        for (int c = 0; c < NCK; ++c) {
+          const unsigned v = xw[c * 64];
+          acc[i][c][0] += g * __uint_as_float(v << 16);
+          acc[i][c][1] += g * __uint_as_float(v & 0xFFFF0000u);
         }
+      } else {
+        const float *xw = xs + tile * TE + p * E + lane;
+#pragma unroll
+        for (int c = 0; c < NCK; ++c) acc[i][c][0] += g * xw[c * 64];
       }
     }
   };
-  if (b_begin < b_end) {
-    fetch_g(b_begin);
-    g_n = g_m;
-    f_n = f_m;
-    p_n = p_m;
-    if (b_begin + 1 < b_end) fetch_g(b_begin + 1);
-  }
   if constexpr (RMAX == 0) {
-    // any T (more than 160 tokens: narrow embeddings): the plain staging loop, one sequence between two barriers
+    // any T (more than 160 tokens: narrow embeddings) or a chunk whose ids do not fit LDS: the plain staging loop, one
+    // sequence between two barriers
     int buf = 0;
     for (int b = b_begin; b < b_end; ++b, buf ^= 1) {
       for (int i = tid; i < TE; i += DW_THREADS) {
@@ -175,33 +129,75 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
         if constexpr (X16) xs16[buf * TE + i] = (unsigned short)(__float_as_uint(bf16_rne(x)) >> 16);
         else xs[buf * TE + i] = a.bf16 ? bf16_rne(x) : x;
       }
+      const float g_l = a.dfeat[(size_t)b * 576 + fo], f_l = a.feat[(size_t)b * 576 + fo];
+      const int pl = a.pos[(size_t)b * 576 + fo];
       __syncthreads();
-      multiply(buf, b);
+      multiply(buf, g_l, f_l, pl);
     }
   } else {
-    if (b_begin < b_end) {
-      load_ids(b_begin);
-      load_vals(vn);
-      store_vals(0);
-      if (b_begin + 1 < b_end) {
-        load_ids(b_begin + 1);
-        load_vals(vn);
+    const int nseq = b_end - b_begin, NG = (nseq + DW_G - 1) / DW_G;
+    for (int i = tid; i < nseq * T; i += DW_THREADS) {
+      const int id = a.ids[(size_t)b_begin * T + i];
+      s_ids[i] = (id < 0 || id >= a.V) ? 0 : id;  // (the forward raised the error flag: the update is cancelled)
+    }
+    __syncthreads();
+    float vq[DW_G][RM], gc[DW_G], fc[DW_G], gn[DW_G], fn[DW_G];
+    int pc[DW_G], pn[DW_G];
+    auto load_group = [&](int grp) {  // values of the group's sequences + their gradient words, all in flight together
+#pragma unroll
+      for (int q = 0; q < DW_G; ++q) {
+        const int sq = grp * DW_G + q;
+        if (sq < nseq) {
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r)
+            if (tq + DW_WAVES * r < T && ce < E) vq[q][r] = a.emb[(size_t)s_ids[sq * T + tq + DW_WAVES * r] * E + ce];
+          gn[q] = a.dfeat[(size_t)(b_begin + sq) * 576 + fo];
+          fn[q] = a.feat[(size_t)(b_begin + sq) * 576 + fo];
+          pn[q] = a.pos[(size_t)(b_begin + sq) * 576 + fo];
+        } else {
+          gn[q] = 0.0f;
+          fn[q] = 0.0f;
+          pn[q] = 0;
+        }
       }
-      if (b_begin + 2 < b_end) {
-        load_ids(b_begin + 2);
-        load_vals(vm);
+    };
+    auto store_group = [&](int grp, int buf) {
+#pragma unroll
+      for (int q = 0; q < DW_G; ++q) {
+        if (grp * DW_G + q < nseq) {
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r)
+            if (tq + DW_WAVES * r < T && ce < E) {
+              const int at = (buf * DW_G + q) * TE + (tq + DW_WAVES * r) * E + ce;
+              if constexpr (X16) xs16[at] = (unsigned short)(__float_as_uint(bf16_rne(vq[q][r])) >> 16);
+              else xs[at] = a.bf16 ? bf16_rne(vq[q][r]) : vq[q][r];
+            }
+        }
+        gc[q] = gn[q];
+        fc[q] = fn[q];
+        pc[q] = pn[q];
       }
-      if (b_begin + 3 < b_end) load_ids(b_begin + 3);
+    };
+    if (NG > 0) {
+      load_group(0);
+      store_group(0, 0);
     }
     __syncthreads();
     int buf = 0;
-    for (int b = b_begin; b < b_end; ++b, buf ^= 1) {
-      multiply(buf, b);
-      if (b + 1 < b_end) store_vals(buf ^ 1);  // vn = sequence b+1 (that buffer was last read before the previous barrier)
+    for (int grp = 0; grp < NG; ++grp, buf ^= 1) {
+      if (grp + 1 < NG) load_group(grp + 1);
+      float g0[DW_G], f0[DW_G];
+      int p0[DW_G];
 #pragma unroll
-      for (int r = 0; r < RMAX; ++r) vn[r] = vm[r];  // b+2 moves up
-      if (b + 3 < b_end) load_vals(vm);              // ids of b+3 arrived an iteration ago
-      if (b + 4 < b_end) load_ids(b + 4);
+      for (int q = 0; q < DW_G; ++q) {
+        g0[q] = gc[q];
+        f0[q] = fc[q];
+        p0[q] = pc[q];
+      }
+#pragma unroll
+      for (int q = 0; q < DW_G; ++q)
+        if (grp * DW_G + q < nseq) multiply(buf * DW_G + q, g0[q], f0[q], p0[q]);
+      if (grp + 1 < NG) store_group(grp + 1, buf ^ 1);  // (those tiles were last read before the previous barrier)
       __syncthreads();
     }
   }
@@ -224,7 +220,7 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
 // (the four bodies are inlined: as calls they took the argument block through scratch and spilled around the call)
 template <int RMAX, bool X16>
 __global__ __launch_bounds__(DW_THREADS) void cnn_dw_kernel(CnnBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];  // [2][T*E] fp32 (or bf16: X16) + 384 floats of pad (read, never used: see multiply)
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [2][DW_G][T*E] fp32 (or bf16: X16) + 384 floats of pad (read, never used: see multiply) + ids
   switch (blockIdx.y) {
     case 0: dw_body<2, 256, RMAX, X16>(a, xs); break;
     case 1: dw_body<3, 128, RMAX, X16>(a, xs); break;
@@ -436,18 +432,24 @@ hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfe
   }
   ra.db_part = db_part;
   ra.nch = a.NCH;
-  const size_t lds = ((size_t)2 * T * E + 384) * sizeof(float);  // (pad: a window read runs up to 5 * 64 elements past its start)
+  const int per = (B + a.NCH - 1) / a.NCH;
+  // LDS: [2 buffers][DW_G tiles][T*E] (fp32, or bf16 in X16 mode: the fp32 size is reserved either way) + 384 floats of pad (a
+  // window read runs up to 5 * 64 elements past its start) + the chunk's token ids
+  const size_t lds_tiles = ((size_t)2 * DW_G * T * E + 384) * sizeof(float), lds_ids = (size_t)per * T * sizeof(int32_t);
+  const bool ids_fit = lds_tiles + lds_ids <= (size_t)150 * 1024;
+  const size_t lds = ids_fit ? lds_tiles + lds_ids : ((size_t)2 * T * E + 384) * sizeof(float);
   const bool x16 = bf16 && (E & 1) == 0;
-  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(a.NCH, 4), dim3(DW_THREADS), lds, st, a); };
+  auto go = [&](auto kern) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(a.NCH, 4), dim3(DW_THREADS), lds, st, a);
+  };
   if (x16) {
-    if (T <= DW_WAVES * 4) go(cnn_dw_kernel<4, true>);
-    else if (T <= DW_WAVES * 6) go(cnn_dw_kernel<6, true>);
-    else if (T <= DW_WAVES * 10) go(cnn_dw_kernel<10, true>);
+    if (ids_fit && T <= DW_WAVES * 8) go(cnn_dw_kernel<8, true>);
+    else if (ids_fit && T <= DW_WAVES * 12) go(cnn_dw_kernel<12, true>);
     else go(cnn_dw_kernel<0, true>);
   } else {
-    if (T <= DW_WAVES * 4) go(cnn_dw_kernel<4, false>);
-    else if (T <= DW_WAVES * 6) go(cnn_dw_kernel<6, false>);
-    else if (T <= DW_WAVES * 10) go(cnn_dw_kernel<10, false>);
+    if (ids_fit && T <= DW_WAVES * 8) go(cnn_dw_kernel<8, false>);
+    else if (ids_fit && T <= DW_WAVES * 12) go(cnn_dw_kernel<12, false>);
     else go(cnn_dw_kernel<0, false>);
   }
   hipLaunchKernelGGL(cnn_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ra);
