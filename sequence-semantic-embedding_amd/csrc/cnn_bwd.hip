@@ -141,28 +141,23 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
       s_ids[i] = (id < 0 || id >= a.V) ? 0 : id;  // (the forward raised the error flag: the update is cancelled)
     }
     __syncthreads();
-    // The multiply exists ONCE in the instruction stream (a runtime loop over the group's sequences; their gradient words go
-    // through a small LDS array): fully unrolled, the four width bodies were 16.6 k instructions -- ~25 KiB of straight-line code
-    // per body and group step, more than the two CUs sharing an instruction cache can hold when they run different widths.
-    float *s_g = reinterpret_cast<float *>(s_ids + per * T);                 // [2][DW_G][NF] masked gradient
-    int *s_p = reinterpret_cast<int *>(s_g + 2 * DW_G * NF);                  // [2][DW_G][NF] position
-    float vq[DW_G][RM], gn[DW_G];
-    int pn[DW_G];
+    float vq[DW_G][RM], gc[DW_G], fc[DW_G], gn[DW_G], fn[DW_G];
+    int pc[DW_G], pn[DW_G];
     auto load_group = [&](int grp) {  // values of the group's sequences + their gradient words, all in flight together
 #pragma unroll
       for (int q = 0; q < DW_G; ++q) {
         const int sq = grp * DW_G + q;
-        gn[q] = 0.0f;
-        pn[q] = 0;
         if (sq < nseq) {
 #pragma unroll
           for (int r = 0; r < RMAX; ++r)
             if (tq + DW_WAVES * r < T && ce < E) vq[q][r] = a.emb[(size_t)s_ids[sq * T + tq + DW_WAVES * r] * E + ce];
-          if (lane < FPW) {
-            const float gv = a.dfeat[(size_t)(b_begin + sq) * 576 + fo], fv = a.feat[(size_t)(b_begin + sq) * 576 + fo];
-            pn[q] = a.pos[(size_t)(b_begin + sq) * 576 + fo];
-            gn[q] = fv > 0.0f ? gv : 0.0f;
-          }
+          gn[q] = a.dfeat[(size_t)(b_begin + sq) * 576 + fo];
+          fn[q] = a.feat[(size_t)(b_begin + sq) * 576 + fo];
+          pn[q] = a.pos[(size_t)(b_begin + sq) * 576 + fo];
+        } else {
+          gn[q] = 0.0f;
+          fn[q] = 0.0f;
+          pn[q] = 0;
         }
       }
     };
@@ -178,10 +173,9 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
               else xs[at] = a.bf16 ? bf16_rne(vq[q][r]) : vq[q][r];
             }
         }
-        if (lane < FPW) {
-          s_g[(buf * DW_G + q) * NF + w * FPW + lane] = gn[q];
-          s_p[(buf * DW_G + q) * NF + w * FPW + lane] = pn[q];
-        }
+        gc[q] = gn[q];
+        fc[q] = fn[q];
+        pc[q] = pn[q];
       }
     };
     if (NG > 0) {
@@ -192,15 +186,18 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
     int buf = 0;
     for (int grp = 0; grp < NG; ++grp, buf ^= 1) {
       if (grp + 1 < NG) load_group(grp + 1);
-      const int nq = min(DW_G, nseq - grp * DW_G);
-#pragma nounroll
-      for (int q = 0; q < nq; ++q) {
-        const int tile = buf * DW_G + q;
-        const float gl = lane < FPW ? s_g[tile * NF + w * FPW + lane] : 0.0f;
-        const int pl = lane < FPW ? s_p[tile * NF + w * FPW + lane] : 0;
-        multiply(tile, gl, 1.0f, pl);
+      float g0[DW_G], f0[DW_G];
+      int p0[DW_G];
+#pragma unroll
+      for (int q = 0; q < DW_G; ++q) {
+        g0[q] = gc[q];
+        f0[q] = fc[q];
+        p0[q] = pc[q];
       }
-      if (grp + 1 < NG) store_group(grp + 1, buf ^ 1);  // (those tiles / words were last read before the previous barrier)
+#pragma unroll
+      for (int q = 0; q < DW_G; ++q)
+        if (grp * DW_G + q < nseq) multiply(buf * DW_G + q, g0[q], f0[q], p0[q]);
+      if (grp + 1 < NG) store_group(grp + 1, buf ^ 1);  // (those tiles were last read before the previous barrier)
       __syncthreads();
     }
   }
@@ -438,8 +435,7 @@ hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfe
   const int per = (B + a.NCH - 1) / a.NCH;
   // LDS: [2 buffers][DW_G tiles][T*E] (fp32, or bf16 in X16 mode: the fp32 size is reserved either way) + 384 floats of pad (a
   // window read runs up to 5 * 64 elements past its start) + the chunk's token ids
-  const size_t lds_tiles = ((size_t)2 * DW_G * T * E + 384) * sizeof(float),
-               lds_ids = (size_t)per * T * sizeof(int32_t) + (size_t)2 * 2 * DW_G * 256 * sizeof(float);  // ids + the groups' gradient / position words
+  const size_t lds_tiles = ((size_t)2 * DW_G * T * E + 384) * sizeof(float), lds_ids = (size_t)per * T * sizeof(int32_t);
   const bool ids_fit = lds_tiles + lds_ids <= (size_t)150 * 1024;
   const size_t lds = ids_fit ? lds_tiles + lds_ids : ((size_t)2 * T * E + 384) * sizeof(float);
   const bool x16 = bf16 && (E & 1) == 0;
