@@ -53,7 +53,7 @@ __device__ __forceinline__ float bf16_rne(float f) {  // nearest bfloat16 (ties 
 // registers while sequence b is multiplied out of LDS, so the two dependent global loads (ids -> embedding row) of a
 // sequence no longer sit between two barriers.  0.55 -> 0.1x ms at 8192 sequences (profiles/r05_notes.txt).
 constexpr int DW_THREADS = 512, DW_WAVES = DW_THREADS / 64;
-constexpr int DW_G = 4;  // sequences staged per barrier
+constexpr int DW_G = 2;  // sequences staged per barrier
 
 template <int FS, int NF, int RMAX, bool X16>
 __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
@@ -89,7 +89,7 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
   // This thread's elements of a [T][E] tile: column ce = lane (idle for ce >= E), tokens tq, tq + 8, .. with tq = its wave.
   const int ce = tid & 63, tq = __builtin_amdgcn_readfirstlane(tid >> 6), w = tq;
   constexpr int RM = RMAX > 0 ? RMAX : 1;
-  int *s_ids = reinterpret_cast<int *>(xs + 2 * DW_G * TE + 384);  // [per][T] (RMAX > 0 only)
+  int *s_ids = reinterpret_cast<int *>(xs + (2 * DW_G * TE) / (X16 ? 2 : 1) + 384);  // [per][T] (RMAX > 0 only; TE even in X16 mode)
   const int fo = b_foff[wi] + w * FPW + (lane < FPW ? lane : 0);    // lane fl holds filter fl's gradient / position
   // (Slots past the window -- k >= K -- read whatever follows in LDS, the next rows / tiles / the pad behind them, into
   // accumulators that are never stored: no per-slot range test, which once made the compiler emit one ds_read -> s_waitcnt ->
@@ -435,10 +435,10 @@ hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfe
   const int per = (B + a.NCH - 1) / a.NCH;
   // LDS: [2 buffers][DW_G tiles][T*E] (fp32, or bf16 in X16 mode: the fp32 size is reserved either way) + 384 floats of pad (a
   // window read runs up to 5 * 64 elements past its start) + the chunk's token ids
-  const size_t lds_tiles = ((size_t)2 * DW_G * T * E + 384) * sizeof(float), lds_ids = (size_t)per * T * sizeof(int32_t);
+  const bool x16 = bf16 && (E & 1) == 0;
+  const size_t lds_tiles = ((size_t)2 * DW_G * T * E / (x16 ? 2 : 1) + 384) * sizeof(float), lds_ids = (size_t)per * T * sizeof(int32_t);
   const bool ids_fit = lds_tiles + lds_ids <= (size_t)150 * 1024;
   const size_t lds = ids_fit ? lds_tiles + lds_ids : ((size_t)2 * T * E + 384) * sizeof(float);
-  const bool x16 = bf16 && (E & 1) == 0;
   auto go = [&](auto kern) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(a.NCH, 4), dim3(DW_THREADS), lds, st, a);
