@@ -20,7 +20,16 @@ pmc() {  # name, counters, command...
   name=$1; ctr=$2; shift 2
   ( cd /tmp && timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$out/${name}_pmc_$(echo $ctr | tr ' ' '_' | cut -c1-24)" -o p -- "$@" > /dev/null 2>&1 )
 }
-if [ -n "${R4:-}" ]; then
+if [ -n "${R5:-}" ]; then
+  # round-5 set: the text-CNN kernels (times, MFMA-busy, FETCH / WRITE), configs[2] scoring on the real rows, the any-shape path
+  run cnn python "$root/tools/bench_cnn.py"
+  pmc cnn "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" python "$root/tools/bench_cnn.py"
+  pmc cnn FETCH_SIZE python "$root/tools/bench_cnn.py"
+  pmc cnn WRITE_SIZE python "$root/tools/bench_cnn.py"
+  run c3 python "$root/tools/bench_c3.py"
+  run generic python "$root/tools/bench_generic.py"
+  run train_default python "$root/tools/bench_train_default.py"
+elif [ -n "${R4:-}" ]; then
   # round-4 set: what changed this round -- the fp32 training kernels (times, MFMA-busy, FETCH / WRITE), the single-query
   # call, the bf16 sweep, the recipe shapes
   SSE_TRAIN_SERIAL=1 run train python "$root/tools/bench_train.py" 8192

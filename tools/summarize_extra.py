@@ -41,7 +41,7 @@ def main():
         for r in csv.DictReader(open(f)):
             if any(k in r["Kernel_Name"] for k in SKIP):
                 continue
-            key = (r["Kernel_Name"].split("(")[0][:60], r["Grid_Size"], r["Counter_Name"])
+            key = (r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:60], r["Grid_Size"], r["Counter_Name"])
             agg[key].append(float(r["Counter_Value"]))
             dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         # only the byte counters belong in this file (cycle counters of the MFMA-busy passes were listed here
@@ -69,7 +69,7 @@ def main():
         for r in csv.DictReader(open(f)):
             if any(k in r["Kernel_Name"] for k in SKIP):
                 continue
-            key = (r["Kernel_Name"].split("(")[0].replace("void ", "")[:60], r["Grid_Size"])
+            key = (r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:60], r["Grid_Size"])
             if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
                 busy[key].append(float(r["Counter_Value"]))
                 dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
