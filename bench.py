@@ -380,12 +380,21 @@ def oracle_encode_parallel(p, cfg, side, ids, procs):
     import multiprocessing as mp
     import numpy as np
     procs = max(1, min(procs, 16, (len(ids) + 511) // 512))
+    if any(k in ("LD_PRELOAD", "HSA_TOOLS_LIB") or k.startswith(("ROCP", "ROCPROF")) for k in os.environ):
+        procs = 1        # under rocprofv3: no child processes at all (a profile run of this command hung in the worker pool)
     if procs == 1:
         return _oracle_encode_chunk((p, cfg, side, ids))
     chunks = np.array_split(ids, procs)
-    env_keep = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
-    for k in env_keep:
-        os.environ[k] = "1"                                 # one BLAS thread per worker: the workers are the parallelism
+    # spawned workers inherit os.environ: one BLAS thread each (the workers are the parallelism), no GPU, and -- when this
+    # process runs under rocprofv3 -- no profiler preload (16 children attaching the tool to the device hung a profile run)
+    tool_vars = [k for k in os.environ if k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE") or k.startswith(("ROCP", "ROCPROF"))]
+    env_keep = {k: os.environ.get(k) for k in ["OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "HIP_VISIBLE_DEVICES",
+                                               "ROCR_VISIBLE_DEVICES"] + tool_vars}
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[k] = "1"
+    os.environ["HIP_VISIBLE_DEVICES"] = os.environ["ROCR_VISIBLE_DEVICES"] = ""
+    for k in tool_vars:
+        os.environ.pop(k, None)
     try:
         with mp.get_context("spawn").Pool(procs) as pool:
             outs = pool.map(_oracle_encode_chunk, [(p, cfg, side, c) for c in chunks])

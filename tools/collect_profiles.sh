@@ -9,9 +9,9 @@ root=$(pwd)
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-python bench.py > "$out/bench.json" 2> "$out/bench.err"
+timeout 300 python bench.py > "$out/bench.json" 2> "$out/bench.err"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o p -- \
+timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o p -- \
     python "$root/bench.py" > "$out/stats.log" 2>&1
 groups=(FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE")
 # PMC_MIN=1: only the three passes bench.py's roofline objects read (GPU-minutes); default: the wait / LDS / instruction mixes too
@@ -22,7 +22,7 @@ if [ -z "${PMC_MIN:-}" ]; then
 fi
 for c in "${groups[@]}"; do
     d="$out/pmc_$(echo $c | tr ' ' '_' | cut -c1-40)"
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$d" -o p -- \
+    timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$d" -o p -- \
         python "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --score-iters 1 --no-shapes-leg --no-realdata-leg --no-sweep-leg > "$out/log_$(basename $d).txt" 2>&1
 done
 cd "$root"
