@@ -23,6 +23,22 @@ def main():
         for r in rows:
             if any(k in r["Name"] for k in OURS):
                 w.writerow(r)
+    # The default line's extra legs launch the dominant kernel at other sizes too (config_sweep: 1 .. 131072 rows, realdata_leg:
+    # T = 50), so its all-calls average in the table above is not the headline launch's: per (kernel, grid) averages from the
+    # kernel trace of the same run, largest total first.
+    trace = os.path.join(stats_dir, "p_kernel_trace.csv")
+    if os.path.exists(trace):
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(trace)):
+            n = r["Kernel_Name"].replace("(anonymous namespace)::", "")
+            if any(k in n for k in ("lstm_fwd_kernel<2, 2, 1, false", "score_topk_kernel<4, true", "cnn_dx_mfma", "cnn_dw_kernel", "conv_pool_bf16", "proj_norm_x3")):
+                per[(n.split("(")[0].replace("void ", ""), str(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"])), r["Workgroup_Size_X"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        with open(os.path.join(root, "%s_kernel_by_grid.txt" % tag), "w") as f:
+            f.write("# rocprofv3 --kernel-trace -- python bench.py: dispatch durations by (kernel, grid size in work-items, workgroup size)\n")
+            f.write("# headline launch = lstm_fwd_kernel<2, 2, 1, false, ...> at grid 131072 (16384 sequences / 64 rows x 512 threads), T = 32\n")
+            for (k, g, wg), v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+                f.write("%-58s grid=%-8s wg=%-4s calls=%-3d avg=%.4f ms  min=%.4f  max=%.4f\n"
+                        % (k, g, wg, len(v), sum(v) / len(v) / 1e6, min(v) / 1e6, max(v) / 1e6))
     out = ["# rocprofv3 --pmc <counters> --kernel-trace (separate passes) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --score-iters 1",
            "# per-dispatch averages by (kernel, grid); FETCH_SIZE/WRITE_SIZE in KB (MI355X_MICROARCH.md: FETCH_SIZE under-reports",
            "# wide 16 B/lane streaming reads 2x on gfx950); SQ_WAVE_CYCLES/SQ_WAIT_*/SQ_ACTIVE_* are quad-cycles summed over waves;",
