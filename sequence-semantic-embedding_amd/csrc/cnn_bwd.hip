@@ -390,7 +390,8 @@ hipError_t launch_rows_scatter(const float *d, const int32_t *rows, int B, int S
 hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfeat, const float *feat, const int32_t *pos,
                           const float *const W[4], float *const dW[4], float *const db[4], float *dw_part,
                           float *db_part, float *wt_scratch /* [E*1728] */, unsigned short *wct_scratch /* cnn_wct_elems(E) */,
-                          float *d_emb, float *sq_part, int B, int T, int E, int V, int bf16, hipStream_t st) {
+                          float *d_emb, float *sq_part, float *hot_part /* [cnn_dx_mfma_blocks(B)][2][64] */, int B, int T, int E, int V, int bf16,
+                          hipStream_t st) {
   static const int fs[4] = {2, 3, 4, 5}, nf[4] = {256, 128, 128, 64};
   if (E > 64) return hipErrorInvalidValue;
   CnnBwdArgs a;
@@ -411,7 +412,7 @@ hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfe
   // bf16 mode: dX as a dense contraction on the bf16 matrix pipe (cnn_bwd_mfma.hip); fp32 mode (and sequences longer than
   // its three t tiles): the gather kernel over the transposed filters
   static const bool no_mfma = getenv("SSE_CNN_DX_GATHER") != nullptr;  // measurement aid: the gather kernel in bf16 mode too
-  const bool dx_mfma = bf16 && wct_scratch && cnn_dx_mfma_ok(T, E) && !no_mfma;
+  const bool dx_mfma = bf16 && wct_scratch && hot_part && cnn_dx_mfma_ok(T, E) && !no_mfma;
   CnnReduceArgs ra;
   size_t off = 0, toff = 0;
   int total = 576;
@@ -453,7 +454,7 @@ hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfe
     else go(cnn_dw_kernel<0, false>);
   }
   hipLaunchKernelGGL(cnn_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ra);
-  if (dx_mfma) return launch_cnn_dx_mfma(ids, dfeat, feat, pos, W, wct_scratch, d_emb, sq_part, B, T, E, V, st);
+  if (dx_mfma) return launch_cnn_dx_mfma(ids, dfeat, feat, pos, W, wct_scratch, d_emb, sq_part, hot_part, B, T, E, V, st);
   hipLaunchKernelGGL(cnn_dx_kernel, dim3(B), dim3(256), (size_t)(T + 1) * sizeof(int), st, a);
   return hipGetLastError();
 }

@@ -41,6 +41,7 @@ struct CnnDxArgs {
   const unsigned short *WcT;  // [108][ET][512] bf16 filter fragments in step order (pack_wct_bf16_kernel)
   float *d_emb;               // [V][E] dense embedding gradient (zeroed by the caller)
   float *sq_part;             // [B]
+  float *hot_part;            // [workgroups][2][64]: the workgroup's dX sums for token ids 0 (PAD) and 1 (EOS)
   int32_t B, T, E, V;
 };
 
@@ -151,24 +152,51 @@ __global__ __launch_bounds__(DX_WAVES * 64) void cnn_dx_mfma_kernel(CnnDxArgs a)
     if (c + 1 < NCHUNK && tid < CHUNK_VEC) reinterpret_cast<u32x4 *>(s_B[(c + 1) & 1])[tid] = stage;  // (last read before the previous barrier)
     __syncthreads();
   }
-  float sq = 0.0f;
+  // PAD (0) and EOS (1) fill most rows of a left-padded batch (and every sequence ends in EOS): their gradient rows would all
+  // be atomics on the same 2 x E addresses -- the kernel ran 0.41 instead of 0.23 ms on a batch with just an EOS column.  They
+  // take no atomics: a wave sums its sequence's rows per hot id in registers, the eight waves meet in LDS and the workgroup's
+  // sums go to hot_part[workgroup]; dx_hot_reduce_kernel (train.hip) adds the workgroups in fixed order.
+  __shared__ float s_hot[DX_WAVES][2][64];
+  float sq = 0.0f, h0[ET], h1[ET];
+#pragma unroll
+  for (int et = 0; et < ET; ++et) h0[et] = h1[et] = 0.0f;
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-    for (int et = 0; et < ET; ++et)
+    for (int r = 0; r < 16; ++r) {
+      const int t = tt * 32 + mfma_row(r, lane);
+      const int id = (t < T && b < a.B) ? s_ids[w][t] : -1;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int t = tt * 32 + mfma_row(r, lane), e = et * 32 + (lane & 31);
+      for (int et = 0; et < ET; ++et) {
+        const int e = et * 32 + (lane & 31);
         const float v = acc[tt][et][r];
         sq += v * v;  // (rows t >= T and columns e >= E are exact zeros: no position matches / zero filter columns)
-        if (v != 0.0f && t < T && e < E && b < a.B) {
-          const int id = s_ids[w][t];
-          if (id >= 0) atomicAdd(a.d_emb + (size_t)id * E + e, v);
-        }
+        h0[et] += (id == 0) ? v : 0.0f;
+        h1[et] += (id == 1) ? v : 0.0f;
+        if (v != 0.0f && id >= 2 && e < E) atomicAdd(a.d_emb + (size_t)id * E + e, v);
       }
+    }
+#pragma unroll
+  for (int et = 0; et < ET; ++et) {
+    h0[et] += __shfl_xor(h0[et], 32);
+    h1[et] += __shfl_xor(h1[et], 32);
+    if (lane < 32) {
+      s_hot[w][0][et * 32 + lane] = h0[et];
+      s_hot[w][1][et * 32 + lane] = h1[et];
+    }
+  }
+  if (ET == 1 && lane < 32) s_hot[w][0][32 + lane] = s_hot[w][1][32 + lane] = 0.0f;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
   if (lane == 0 && b < a.B) a.sq_part[b] = sq;
+  __syncthreads();
+  if (tid < 128) {
+    const int hid = tid >> 6, e = tid & 63;
+    float v = 0.0f;
+#pragma unroll
+    for (int i = 0; i < DX_WAVES; ++i) v += s_hot[i][hid][e];
+    a.hot_part[((size_t)blockIdx.x * 2 + hid) * 64 + e] = v;
+  }
 }
 
 // Filters W_wi [fs*E][nf] (fp32 masters) -> bf16 fragments of the dX contraction in STEP order: block (step, et), step = width,
@@ -195,12 +223,14 @@ __global__ void pack_wct_bf16_kernel(WctArgs a) {
 
 }  // namespace
 
+int cnn_dx_mfma_blocks(int B) { return (B + DX_WAVES - 1) / DX_WAVES; }
 bool cnn_dx_mfma_ok(int T, int E) { return T >= 5 && T <= DX_TMAX && E >= 1 && E <= 64; }
 size_t cnn_wct_elems(int E) { return (size_t)DX_STEPS * ((E + 31) / 32) * 512; }
 
 // dX of the whole batch on the bf16 matrix pipe; wct_scratch: cnn_wct_elems(E) bf16, rebuilt here from the masters
 hipError_t launch_cnn_dx_mfma(const int32_t *ids, const float *dfeat, const float *feat, const int32_t *pos, const float *const W[4],
-                              unsigned short *wct_scratch, float *d_emb, float *sq_part, int B, int T, int E, int V, hipStream_t st) {
+                              unsigned short *wct_scratch, float *d_emb, float *sq_part, float *hot_part /* [ceil(B/8)][2][64] */, int B, int T, int E, int V,
+                              hipStream_t st) {
   if (!cnn_dx_mfma_ok(T, E)) return hipErrorInvalidValue;
   const int ET = (E + 31) / 32, TT = (T + 31) / 32;
   WctArgs wa;
@@ -209,7 +239,7 @@ hipError_t launch_cnn_dx_mfma(const int32_t *ids, const float *dfeat, const floa
   wa.E = E;
   wa.ET = ET;
   hipLaunchKernelGGL(pack_wct_bf16_kernel, dim3((int)((cnn_wct_elems(E) + 255) / 256)), dim3(256), 0, st, wa);
-  CnnDxArgs a{ids, dfeat, feat, pos, wct_scratch, d_emb, sq_part, B, T, E, V};
+  CnnDxArgs a{ids, dfeat, feat, pos, wct_scratch, d_emb, sq_part, hot_part, B, T, E, V};
   const dim3 grid((B + DX_WAVES - 1) / DX_WAVES), block(DX_WAVES * 64);
 #define DX_GO(tt, et) hipLaunchKernelGGL((cnn_dx_mfma_kernel<tt, et>), grid, block, 0, st, a)
   if (ET == 1) {
@@ -222,5 +252,5 @@ hipError_t launch_cnn_dx_mfma(const int32_t *ids, const float *dfeat, const floa
     else DX_GO(3, 2);
   }
 #undef DX_GO
-  return hipGetLastError();
+  return launch_dx_hot_reduce(hot_part, (int)grid.x, E, V, d_emb, st);
 }

@@ -2119,6 +2119,7 @@ static int cnn_train_grads_locked(sse_handle *h, const int32_t *src_ids_host, co
   if (reserve(h, ts.dbias_part, (size_t)cnn_bwd_chunks(B) * 576 * sizeof(float))) return 1;
   if (reserve(h, ts.wt, (size_t)E * 1728 * sizeof(float))) return 1;
   if (reserve(h, ts.wct, cnn_wct_elems(E) * sizeof(unsigned short))) return 1;
+  if (reserve(h, ts.hot_part[0], (size_t)cnn_dx_mfma_blocks(B) * 2 * 64 * sizeof(float))) return 1;
   if (reserve(h, ts.dm_part[0], (size_t)proj_bwd_chunks(Bp) * 576 * S * sizeof(float))) return 1;
   if (reserve(h, ts.sq_part, (size_t)2 * B * sizeof(float))) return 1;
   if (reserve(h, ts.row_loss, (size_t)B * sizeof(float))) return 1;
@@ -2162,7 +2163,7 @@ static int cnn_train_grads_locked(sse_handle *h, const int32_t *src_ids_host, co
   float *sq = (float *)ts.sq_part.p;
   HIPCHECK(h, launch_cnn_bwd((const int32_t *)ts.ids[0].p, emb.dev, (const float *)ts.dfeat.p, (const float *)ts.feat_rm.p,
                              (const int32_t *)ts.pos.p, W, dW, db, (float *)ts.dw_part.p, (float *)ts.dbias_part.p,
-                             (float *)ts.wt.p, (unsigned short *)ts.wct.p, emb.grad, sq, B, T, E, V, h->cnn_bf16 ? 1 : 0, st));
+                             (float *)ts.wt.p, (unsigned short *)ts.wct.p, emb.grad, sq, (float *)ts.hot_part[0].p, B, T, E, V, h->cnn_bf16 ? 1 : 0, st));
   HIPCHECK(h, launch_rows_scatter((const float *)ts.draw[1].p, (const int32_t *)ts.ids[1].p, B, S, table.rows, table.grad, sq + B, st));
   // tail[0]: both lookups are IndexedSlices -> raw slice norms
   HIPCHECK(h, launch_sum(sq, 2 * B, (float)B, tail, st));

@@ -100,13 +100,15 @@ hipError_t launch_rows_scatter(const float *d, const int32_t *rows, int B, int S
                                hipStream_t st);
 hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfeat, const float *feat, const int32_t *pos,
                           const float *const W[4], float *const dW[4], float *const db[4], float *dw_part,
-                          float *db_part, float *wt_scratch, unsigned short *wct_scratch, float *d_emb, float *sq_part, int B,
-                          int T, int E, int V, int bf16, hipStream_t st);
+                          float *db_part, float *wt_scratch, unsigned short *wct_scratch, float *d_emb, float *sq_part,
+                          float *hot_part, int B, int T, int E, int V, int bf16, hipStream_t st);
 // dX of the text-CNN on the bf16 matrix pipe (cnn_bwd_mfma.hip; option cnn_bf16, T <= 96)
 bool cnn_dx_mfma_ok(int T, int E);
 size_t cnn_wct_elems(int E);
 hipError_t launch_cnn_dx_mfma(const int32_t *ids, const float *dfeat, const float *feat, const int32_t *pos, const float *const W[4],
-                              unsigned short *wct_scratch, float *d_emb, float *sq_part, int B, int T, int E, int V, hipStream_t st);
+                              unsigned short *wct_scratch, float *d_emb, float *sq_part, float *hot_part, int B, int T, int E, int V,
+                              hipStream_t st);
+int cnn_dx_mfma_blocks(int B);
 // out[b][0..T) = corpus[rows[b]][0..T)  (rows outside [0, N): error flag bit 1, row 0 used)
 hipError_t launch_gather_id_rows(const int32_t *corpus, const int32_t *rows, int B, int T, int64_t N, int32_t *out,
                                  int32_t *err, hipStream_t st);

@@ -52,6 +52,7 @@ for bf16 in (0, 1):
     h.set_option("cnn_bf16", bf16)
     for Bt in (1024, 8192):
         src = np.repeat(rng.randint(2, V, size=(Bt // 2, T)).astype(np.int32), 2, axis=0)
+        src[:, -1] = 1                                       # every real sequence ends in EOS (sse_index.py:79-85): a hot embedding row
         rows = rng.randint(0, 571, size=Bt).astype(np.int32)
         z = np.tile(np.array([1.0, 0.0], np.float32), Bt // 2)
         for _ in range(2):
