@@ -37,6 +37,7 @@ struct CnnBwdArgs {
   float *db_part;       // [NCH][576]
   float *d_emb;         // [V][E] dense embedding gradient (zeroed by the caller)
   float *sq_part;       // [B]
+  float *hot_part;      // cnn_dx_kernel: [B][2][64] per-sequence dX sums for token ids 0 (PAD) and 1 (EOS), or null
   int32_t B, T, E, NCH, V;  // V: token ids outside [0, V) read row 0 / add nothing (the forward raised the error flag: the update is cancelled)
   int32_t bf16;         // option cnn_bf16: the forward ran on bf16-rounded embeddings / filters; the backward
                         // differentiates THAT function (dW from the rounded windows, dX from the rounded filters)
@@ -305,6 +306,11 @@ __global__ __launch_bounds__(256) void cnn_dx_kernel(CnnBwdArgs a) {
     gl_s[x] = g_s[f];
   }
   __syncthreads();
+  // PAD (0) / EOS (1) rows (most rows of a left-padded batch, the last of every sequence): summed per sequence in LDS, added
+  // to the dense gradient by dx_hot_reduce_kernel in fixed order -- as global atomics they all hit the same 2 x E addresses
+  __shared__ float s_hot[2][64];
+  if (tid < 128) s_hot[tid >> 6][tid & 63] = 0.0f;
+  __syncthreads();
   const float *Wt = a.Wt[0];
   float sq = 0.0f;
   for (int i = tid; i < T * E; i += 256) {
@@ -320,7 +326,10 @@ __global__ __launch_bounds__(256) void cnn_dx_kernel(CnnBwdArgs a) {
     }
     sq += acc * acc;
     const int id = a.ids[(size_t)b * T + t];
-    if (acc != 0.0f && id >= 0 && id < a.V) atomicAdd(a.d_emb + (size_t)id * E + e, acc);
+    if (acc != 0.0f && id >= 0 && id < a.V) {
+      if (id < 2 && a.hot_part) atomicAdd(&s_hot[id][e], acc);
+      else atomicAdd(a.d_emb + (size_t)id * E + e, acc);
+    }
   }
   red[tid] = sq;
   __syncthreads();
@@ -329,6 +338,7 @@ __global__ __launch_bounds__(256) void cnn_dx_kernel(CnnBwdArgs a) {
     __syncthreads();
   }
   if (tid == 0) a.sq_part[b] = red[0];
+  if (a.hot_part && tid < 128) a.hot_part[((size_t)b * 2 + (tid >> 6)) * 64 + (tid & 63)] = s_hot[tid >> 6][tid & 63];  // (after the reduction's barriers)
 }
 
 // Wt[f][k] = W[k][f]  (rounded to bf16 when the forward used the rounded filters)
@@ -390,7 +400,7 @@ hipError_t launch_rows_scatter(const float *d, const int32_t *rows, int B, int S
 hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfeat, const float *feat, const int32_t *pos,
                           const float *const W[4], float *const dW[4], float *const db[4], float *dw_part,
                           float *db_part, float *wt_scratch /* [E*1728] */, unsigned short *wct_scratch /* cnn_wct_elems(E) */,
-                          float *d_emb, float *sq_part, float *hot_part /* [cnn_dx_mfma_blocks(B)][2][64] */, int B, int T, int E, int V, int bf16,
+                          float *d_emb, float *sq_part, float *hot_part /* [max(B, cnn_dx_mfma_blocks(B))][2][64] */, int B, int T, int E, int V, int bf16,
                           hipStream_t st) {
   static const int fs[4] = {2, 3, 4, 5}, nf[4] = {256, 128, 128, 64};
   if (E > 64) return hipErrorInvalidValue;
@@ -403,6 +413,7 @@ hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfe
   a.db_part = db_part;
   a.d_emb = d_emb;
   a.sq_part = sq_part;
+  a.hot_part = hot_part;
   a.B = B;
   a.T = T;
   a.E = E;
@@ -456,5 +467,6 @@ hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfe
   hipLaunchKernelGGL(cnn_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ra);
   if (dx_mfma) return launch_cnn_dx_mfma(ids, dfeat, feat, pos, W, wct_scratch, d_emb, sq_part, hot_part, B, T, E, V, st);
   hipLaunchKernelGGL(cnn_dx_kernel, dim3(B), dim3(256), (size_t)(T + 1) * sizeof(int), st, a);
+  if (hot_part) return launch_dx_hot_reduce(hot_part, B, E, V, d_emb, st);
   return hipGetLastError();
 }

@@ -2119,7 +2119,7 @@ static int cnn_train_grads_locked(sse_handle *h, const int32_t *src_ids_host, co
   if (reserve(h, ts.dbias_part, (size_t)cnn_bwd_chunks(B) * 576 * sizeof(float))) return 1;
   if (reserve(h, ts.wt, (size_t)E * 1728 * sizeof(float))) return 1;
   if (reserve(h, ts.wct, cnn_wct_elems(E) * sizeof(unsigned short))) return 1;
-  if (reserve(h, ts.hot_part[0], (size_t)cnn_dx_mfma_blocks(B) * 2 * 64 * sizeof(float))) return 1;
+  if (reserve(h, ts.hot_part[0], (size_t)std::max(B, cnn_dx_mfma_blocks(B)) * 2 * 64 * sizeof(float))) return 1;
   if (reserve(h, ts.dm_part[0], (size_t)proj_bwd_chunks(Bp) * 576 * S * sizeof(float))) return 1;
   if (reserve(h, ts.sq_part, (size_t)2 * B * sizeof(float))) return 1;
   if (reserve(h, ts.row_loss, (size_t)B * sizeof(float))) return 1;
