@@ -1684,7 +1684,7 @@ hipError_t launch_proj_bwd(const float *hT, const float *d, const float *M, int 
     hipLaunchKernelGGL(proj_bwd_dm_reduce_kernel, dim3((H * S + 255) / 256), dim3(256), 0, st, dm_part, nch, H * S, dM);
   static const bool dh_valu = getenv("SSE_PROJ_DH_VALU") != nullptr;  // measurement aid: the LDS-tiled VALU kernel
   if (S % 8 == 0 && !dh_valu && (reinterpret_cast<uintptr_t>(d) & 15) == 0 && (reinterpret_cast<uintptr_t>(M) & 15) == 0)
-    hipLaunchKernelGGL(proj_bwd_dh_mfma_kernel, dim3((Hp / 32 + 3) / 4, (Bp + 31) / 32), dim3(256), 0, st, d, M, Bp, H, Hp, S, dh);
+    hipLaunchKernelGGL(proj_bwd_dh_mfma_kernel, dim3(((Hp + 31) / 32 + 3) / 4, (Bp + 31) / 32), dim3(256), 0, st, d, M, Bp, H, Hp, S, dh);  // (Hp is any multiple of 8 on the any-shape path)
   else
     hipLaunchKernelGGL(proj_bwd_dh_kernel, dim3((Hp + PB_TILE - 1) / PB_TILE, (Bp + PB_TILE - 1) / PB_TILE), dim3(256), 0, st, d,
                        M, Bp, H, Hp, S, dh);

@@ -56,6 +56,8 @@ def test_generic_train_step_matches_oracle_and_fused_path(mode, V, E, Hs, Ht, S,
     ("dual-encoder", 120, 100, 128, 96, 64, 8, 24),       # --embedding_size=100 > 64
     ("dual-encoder", 100, 128, 600, 96, 72, 5, 8),        # source cell size 600 > 512: generic inference AND training, mixed with a fused-size target
     ("source-encoder-only", 90, 70, 64, 64, 40, 6, 10),   # builder-defined mode (free target matrix), E > 64
+    ("dual-encoder", 90, 70, 520, 7, 16, 5, 6),           # cell sizes whose padded width is not a multiple of 32 (520; 7 -> 8): found by
+    ("shared-encoder", 300, 100, 5, 5, 256, 6, 128),      # tools/fuzz_parity.py -- the dh GEMM's grid rounded the tile count DOWN
 ])
 def test_shapes_outside_the_fused_kernels_train_and_encode(mode, V, E, Hs, Ht, S, T, B):
     params = model_params(mode, V, E, Hs, Ht, S, T, N=13, lr=0.9)
