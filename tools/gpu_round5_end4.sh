@@ -1,0 +1,9 @@
+#!/bin/bash
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-.}"
+o=gpurun_out/r05end; mkdir -p $o
+timeout 600 python -m pytest tests -m gpu -q --timeout 300 -p no:cacheprovider > $o/tests.log 2>&1; echo "tests rc=$?" | tee -a $o/tests.log
+grep -n "passed\|failed\|^FAILED" $o/tests.log | tail -5
+PMC_MIN=1 timeout 600 bash tools/collect_profiles.sh r05z > $o/collect.log 2>&1; tail -1 $o/collect.log
+R5=1 timeout 400 bash tools/collect_profiles_extra.sh r05x > $o/collect_extra.log 2>&1; tail -1 $o/collect_extra.log
+timeout 120 python __graft_entry__.py --smoke 2>&1 | tail -1
