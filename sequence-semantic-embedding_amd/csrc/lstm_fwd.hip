@@ -753,6 +753,18 @@ static hipError_t launch_cfg(const LstmFwdArgs &a_in, hipStream_t stream) {
 int lstm_fwd_rows_per_wg(int Hp, int B, int tiles_elsewhere) {
   if (Hp == 512) return 32;
   if ((Hp == 256 || Hp == 128) && (B + 31) / 32 + tiles_elsewhere <= 256) return 32;
+  if (tiles_elsewhere == 0 && (Hp == 256 || Hp == 128)) {
+    // Rounds (round 5).  64-row tiles: one workgroup per CU, ceil(n64 / 256) rounds; a round with two workgroups costs as much
+    // as a full one -- 16,491 queries = 258 tiles ran 7.53 ms where 16,384 run 3.7.  32-row tiles: two workgroups per CU, a
+    // full round of 512 costs 1.006 (Hp = 256) / 1.06 (Hp = 128) of a 64-row round (profiles/r02_notes.txt), a last round of
+    // <= 256 workgroups (one per CU: half the per-step latency) 0.55.  Take 32 rows when the model says > 7 % less:
+    // 16,491 rows 7.53 -> 5.74 ms measured (profiles/r05_notes.txt); 16,384 and 32,060 rows keep 64.
+    const int n64 = (B + 63) / 64, n32 = (B + 31) / 32;
+    const double full = Hp == 256 ? 1.006 : 1.06;
+    const int rem = n32 % 512;
+    const double t64 = (double)((n64 + 255) / 256), t32 = (n32 / 512) * full + (rem == 0 ? 0.0 : rem <= 256 ? 0.55 : full);
+    if (t32 < 0.93 * t64) return 32;
+  }
   return 64;
 }
 

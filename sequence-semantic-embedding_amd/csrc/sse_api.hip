@@ -174,6 +174,7 @@ struct sse_handle {
   int32_t score_seq = 0;  // call number the re-scoring pass stores into the pinned completion flags (ScoreMirror)
   DevBuf s_pb, s_cthr, s_cslot, s_ccnt, s_cbuf;  // per-split bounds; collect path: thresholds, slots, counters, row buffers
   const int32_t *cur_row_map = nullptr;  // set by sse_encode around its launch
+  bool cur_padded_hint = false;          // ... together with this: the batch's mean leading-PAD count is >= T / 4
   // training
   float lr = 0.9f;
   int64_t global_step = 0;
@@ -838,6 +839,10 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
     if (ensure_pad_table(h, side, T, st)) return 1;
     a.pad_h = e.pad_h;
     a.pad_c = e.pad_c;
+    // a heavily left-padded batch sorted by pad count (sse_encode's host path knows both): tiles differ in length, the finer
+    // 32-row granularity with two workgroups per CU balances them better -- crosslingual index build 2.96 -> 2.64 ms, queries
+    // 1.24 -> 0.84 ms (profiles/r05_notes.txt)
+    if (h->cur_padded_hint && h->cur_row_map && e.Hp <= 256) a.force_rows = 32;
   }
   HIPCHECK(h, launch_lstm_fwd(a, e.Hp, st));
   return 0;
@@ -1491,6 +1496,9 @@ static int encode_host_ids_locked(sse_handle *h, int side, const int32_t *ids_ho
     }
     for (int i = 1; i <= T + 1; ++i) start[i] += start[i - 1];
     for (int b = 0; b < B; ++b) order[start[T - lead[b]]++] = b;
+    int64_t lead_sum = 0;
+    for (int b = 0; b < B; ++b) lead_sum += lead[b];
+    h->cur_padded_hint = lead_sum * 4 >= (int64_t)B * T;
     if (reserve(h, h->s_map, (size_t)B * sizeof(int32_t))) return 1;
     HIPCHECK(h, hipMemcpyAsync(h->s_map.p, order.data(), (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIPCHECK(h, hipStreamSynchronize(st));  // `order` is a local
@@ -1500,6 +1508,7 @@ static int encode_host_ids_locked(sse_handle *h, int side, const int32_t *ids_ho
   h->cur_row_map = row_map_dev;
   int rc = encode_dev_locked(h, side, (const int32_t *)h->s_ids.p, B, T, normalize, (float *)h->s_out.p, st);
   h->cur_row_map = nullptr;
+  h->cur_padded_hint = false;
   if (rc) return 1;
   if (defer_check) return 0;
   int32_t bits = 0;
