@@ -607,6 +607,131 @@ def config_sweep_leg(sse_amd, torch, dev, h_main, full_c4=True):
     return out
 
 
+HEADLINE_MAX_BYTES = 6000      # the driver's parser lost the 23.5 KB line of round 5
+LEGS_FILE = os.path.join("profiles", "bench_legs_latest.json")
+
+
+def _r(x, nd=4):
+    """Round floats to nd significant digits (the headline is a summary; full precision lives in the legs file)."""
+    if isinstance(x, float):
+        return float("%.*g" % (nd, x)) if x == x and abs(x) != float("inf") else None
+    return x
+
+
+def _leg(d, ms_key, roof=None, **extra):
+    """One compact number set of a secondary leg: the time, the roofline fraction, and whatever else is named."""
+    if not isinstance(d, dict):
+        return None
+    out = {"ms": _r(d.get(ms_key))}
+    r = d.get("roofline") if roof is None else roof
+    if isinstance(r, dict):
+        out["frac"] = _r(r.get("frac"))
+        if isinstance(r.get("mfma_busy"), float):
+            out["mfma_busy"] = _r(r["mfma_busy"])
+    for k, v in extra.items():
+        out[k] = _r(v)
+    return out
+
+
+def compact_headline(full):
+    """The ONE line the driver parses: the contract keys, `roofline` and `cpu_baseline` without prose, and one compact
+    number set per secondary leg.  Everything else is in LEGS_FILE (and on the BENCH_LEGS line printed before it)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "cosine_scores_per_s", "top1_match_vs_oracle", "encode_max_abs_err_vs_oracle",
+            "speedup_vs_cpu_baseline", "rccl_ranks_seen", "shard_bounds")
+    line = {k: _r(full[k], 7) for k in keep if k in full}
+    rf = full["roofline"]
+    line["roofline"] = {k: _r(rf.get(k), 6) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "mfma_busy",
+                                                        "avg_kernel_ms", "algorithmic_flop_per_launch", "pmc_source",
+                                                        "traffic_measured_in_this_run")}
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: _r(cb.get(k), 6) for k in ("value", "unit", "cores", "kind", "host_cores", "replicas",
+                                                               "threads_per_replica", "host_cpu_model", "scoring_scores_per_s")}
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+    legs = {}
+    g = full.get
+    if g("scoring_leg"):
+        legs["score_bf16_sweep"] = _leg(g("scoring_leg"), "ms_per_pass", planted_top1=g("scoring_leg")["top1_planted_acc"],
+                                        identical_to_fp32=g("scoring_leg")["identical_to_fp32_candidates"])
+        legs["score_fp32_sweep"] = _leg(g("scoring_leg_fp32_candidates"), "ms_per_pass")
+    if g("encode_leg_split_bf16"):
+        legs["encode_split_bf16"] = _leg(g("encode_leg_split_bf16"), "encode_kernel_ms")
+    if g("encode_leg_mid_batch"):
+        for rows, d in g("encode_leg_mid_batch")["rows"].items():
+            legs["encode_rows_%s" % rows] = _leg(d, "encode_ms", identical=d["identical_to_matrix_kernel"])
+    if g("latency_leg"):
+        la = g("latency_leg")
+        legs["latency_q1"] = {k2: _r(v) for k2, v in la.items() if k2.endswith("_ms") or "_ms_" in k2}
+        legs["latency_q1"]["sweep_hbm_frac"] = _r(la["roofline"]["frac"])
+    if g("train_leg"):
+        legs["train_fp32"] = _leg(g("train_leg"), "ms_per_step", rows=g("train_leg")["pair_rows_per_gpu"],
+                                  split_bf16_ms=g("train_leg")["ms_per_step_split_bf16_opt_in"])
+        if "default_shape" in g("train_leg"):
+            legs["train_default_shape"] = {k2: _r(v) for k2, v in g("train_leg")["default_shape"].items()
+                                           if isinstance(v, (int, float))}
+    if g("encode_leg_reference_shapes"):
+        legs["encode_recipe_shapes"] = [{"H": sh.get("H"), "T": sh.get("T"), "ms": _r(sh.get("encode_ms")),
+                                         "frac": _r((sh.get("roofline") or {}).get("frac"))}
+                                        for sh in g("encode_leg_reference_shapes")["shapes"]]
+    if g("cnn_leg"):
+        c = g("cnn_leg")
+        legs["cnn"] = {"encode_fp32": _leg(c.get("encode_fp32"), "encode_ms"), "encode_bf16": _leg(c.get("encode_bf16"), "encode_ms")}
+        for name, d in (c.get("train") or {}).items():
+            if isinstance(d, dict):
+                legs["cnn"]["train_" + name] = _leg(d, "ms_per_step")
+    if g("realdata_leg"):
+        rd = g("realdata_leg")
+        out = {"whole_job_ms": _r(rd.get("whole_job_ms"))}
+        for ps in ("pad_skip_0", "pad_skip_1"):
+            for part in ("index_build", "query_encode"):
+                d = (rd.get(ps) or {}).get(part)
+                if isinstance(d, dict):
+                    out["%s_%s" % (part, ps)] = _leg(d, "encode_ms")
+        if isinstance(rd.get("score"), dict):
+            out["score"] = _leg(rd["score"], "ms_per_pass")
+        pv = rd.get("parity_vs_oracle") or {}
+        out["top1_equal_vs_oracle"] = "%s/%s" % (pv.get("top1_equal"), pv.get("queries_checked"))
+        legs["realdata_c3"] = out
+    if g("config_sweep"):
+        cs = g("config_sweep")
+        legs["c2_batch_sweep"] = [{"B": e["B"], "src_ms": _r(e["src"]["ms_per_call"]),
+                                   "frac": _r(e["src"].get("frac_of_f32_mfma_peak"))} for e in cs.get("c2_batch_sweep", [])]
+        if cs.get("c4_full"):
+            legs["c4_full_1gpu"] = {"total_s": _r(cs["c4_full"]["total_s"]), "frac": _r(cs["c4_full"]["roofline"]["frac"]),
+                                    "planted_top1": cs["c4_full"]["planted_top1_acc"]}
+    line["legs"] = legs
+    line["legs_file"] = LEGS_FILE
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > HEADLINE_MAX_BYTES:            # never let a new leg push the line past the parser again: shed legs, largest first
+        for name in sorted(legs, key=lambda n: -len(json.dumps(legs[n]))):
+            legs.pop(name)
+            line["legs_truncated"] = True
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) <= HEADLINE_MAX_BYTES:
+                break
+    return text
+
+
+def emit(full):
+    """Full legs -> LEGS_FILE and an earlier, non-'{'-leading stdout line; the compact headline is the LAST line."""
+    try:
+        os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+        with open(os.path.join(ROOT, LEGS_FILE), "w") as f:
+            json.dump(full, f, indent=1)
+    except OSError:
+        pass
+    # RCCL (NCCL_DEBUG=VERSION on the GPU boxes) prints its banner through C stdio, which would otherwise be
+    # flushed at exit, AFTER this line: push it out first so that the JSON line is the last line of stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print("BENCH_LEGS " + json.dumps(full), flush=True)
+    print(compact_headline(full), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -658,6 +783,13 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # proof that RCCL saw every rank: an all-reduce of ones over the job's process group
+    rccl_ranks_seen = 1
+    if use_dist:
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks_seen = int(ones.item())
 
     params = dict(forward_only=True, network_mode="dual-encoder", predict_nbest=10, max_seq_length=T,
                   vocab_size=V, embedding_size=E, encoding_size=S, src_cell_size=H, tgt_cell_size=H,
@@ -791,6 +923,7 @@ def main():
 
     # ---- secondary leg: ranking-scale sharded scoring with RCCL all-gather of per-shard top-k
     scoring = None
+    shard_bounds = None
     if not args.no_scoring_leg:
         Ns, Q, k = args.score_rows, args.score_queries, 10
         g = torch.Generator(device=dev).manual_seed(7 + rank)
@@ -803,6 +936,14 @@ def main():
         sharded = sse_amd.ShardedIndex(h, rank, world, Ns * world, always_gather=force_dist)
         sharded.set_local_rows(shard)
         del shard
+        # every rank's [start, end) of the global index, gathered (not recomputed) so that the line shows what each rank used
+        if use_dist:
+            sb = torch.tensor([sharded.start, sharded.end], dtype=torch.int64, device=dev)
+            allsb = [torch.empty_like(sb) for _ in range(world)]
+            dist.all_gather(allsb, sb)
+            shard_bounds = [[int(x[0]), int(x[1])] for x in allsb]
+        else:
+            shard_bounds = [[sharded.start, sharded.end]]
         state = {}
 
         def score_step():
@@ -1005,6 +1146,8 @@ def main():
                        "batch_per_gpu": B, "seq_len": T, "targets": N_TARGETS, "parallelism": "dp%d" % world,
                        "weights": "random-init (reference initialisers, seed 0)"},
             "cosine_scores_per_s": value * N_TARGETS,
+            "rccl_ranks_seen": rccl_ranks_seen,
+            "shard_bounds": shard_bounds,
             "top1_match_vs_oracle": top1_match, "encode_max_abs_err_vs_oracle": enc_err,
             "roofline": {"kernel": "lstm_fwd_kernel<2>", "bound": "mfma", "achieved": achieved_tflops,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
@@ -1041,14 +1184,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
-        # RCCL (NCCL_DEBUG=VERSION on the GPU boxes) prints its banner through C stdio, which would otherwise be
-        # flushed at exit, AFTER this line: push it out first so that the JSON line is the last line of stdout
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps(line), flush=True)
+        emit(line)
     if use_dist:
         dist.destroy_process_group()
 

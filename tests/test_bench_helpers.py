@@ -70,3 +70,27 @@ def test_busy_of_selects_kernels_by_name_prefix(monkeypatch):
     assert bench.busy_of("cnn_") is None
     monkeypatch.setattr(bench, "PMC", {"stale": "sources changed"})
     assert bench.busy_of("lstm_bwd") is None
+
+
+def test_headline_line_stays_small_and_keeps_the_contract_keys():
+    """the 23.5 KB line of round 5 came back from the driver with `parsed: null`.  The headline is now a
+    compact summary (full legs go to profiles/bench_legs_latest.json and an earlier BENCH_LEGS line); checked here on the
+    round-5 full line, and on one with every leg inflated so the shedding guard is exercised."""
+    full = json.load(open(os.path.join(bench.ROOT, "profiles", "r05z_bench.json")))
+    text = bench.compact_headline(full)
+    assert len(text) < bench.HEADLINE_MAX_BYTES < 8192 and "\n" not in text
+    d = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline",
+                "top1_match_vs_oracle", "legs"):
+        assert key in d, key
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
+    assert d["roofline"]["frac"] == float("%.6g" % full["roofline"]["frac"]) and d["config"] == full["config"]
+    assert d["legs"]["train_fp32"]["ms"] > 0 and d["legs"]["c4_full_1gpu"]["planted_top1"] == 1.0
+    fat = dict(full)
+    fat["encode_leg_reference_shapes"] = dict(full["encode_leg_reference_shapes"],
+                                              shapes=full["encode_leg_reference_shapes"]["shapes"] * 60)
+    text = bench.compact_headline(fat)
+    d = json.loads(text)
+    assert len(text) <= bench.HEADLINE_MAX_BYTES and d["legs_truncated"] and "roofline" in d and "cpu_baseline" in d
