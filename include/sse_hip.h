@@ -89,6 +89,11 @@ int sse_encode_dev(sse_handle *h, int side, const int32_t *ids_dev, int32_t B, i
  * every 64-row tile exactly -- the LSTM state after p leading PAD (id 0) steps is
  * sequence-independent (sse_index.py:79-85 left-pads; sse_model.py:240-242 runs all T steps),
  * so it is precomputed per p with the same kernel; results are bit-identical to pad_skip = 0.
+ * "pad_sort_dev" (default 1): with pad_skip, sse_encode_dev buckets the rows of a device-resident id matrix by their
+ * leading-PAD count on the device (two small launches on the caller's stream, no host round trip) so that every row tile
+ * skips its whole common prefix -- what sse_encode does with a host counting sort; outputs keep the caller's row order and
+ * are bit-identical.  1 = adaptive (each eligible call measures its batch; rows are bucketed while the latest completed call
+ * of that side saw padding, 32-row tiles while its mean prefix was >= T / 4), 2 = always, 0 = off.  Counter "pad_sorted_calls".
  * "lstm_small_rows" (default 1024): LSTM encodes of at most this many rows (a demo / web query, an evaluator batch of
  * 600, the tail batch of an index build) run on the few-sequences kernel -- one workgroup per 4 rows, gate GEMV on the
  * vector ALUs streaming the kernel matrix from L2 instead of ~38 us per step for a 32-row matrix tile; the same fp32
@@ -179,9 +184,15 @@ int sse_merge_topk_strided_dev(sse_handle *h, const double *in_scores_dev, const
                                int64_t *out_ids_dev, void *stream);
 
 /* The exchange step WITHOUT torch: RCCL from the C ABI, so that the reference-side binding of
- * INTEGRATION.md can shard an index with ctypes alone.  `nccl_comm` is an ncclComm_t of the caller's RCCL (one rank per GPU,
- * created on the handle's device); the library resolves ncclAllGather in the process image or in librccl.so.1 at first use
- * (libsse_hip.so itself does not link RCCL).
+ * INTEGRATION.md can shard an index with ctypes alone.  `nccl_comm` is an ncclComm_t (one rank per GPU, created on the handle's
+ * device) OF THE RCCL INSTANCE THIS LIBRARY BOUND: libsse_hip.so does not link RCCL, it binds every entry point it needs from
+ * ONE library at first use -- $SSE_RCCL_LIB when set; else an RCCL already mapped into the process, whatever its visibility
+ * (a host that imported torch: torch's copy); else librccl.so.1.  sse_rccl_library_path() names it (NULL: none loadable).
+ * A communicator from sse_rccl_comm_init_rank is always of that instance; one the host made itself is valid here only if the
+ * host's RCCL is the file sse_rccl_library_path() reports (two RCCL instances in one process do not share communicators).
+ * Threads: one thread or process per rank.  ncclCommInitRank blocks until every rank has called it, so ONE thread driving
+ * several handles must bracket its sse_rccl_comm_init_rank calls with sse_rccl_group_start / sse_rccl_group_end
+ * (ncclGroupStart / ncclGroupEnd); the handle's mutex is held for the duration of the call.
  *   sse_allgather_merge_topk_dev  this rank's [Q][k] lists (global row ids) -> ONE ncclAllGather of the packed
  *       (float64 score bits | int64 ids) words on `stream` -> k-way merge: the unsharded result on every rank;
  *   sse_score_topk_sharded_dev    sse_score_topk_dev on this rank's shard (rows set with id_base = shard offset) + the above;
@@ -190,6 +201,9 @@ int sse_merge_topk_strided_dev(sse_handle *h, const double *in_scores_dev, const
  *       rank 0 creates it and hands it to the other ranks by whatever channel the host has -- file, socket, MPI).
  * Replaces nothing in the reference (it has no distributed code); consumes what sse_evaluator.py:110-111 / data_utils.py:263-267
  * compute per shard. */
+const char *sse_rccl_library_path(void);
+int sse_rccl_group_start(void);
+int sse_rccl_group_end(void);
 int sse_rccl_get_unique_id(char *id128);
 int sse_rccl_comm_init_rank(sse_handle *h, void **comm, int32_t world, int32_t rank, const char *id128);
 int sse_rccl_comm_destroy(sse_handle *h, void *comm);

@@ -48,6 +48,9 @@ SYMBOLS = {
     "sse_encode_score_topk": (C.c_int, [_P, C.c_int, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "sse_merge_topk_dev": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "sse_merge_topk_strided_dev": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "sse_rccl_library_path": (C.c_char_p, []),
+    "sse_rccl_group_start": (C.c_int, []),
+    "sse_rccl_group_end": (C.c_int, []),
     "sse_rccl_get_unique_id": (C.c_int, [_P]),
     "sse_rccl_comm_init_rank": (C.c_int, [_P, C.POINTER(_P), C.c_int32, C.c_int32, _P]),
     "sse_rccl_comm_destroy": (C.c_int, [_P, _P]),
@@ -266,6 +269,20 @@ class Handle(object):
         if self.lib.sse_rccl_get_unique_id(buf) != 0:
             raise SSEError("RCCL (librccl.so.1) is not loadable in this process")
         return buf.raw
+
+    def rccl_library_path(self):
+        """The ONE RCCL instance the library bound ($SSE_RCCL_LIB, else one already mapped into the process, else
+        librccl.so.1); None when no RCCL is loadable.  Communicators must come from this instance."""
+        p = self.lib.sse_rccl_library_path()
+        return p.decode() if p else None
+
+    def rccl_group_start(self):
+        if self.lib.sse_rccl_group_start() != 0:
+            raise SSEError("ncclGroupStart failed (or RCCL is not loadable in this process)")
+
+    def rccl_group_end(self):
+        if self.lib.sse_rccl_group_end() != 0:
+            raise SSEError("ncclGroupEnd failed (or RCCL is not loadable in this process)")
 
     def rccl_comm_init_rank(self, world, rank, unique_id):
         """ncclCommInitRank on the handle's device; returns the communicator as an integer handle (void*)."""

@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, os.environ.get("SSE_LIB_NAME", "libsse_hip.so"))   # SS
 # library WITHOUT the HIP runtime: reading a checkpoint or parsing an index file must not initialise a GPU (or import torch)
 HOST_LIB = os.path.join(HERE, "libsse_host.so")
 HOST_SOURCES = ["index_io.cpp"]
-SOURCES = ["sse_api.hip", "lstm_fwd.hip", "lstm_small.hip", "lstm_persist.hip", "lstm_cluster.hip", "lstm_fwd_x3.hip", "cnn_fwd.hip", "cnn_fwd_bf16.hip", "score_topk.hip", "pack.hip", "train.hip", "lstm_bwd2.hip", "cnn_bwd.hip", "cnn_bwd_mfma.hip", "lstm_generic.hip", "index_io.cpp"]
+SOURCES = ["sse_api.hip", "lstm_fwd.hip", "lstm_fwd_gs.hip", "lstm_small.hip", "lstm_persist.hip", "lstm_cluster.hip", "lstm_fwd_x3.hip", "cnn_fwd.hip", "cnn_fwd_bf16.hip", "score_topk.hip", "pack.hip", "train.hip", "lstm_bwd2.hip", "cnn_bwd.hip", "cnn_bwd_mfma.hip", "lstm_generic.hip", "index_io.cpp"]
 EXTRA = os.environ.get("SSE_HIPCC_EXTRA", "").split()   # e.g. -DSSE_SCORE_MEASURE for the measurement builds of tools/
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 

@@ -776,6 +776,15 @@ hipError_t launch_lstm_fwd(const LstmFwdArgs &a, int Hp, hipStream_t stream) {
     if (Hp <= 256 && (r == 32 || r == 64)) rows = r;
   }
   if (rows == 64 && a.NT32 > 0 && (a.NT32 & 1)) return hipErrorInvalidValue;  // tapes are laid out per 32-row tile
+  if (Hp == 128 && rows == 64 && a.gate_split && a.tape_g == nullptr && a.rec_h == nullptr && a.NTS <= 16 &&
+      lstm_fwd_gs_ok(a.KGx, a.KGh, a.H > 0 ? a.H : Hp)) {
+    const char *ev = getenv("SSE_FWD_GS");  // measurement aid: 0 = lstm_fwd_kernel<2,1,1>
+    if (!(ev && atoi(ev) == 0)) {
+      LstmFwdArgs g = a;
+      if (g.H <= 0) g.H = Hp;
+      return launch_lstm_fwd_gs(g, stream);
+    }
+  }
   if (Hp == 128) return rows == 32 ? launch_cfg<1, 1, 1, true>(a, stream) : launch_cfg<2, 1, 1>(a, stream);
   if (Hp == 256) return rows == 32 ? launch_cfg<1, 1, 1>(a, stream) : launch_cfg<2, 2, 1>(a, stream);
   if (Hp == 512) return launch_cfg<1, 1, 2>(a, stream);

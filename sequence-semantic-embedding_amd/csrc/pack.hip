@@ -389,3 +389,121 @@ hipError_t launch_pack_kT(const float *K, int row0, int nrows, int RT, int H, in
                      reinterpret_cast<f32x4 *>(out));
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// PAD-prefix bucketing of a device-resident id matrix (sse_encode_dev; sse_index.py:79-85 left-pads every row).  What the
+// host-buffer entry point does with a counting sort on the host (sse_api.hip, encode_host_ids_locked) for ids that are already
+// in HBM: the row numbers ordered by leading-PAD count so that every row tile of the matrix kernel can skip its whole common
+// prefix -- SHORTEST prefix first: the tiles with the most steps left are dispatched first and the short ones fill the tail
+// (longest-first left the T-step tiles for last: real crosslingual queries 0.85 -> 1.04 ms, profiles/r06_notes.txt).  Two launches, no host round trip:
+//   pad_lead_kernel   one wavefront per row (lanes over the time axis, ballot + ffs), lead[b] kept, a histogram over lead
+//                     through LDS; the LAST workgroup to finish (ticket counter) turns the histogram into bucket starts,
+//                     re-zeroes histogram + ticket for the next call, and stores the batch's statistics to `stat`
+//   pad_scatter_kernel  order[start[lead[b]]++] = b  (the order inside a bucket is whatever the atomics yield: every
+//                     row's result is independent of its tile mates, bit for bit -- tests/test_gpu_encode.py)
+// hist: [T + 2] int32 zero on entry (and on exit) | ticket: one int32, same | start: [T + 2] | stat (pinned host memory, may be
+// null): {call number, 0 dense / 1 some padding / 2 mean prefix >= T / 4}.
+__global__ void __launch_bounds__(256) pad_lead_kernel(const int32_t *__restrict__ ids, int B, int T, int32_t *__restrict__ lead,
+                                                        int32_t *hist, int32_t *ticket, int32_t *__restrict__ start,
+                                                        volatile int32_t *stat, int32_t seq) {
+  extern __shared__ int32_t lh[];  // [T + 2]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int i = tid; i < T + 2; i += 256) lh[i] = 0;
+  __syncthreads();
+  for (int b = (blockIdx.x * 4 + w); b < B; b += gridDim.x * 4) {
+    const int32_t *row = ids + (size_t)b * T;
+    int l = T;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+      const int t = t0 + lane;
+      const unsigned long long m = __ballot(t < T && row[t] != 0);
+      if (m) {
+        l = t0 + __ffsll((long long)m) - 1;
+        break;
+      }
+    }
+    if (lane == 0) {
+      lead[b] = l;
+      atomicAdd(&lh[l + 1], 1);  // bucket l (no padding = bucket 0), shifted by one for the exclusive scan
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < T + 2; i += 256)
+    if (lh[i]) atomicAdd(&hist[i], lh[i]);
+  __threadfence();
+  __shared__ int last;
+  __syncthreads();
+  if (tid == 0) last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  // the last workgroup: exclusive scan of hist[0 .. T+1] (hist[0] is 0) -> start[], statistics, and the zero invariant back
+  for (int i = tid; i < T + 2; i += 256) lh[i] = __hip_atomic_load(&hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (w == 0) {
+    int carry = 0;
+    long long lead_sum = 0;
+    for (int i0 = 0; i0 < T + 2; i0 += 64) {
+      const int i = i0 + lane;
+      const int v = i < T + 2 ? lh[i] : 0;
+      if (i >= 1 && i < T + 2) lead_sum += (long long)v * (i - 1);  // rows of bucket i-1 have lead = i-1
+      int s = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(s, o);
+        if (lane >= o) s += u;
+      }
+      if (i < T + 2) start[i] = carry + s;  // inclusive over the shifted histogram = exclusive bucket starts
+      carry += __shfl(s, 63);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lead_sum += __shfl_xor(lead_sum, o);
+    if (lane == 0 && stat) {
+      stat[1] = lead_sum == 0 ? 0 : (lead_sum * 4 >= (long long)B * T ? 2 : 1);
+      __threadfence_system();
+      stat[0] = seq;
+    }
+  }
+  for (int i = tid; i < T + 2; i += 256) hist[i] = 0;
+  if (tid == 0) *ticket = 0;
+}
+
+// The cheap check for batches expected to be dense (the latest completed call of that side saw no padding): one thread per
+// row looks at the row's FIRST token only; nothing is written unless a padded row shows up -- no atomics, no second launch
+// (the two-launch bucketing cost the dense 16384-row headline batch 0.07 ms of 2.4, profiles/r06_notes.txt).
+__global__ void __launch_bounds__(256) pad_detect_kernel(const int32_t *__restrict__ ids, int B, int T, volatile int32_t *stat,
+                                                          int32_t seq) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  const bool padded = b < B && ids[(size_t)b * T] == 0;
+  if (__ballot(padded) != 0 && (threadIdx.x & 63) == 0) {  // (racing waves store the same two words)
+    stat[1] = 1;
+    __threadfence_system();
+    stat[0] = seq;
+  }
+}
+
+__global__ void __launch_bounds__(256) pad_scatter_kernel(const int32_t *__restrict__ lead, int B, int T, int32_t *start,
+                                                           int32_t *__restrict__ order) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  order[atomicAdd(&start[lead[b]], 1)] = b;
+}
+
+// zeroed: int32 [SSE_PAD_SORT_MAX_T + 3] = hist [T + 2] ... | ticket (last word) -- zero on first use (the caller memsets the
+// allocation once), zero again when the launch has finished, for any T.  work: int32 [T + 2 + B] = start | lead.
+// scatter = false: pad_detect_kernel only (the caller saw dense batches and wants them re-checked).
+size_t pad_sort_zeroed_words() { return (size_t)SSE_PAD_SORT_MAX_T + 3; }
+size_t pad_sort_work_words(int B, int T) { return (size_t)(T + 2) + (size_t)B; }
+hipError_t launch_pad_sort(const int32_t *ids, int B, int T, int32_t *zeroed, int32_t *work, int32_t *order, int32_t *stat_pinned,
+                           int32_t seq, bool scatter, hipStream_t stream) {
+  if (T > SSE_PAD_SORT_MAX_T) return hipErrorInvalidValue;
+  if (!scatter) {
+    hipLaunchKernelGGL(pad_detect_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, ids, B, T, stat_pinned, seq);
+    return hipGetLastError();
+  }
+  int32_t *hist = zeroed, *ticket = zeroed + SSE_PAD_SORT_MAX_T + 2, *start = work, *lead = work + (T + 2);
+  const int grid = (B + 3) / 4 < 1024 ? (B + 3) / 4 : 1024;
+  hipLaunchKernelGGL(pad_lead_kernel, dim3(grid), dim3(256), (size_t)(T + 2) * sizeof(int32_t), stream, ids, B, T, lead, hist,
+                     ticket, start, stat_pinned, seq);
+  hipLaunchKernelGGL(pad_scatter_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, lead, B, T, start, order);
+  return hipGetLastError();
+}

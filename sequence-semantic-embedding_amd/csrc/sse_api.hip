@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cstring>
 #include <dlfcn.h>
+#include <link.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -110,6 +111,16 @@ struct sse_handle {
   bool packed_dirty = true;
   bool mp_fresh = false;     // the packed projections match the variables although packed_dirty is set (ensure_proj_packed)
   bool pad_skip = true;      // option "pad_skip": exact left-pad prefix skip in inference encodes
+  // option "pad_sort_dev": PAD-prefix bucketing of device-resident id matrices (sse_encode_dev) by two small kernels (pack.hip):
+  // 0 off | 1 adaptive: every eligible call measures its batch; rows are bucketed while the latest completed call of that side
+  // saw any padding, 32-row tiles while it saw a mean prefix >= T / 4 (no host round trip: an index build's batches look alike)
+  // | 2 always bucket + 32-row tiles (deterministic: tests, tools)
+  int pad_sort_dev = 1;
+  bool lstm_gate_split = true;  // option "lstm_gate_split": small cells (H <= 128) at 64-row tiles on lstm_fwd_gs.hip (bit-identical)
+  DevBuf s_padzero, s_padwork, s_padorder;
+  int32_t *pad_stat = nullptr;  // pinned host words the device stores to: [side] {call number, class 0 / 1 / 2}
+  int32_t pad_seq = 0;
+  int64_t pad_sorted_calls = 0;  // counter "pad_sorted_calls"
   bool lstm_x3 = false;       // option "lstm_x3": large inference encodes (Hp = 256) on the bf16 matrix pipe with split operands
   unsigned short *emb16 = nullptr;  // split embedding table of that path
   bool emb16_valid = false;
@@ -413,6 +424,7 @@ void fill_fwd_args(sse_handle *h, Encoder &e, LstmFwdArgs &a) {
   a.KGhe = (e.H + 7) / 8;
   a.S = c.encoding_size;
   a.NTS = (c.encoding_size + 31) / 32;
+  a.gate_split = h->lstm_gate_split ? 1 : 0;
 }
 
 // state after p leading PAD steps for p = 0..T: one all-PAD row through the SAME kernel
@@ -572,6 +584,32 @@ static int encode_generic_locked(sse_handle *h, Encoder &e, const int32_t *ids, 
     HIPCHECK(h, launch_gen_project((const float *)h->g_hl.p, (const float *)h->g_MT.p, d, S, (float *)h->g_raw.p, st));
     if (normalize) HIPCHECK(h, launch_l2_normalize((const float *)h->g_raw.p, out + (size_t)b0 * S, nb, S, st));
     else HIPCHECK(h, hipMemcpyAsync(out + (size_t)b0 * S, h->g_raw.p, (size_t)nb * S * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+  return 0;
+}
+
+// PAD-prefix bucketing for ids that are already on the device (sse_index.py:79-85 left-pads every row):
+// what encode_host_ids_locked does with a host counting sort, as two launches on the caller's stream.  *row_map / *padded
+// keep the caller's values when the batch is not bucketed.
+static int device_pad_sort(sse_handle *h, int side, const int32_t *ids, int B, int T, hipStream_t st, const int32_t **row_map,
+                           bool *padded) {
+  if (*row_map || !h->pad_skip || h->pad_sort_dev == 0 || T < 2 || T > SSE_PAD_SORT_MAX_T || B <= 64) return 0;
+  volatile int32_t *stat = h->pad_stat + 2 * side;
+  const int seen = h->pad_sort_dev == 2 ? 2 : (stat[0] != 0 ? (int)stat[1] : 1);  // nothing seen yet: bucket, keep the tile policy
+  const bool scatter = seen != 0;
+  if (!h->s_padzero.p) {
+    if (reserve(h, h->s_padzero, pad_sort_zeroed_words() * sizeof(int32_t))) return 1;
+    HIPCHECK(h, hipMemsetAsync(h->s_padzero.p, 0, h->s_padzero.cap, st));
+  }
+  if (reserve(h, h->s_padwork, pad_sort_work_words(B, T) * sizeof(int32_t))) return 1;
+  if (scatter && reserve(h, h->s_padorder, (size_t)B * sizeof(int32_t))) return 1;
+  h->pad_seq = h->pad_seq == INT32_MAX ? 1 : h->pad_seq + 1;
+  HIPCHECK(h, launch_pad_sort(ids, B, T, (int32_t *)h->s_padzero.p, (int32_t *)h->s_padwork.p, (int32_t *)h->s_padorder.p,
+                              h->pad_stat + 2 * side, h->pad_seq, scatter, st));
+  if (scatter) {
+    *row_map = (const int32_t *)h->s_padorder.p;
+    *padded = seen == 2;
+    h->pad_sorted_calls += 1;
   }
   return 0;
 }
@@ -793,6 +831,10 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
     xa.NTS = (c.encoding_size + 31) / 32;
     xa.normalize = normalize ? 1 : 0;
     xa.row_map = h->cur_row_map;
+    {
+      bool padded_x3 = false;
+      if (device_pad_sort(h, side, ids, B, T, st, &xa.row_map, &padded_x3)) return 1;
+    }
     if (h->pad_skip && T > 1) {
       // pad-prefix table of THIS path: one all-PAD row through the same kernel, recorded step by step
       if (!(own.pad_valid_x3 && own.pad_T_x3 >= T)) {
@@ -835,6 +877,8 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
   a.T = T;
   a.normalize = normalize ? 1 : 0;
   a.row_map = h->cur_row_map;
+  bool padded_hint = h->cur_padded_hint;
+  if (device_pad_sort(h, side, ids, B, T, st, &a.row_map, &padded_hint)) return 1;
   if (h->pad_skip && T > 1) {
     if (ensure_pad_table(h, side, T, st)) return 1;
     a.pad_h = e.pad_h;
@@ -842,7 +886,7 @@ int encode_dev_locked(sse_handle *h, int side, const int32_t *ids, int B, int T,
     // a heavily left-padded batch sorted by pad count (sse_encode's host path knows both): tiles differ in length, the finer
     // 32-row granularity with two workgroups per CU balances them better -- crosslingual index build 2.96 -> 2.64 ms, queries
     // 1.24 -> 0.84 ms (profiles/r05_notes.txt)
-    if (h->cur_padded_hint && h->cur_row_map && e.Hp <= 256) a.force_rows = 32;
+    if (padded_hint && a.row_map && e.Hp <= 256) a.force_rows = 32;
   }
   HIPCHECK(h, launch_lstm_fwd(a, e.Hp, st));
   return 0;
@@ -1327,6 +1371,12 @@ int sse_create(const sse_config *cfg, sse_handle **out) {
   if (hipMalloc((void **)&h->err_flag, sizeof(int32_t)) != hipSuccess) CREATE_FAIL("hipMalloc failed");
   if (hipHostMalloc((void **)&h->pin_small, 64 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) CREATE_FAIL("hipHostMalloc failed");
   hipMemset(h->err_flag, 0, sizeof(int32_t));
+  if (hipHostMalloc((void **)&h->pad_stat, 8 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) CREATE_FAIL("hipHostMalloc failed");
+  if (const char *ev = getenv("SSE_PAD_SORT_DEV")) {  // measurement aid: the option's initial value
+    const int v = atoi(ev);
+    if (v >= 0 && v <= 2) h->pad_sort_dev = v;
+  }
+  memset(h->pad_stat, 0, 8 * sizeof(int32_t));
   if (hipDeviceSynchronize() != hipSuccess) CREATE_FAIL("device initialisation failed");
 #undef CREATE_FAIL
   *out = h;
@@ -1361,6 +1411,7 @@ void sse_destroy(sse_handle *h) {
   }
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->pin_small) (void)hipHostFree(h->pin_small);
+  if (h->pad_stat) (void)hipHostFree(h->pad_stat);
   if (h->emb_pad) hipFree(h->emb_pad);
   if (h->emb16) (void)hipFree(h->emb16);
   if (h->err_flag) hipFree(h->err_flag);
@@ -1485,17 +1536,18 @@ static int encode_host_ids_locked(sse_handle *h, int side, const int32_t *ids_ho
   const int32_t *row_map_dev = nullptr;
   const bool to_cluster = lstm_side && h->enc[side].kernel >= 0 && cluster_takes(h, h->enc[side], B, T);  // (takes rows as they come)
   if (h->pad_skip && lstm_side && B > 64 && B > h->lstm_small_rows && !to_cluster && !h->enc[side].generic) {
-    // counting sort of the row numbers by leading-PAD count, longest prefix first
+    // counting sort of the row numbers by leading-PAD count, shortest prefix first (the tiles with the most steps left are
+    // dispatched first; see pack.hip, pad_lead_kernel)
     std::vector<int32_t> lead(B), start(T + 2, 0), order(B);
     for (int b = 0; b < B; ++b) {
       const int32_t *row = ids_host + (size_t)b * T;
       int t = 0;
       while (t < T && row[t] == 0) ++t;
       lead[b] = t;
-      ++start[T - t + 1];
+      ++start[t + 1];
     }
     for (int i = 1; i <= T + 1; ++i) start[i] += start[i - 1];
-    for (int b = 0; b < B; ++b) order[start[T - lead[b]]++] = b;
+    for (int b = 0; b < B; ++b) order[start[lead[b]]++] = b;
     int64_t lead_sum = 0;
     for (int b = 0; b < B; ++b) lead_sum += lead[b];
     h->cur_padded_hint = lead_sum * 4 >= (int64_t)B * T;
@@ -1668,6 +1720,10 @@ int sse_get_counter(sse_handle *h, const char *name, int64_t *value) {
     *value = h->persist_fallbacks;
     return 0;
   }
+  if (strcmp(name, "pad_sorted_calls") == 0) {  // encodes of device-resident ids whose rows were bucketed by PAD prefix on the device
+    *value = h->pad_sorted_calls;
+    return 0;
+  }
   if (strcmp(name, "lstm_coop_refused") == 0) {  // process-wide: cooperative launches refused by the runtime (plain launch taken)
     *value = (int64_t)lstm_coop_refused();
     return 0;
@@ -1740,6 +1796,15 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value) {
   }
   if (strcmp(name, "pad_skip") == 0) {
     h->pad_skip = value != 0;
+    return 0;
+  }
+  if (strcmp(name, "lstm_gate_split") == 0) {
+    h->lstm_gate_split = value != 0;
+    return 0;
+  }
+  if (strcmp(name, "pad_sort_dev") == 0) {
+    if (value < 0 || value > 2) return fail(h, "pad_sort_dev must be 0 (off), 1 (adaptive) or 2 (always)");
+    h->pad_sort_dev = (int)value;
     return 0;
   }
   if (strcmp(name, "lstm_x3") == 0) {
@@ -1884,9 +1949,14 @@ int sse_merge_topk_dev(sse_handle *h, const double *in_scores_dev, const int64_t
 
 // ---------------------------------------------------------------------------
 // Torch-free exchange step of the row-sharded index (BASELINE configs[3]): RCCL straight from the C ABI.
-// The library does not LINK librccl: the few entry points it needs are looked up at first use -- in the process image first
-// (a host that already loaded RCCL, e.g. through torch, keeps ONE copy), then in librccl.so.1 -- so libsse_hip.so loads on a
-// box without RCCL and every other entry point works there.
+// The library does not LINK librccl: the few entry points it needs are bound at first use, ALL from ONE library instance
+// (a per-symbol dlsym(RTLD_DEFAULT) misses an RCCL the host loaded RTLD_LOCAL -- the Python default, torch's
+// bundled copy -- and a second instance opened beside it would be handed the first one's ncclComm_t).  Order:
+//   1. $SSE_RCCL_LIB, when set: that file (the host names its RCCL explicitly);
+//   2. an RCCL already mapped into the process (dl_iterate_phdr, any visibility): dlopen(its path, RTLD_NOLOAD) returns THAT
+//      instance, so a communicator the host created with it and this library's ncclAllGather agree;
+//   3. librccl.so.1 / librccl.so from the loader path.
+// sse_rccl_library_path() reports the choice.  libsse_hip.so still loads on a box without RCCL; every other entry point works.
 namespace {
 typedef struct { char internal[128]; } sse_nccl_uid;  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
 struct RcclApi {
@@ -1894,28 +1964,57 @@ struct RcclApi {
   int (*comm_init_rank)(void **, int, sse_nccl_uid, int) = nullptr;
   int (*comm_destroy)(void *) = nullptr;
   int (*all_gather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  int (*group_start)() = nullptr;
+  int (*group_end)() = nullptr;
   const char *(*error_string)(int) = nullptr;
   const char *why = nullptr;
+  std::string path;  // the library instance everything above came from
 };
+int find_mapped_rccl(struct dl_phdr_info *info, size_t, void *data) {
+  const char *name = info->dlpi_name;
+  if (!name || !*name) return 0;
+  const char *base = strrchr(name, '/');
+  base = base ? base + 1 : name;
+  if (strncmp(base, "librccl.so", 10) != 0) return 0;
+  *static_cast<std::string *>(data) = name;
+  return 1;  // first match: stop
+}
 const RcclApi *rccl_api_ptr() {
   static const RcclApi api = [] {
     RcclApi a;
     void *lib = nullptr;
-    auto sym = [&](const char *name) -> void * {
-      void *p = dlsym(RTLD_DEFAULT, name);
-      if (!p) {
-        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (lib) p = dlsym(lib, name);
+    if (const char *env = getenv("SSE_RCCL_LIB")) {
+      if (*env) {
+        lib = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+        if (!lib) {
+          a.why = "SSE_RCCL_LIB is set but that file does not load as a library";
+          return a;
+        }
+        a.path = env;
       }
-      return p;
-    };
-    a.get_unique_id = reinterpret_cast<int (*)(sse_nccl_uid *)>(sym("ncclGetUniqueId"));
-    a.comm_init_rank = reinterpret_cast<int (*)(void **, int, sse_nccl_uid, int)>(sym("ncclCommInitRank"));
-    a.comm_destroy = reinterpret_cast<int (*)(void *)>(sym("ncclCommDestroy"));
-    a.all_gather = reinterpret_cast<int (*)(const void *, void *, size_t, int, void *, hipStream_t)>(sym("ncclAllGather"));
-    a.error_string = reinterpret_cast<const char *(*)(int)>(sym("ncclGetErrorString"));
-    if (!a.get_unique_id || !a.comm_init_rank || !a.comm_destroy || !a.all_gather) a.why = "RCCL (librccl.so.1) is not loadable in this process";
+    }
+    if (!lib) {
+      std::string mapped;
+      dl_iterate_phdr(find_mapped_rccl, &mapped);
+      if (!mapped.empty() && (lib = dlopen(mapped.c_str(), RTLD_NOW | RTLD_NOLOAD)) != nullptr) a.path = mapped;
+    }
+    for (const char *cand : {"librccl.so.1", "librccl.so"}) {
+      if (lib) break;
+      if ((lib = dlopen(cand, RTLD_NOW | RTLD_LOCAL)) != nullptr) a.path = cand;
+    }
+    if (!lib) {
+      a.why = "RCCL (librccl.so.1) is not loadable in this process";
+      return a;
+    }
+    a.get_unique_id = reinterpret_cast<int (*)(sse_nccl_uid *)>(dlsym(lib, "ncclGetUniqueId"));
+    a.comm_init_rank = reinterpret_cast<int (*)(void **, int, sse_nccl_uid, int)>(dlsym(lib, "ncclCommInitRank"));
+    a.comm_destroy = reinterpret_cast<int (*)(void *)>(dlsym(lib, "ncclCommDestroy"));
+    a.all_gather = reinterpret_cast<int (*)(const void *, void *, size_t, int, void *, hipStream_t)>(dlsym(lib, "ncclAllGather"));
+    a.group_start = reinterpret_cast<int (*)()>(dlsym(lib, "ncclGroupStart"));
+    a.group_end = reinterpret_cast<int (*)()>(dlsym(lib, "ncclGroupEnd"));
+    a.error_string = reinterpret_cast<const char *(*)(int)>(dlsym(lib, "ncclGetErrorString"));
+    if (!a.get_unique_id || !a.comm_init_rank || !a.comm_destroy || !a.all_gather || !a.group_start || !a.group_end)
+      a.why = "the RCCL library found in this process lacks an entry point this library binds";
     return a;
   }();
   return &api;
@@ -1926,6 +2025,22 @@ int rccl_fail(sse_handle *h, const char *what, int rc) {
   return fail(h, "%s: RCCL error %d (%s)", what, rc, r.error_string ? r.error_string(rc) : "?");
 }
 }  // namespace
+
+const char *sse_rccl_library_path(void) {
+  const RcclApi &r = *rccl_api_ptr();
+  return r.why ? nullptr : r.path.c_str();
+}
+
+/* ncclGroupStart / ncclGroupEnd of the bound RCCL: ONE thread that drives several handles (one per GPU) must bracket its
+ * sse_rccl_comm_init_rank calls with these, or the first (blocking) call waits for ranks that the thread has not reached yet. */
+int sse_rccl_group_start(void) {
+  const RcclApi &r = *rccl_api_ptr();
+  return r.why ? 1 : (r.group_start() != 0);
+}
+int sse_rccl_group_end(void) {
+  const RcclApi &r = *rccl_api_ptr();
+  return r.why ? 1 : (r.group_end() != 0);
+}
 
 int sse_rccl_get_unique_id(char *id128) {
   const RcclApi &r = *rccl_api_ptr();

@@ -124,6 +124,8 @@ struct LstmFwdArgs {
   int32_t tiles_elsewhere = 0;  // 32-row tiles of launches that run CONCURRENTLY on other streams (the other encoder of a
                                 // train step): the 32- vs 64-row tile choice looks at the chip, not at this launch alone
   int32_t force_rows = 0;       // 32 / 64: override the tile choice (Hp = 256; measurement aid, option lstm_train_rows)
+  int32_t gate_split = 1;       // Hp = 128 inference at 64-row tiles: lstm_fwd_gs.hip (two phase-shifted row groups, one gate per
+                                // wave) instead of lstm_fwd_kernel<2,1,1>; bit-identical results (option "lstm_gate_split")
   // Left-pad prefix skip (exact): the state after p leading PAD (id 0) steps does not depend on
   // the sequence, so a tile starts at t0 = min over its rows of the leading-PAD count with
   // (h, c) = pad_h/pad_c[t0].  pad_* [T+1][Hp] come from rec_* of an all-PAD launch by the same
@@ -146,6 +148,10 @@ size_t lstm_fwd_lds_bytes(int KGx, int KGh, int RT);
 bool lstm_fwd_x_double(int KGx, int KGh, int RT);
 int lstm_fwd_rows_per_wg(int Hp, int B, int tiles_elsewhere = 0);
 hipError_t launch_lstm_fwd(const LstmFwdArgs &a, int Hp, hipStream_t stream);
+// small cells (H <= 128), inference, 64-row tiles: lstm_fwd_gs.hip
+size_t lstm_fwd_gs_lds_bytes(int KGx, int NB);
+bool lstm_fwd_gs_ok(int KGx, int KGh, int H);
+hipError_t launch_lstm_fwd_gs(const LstmFwdArgs &a, hipStream_t stream);
 
 // few-sequences LSTM forward (lstm_small.hip): one workgroup per 4 sequences, vector-ALU GEMV on the master variables
 struct LstmSmallArgs {
@@ -410,6 +416,12 @@ void pack_job_kT(PackJobs &js, const float *K, int row0, int nrows, int RT, int 
 hipError_t launch_pack_multi(const PackJobs &js, hipStream_t stream);
 hipError_t launch_pack_kn(const float *X, int K, int N, int KGp, float *out, hipStream_t stream);
 hipError_t launch_pad_rows(const float *in, int64_t R, int C, int Cp, int one_col, float *out, hipStream_t stream);
+// PAD-prefix bucketing of device-resident ids (pack.hip): row numbers by leading-PAD count, longest prefix first
+#define SSE_PAD_SORT_MAX_T 8192
+size_t pad_sort_zeroed_words();
+size_t pad_sort_work_words(int B, int T);
+hipError_t launch_pad_sort(const int32_t *ids, int B, int T, int32_t *zeroed, int32_t *work, int32_t *order, int32_t *stat_pinned,
+                           int32_t seq, bool scatter, hipStream_t stream);
 hipError_t launch_row_norm2_max(const float *x, int64_t rows, int cols, float *out_bits, hipStream_t stream);
 hipError_t launch_fill(float *p, int64_t n, float v, hipStream_t stream);
 hipError_t launch_exact_topk(const float *q, const float *idxp, const double *idx64, const int32_t *cert,

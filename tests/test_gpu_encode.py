@@ -680,3 +680,96 @@ def test_small_cells_at_64_row_tiles_are_bit_identical_to_the_other_kernels(H):
         m.handle.set_option("lstm_cluster_rows", 1024)
         assert np.array_equal(big[pick], small)
     m.handle.set_option("pad_skip", 1)
+
+
+@pytest.mark.parametrize("T,B,H,x3", [(50, 3000, 256, 0), (40, 1500, 96, 0), (130, 2100, 128, 0), (50, 2500, 256, 1)])
+def test_device_pad_prefix_bucketing_is_bit_identical_in_caller_order(T, B, H, x3):
+    """sse_encode_dev on left-padded rows (sse_index.py:79-85) already in HBM: the rows are bucketed by leading-PAD count on
+    the device (pack.hip, option pad_sort_dev) as sse_encode does on the host; outputs stay in the caller's row order and equal
+    the unbucketed run bit for bit.  Adaptive mode: the first call buckets (nothing seen yet), a dense batch switches the
+    bucketing off for the following call, a padded one switches it on again -- results identical throughout."""
+    import torch
+    params = model_params("dual-encoder", 400, 50, H, H, 64, T)
+    m, p = make_pair(params, seed=9)
+    h = m.handle
+    h.set_option("lstm_small_rows", 0)                   # the matrix kernel at every size
+    h.set_option("lstm_cluster_rows", 0)
+    h.set_option("lstm_x3", x3)
+    rng = np.random.RandomState(T + B)
+    ids = random_ids(rng, B, T, 400, pad_frac=0.98)
+    ids[5, :] = 0                                        # all PAD (lead = T)
+    ids[6, :] = rng.randint(2, 400, size=T)              # no padding
+    ids[9, :-1] = 0                                      # only EOS
+    ids[9, -1] = 1
+    dense = random_ids(rng, B, T, 400)
+    dev = torch.device("cuda", 0)
+    out = torch.empty((B, 64), dtype=torch.float32, device=dev)
+
+    def run(a, sort, skip=1):
+        h.set_option("pad_skip", skip)
+        h.set_option("pad_sort_dev", sort)
+        d = torch.from_numpy(a).to(dev)
+        h.encode_dev(0, d.data_ptr(), B, T, True, out.data_ptr())
+        h.synchronize()
+        return out.cpu().numpy().copy()
+
+    want = run(ids, 0)
+    assert np.array_equal(want, run(ids, 0, skip=0))
+    n0 = h.get_counter("pad_sorted_calls")
+    assert np.array_equal(run(ids, 2), want)             # always bucket, 32-row tiles
+    assert h.get_counter("pad_sorted_calls") == n0 + 1
+    want_dense = run(dense, 0)
+    assert np.array_equal(run(dense, 2), want_dense)     # a dense batch through the bucketing: one bucket, same results
+    n0 = h.get_counter("pad_sorted_calls")
+    assert np.array_equal(run(ids, 1), want)             # adaptive: last completed call saw a dense batch -> class 0 ...
+    assert np.array_equal(run(ids, 1), want)             # ... this one saw padding -> bucketed from here on
+    assert np.array_equal(run(dense, 1), want_dense)
+    assert np.array_equal(run(dense, 1), want_dense)     # not bucketed any more
+    assert np.array_equal(run(ids, 1), want)
+    assert h.get_counter("pad_sorted_calls") == n0 + 2   # calls 2 and 3 of the five
+    if not x3:
+        tol = TOL
+        assert np.abs(want[:64] - O.encode(p, params, "src", ids[:64])).max() <= tol
+    h.set_option("pad_skip", 1)
+    h.set_option("pad_sort_dev", 1)
+
+
+@pytest.mark.parametrize("H,S,T,B", [(96, 64, 24, 9000), (64, 64, 20, 8300), (128, 128, 16, 8500), (40, 50, 12, 8200),
+                                     (100, 64, 9, 8193), (17, 40, 30, 8400), (96, 300, 10, 8257)])
+def test_gate_split_kernel_is_bit_identical_to_the_unit_block_kernel(H, S, T, B):
+    """lstm_fwd_gs.hip (small cells at 64-row tiles: one gate per wave, two phase-shifted row groups, no workgroup barrier in
+    the time loop) against lstm_fwd_kernel<2,1,1> (option lstm_gate_split = 0): every bit equal -- dense and left-padded rows,
+    with and without the prefix skip, a ragged last tile, both encoders (dual: separate weights), against the oracle too."""
+    import torch
+    params = model_params("dual-encoder", 400, 50, H, H, S, T)
+    m, p = make_pair(params, seed=31)
+    h = m.handle
+    h.set_option("lstm_small_rows", 0)
+    h.set_option("lstm_cluster_rows", 0)
+    h.set_option("pad_sort_dev", 0)                     # caller order, 64-row tiles
+    rng = np.random.RandomState(H + T)
+    ids = random_ids(rng, B, T, 400, pad_frac=0.7)
+    ids[:64] = random_ids(rng, 64, T, 400)               # one dense tile
+    ids[70, :] = 0                                       # an all-PAD row
+    dev = torch.device("cuda", 0)
+    d = torch.from_numpy(ids).to(dev)
+    out = torch.empty((B, S), dtype=torch.float32, device=dev)
+    res = {}
+    for side in (0, 1):
+        for skip in (1, 0):
+            h.set_option("pad_skip", skip)
+            for gs in (1, 0):
+                h.set_option("lstm_gate_split", gs)
+                for norm in (True, False):
+                    out.zero_()
+                    h.encode_dev(side, d.data_ptr(), B, T, norm, out.data_ptr())
+                    h.synchronize()
+                    res[(side, skip, gs, norm)] = out.cpu().numpy().copy()
+            for norm in (True, False):
+                assert np.array_equal(res[(side, skip, 1, norm)], res[(side, skip, 0, norm)]), (side, skip, norm)
+        assert np.array_equal(res[(side, 1, 1, True)], res[(side, 0, 1, True)])
+        want = O.encode(p, params, "src" if side == 0 else "tgt", ids[:200])
+        assert np.abs(res[(side, 1, 1, True)][:200] - want).max() <= TOL
+    h.set_option("pad_skip", 1)
+    h.set_option("lstm_gate_split", 1)
+    h.set_option("pad_sort_dev", 1)

@@ -145,3 +145,68 @@ def test_torch_free_rccl_exchange_through_the_c_abi():
     sh2.close()
     with pytest.raises(sse_amd.SSEError):
         h.allgather_merge_topk_dev(0, 1, ls.data_ptr(), li.data_ptr(), 260, 10, o2s.data_ptr(), o2i.data_ptr())
+
+
+@pytest.mark.parametrize("Q,k,P", [(260, 10, 2), (37, 3, 3), (1000, 16, 8)])
+def test_merge_of_the_layout_a_multi_rank_gather_produces(Q, k, P):
+    """the world > 1 semantics of sse_allgather_merge_topk_dev / sse_score_topk_sharded_dev on the ONE GPU of
+    a test box.  What ncclAllGather delivers on every rank is rank-major: world x [this rank's float64 score bits [Q][k] |
+    int64 ids [Q][k]]  (sse_api.hip, allgather_merge_locked).  Here P handles on the one device play the ranks: each holds an
+    uneven row shard with its own id_base != 0 (the last one a short tail), scores its shard into its slot of that buffer --
+    laid out by hand exactly as the gather would -- and the strided merge (shard_stride = 2*Q*k words) must return the
+    unsharded result: global row ids, float64 scores, the tie rule (lower row id first) across shard boundaries."""
+    import torch
+    import sse_amd
+    from sse_amd.sharded import shard_bounds
+    S, N = 32, 9001
+    rng = np.random.RandomState(Q + k)
+    t = rng.standard_normal((N, S)).astype(np.float32)
+    t[N // 2 + 3] = t[11]                                                  # an exact tie across a shard boundary (P = 2: rows 11 and 4503)
+    t[N - 1] = t[11]                                                       # ... and in the last rank's tail
+    q = rng.standard_normal((Q, S)).astype(np.float32)
+    q[0] = t[11]                                                           # query 0's best three are the tied rows
+    params = model_params("dual-encoder", 50, 8, 16, 16, S, 4)
+    handles = [make_pair(params)[0].handle for _ in range(P)]
+    bounds = shard_bounds(N, P)
+    assert bounds[-1][1] == N and all(b[0] > 0 for b in bounds[1:])
+    qd = torch.from_numpy(q).cuda()
+    n = Q * k
+    gathered = torch.empty((P, 2, Q, k), dtype=torch.int64, device="cuda")  # the all-gather's receive buffer, rank-major
+    for r, (h, (a, b)) in enumerate(zip(handles, bounds)):
+        rows = torch.from_numpy(t[a:b]).cuda()
+        h.index_set_dev(rows.data_ptr(), b - a, S, id_base=a)
+        h.score_topk_dev(qd.data_ptr(), Q, k, gathered[r, 0].data_ptr(), gathered[r, 1].data_ptr())
+        h.synchronize()
+    out_s = torch.empty((Q, k), dtype=torch.float64, device="cuda")
+    out_i = torch.empty((Q, k), dtype=torch.int64, device="cuda")
+    base = gathered.data_ptr()
+    handles[P - 1].merge_topk_strided_dev(base, base + n * 8, 2 * n, P, Q, k, out_s.data_ptr(), out_i.data_ptr())   # any rank merges alike
+    torch.cuda.synchronize()
+    wsc, wids = O.topk(O.scores_f64(q, t.astype(np.float64)), k)
+    assert np.array_equal(out_i.cpu().numpy(), wids)
+    assert np.abs(out_s.cpu().numpy() - wsc).max() < 1e-12
+    tied = [11, N // 2 + 3, N - 1][:k]
+    assert list(out_i[0, :len(tied)].cpu().numpy()) == tied
+    # every rank's slot holds GLOBAL ids of its own range only
+    for r, (a, b) in enumerate(bounds):
+        ids_r = gathered[r, 1].cpu().numpy()
+        assert ids_r.min() >= a and ids_r.max() < b
+    for h in handles:
+        h.close()
+
+
+def test_rccl_binding_is_one_library_instance():
+    """every RCCL entry point is bound from ONE library instance -- $SSE_RCCL_LIB, else an RCCL already
+    mapped into the process (torch's, even when loaded RTLD_LOCAL), else librccl.so.1 -- and the library says which."""
+    import torch  # noqa: F401  (maps torch's RCCL into the process before the first use below)
+    params = model_params("dual-encoder", 50, 8, 16, 16, 32, 4)
+    m, _ = make_pair(params)
+    path = m.handle.rccl_library_path()
+    assert path and "rccl" in os.path.basename(path)
+    mapped = [l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l]
+    assert mapped, "no RCCL mapped after use?"
+    if os.path.isabs(path):
+        assert path in mapped
+    assert len({os.path.realpath(x) for x in mapped}) == 1, "two RCCL instances in one process: %s" % sorted(set(mapped))
+    m.handle.rccl_group_start()
+    m.handle.rccl_group_end()
