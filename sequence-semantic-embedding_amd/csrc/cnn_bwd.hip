@@ -84,7 +84,7 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
   float bsum = 0.0f;  // lane fl < FPW: d bias of this wave's filter fl
   // Staging, third version.  Ablation of the second (one sequence per barrier, 16 waves; profiles/r05_notes.txt): with the
   // multiply AND every global load switched off the kernel still took half its time -- the per-sequence barrier and the loop
-  // skeleton, ~1 us per iteration.  Now DW_G = 4 sequences per barrier: the chunk's token ids sit in LDS (staged once,
+  // skeleton, ~1 us per iteration.  Now DW_G (= 2, see above; 4 was measured first) sequences per barrier: the chunk's token ids sit in LDS (staged once,
   // validated), the next group's embedding values and gradient / mask / position words are loaded at the top of a group step
   // and stored / taken over at its bottom, four multiplies later.
   // This thread's elements of a [T][E] tile: column ce = lane (idle for ce >= E), tokens tq, tq + 8, .. with tq = its wave.
@@ -119,7 +119,7 @@ __device__ __forceinline__ void dw_body(const CnnBwdArgs &a, float *xs) {
     }
   };
   if constexpr (RMAX == 0) {
-    // any T (more than 160 tokens: narrow embeddings) or a chunk whose ids do not fit LDS: the plain staging loop, one
+    // any T (more than DW_WAVES * 12 = 96 tokens) or a chunk whose ids do not fit LDS: the plain staging loop, one
     // sequence between two barriers
     int buf = 0;
     for (int b = b_begin; b < b_end; ++b, buf ^= 1) {
@@ -451,9 +451,13 @@ hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfe
   const size_t lds_tiles = ((size_t)2 * DW_G * T * E / (x16 ? 2 : 1) + 384) * sizeof(float), lds_ids = (size_t)per * T * sizeof(int32_t);
   const bool ids_fit = lds_tiles + lds_ids <= (size_t)150 * 1024;
   const size_t lds = ids_fit ? lds_tiles + lds_ids : ((size_t)2 * T * E + 384) * sizeof(float);
+  // the dW kernel's own LDS need, checked here (a T * E that passed the forward's check but needs more than 160 KiB here
+  // used to surface as a bare launch error); cnn_train_grads_locked reports it with the limit in the message
+  if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
+  hipError_t attr_err = hipSuccess;
   auto go = [&](auto kern) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(a.NCH, 4), dim3(DW_THREADS), lds, st, a);
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr_err == hipSuccess) hipLaunchKernelGGL(kern, dim3(a.NCH, 4), dim3(DW_THREADS), lds, st, a);
   };
   if (x16) {
     if (ids_fit && T <= DW_WAVES * 8) go(cnn_dw_kernel<8, true>);
@@ -464,6 +468,7 @@ hipError_t launch_cnn_bwd(const int32_t *ids, const float *emb, const float *dfe
     else if (ids_fit && T <= DW_WAVES * 12) go(cnn_dw_kernel<12, false>);
     else go(cnn_dw_kernel<0, false>);
   }
+  if (attr_err != hipSuccess) return attr_err;
   hipLaunchKernelGGL(cnn_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ra);
   if (dx_mfma) return launch_cnn_dx_mfma(ids, dfeat, feat, pos, W, wct_scratch, d_emb, sq_part, hot_part, B, T, E, V, st);
   hipLaunchKernelGGL(cnn_dx_kernel, dim3(B), dim3(256), (size_t)(T + 1) * sizeof(int), st, a);

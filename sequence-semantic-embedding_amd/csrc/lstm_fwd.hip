@@ -750,26 +750,28 @@ static hipError_t launch_cfg(const LstmFwdArgs &a_in, hipStream_t stream) {
 
 // rows per workgroup the launcher will use for (Hp, B): 64, or 32 when 64-row tiles cannot fill
 // the 256 CUs (half the per-step latency, all tiles still resident) and for Hp = 512
-int lstm_fwd_rows_per_wg(int Hp, int B, int tiles_elsewhere) {
+int lstm_fwd_rows_per_wg(int Hp, int B, int tiles_elsewhere, int cus) {
+  if (cus <= 0) cus = 256;  // MI355X
   if (Hp == 512) return 32;
-  if ((Hp == 256 || Hp == 128) && (B + 31) / 32 + tiles_elsewhere <= 256) return 32;
+  if ((Hp == 256 || Hp == 128) && (B + 31) / 32 + tiles_elsewhere <= cus) return 32;
   if (tiles_elsewhere == 0 && (Hp == 256 || Hp == 128)) {
-    // Rounds (round 5).  64-row tiles: one workgroup per CU, ceil(n64 / 256) rounds; a round with two workgroups costs as much
-    // as a full one -- 16,491 queries = 258 tiles ran 7.53 ms where 16,384 run 3.7.  32-row tiles: two workgroups per CU, a
-    // full round of 512 costs 1.006 (Hp = 256) / 1.06 (Hp = 128) of a 64-row round (profiles/r02_notes.txt), a last round of
-    // <= 256 workgroups (one per CU: half the per-step latency) 0.55.  Take 32 rows when the model says > 7 % less:
+    // Rounds (round 5; the CU count is the device's since round 6).  64-row tiles: one workgroup per CU,
+    // ceil(n64 / cus) rounds; a round with two workgroups costs as much as a full one -- 16,491 queries = 258 tiles ran 7.53 ms
+    // where 16,384 run 3.7 on 256 CUs.  32-row tiles: two workgroups per CU, a full round of 2 * cus costs 1.006 (Hp = 256) /
+    // 1.06 (Hp = 128) of a 64-row round (profiles/r02_notes.txt; cost ratios measured on MI355X), a last round of <= cus
+    // workgroups (one per CU: half the per-step latency) 0.55.  Take 32 rows when the model says > 7 % less:
     // 16,491 rows 7.53 -> 5.74 ms measured (profiles/r05_notes.txt); 16,384 and 32,060 rows keep 64.
     const int n64 = (B + 63) / 64, n32 = (B + 31) / 32;
     const double full = Hp == 256 ? 1.006 : 1.06;
-    const int rem = n32 % 512;
-    const double t64 = (double)((n64 + 255) / 256), t32 = (n32 / 512) * full + (rem == 0 ? 0.0 : rem <= 256 ? 0.55 : full);
+    const int rem = n32 % (2 * cus);
+    const double t64 = (double)((n64 + cus - 1) / cus), t32 = (n32 / (2 * cus)) * full + (rem == 0 ? 0.0 : rem <= cus ? 0.55 : full);
     if (t32 < 0.93 * t64) return 32;
   }
   return 64;
 }
 
 hipError_t launch_lstm_fwd(const LstmFwdArgs &a, int Hp, hipStream_t stream) {
-  int rows = lstm_fwd_rows_per_wg(Hp, a.B, a.tiles_elsewhere);
+  int rows = lstm_fwd_rows_per_wg(Hp, a.B, a.tiles_elsewhere, a.cu_count);
   if (Hp <= 256 && (a.force_rows == 32 || a.force_rows == 64)) rows = a.force_rows;
   if (const char *ev = getenv("SSE_FWD_ROWS")) {  // measurement aid
     const int r = atoi(ev);

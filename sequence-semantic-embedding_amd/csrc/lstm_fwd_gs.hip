@@ -27,6 +27,32 @@
 #include "sse_kernels.h"
 
 #define GS_THREADS 512
+// Wave priority: 1 in the GEMM phase; in the tail 3 where the tail is the longer leg of a group's step (NB = 2: 0.528 -> 0.490 ms
+// at H = 64, NB = 4: 2.10 -> 2.08 at H = 128), 0 at NB = 3 (H = 96: 1.393 vs 1.419 ms) -- profiles/r06_notes.txt.  Priorities
+// move little: the fp32 MFMA executes at the vector rate on the SIMD's own lanes (157.3 TF = the v_fma_f32 peak), so another
+// wave's activation arithmetic is NOT hidden under a running MFMA stream (activations of a group 2.4 k cycles alone, 7.0 k beside
+// the other group's GEMM) -- what the two groups hide from each other is latency: flag waits, LDS round trips, operand refills.
+#ifndef GS_PRIO_GEMM
+#define GS_PRIO_GEMM 1
+#endif
+#ifndef GS_PRIO_TAIL
+#define GS_PRIO_TAIL (NB == 3 ? 0 : 3)
+#endif
+
+#ifdef SSE_GS_CLOCK  // measurement builds: cycles per phase of a step, summed over the steps, workgroup 0
+#include <cstdio>
+__device__ long long g_gs_clk[8 * 8];
+#define GS_CLK_DECL long long ck_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ck_t = clock64();
+#define GS_CLK(i)                   \
+  {                                 \
+    const long long n_ = clock64(); \
+    ck_[i] += n_ - ck_t;            \
+    ck_t = n_;                      \
+  }
+#else
+#define GS_CLK_DECL
+#define GS_CLK(i)
+#endif
 
 namespace {
 
@@ -44,7 +70,11 @@ __device__ __forceinline__ int gs_slot(int j, int qw) { return j - (j > qw ? 1 :
 template <int NB, int Q>
 __device__ __forceinline__ void gs_tail(const f32x16 (&acc)[NB], f32x4 (&c)[NB], float *ex /* exchange area of the group */,
                                         float *hb /* h tile of the group */, volatile int *fl_act, volatile int *fl_h, int lane,
-                                        int step1 /* t + 1 */) {
+                                        int step1 /* t + 1 */
+#ifdef SSE_GS_CLOCK
+                                        , long long (&ck_)[8], long long &ck_t
+#endif
+) {
   // 1. this wave's non-linearity on all of its gate; the three foreign quads go to their owners
   f32x4 own[NB];
 #pragma unroll
@@ -60,6 +90,7 @@ __device__ __forceinline__ void gs_tail(const f32x16 (&acc)[NB], f32x4 (&c)[NB],
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS operations of a wave complete in order, the flag follows the data
   if (lane == 0) fl_act[Q] = step1;
+  GS_CLK(4)
   // 2. wait for the other three gates of this group
   for (;;) {
     const int f0 = fl_act[0], f1 = fl_act[1], f2 = fl_act[2], f3 = fl_act[3];
@@ -67,6 +98,7 @@ __device__ __forceinline__ void gs_tail(const f32x16 (&acc)[NB], f32x4 (&c)[NB],
     __builtin_amdgcn_s_sleep(1);
   }
   asm volatile("" ::: "memory");
+  GS_CLK(5)
   // 3. combine for the owned quad of every block (BasicLSTMCell, TF 1.x; the forget bias rides in the packed bias row)
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -89,6 +121,7 @@ __device__ __forceinline__ void gs_tail(const f32x16 (&acc)[NB], f32x4 (&c)[NB],
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);
   if (lane == 0) fl_h[Q] = step1;
+  GS_CLK(6)
 }
 
 }  // namespace
@@ -104,7 +137,8 @@ bool lstm_fwd_gs_ok(int KGx, int KGh, int H) {
 template <int NB>
 __global__ __launch_bounds__(GS_THREADS) void lstm_fwd_gs_kernel(LstmFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and known to be: scalar branches / buffer offsets
   const int g = w >> 2, q = w & 3, tg = tid & 255;
   const int KGx = a.KGx, KGh = a.KGh, KG = KGx + KGh, T = a.T;
   const int KGhe = (a.KGhe > 0 && a.KGhe < KGh) ? a.KGhe : KGh;
@@ -155,7 +189,7 @@ __global__ __launch_bounds__(GS_THREADS) void lstm_fwd_gs_kernel(LstmFwdArgs a) 
     if (lane == 0) red[w] = lead;
     __syncthreads();
     lead = min(min(red[g * 4], red[g * 4 + 1]), min(red[g * 4 + 2], red[g * 4 + 3]));
-    t0 = min(lead, T - 1);
+    t0 = __builtin_amdgcn_readfirstlane(min(lead, T - 1));  // uniform: the step loop and the k-group offsets stay scalar
   }
 
   // --- prologue: x_{t0} -> x buffer (t0 & 1); h_{t0-1} = state after t0 PAD steps (0 when t0 = 0)
@@ -197,7 +231,9 @@ __global__ __launch_bounds__(GS_THREADS) void lstm_fwd_gs_kernel(LstmFwdArgs a) 
   }
 
   constexpr int R = 3;
+  GS_CLK_DECL
   for (int t = t0; t < T; ++t) {
+    GS_CLK(7)
     const bool have_next = (t + 1) < T;
     f32x4 nlo = {0, 0, 0, 0}, nhi = {0, 0, 0, 0};
     if (have_next) {
@@ -219,6 +255,7 @@ __global__ __launch_bounds__(GS_THREADS) void lstm_fwd_gs_kernel(LstmFwdArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
 
+    GS_CLK(0)
     // h_{t-1} complete? (every wave of the group has published its quads of step t-1)
     if (t > t0) {
       for (;;) {
@@ -229,6 +266,7 @@ __global__ __launch_bounds__(GS_THREADS) void lstm_fwd_gs_kernel(LstmFwdArgs a) 
       asm volatile("" ::: "memory");
     }
 
+    GS_CLK(1)
     auto a_frag = [&](int kg) -> f32x4 {
       return *reinterpret_cast<const f32x4 *>(kg < KGx ? xa + kg * 256 : ha + (kg - KGx) * 256);
     };
@@ -247,7 +285,7 @@ __global__ __launch_bounds__(GS_THREADS) void lstm_fwd_gs_kernel(LstmFwdArgs a) 
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[s][b][e], af[s][e], acc[b], 0, 0, 0);
     };
-    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(GS_PRIO_GEMM);
     int kg = 0;
     for (; kg + R <= kend; kg += R) {
 #pragma unroll
@@ -264,18 +302,29 @@ __global__ __launch_bounds__(GS_THREADS) void lstm_fwd_gs_kernel(LstmFwdArgs a) 
 #pragma unroll
     for (int s = 0; s < R - 1; ++s)
       if (kg + s < kend) mfmas(s);
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(GS_PRIO_TAIL);
+    GS_CLK(2)
 
     // x_{t+1}: its buffer was last read in step t-1 (every wave of the group is past that GEMM: it published h_{t-1})
     if (have_next && xq < KGx) x_store(cur ^ 1, nlo, nhi);
+    GS_CLK(3)
 
+#ifdef SSE_GS_CLOCK
+#define GS_TAIL_EXTRA , ck_, ck_t
+#else
+#define GS_TAIL_EXTRA
+#endif
     switch (q) {
-      case 0: gs_tail<NB, 0>(acc, c, ex, hb, fl_act, fl_h, lane, t + 1); break;
-      case 1: gs_tail<NB, 1>(acc, c, ex, hb, fl_act, fl_h, lane, t + 1); break;
-      case 2: gs_tail<NB, 2>(acc, c, ex, hb, fl_act, fl_h, lane, t + 1); break;
-      default: gs_tail<NB, 3>(acc, c, ex, hb, fl_act, fl_h, lane, t + 1); break;
+      case 0: gs_tail<NB, 0>(acc, c, ex, hb, fl_act, fl_h, lane, t + 1 GS_TAIL_EXTRA); break;
+      case 1: gs_tail<NB, 1>(acc, c, ex, hb, fl_act, fl_h, lane, t + 1 GS_TAIL_EXTRA); break;
+      case 2: gs_tail<NB, 2>(acc, c, ex, hb, fl_act, fl_h, lane, t + 1 GS_TAIL_EXTRA); break;
+      default: gs_tail<NB, 3>(acc, c, ex, hb, fl_act, fl_h, lane, t + 1 GS_TAIL_EXTRA); break;
     }
   }
+#ifdef SSE_GS_CLOCK
+  if (blockIdx.x == 0 && lane == 0)
+    for (int i = 0; i < 8; ++i) g_gs_clk[w * 8 + i] = ck_[i];
+#endif
   __syncthreads();  // both groups: h_T complete
 
   // --- projection  out = h_T . M  (+ optional l2_normalize): the four waves of a group share its row tile,
@@ -360,6 +409,21 @@ static hipError_t gs_launch(const LstmFwdArgs &a, hipStream_t stream) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_fwd_gs_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((lstm_fwd_gs_kernel<NB>), dim3((a.B + 63) / 64), dim3(GS_THREADS), lds, stream, a);
+#ifdef SSE_GS_CLOCK
+  {
+    static int n = 0;
+    if (a.B >= 1024 && n++ % 16 == 4) {
+      long long v[64];
+      (void)hipStreamSynchronize(stream);
+      (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_gs_clk), sizeof v);
+      for (int w = 0; w < 8; ++w)
+        fprintf(stderr, "[gs clock NB=%d B=%d H=%d T=%d] wave %d (group %d gate %d) cycles/step: id+emb issue %lld | wait h %lld | gemm %lld | x store %lld | act+publish %lld | wait act %lld | combine+h %lld | loop %lld | total %lld\n",
+                NB, a.B, a.H, a.T, w, w >> 2, w & 3, v[w * 8 + 0] / a.T, v[w * 8 + 1] / a.T, v[w * 8 + 2] / a.T, v[w * 8 + 3] / a.T, v[w * 8 + 4] / a.T,
+                v[w * 8 + 5] / a.T, v[w * 8 + 6] / a.T, v[w * 8 + 7] / a.T,
+                (v[w * 8 + 0] + v[w * 8 + 1] + v[w * 8 + 2] + v[w * 8 + 3] + v[w * 8 + 4] + v[w * 8 + 5] + v[w * 8 + 6] + v[w * 8 + 7]) / a.T);
+    }
+  }
+#endif
   return hipGetLastError();
 }
 

@@ -246,16 +246,18 @@ __global__ void gen_gates_bwd_kernel(GenGatesBwdArgs a) {
 }
 
 // dX_t = x columns of dA_t: one wave per row -- scatter-add into the dense d word_embedding, sum of squares of the raw slice
+// (a token id outside [0, V) adds nothing: the forward raised the error flag for it and the update is cancelled on the device)
 __global__ void gen_dx_scatter_kernel(const float *__restrict__ dA, int lda, const int32_t *__restrict__ ids, int t, int T, int B, int E,
-                                      float *__restrict__ d_emb, float *__restrict__ sq) {
+                                      int V, float *__restrict__ d_emb, float *__restrict__ sq) {
   const int lane = threadIdx.x & 63, b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (b >= B) return;
   const int id = ids[(size_t)b * T + t];
+  const bool ok = id >= 0 && id < V;
   float acc = 0.0f;
   for (int e = lane; e < E; e += 64) {
     const float v = dA[(size_t)b * lda + e];
     acc += v * v;
-    if (v != 0.0f) atomicAdd(d_emb + (size_t)id * E + e, v);
+    if (ok && v != 0.0f) atomicAdd(d_emb + (size_t)id * E + e, v);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -333,7 +335,7 @@ hipError_t launch_gen_project(const float *h_last, const float *MT, const GenLst
 // backward: dh_last [Bp][ldh_last] -> dG for all steps, d word_embedding (+ sq[t*B + b]), then dK, db
 hipError_t launch_gen_backward(const int32_t *ids, const float *Kq, const GenLstmDims &d, const float *A, const float *tape,
                                const float *dh_last, int ldh_last, float *dG, float *dA, float *dc, float *dk_part, int accumulate,
-                               float *dK, float *db, float *d_emb, float *sq, hipStream_t st) {
+                               float *dK, float *db, float *d_emb, float *sq, int V, hipStream_t st) {
   const int64_t nc = (int64_t)d.Bp * d.Hq;
   hipError_t e = hipMemsetAsync(dc, 0, (size_t)nc * sizeof(float), st);
   if (e != hipSuccess) return e;
@@ -351,7 +353,7 @@ hipError_t launch_gen_backward(const int32_t *ids, const float *Kq, const GenLst
     hipLaunchKernelGGL(gen_gates_bwd_kernel, dim3((int)((nc + 255) / 256)), dim3(256), 0, st, ba);
     // dA_t [Bp][Kp] = dG_t [Bp][4Hq] . Kq^T   (Kq [Kp][4Hq]: both along the reduction)
     gemm_nt(ba.dG, 4 * d.Hq, Kq, 4 * d.Hq, dA, d.Kp, d.Bp, d.Kp, 4 * d.Hq, st);
-    hipLaunchKernelGGL(gen_dx_scatter_kernel, dim3((d.B + 3) / 4), dim3(256), 0, st, dA, d.Kp, ids, t, d.T, d.B, d.E, d_emb, sq);
+    hipLaunchKernelGGL(gen_dx_scatter_kernel, dim3((d.B + 3) / 4), dim3(256), 0, st, dA, d.Kp, ids, t, d.T, d.B, d.E, V, d_emb, sq);
   }
   // dK = A^T dG over all T * Bp rows (the batch and the steps are the reduction); db = column sums of dG
   const int64_t R = (int64_t)d.T * d.Bp;

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   // launch is sized for the worst case and the workgroups past the set return at once
   const int Qeff = a.q_count ? min(a.Q, *a.q_count) : a.Q;
   if (qb * NQ * 32 >= Qeff) return;
-  if (COLLECT) {  // collect pass: only blocks with an open query run
+  if (COLLECT && a.lane_max == nullptr) {  // collect pass: only blocks with an open query run
     int open_q = 0;
     for (int i = tid; i < NQ * 32; i += SC_THREADS) {
       const int qq = qb * NQ * 32 + i;
@@ -357,11 +357,15 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
   // COLLECT: this lane's query threshold and buffer slot per query tile
   float cthr[NQ];
   int cslot[NQ];
+  // MAX-ONLY mode of the collect variant (a.lane_max set; first pass of the two-pass path for mid-size indexes, see
+  // launch_lane_max_threshold): no lists, no buffers -- a lane keeps the largest score it has seen per query tile.
+  float lmax[NQ];
   if constexpr (COLLECT) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int query = (qb * NQ + q) * 32 + (lane & 31);
-      cslot[q] = (query < a.Q) ? a.col_slot[query] : -1;
+      lmax[q] = NEG_INF;
+      cslot[q] = (query < a.Q && a.lane_max == nullptr) ? a.col_slot[query] : -1;
       cthr[q] = (cslot[q] >= 0) ? a.col_thr[query] : __builtin_inff();
     }
   }
@@ -585,6 +589,28 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
 
     const int nrow0 = tile * 32;
     if constexpr (COLLECT) {
+      if (a.lane_max != nullptr) {
+        // max-only: five v_max3_f32 per query tile; the zero padding rows of the index's last tile are masked (wave-uniform branch)
+        const bool tail = (tile == tail_tile);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          if (tail) {
+            int nb = nrow0 + 4 * (lane >> 5);
+            asm volatile("" : "+v"(nb));
+            const int nlim = (int)a.N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = (nb + (r & 3) + 8 * (r >> 2) >= nlim) ? NEG_INF : acc[q][r];
+          }
+          float m = lmax[q];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            m = fmaxf(fmaxf(m, acc[q][4 * g4]), acc[q][4 * g4 + 1]);
+            m = fmaxf(fmaxf(m, acc[q][4 * g4 + 2]), acc[q][4 * g4 + 3]);
+          }
+          lmax[q] = m;
+        }
+        continue;
+      }
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         float m = NEG_INF;
@@ -742,7 +768,17 @@ __global__ __launch_bounds__(SC_THREADS) void score_topk_kernel(ScoreArgs a) {
       }
     }
   }
-  if constexpr (COLLECT) return;
+  if constexpr (COLLECT) {
+    if (a.lane_max != nullptr) {
+      // [query][split][16 lists]: list = (wave, lane half) -- the rows a lane saw are disjoint from every other lane's of its query
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int query = (qb * NQ + q) * 32 + (lane & 31);
+        if (query < Qeff) a.lane_max[((size_t)query * a.NSPLIT + split) * 16 + w * 2 + (lane >> 5)] = lmax[q];
+      }
+    }
+    return;
+  }
 #ifdef SSE_SCORE_CLOCK
   SC_CLK(3)
   if (blockIdx.x == 0 && lane == 0 && NQ == 4) {
@@ -1192,8 +1228,11 @@ hipError_t launch_score_topk(const ScoreArgs &a_in, hipStream_t stream) {
   if (a.q_rows && ((a.NQ != 1 && !a.COLLECT) || a.S < 1)) return hipErrorInvalidValue;
   if (a.NSPLIT > 8 && (a.NSPLIT & 7)) return hipErrorInvalidValue;
   if (a.NSPLIT < 8 && (8 % a.NSPLIT)) return hipErrorInvalidValue;
-  if (a.COLLECT) {  // collect pass: fp32 scores only (the thresholds are fp32 bounds)
-    if (a.BF || !a.col_thr || !a.col_slot || !a.col_cnt || !a.col_buf) return hipErrorInvalidValue;
+  if (a.COLLECT) {
+    // collect pass.  fp32 scores (the thresholds are fp32 bounds of the exact k-th score), or -- the two-pass path for mid-size
+    // indexes, NQ = 4 -- bf16 scores against thresholds widened by the bf16 bound; lane_max set: its max-only first pass
+    if (!a.lane_max && (!a.col_thr || !a.col_slot || !a.col_cnt || !a.col_buf)) return hipErrorInvalidValue;
+    if (a.BF) return a.NQ == 4 ? launch_score_variant<4, true, true>(a, stream) : hipErrorInvalidValue;
     if (a.NQ == 1) return launch_score_variant<1, false, true>(a, stream);
     if (a.NQ == 2) return launch_score_variant<2, false, true>(a, stream);
     if (a.NQ == 4) return launch_score_variant<4, false, true>(a, stream);
@@ -1855,6 +1894,60 @@ hipError_t launch_kth_bound(const float *q, const float *part_scores, const int3
   while (n2 < NC) n2 <<= 1;
   hipLaunchKernelGGL(kth_bound_kernel, dim3(Q), dim3(256), (size_t)n2 * sizeof(unsigned long long), st, q, part_scores, part_ids,
                      Q, S, NC, k, eps, col_thr, col_slot);
+  return hipGetLastError();
+}
+
+// Two-pass path for mid-size indexes (10^4 .. 10^5 rows under thousands of queries -- the reference's real evaluation sizes,
+// sse_evaluator.py:104-112 on rawdata-crosslingual: 16,491 x 32,060).  The list sweep is built for long streams: a lane list
+// settles after ~30 tiles of its own, and with 64 independent thresholds per wave a register holds a hit in SOME lane in most
+// tiles until the workgroup has seen ~16 k rows -- at 8 k rows per split the insertion passes cost 5x the MFMAs (0.83 ms for
+// 0.16 ms of matrix work, profiles/r06_notes.txt).  Instead:
+//   pass 1  the same sweep with no lists at all (score_topk_kernel<.., COLLECT> in max-only mode): every lane keeps the largest
+//           bf16 score it saw; the NSPLIT x 16 lane maxima of a query belong to DISJOINT row sets, so their 16th largest is
+//           reached by 16 distinct rows: theta_q <= the 16th best bf16 score of the whole index (in practice the ~18th best);
+//   here    theta_q - 2 E, E = (bf16 + fp32 accumulation bound) |q| max|t|: 16 rows have an exact score >= theta - E, so has the
+//           exact 16th best, so every exact top-k row (k <= 16), whose bf16 score is therefore >= theta - 2 E;
+//   pass 2  the collect sweep on bf16 scores gathers every such row (~20 - 30 per query), select_topk_kernel re-scores them in
+//           float64 and sorts (score descending, lower row first): provably the exact top-k; a buffer overflow (more than
+//           col_cap rows within 2 E of the 16th best: crowded scores) leaves the query to the float64 brute force.
+// One wave per query, NV = NSPLIT * 16 <= 256 maxima.
+__global__ __launch_bounds__(256) void lane_max_threshold_kernel(const float *q, const float *lane_max, int Q, int S, int NV, float eps,
+                                                                  float *col_thr, int32_t *col_slot) {
+  const int lane = threadIdx.x & 63, qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= Q) return;
+  double qn = 0.0;
+  for (int d = lane; d < S; d += 64) qn += (double)q[(size_t)qi * S + d] * q[(size_t)qi * S + d];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = (j * 64 + lane < NV) ? lane_max[(size_t)qi * NV + j * 64 + lane] : -__builtin_inff();
+  float kth = -__builtin_inff();
+  for (int round = 0; round < 16; ++round) {  // the 16th largest: 16 times "take the maximum out"
+    float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    kth = m;
+    const unsigned long long has = __ballot(v[0] == m || v[1] == m || v[2] == m || v[3] == m);
+    if (has == 0ull) break;  // (NaN scores: give up, threshold -inf below)
+    if (lane == __ffsll((long long)has) - 1) {
+      if (v[0] == m) v[0] = -__builtin_inff();
+      else if (v[1] == m) v[1] = -__builtin_inff();
+      else if (v[2] == m) v[2] = -__builtin_inff();
+      else v[3] = -__builtin_inff();
+    }
+  }
+  if (lane == 0) {
+    float thr = -__builtin_inff();
+    if (kth > -__builtin_inff() && kth == kth) thr = __double2float_rd((double)kth - 2.0 * (double)eps * sqrt(qn));
+    col_thr[qi] = thr;
+    col_slot[qi] = qi;
+  }
+}
+hipError_t launch_lane_max_threshold(const float *q, const float *lane_max, int Q, int S, int NV, float eps, float *col_thr,
+                                     int32_t *col_slot, hipStream_t st) {
+  if (NV < 16 || NV > 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(lane_max_threshold_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, q, lane_max, Q, S, NV, eps, col_thr, col_slot);
   return hipGetLastError();
 }
 

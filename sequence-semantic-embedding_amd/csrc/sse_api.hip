@@ -72,6 +72,7 @@ struct TrainState {
   DevBuf ids[2], labels, raw[2], draw[2], tape_g[2], tape_a[2], h_last[2], dh_last[2], dg_a[2], dg_b[2], db_part[2],
       dk_part[2], dm_part[2], sq_part, norm_part, row_loss, row_acc, scal;
   DevBuf feat_rm, pos, dfeat, dw_part, dbias_part, wt, wct;  // text-CNN training
+  uint64_t gen_ver[2] = {0, 0};  // weights_version the any-shape packs gen_KT / gen_Kq / gen_MT were built from
   DevBuf gen_A[2], gen_tape[2], gen_dG[2], gen_hl[2], gen_KT[2], gen_Kq[2], gen_MT[2], gen_G, gen_c, gen_dA, gen_dc, gen_dkp;  // any-shape LSTM path
   hipStream_t side[2] = {nullptr, nullptr};  // the two encoders run concurrently (forward and backward)
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
@@ -109,6 +110,7 @@ struct sse_handle {
   std::vector<Variable> vars;
   Encoder enc[2];
   bool packed_dirty = true;
+  uint64_t weights_version = 1;  // bumped with every change of a variable: the any-shape path's packs (lstm_generic.hip) are cached against it
   bool mp_fresh = false;     // the packed projections match the variables although packed_dirty is set (ensure_proj_packed)
   bool pad_skip = true;      // option "pad_skip": exact left-pad prefix skip in inference encodes
   // option "pad_sort_dev": PAD-prefix bucketing of device-resident id matrices (sse_encode_dev) by two small kernels (pack.hip):
@@ -116,6 +118,10 @@ struct sse_handle {
   // saw any padding, 32-row tiles while it saw a mean prefix >= T / 4 (no host round trip: an index build's batches look alike)
   // | 2 always bucket + 32-row tiles (deterministic: tests, tools)
   int pad_sort_dev = 1;
+  // option "score_two_pass_rows": indexes of 8192 .. this many rows under >= 1024 queries (k <= 16, bf16 candidates) are ranked by a
+  // max-only sweep + a collect sweep instead of the list sweep (exact, same ids and scores); 0 = off
+  int64_t score_two_pass_rows = 262144;
+  DevBuf s_lmax;
   bool lstm_gate_split = true;  // option "lstm_gate_split": small cells (H <= 128) at 64-row tiles on lstm_fwd_gs.hip (bit-identical)
   DevBuf s_padzero, s_padwork, s_padorder;
   int32_t *pad_stat = nullptr;  // pinned host words the device stores to: [side] {call number, class 0 / 1 / 2}
@@ -175,7 +181,9 @@ struct sse_handle {
   DevBuf s_ids, s_out, s_q, s_qp, s_ps, s_pi, s_cert, s_os, s_oi, s_tmp, s_tmp2, s_feat, s_zero, s_map;
   DevBuf s_qmap, s_qc;     // fp32 second chance of the bf16 candidate pass: the uncertified queries as a dense set
   DevBuf s_qp32, s_fb_cnt;  // fp32 second chance of the bf16 candidate pass: fp32 query fragments, counter
-  DevBuf g_A, g_G, g_c, g_hl, g_KT, g_Kq, g_MT, g_raw;  // any-shape LSTM encode (lstm_generic.hip)
+  DevBuf g_A, g_G, g_c, g_hl, g_raw;  // any-shape LSTM encode (lstm_generic.hip)
+  DevBuf g_KT[2], g_Kq[2], g_MT[2];    // ... its packed weights per side, valid while g_ver[side] == weights_version (they
+  uint64_t g_ver[2] = {0, 0};          //     were rebuilt by every call)
   DevBuf s_xchg;     // sse_score_topk_sharded_dev: [local lists | gathered lists] of the RCCL exchange
   DevBuf s_persist;  // lstm_persist.hip: h_t / raw-encoding exchange buffers and arrival counters
   DevBuf s_cluster;  // lstm_cluster.hip: h_t / sum-of-squares exchange buffers
@@ -425,6 +433,7 @@ void fill_fwd_args(sse_handle *h, Encoder &e, LstmFwdArgs &a) {
   a.S = c.encoding_size;
   a.NTS = (c.encoding_size + 31) / 32;
   a.gate_split = h->lstm_gate_split ? 1 : 0;
+  a.cu_count = h->cu_count;  // (set by sse_create)
 }
 
 // state after p leading PAD steps for p = 0..T: one all-PAD row through the SAME kernel
@@ -572,16 +581,23 @@ static int encode_generic_locked(sse_handle *h, Encoder &e, const int32_t *ids, 
   const GenLstmDims dm = gen_lstm_dims(std::min(rows, B), T, E, e.H);
   if (reserve(h, h->g_A, gen_lstm_a_floats(dm) * sizeof(float)) || reserve(h, h->g_G, (size_t)dm.Bp * 4 * dm.Hq * sizeof(float)) ||
       reserve(h, h->g_c, (size_t)dm.Bp * dm.Hq * sizeof(float)) || reserve(h, h->g_hl, (size_t)dm.Bp * dm.Hq * sizeof(float)) ||
-      reserve(h, h->g_KT, gen_lstm_kt_floats(dm) * sizeof(float)) || reserve(h, h->g_Kq, gen_lstm_kt_floats(dm) * sizeof(float)) ||
-      reserve(h, h->g_MT, (size_t)S * dm.Hq * sizeof(float)) || reserve(h, h->g_raw, (size_t)dm.Bp * S * sizeof(float)))
+      reserve(h, h->g_raw, (size_t)dm.Bp * S * sizeof(float)))
     return 1;
-  HIPCHECK(h, launch_gen_pack(h->vars[e.kernel].dev, h->vars[e.proj].dev, dm, S, (float *)h->g_KT.p, (float *)h->g_Kq.p, (float *)h->g_MT.p, st));
+  const int side = (&e == &h->enc[1]) ? 1 : 0;
+  if (h->g_ver[side] != h->weights_version || !h->g_KT[side].p) {
+    if (reserve(h, h->g_KT[side], gen_lstm_kt_floats(dm) * sizeof(float)) || reserve(h, h->g_Kq[side], gen_lstm_kt_floats(dm) * sizeof(float)) ||
+        reserve(h, h->g_MT[side], (size_t)S * dm.Hq * sizeof(float)))
+      return 1;
+    HIPCHECK(h, launch_gen_pack(h->vars[e.kernel].dev, h->vars[e.proj].dev, dm, S, (float *)h->g_KT[side].p, (float *)h->g_Kq[side].p,
+                                (float *)h->g_MT[side].p, st));
+    h->g_ver[side] = h->weights_version;
+  }
   for (int b0 = 0; b0 < B; b0 += rows) {
     const int nb = std::min(rows, B - b0);
     const GenLstmDims d = gen_lstm_dims(nb, T, E, e.H);
-    HIPCHECK(h, launch_gen_forward(ids + (size_t)b0 * T, h->vars[0].dev, c.vocab_size, (const float *)h->g_KT.p, h->vars[e.bias].dev, d,
+    HIPCHECK(h, launch_gen_forward(ids + (size_t)b0 * T, h->vars[0].dev, c.vocab_size, (const float *)h->g_KT[side].p, h->vars[e.bias].dev, d,
                                    (float *)h->g_A.p, (float *)h->g_G.p, (float *)h->g_c.p, nullptr, (float *)h->g_hl.p, h->err_flag, st));
-    HIPCHECK(h, launch_gen_project((const float *)h->g_hl.p, (const float *)h->g_MT.p, d, S, (float *)h->g_raw.p, st));
+    HIPCHECK(h, launch_gen_project((const float *)h->g_hl.p, (const float *)h->g_MT[side].p, d, S, (float *)h->g_raw.p, st));
     if (normalize) HIPCHECK(h, launch_l2_normalize((const float *)h->g_raw.p, out + (size_t)b0 * S, nb, S, st));
     else HIPCHECK(h, hipMemcpyAsync(out + (size_t)b0 * S, h->g_raw.p, (size_t)nb * S * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
@@ -1144,9 +1160,59 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
     HIPCHECK(h, launch_frag32_to_bf16(h->idxp, NT, KG, h->idxp16, st));
     h->idxp16_valid = true;
   }
-  const int POOL = std::min(Q, 1024);  // collect-buffer slots for uncertified queries (the rest: float64 brute force)
   if (ensure_counters(h, st)) return 1;
   unsigned long long *counters = (unsigned long long *)h->s_fb_cnt.p;
+  // ---- mid-size indexes under many queries: max-only sweep -> per-query threshold -> collect sweep -> float64 select (see
+  // lane_max_threshold_kernel in score_topk.hip for the argument).  Everything is final after it: no certificates to follow up.
+  if (bf && NQ == 4 && Q >= 1024 && nsplit <= 16 && h->idx_N <= h->score_two_pass_rows && !mirror) {
+    if (phase == SCORE_REST) return 0;
+    constexpr int MID_CAP = 512;  // rows one query may collect (typically 20 - 30); more: float64 brute force for that query
+    const float eps32 = (float)(2.0 * (S + 2) * 5.97e-8 * h->idx_norm_max);
+    const float eps_bf = eps32 + (float)(1.02 * (1.0 / 256.0 + 1.0 / 262144.0) * h->idx_norm_max);
+    if (reserve(h, h->s_qp, (size_t)QB * NQ * KG * 256 * sizeof(float))) return 1;
+    if (reserve(h, h->s_lmax, (size_t)Q * nsplit * 16 * sizeof(float))) return 1;
+    if (reserve(h, h->s_cert, (size_t)Q * sizeof(int32_t))) return 1;
+    if (reserve(h, h->s_cthr, (size_t)Q * sizeof(float)) || reserve(h, h->s_cslot, (size_t)Q * sizeof(int32_t)) ||
+        reserve(h, h->s_ccnt, (size_t)(Q + 1) * sizeof(int32_t)) || reserve(h, h->s_cbuf, (size_t)Q * MID_CAP * sizeof(int32_t)))
+      return 1;
+    HIPCHECK(h, launch_pack_rows_bf16(q, Q, S, h->s_qp.p, st));
+    HIPCHECK(h, hipMemsetAsync(h->s_ccnt.p, 0, (size_t)(Q + 1) * sizeof(int32_t), st));
+    HIPCHECK(h, hipMemsetAsync(h->s_cert.p, 0, (size_t)Q * sizeof(int32_t), st));
+    ScoreArgs m1;
+    m1.BF = 1;
+    m1.COLLECT = 1;
+    m1.idxp = (const float *)h->idxp16;
+    m1.qp = (const float *)h->s_qp.p;
+    m1.N = h->idx_N;
+    m1.Q = Q;
+    m1.KG = KG16;
+    m1.NT = (int)NT;
+    m1.QT = QT;
+    m1.NSPLIT = nsplit;
+    m1.KC = 16;
+    m1.NQ = NQ;
+    m1.lane_max = (float *)h->s_lmax.p;
+    HIPCHECK(h, launch_score_topk(m1, st));
+    HIPCHECK(h, launch_lane_max_threshold(q, (const float *)h->s_lmax.p, Q, S, nsplit * 16, eps_bf, (float *)h->s_cthr.p,
+                                          (int32_t *)h->s_cslot.p, st));
+    ScoreArgs m2 = m1;
+    m2.lane_max = nullptr;
+    m2.col_thr = (const float *)h->s_cthr.p;
+    m2.col_slot = (const int32_t *)h->s_cslot.p;
+    m2.col_cnt = (int32_t *)h->s_ccnt.p;
+    m2.col_buf = (int32_t *)h->s_cbuf.p;
+    m2.col_cap = MID_CAP;
+    HIPCHECK(h, launch_score_topk(m2, st));
+    SelectArgs sel{q, h->idxp, h->idx64, m2.col_slot, m2.col_cnt, m2.col_buf, MID_CAP, out_s, out_i, (int32_t *)h->s_cert.p, h->idx_base,
+                   Q, S, k, nullptr};
+    HIPCHECK(h, launch_select_topk(sel, st));
+    // a query whose buffer overflowed (or that saw fewer than k rows): float64 brute force
+    HIPCHECK(h, launch_exact_topk(q, h->idxp, h->idx64, (const int32_t *)h->s_cert.p, out_s, out_i, h->idx_base, h->idx_N, Q, S, k, st,
+                                  counters + 2));
+    if (split) *split = 0;  // nothing is left for a SCORE_REST call
+    return 0;
+  }
+  const int POOL = std::min(Q, 1024);  // collect-buffer slots for uncertified queries (the rest: float64 brute force)
   if (reserve(h, h->s_qp, (size_t)QB * NQ * KG * 256 * sizeof(float))) return 1;
   if (reserve(h, h->s_ps, (size_t)Q * (bf ? NCmax : NC) * sizeof(float))) return 1;
   if (reserve(h, h->s_pi, (size_t)Q * (bf ? NCmax : NC) * sizeof(int32_t))) return 1;
@@ -1372,6 +1438,10 @@ int sse_create(const sse_config *cfg, sse_handle **out) {
   if (hipHostMalloc((void **)&h->pin_small, 64 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) CREATE_FAIL("hipHostMalloc failed");
   hipMemset(h->err_flag, 0, sizeof(int32_t));
   if (hipHostMalloc((void **)&h->pad_stat, 8 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) CREATE_FAIL("hipHostMalloc failed");
+  {  // compute units of the device: the tile policy of the matrix LSTM kernel counts rounds of them, the cluster kernels check co-residency
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) h->cu_count = prop.multiProcessorCount;
+  }
   if (const char *ev = getenv("SSE_PAD_SORT_DEV")) {  // measurement aid: the option's initial value
     const int v = atoi(ev);
     if (v >= 0 && v <= 2) h->pad_sort_dev = v;
@@ -1466,6 +1536,7 @@ int sse_set_variable(sse_handle *h, const char *name, const float *host, int64_t
   HIPCHECK(h, hipMemcpy(slot ? h->vars[i].slot : h->vars[i].dev, host, count * sizeof(float), hipMemcpyHostToDevice));
   if (!slot) {
     h->packed_dirty = true;
+    h->weights_version += 1;
     h->mp_fresh = false;
     if (h->train) h->train->packed_dirty = h->train->fp32_dirty = true;
   }
@@ -1796,6 +1867,11 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value) {
   }
   if (strcmp(name, "pad_skip") == 0) {
     h->pad_skip = value != 0;
+    return 0;
+  }
+  if (strcmp(name, "score_two_pass_rows") == 0) {
+    if (value < 0) return fail(h, "score_two_pass_rows must be >= 0");
+    h->score_two_pass_rows = value;
     return 0;
   }
   if (strcmp(name, "lstm_gate_split") == 0) {
@@ -2220,6 +2296,10 @@ static int cnn_train_grads_locked(sse_handle *h, const int32_t *src_ids_host, co
   const int Ep8 = round_up(E, 8);
   if ((h->cnn_bf16 ? cnn_bf16_lds_bytes(T, Ep8, 1) : cnn_lds_bytes(T, Ep, 1)) > 160 * 1024)
     return fail(h, "source_only_cnn training: T*E = %d*%d does not fit the LDS tile of the gfx950 kernel", T, E);
+  // the weight-gradient kernel stages two [T][E] fp32 tiles + 384 floats (cnn_bwd.hip): its own limit, named here
+  if (((size_t)2 * T * E + 384) * sizeof(float) > (size_t)160 * 1024)
+    return fail(h, "source_only_cnn training: T*E = %d*%d needs %zu bytes of LDS in the weight-gradient kernel (limit 160 KiB: T*E <= 20288)",
+                T, E, ((size_t)2 * T * E + 384) * sizeof(float));
   if (ensure_arena(h)) return 1;
   if (ensure_packed(h, st)) return 1;
   float *tail = ts.arena + grad_arena_count(h) - 4;
@@ -2354,14 +2434,18 @@ static int train_grads_generic_locked(sse_handle *h, const int32_t *src_ids_host
         reserve(h, ts.gen_KT[s], gen_lstm_kt_floats(d) * sizeof(float)) || reserve(h, ts.gen_Kq[s], gen_lstm_kt_floats(d) * sizeof(float)) ||
         reserve(h, ts.gen_MT[s], (size_t)S * d.Hq * sizeof(float)))
       return 1;
-    HIPCHECK(h, launch_gen_pack(h->vars[e.kernel].dev, h->vars[e.proj].dev, d, S, (float *)ts.gen_KT[s].p, (float *)ts.gen_Kq[s].p,
-                                (float *)ts.gen_MT[s].p, st));
+    if (ts.gen_ver[s] != h->weights_version) {  // (every step changes the weights; repeated sse_train_grads calls on one set do not)
+      HIPCHECK(h, launch_gen_pack(h->vars[e.kernel].dev, h->vars[e.proj].dev, d, S, (float *)ts.gen_KT[s].p, (float *)ts.gen_Kq[s].p,
+                                  (float *)ts.gen_MT[s].p, st));
+      ts.gen_ver[s] = h->weights_version;
+    }
     HIPCHECK(h, launch_gen_forward((const int32_t *)ts.ids[s].p, emb.dev, V, (const float *)ts.gen_KT[s].p, h->vars[e.bias].dev, d,
                                    (float *)ts.gen_A[s].p, (float *)ts.gen_G.p, (float *)ts.gen_c.p, (float *)ts.gen_tape[s].p,
                                    (float *)ts.gen_hl[s].p, h->err_flag, st));
     HIPCHECK(h, launch_gen_project((const float *)ts.gen_hl[s].p, (const float *)ts.gen_MT[s].p, d, S, (float *)ts.raw[s].p, st));
   }
-  if (check_err_flag(h, st)) return 1;  // (the scatter of the backward pass trusts the ids)
+  // (no host round trip here any more: gen_dx_scatter_kernel validates the ids itself, as rows_scatter_kernel and cnn_dx_kernel do;
+  // the forward raised the error flag, the update is cancelled on the device and sse_train_apply reports it)
   // ---- loss, train accuracy, d(raw encodings)
   if (reserve(h, ts.row_loss, (size_t)B * sizeof(float))) return 1;
   if (reserve(h, ts.row_acc, (size_t)B * sizeof(float))) return 1;
@@ -2387,7 +2471,7 @@ static int train_grads_generic_locked(sse_handle *h, const int32_t *src_ids_host
     HIPCHECK(h, launch_gen_backward((const int32_t *)ts.ids[s].p, (const float *)ts.gen_Kq[s].p, d, (const float *)ts.gen_A[s].p,
                                     (const float *)ts.gen_tape[s].p, (const float *)ts.dh_last[s].p, d.Hq, (float *)ts.gen_dG[s].p,
                                     (float *)ts.gen_dA.p, (float *)ts.gen_dc.p, (float *)ts.gen_dkp.p, (shared && s == 1) ? 1 : 0,
-                                    h->vars[e.kernel].grad, h->vars[e.bias].grad, emb.grad, (float *)ts.sq_part.p + (size_t)s * T * B, st));
+                                    h->vars[e.kernel].grad, h->vars[e.bias].grad, emb.grad, (float *)ts.sq_part.p + (size_t)s * T * B, V, st));
   }
   HIPCHECK(h, launch_sum((const float *)ts.sq_part.p, n_sq, (float)B, tail, st));
   ts.grads_ready = true;
@@ -2774,6 +2858,7 @@ static int train_apply_locked(sse_handle *h, float *loss, float *train_acc) {
   // ---- Adagrad (dense for every tensor; rows of word_embedding with zero gradient are unchanged)
   HIPCHECK(h, launch_adagrad_multi(all, scal, h->lr, st));
   h->packed_dirty = true;
+  h->weights_version += 1;
   h->mp_fresh = false;
   ts.packed_dirty = ts.fp32_dirty = true;
   ts.grads_ready = false;

@@ -124,6 +124,7 @@ struct LstmFwdArgs {
   int32_t tiles_elsewhere = 0;  // 32-row tiles of launches that run CONCURRENTLY on other streams (the other encoder of a
                                 // train step): the 32- vs 64-row tile choice looks at the chip, not at this launch alone
   int32_t force_rows = 0;       // 32 / 64: override the tile choice (Hp = 256; measurement aid, option lstm_train_rows)
+  int32_t cu_count = 0;         // compute units of the device (0: 256, MI355X): the tile policy counts rounds of them
   int32_t gate_split = 1;       // Hp = 128 inference at 64-row tiles: lstm_fwd_gs.hip (two phase-shifted row groups, one gate per
                                 // wave) instead of lstm_fwd_kernel<2,1,1>; bit-identical results (option "lstm_gate_split")
   // Left-pad prefix skip (exact): the state after p leading PAD (id 0) steps does not depend on
@@ -146,7 +147,7 @@ struct LstmFwdArgs {
 // Hp = 128 * UB hidden units; 512 threads; dynamic LDS = lstm_fwd_lds_bytes()
 size_t lstm_fwd_lds_bytes(int KGx, int KGh, int RT);
 bool lstm_fwd_x_double(int KGx, int KGh, int RT);
-int lstm_fwd_rows_per_wg(int Hp, int B, int tiles_elsewhere = 0);
+int lstm_fwd_rows_per_wg(int Hp, int B, int tiles_elsewhere = 0, int cus = 0 /* 0: 256 */);
 hipError_t launch_lstm_fwd(const LstmFwdArgs &a, int Hp, hipStream_t stream);
 // small cells (H <= 128), inference, 64-row tiles: lstm_fwd_gs.hip
 size_t lstm_fwd_gs_lds_bytes(int KGx, int NB);
@@ -276,6 +277,8 @@ struct ScoreArgs {
   int32_t *col_cnt = nullptr;         // [slots] rows appended (may exceed col_cap: overflow)
   int32_t *col_buf = nullptr;         // [slots][col_cap] local row numbers
   int32_t col_cap = 0;
+  float *lane_max = nullptr;          // COLLECT variant, max-only mode: [Q][NSPLIT][16] largest score per (query, split, lane list); no
+                                      // lists, no buffers (first pass of the two-pass path for mid-size indexes)
   int32_t dbg = 0;  // builds with -DSSE_SCORE_MEASURE only (env SSE_SCORE_DBG): bit 0 = skip the top-k epilogue of the sweep
   // NQ == 1 (<= 32 queries, the latency path) and every COLLECT sweep: the workgroups build their query fragments from the row-major fp32 queries
   // themselves (q_rows [Q][S]; fp32 or rounded to bf16 exactly as launch_pack_rows / launch_pack_rows_bf16 would) -- qp is
@@ -284,6 +287,9 @@ struct ScoreArgs {
   int32_t S = 0;
 };
 hipError_t launch_score_topk(const ScoreArgs &a, hipStream_t stream);
+// two-pass path for mid-size indexes: threshold per query from the lane maxima of a max-only sweep (ScoreArgs::lane_max)
+hipError_t launch_lane_max_threshold(const float *q, const float *lane_max, int Q, int S, int NV, float eps, float *col_thr,
+                                     int32_t *col_slot, hipStream_t st);
 // query tiles per workgroup (4 / 2 / 1) whose LDS query block fits for index dimension S in every variant of a call
 // (0: none); dynamic LDS of one variant
 #define SSE_MAX_INDEX_DIM 1024

@@ -89,7 +89,7 @@ hipError_t launch_gen_forward(const int32_t *ids, const float *emb, int V, const
 hipError_t launch_gen_project(const float *h_last, const float *MT, const GenLstmDims &d, int S, float *raw, hipStream_t st);
 hipError_t launch_gen_backward(const int32_t *ids, const float *Kq, const GenLstmDims &d, const float *A, const float *tape,
                                const float *dh_last, int ldh_last, float *dG, float *dA, float *dc, float *dk_part, int accumulate,
-                               float *dK, float *db, float *d_emb, float *sq, hipStream_t st);
+                               float *dK, float *db, float *d_emb, float *sq, int V, hipStream_t st);
 
 // text-CNN training path (cnn_bwd.hip)
 int cnn_bwd_chunks(int B);

@@ -96,3 +96,35 @@ def test_wide_encoding_and_big_cell_inference_rows_in_chunks():
     with pytest.raises(sse_amd.SSEError):
         m.encode_source(bad)
     assert np.abs(m.encode_source(ids) - want).max() < 1e-4             # the handle stays usable
+
+
+def test_generic_path_caches_its_packs_and_cancels_a_step_with_a_bad_id():
+    """the any-shape path rebuilt its packed weights with every encode and forced a host round trip in every train
+    step.  Now the packs are cached against the handle's weight version (an update or sse_set_variable invalidates them) and
+    gen_dx_scatter_kernel validates the ids itself: a token id out of range raises through the deferred check, the update is
+    cancelled on the device (weights AND Adagrad slots unchanged), the handle stays usable."""
+    import sse_amd
+    params = model_params("dual-encoder", 90, 70, 300, 300, 64, 6, lr=0.9)   # E = 70 > 64, H = 300: generic for training and inference
+    m, p = make_pair(params, seed=3)
+    st = O.new_optimizer_state(p)
+    rng = np.random.RandomState(8)
+    src, tgt, z = _batch(rng, 16, 6, 90)
+    ids = random_ids(rng, 40, 6, 90, 0.3)
+    first = m.encode_source(ids)
+    assert np.array_equal(m.encode_source(ids), first)                      # second call: cached packs, same bits
+    assert np.abs(first - O.encode(p, params, "src", ids)).max() < 1e-4
+    before = m.get_variables(with_slots=True)
+    bad = src.copy()
+    bad[3, 2] = 90
+    with pytest.raises(sse_amd.SSEError, match="out of range"):
+        m.train_step(bad, tgt, z)
+    after = m.get_variables(with_slots=True)
+    for k in before:
+        assert np.array_equal(before[k], after[k]), k
+    _check_step(m, p, params, st, src, tgt, z)                               # a good step afterwards: matches the oracle ...
+    got = m.encode_source(ids)                                               # ... and the encode sees the UPDATED weights
+    assert np.abs(got - O.encode(p, params, "src", ids)).max() < 1e-4
+    assert not np.array_equal(got, first)
+    p2 = {k: (v * 0.5).astype(np.float32) for k, v in p.items()}
+    m.set_variables(p2)                                                      # sse_set_variable invalidates the packs too
+    assert np.abs(m.encode_source(ids) - O.encode(p2, params, "src", ids)).max() < 1e-4

@@ -505,3 +505,52 @@ def test_alternating_shapes_share_the_pinned_mirror_block():
                 margin_ok = bool(np.all(np.diff(-ws, axis=1) > 1e-5))
             if margin_ok:
                 assert np.array_equal(ei, wi), (rep, Q, k)
+
+
+@pytest.mark.parametrize("Q,N,S,k", [(2048, 32060, 256, 10), (1100, 9000, 64, 16), (3000, 20011, 128, 1), (1024, 50000, 50, 10)])
+def test_two_pass_path_for_mid_size_indexes_is_exact(Q, N, S, k):
+    """Indexes of 10^4 .. 10^5 rows under >= 1024 queries (the reference's real evaluation shape: 16,491 x 32,060) are ranked by
+    a max-only bf16 sweep -> per-query threshold from the lane maxima -> bf16 collect sweep -> float64 select (option
+    score_two_pass_rows) instead of the list sweep.  Same exact ids (ties: lower row first) and float64 scores as the list sweep
+    and the oracle: random unit vectors; an exact tie across the index; a query whose best rows are CROWDED inside the bf16 bound
+    (hundreds of rows within 1e-4 of each other: the collect buffer overflows and the float64 brute force serves it); an
+    id_base; a ragged last tile."""
+    rng = np.random.RandomState(Q + N)
+    t = _unit(rng, N, S).astype(np.float64)
+    q = _unit(rng, Q, S)
+    t[N - 1] = t[17]                                          # exact duplicates: tie -> lower row first
+    t[N // 2] = t[17]
+    q[3] = t[17].astype(np.float32)
+    base = q[5].astype(np.float64)
+    base /= np.linalg.norm(base)
+    crowd = rng.choice(np.arange(100, N - 100), 700, replace=False)
+    for j, r in enumerate(crowd):                              # 700 rows within 7e-5 of the top score of query 5
+        u = rng.standard_normal(S)
+        u -= u.dot(base) * base
+        u /= np.linalg.norm(u)
+        c = 1.0 - 1e-7 * j
+        t[r] = c * base + np.sqrt(max(0.0, 1.0 - c * c)) * u
+    h = _scorer_bf16()
+    h.index_upload(t, id_base=1000)
+    wsc, wids = O.topk(O.scores_f64(q, t), k)
+    h.set_option("score_two_pass_rows", 0)
+    sc0, ids0 = h.score_topk(q, k)
+    assert np.array_equal(ids0, wids + 1000) and np.abs(sc0 - wsc).max() < 1e-12
+    h.set_option("score_two_pass_rows", 262144)
+    b0 = h.get_counter("score_bruteforce_queries")
+    sc1, ids1 = h.score_topk(q, k)
+    assert np.array_equal(ids1, wids + 1000)
+    assert np.array_equal(sc1, sc0)                           # float64 scores of the same rows in the same arithmetic: identical bits
+    assert list(ids1[3, :min(k, 3)]) == [1017, 1000 + N // 2, 1000 + N - 1][:k]
+    assert 1 <= h.get_counter("score_bruteforce_queries") - b0 <= 4   # the crowded query (its duplicates' neighbours at most)
+    # device-buffer entry point, asynchronous on a side stream
+    import torch
+    dev = torch.device("cuda", 0)
+    qd = torch.from_numpy(q).to(dev)
+    os_ = torch.empty((Q, k), dtype=torch.float64, device=dev)
+    oi_ = torch.empty((Q, k), dtype=torch.int64, device=dev)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        h.score_topk_dev(qd.data_ptr(), Q, k, os_.data_ptr(), oi_.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    assert np.array_equal(oi_.cpu().numpy(), wids + 1000) and np.array_equal(os_.cpu().numpy(), sc0)
