@@ -118,9 +118,13 @@ struct sse_handle {
   // saw any padding, 32-row tiles while it saw a mean prefix >= T / 4 (no host round trip: an index build's batches look alike)
   // | 2 always bucket + 32-row tiles (deterministic: tests, tools)
   int pad_sort_dev = 1;
-  // option "score_two_pass_rows": indexes of 8192 .. this many rows under >= 1024 queries (k <= 16, bf16 candidates) are ranked by a
-  // max-only sweep + a collect sweep instead of the list sweep (exact, same ids and scores); 0 = off
-  int64_t score_two_pass_rows = 262144;
+  // options "score_two_pass_min_rows" / "score_two_pass_rows": indexes of min .. max rows under >= 1024 queries (k <= 16, bf16
+  // candidates) are ranked by a max-only sweep + a collect sweep instead of the list sweep (exact, same ids and scores); max 0 = off.
+  // Window measured on well-spread unit vectors, S = 256 (tools/bench_c3.py, tools/bench_score.py, profiles/r06_notes.txt), two-pass /
+  // list sweep in ms: 16,491 queries x 32 k rows 1.19 / 1.03, 64 k 1.58 / 1.72, 128 k 2.39 / 3.07, 256 k 4.13 / 5.51, 512 k 7.61 / 10.17;
+  // 1024 x 300 k 0.44 / 0.57; but 8192 x 1.25 M 7.83 / 4.91 (a list-free sweep runs at 0.54 of the bf16 peak there, the list sweep at 0.43)
+  int64_t score_two_pass_min_rows = 49152, score_two_pass_rows = 524288;
+  int64_t two_pass_calls = 0;  // counter "score_two_pass_calls"
   DevBuf s_lmax;
   bool lstm_gate_split = true;  // option "lstm_gate_split": small cells (H <= 128) at 64-row tiles on lstm_fwd_gs.hip (bit-identical)
   DevBuf s_padzero, s_padwork, s_padorder;
@@ -1164,13 +1168,15 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   unsigned long long *counters = (unsigned long long *)h->s_fb_cnt.p;
   // ---- mid-size indexes under many queries: max-only sweep -> per-query threshold -> collect sweep -> float64 select (see
   // lane_max_threshold_kernel in score_topk.hip for the argument).  Everything is final after it: no certificates to follow up.
-  if (bf && NQ == 4 && Q >= 1024 && nsplit <= 16 && h->idx_N <= h->score_two_pass_rows && !mirror) {
+  if (bf && NQ == 4 && Q >= 1024 && h->idx_N >= h->score_two_pass_min_rows && h->idx_N <= h->score_two_pass_rows && !mirror) {
+    const int ns2 = std::min(nsplit, 16);  // (the threshold kernel takes up to 16 x 16 lane maxima per query)
     if (phase == SCORE_REST) return 0;
+    h->two_pass_calls += 1;
     constexpr int MID_CAP = 512;  // rows one query may collect (typically 20 - 30); more: float64 brute force for that query
     const float eps32 = (float)(2.0 * (S + 2) * 5.97e-8 * h->idx_norm_max);
     const float eps_bf = eps32 + (float)(1.02 * (1.0 / 256.0 + 1.0 / 262144.0) * h->idx_norm_max);
     if (reserve(h, h->s_qp, (size_t)QB * NQ * KG * 256 * sizeof(float))) return 1;
-    if (reserve(h, h->s_lmax, (size_t)Q * nsplit * 16 * sizeof(float))) return 1;
+    if (reserve(h, h->s_lmax, (size_t)Q * ns2 * 16 * sizeof(float))) return 1;
     if (reserve(h, h->s_cert, (size_t)Q * sizeof(int32_t))) return 1;
     if (reserve(h, h->s_cthr, (size_t)Q * sizeof(float)) || reserve(h, h->s_cslot, (size_t)Q * sizeof(int32_t)) ||
         reserve(h, h->s_ccnt, (size_t)(Q + 1) * sizeof(int32_t)) || reserve(h, h->s_cbuf, (size_t)Q * MID_CAP * sizeof(int32_t)))
@@ -1188,12 +1194,12 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
     m1.KG = KG16;
     m1.NT = (int)NT;
     m1.QT = QT;
-    m1.NSPLIT = nsplit;
+    m1.NSPLIT = ns2;
     m1.KC = 16;
     m1.NQ = NQ;
     m1.lane_max = (float *)h->s_lmax.p;
     HIPCHECK(h, launch_score_topk(m1, st));
-    HIPCHECK(h, launch_lane_max_threshold(q, (const float *)h->s_lmax.p, Q, S, nsplit * 16, eps_bf, (float *)h->s_cthr.p,
+    HIPCHECK(h, launch_lane_max_threshold(q, (const float *)h->s_lmax.p, Q, S, ns2 * 16, eps_bf, (float *)h->s_cthr.p,
                                           (int32_t *)h->s_cslot.p, st));
     ScoreArgs m2 = m1;
     m2.lane_max = nullptr;
@@ -1791,6 +1797,10 @@ int sse_get_counter(sse_handle *h, const char *name, int64_t *value) {
     *value = h->persist_fallbacks;
     return 0;
   }
+  if (strcmp(name, "score_two_pass_calls") == 0) {  // sse_score_topk* calls ranked by the two-pass path for mid-size indexes
+    *value = h->two_pass_calls;
+    return 0;
+  }
   if (strcmp(name, "pad_sorted_calls") == 0) {  // encodes of device-resident ids whose rows were bucketed by PAD prefix on the device
     *value = h->pad_sorted_calls;
     return 0;
@@ -1867,6 +1877,11 @@ int sse_set_option(sse_handle *h, const char *name, int32_t value) {
   }
   if (strcmp(name, "pad_skip") == 0) {
     h->pad_skip = value != 0;
+    return 0;
+  }
+  if (strcmp(name, "score_two_pass_min_rows") == 0) {
+    if (value < 0) return fail(h, "score_two_pass_min_rows must be >= 0");
+    h->score_two_pass_min_rows = value;
     return 0;
   }
   if (strcmp(name, "score_two_pass_rows") == 0) {

@@ -161,6 +161,8 @@ def test_merge_of_the_layout_a_multi_rank_gather_produces(Q, k, P):
     S, N = 32, 9001
     rng = np.random.RandomState(Q + k)
     t = rng.standard_normal((N, S)).astype(np.float32)
+    t[11] = rng.choice([-4.0, 0.0, 4.0], size=S)                           # (small integers: the oracle's float64 dots of the duplicates are
+                                                                           # exact in any summation order, so its tie is an exact tie too)
     t[N // 2 + 3] = t[11]                                                  # an exact tie across a shard boundary (P = 2: rows 11 and 4503)
     t[N - 1] = t[11]                                                       # ... and in the last rank's tail
     q = rng.standard_normal((Q, S)).astype(np.float32)

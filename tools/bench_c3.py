@@ -30,6 +30,7 @@ ref_ids = None
 for bf, tp in ((1, 262144), (1, 0), (0, 0)):
     h.set_option("score_bf16", bf)
     h.set_option("score_two_pass_rows", tp)
+    h.set_option("score_two_pass_min_rows", 0)
     h.index_set_dev(te.data_ptr(), N, 256)
     c0 = [h.get_counter(c) for c in names]
     h.score_topk_dev(se.data_ptr(), Q, 10, s.data_ptr(), i.data_ptr())
@@ -54,7 +55,7 @@ for NN in (N, 65536, 131072, 262144, 524288):
     t2 = torch.nn.functional.normalize(torch.randn((NN, 256), generator=g, device=dev), dim=1)
     h.index_set_dev(t2.data_ptr(), NN, 256)
     line = "random unit vectors, %d x %d:" % (Q, NN)
-    for tp in (1 << 30, 0):
+    for tp in (2147483647, 0):
         h.set_option("score_two_pass_rows", tp)
         h.score_topk_dev(q2.data_ptr(), Q, 10, s.data_ptr(), i.data_ptr())
         torch.cuda.synchronize()

@@ -23,7 +23,9 @@ t = torch.nn.functional.normalize(torch.randn((N, S), generator=g, device=dev), 
 q = torch.nn.functional.normalize(torch.randn((Q, S), generator=g, device=dev), dim=1)
 h.index_set_dev(t.data_ptr(), N, S)
 out = {}
-for name, opts in (("bf16", dict(score_bf16=1)), ("fp32", dict(score_bf16=0))):
+for name, opts in (("bf16", dict(score_bf16=1, score_two_pass_rows=0)),
+                   ("bf16 two-pass", dict(score_bf16=1, score_two_pass_rows=2147483647, score_two_pass_min_rows=0)),
+                   ("fp32", dict(score_bf16=0, score_two_pass_rows=0))):
     for k_, v in opts.items():
         h.set_option(k_, v)
     s = torch.empty((Q, 10), dtype=torch.float64, device=dev)
@@ -38,10 +40,12 @@ for name, opts in (("bf16", dict(score_bf16=1)), ("fp32", dict(score_bf16=0))):
     dt = (time.perf_counter() - t0) / n
     out[name] = (s.clone(), i.clone())
     peak = 2500.0 if name != "fp32" else 157.3
-    print("%-14s Q=%d N=%d S=%d: %.3f ms/pass, %.3g scores/s, %.0f TFLOP/s algorithmic = %.2f of the %s peak"
+    print("%-16s Q=%d N=%d S=%d: %.3f ms/pass, %.3g scores/s, %.0f TFLOP/s algorithmic = %.2f of the %s peak"
           % (name, Q, N, S, dt * 1e3, Q * N / dt, 2.0 * S * Q * N / dt / 1e12, 2.0 * S * Q * N / dt / 1e12 / peak,
              "bf16" if name != "fp32" else "fp32"))
 ref = out["fp32"]
-print("bf16 identical to fp32 candidates:", bool(torch.equal(out["bf16"][0], ref[0]) and torch.equal(out["bf16"][1], ref[1])))
+print("bf16 identical to fp32 candidates:", bool(torch.equal(out["bf16"][0], ref[0]) and torch.equal(out["bf16"][1], ref[1])),
+      "| two-pass identical:", bool(torch.equal(out["bf16 two-pass"][0], ref[0]) and torch.equal(out["bf16 two-pass"][1], ref[1])),
+      "| two-pass calls", h.get_counter("score_two_pass_calls"))
 print("second chance / collect / brute force:", h.get_counter("score_bf16_second_chance_queries"), h.get_counter("score_collect_queries"),
       h.get_counter("score_bruteforce_queries"))
