@@ -1144,9 +1144,12 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   // re-scoring pass ranks 16 candidates per split
   const int nsplit = choose_nsplit(NQ, QB, NT);
   // the fp32 second chance of the bf16 pass sweeps for a dense set of FEW queries (typically a handful of query blocks): it
-  // takes its parallelism from the index instead -- at least 32 splits -- or three workgroups would walk 1.25 M rows alone
+  // takes its parallelism from the index instead -- up to 128 splits -- or three workgroups would walk 1.25 M rows alone
   int nsplit2 = nsplit;
-  while (nsplit2 < 32 && NT / (nsplit2 * 2 * 2) >= 16) nsplit2 *= 2;
+  // (up to 128 since round 6: with 32, the 30 uncertified of 16384 random queries against 1.25 M rows -- one query block -- kept 32
+  // workgroups busy for 4 ms on an otherwise idle chip: 13.5 ms per pass, 9.75 with 128; env: measurement aid)
+  static const int split2_max = getenv("SSE_SPLIT2_MAX") ? atoi(getenv("SSE_SPLIT2_MAX")) : 128;
+  while (nsplit2 < split2_max && NT / (nsplit2 * 2 * 2) >= 16) nsplit2 *= 2;
   // many queries against a small index (the evaluator's 16384 x 571): one launch forms all N scores per query and selects the
   // 16 best exactly (launch_score_small_index) instead of the list sweep
   const bool small_idx = h->score_small_index && !bf && score_small_index_applies(Q, KG, NT);
@@ -2517,8 +2520,14 @@ static int train_grads_locked(sse_handle *h, const int32_t *src_ids_host, const 
   hipStream_t st = h->stream;
   TrainState &ts = *h->train;
   if (!ts.side[0]) {
+    // The two encoders of a step run side by side on these two streams.  Streams of ONE priority share the runtime's small pool
+    // of hardware queues, and in a process that has created and destroyed many streams both can land on the same queue: the
+    // encoders then run one after the other (the qna recipe, T = 1000: 26 ms / step alone, 52 inside the whole test suite, equal
+    // to option train_serial; profiles/r06_notes.txt).  Different priorities come from different queue pools.
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     for (int s = 0; s < 2; ++s) {
-      HIPCHECK(h, hipStreamCreateWithFlags(&ts.side[s], hipStreamNonBlocking));
+      HIPCHECK(h, hipStreamCreateWithPriority(&ts.side[s], hipStreamNonBlocking, s == 0 ? prio_least : prio_greatest));
       HIPCHECK(h, hipEventCreateWithFlags(&ts.ev_join[s], hipEventDisableTiming));
     }
     HIPCHECK(h, hipEventCreateWithFlags(&ts.ev_fork, hipEventDisableTiming));

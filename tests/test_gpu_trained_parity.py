@@ -269,6 +269,24 @@ def test_qna_recipe_learns_on_real_data_and_the_trained_model_matches_the_oracle
     h.corpus_upload(1, tgt)
     rng = np.random.RandomState(0)
     batch, spc = 32, 10
+    # diagnostic (printed, not asserted): are the two encoders of a step running side by side?  Inside the whole suite this test has
+    # been seen at 52 ms / step against 26 ms alone (profiles/r06_notes.txt); a scratch model, 15 steps each way
+    probe = sse_amd.SSEModel(cfg)
+    probe.init_variables(seed=1)
+    probe.handle.corpus_upload(0, src)
+    probe.handle.corpus_upload(1, tgt)
+    prow = np.repeat(np.arange(32, dtype=np.int32), 2)
+    ptgt = (np.arange(64, dtype=np.int32) * 7) % len(tgt)
+    pz = np.tile(np.array([1.0, 0.0], np.float32), 32)
+    probe_ms = {}
+    for serial in (0, 1, 0):
+        probe.handle.set_option("train_serial", serial)
+        probe.handle.train_step_rows(prow, ptgt, pz)
+        t0 = time.perf_counter()
+        for _ in range(15):
+            probe.handle.train_step_rows(prow, ptgt, pz)
+        probe_ms[serial] = (time.perf_counter() - t0) / 15 * 1e3
+    probe.handle.close()
     steps = QNA_EPOCHS * (len(src) // batch)
     previous, window_acc, first_window, last_window = [], 0.0, None, None
     t0 = time.perf_counter()
@@ -313,8 +331,9 @@ def test_qna_recipe_learns_on_real_data_and_the_trained_model_matches_the_oracle
     K = [k for k in p if k.endswith("/kernel")]
     with capsys.disabled():
         print("\n[qna] makefile:17 shapes, T = %d, lr %.4g, %d epochs = %d steps on the device in %.1f s (%.1f ms/step incl. batch sampling); "
-              "train_binary_acc first / last window %.3f / %.3f; learning rate at the end %.5f"
-              % (T, QNA_LR, QNA_EPOCHS, steps, t_train, t_train / steps * 1e3, first_window, last_window, h.learning_rate))
+              "train_binary_acc first / last window %.3f / %.3f; learning rate at the end %.5f; probe: encoders side by side %.1f ms/step, "
+              "option train_serial %.1f ms/step"
+              % (T, QNA_LR, QNA_EPOCHS, steps, t_train, t_train / steps * 1e3, first_window, last_window, h.learning_rate, probe_ms[0], probe_ms[1]))
         print("[qna] oracle on the TRAINED weights (%.1f s of CPU): max |encoding diff| %.2e; top 1/3/10 oracle %s device %s; top-1 ids equal "
               "%d of %d (oracle top-2 margin > %.1e: %d queries, all equal there: %s); median top-2 margin %.2e; max |LSTM kernel| %.3f, max |projection| %.3f"
               % (t_oracle, enc_err, ["%.4f" % a for a in acc_o], ["%.4f" % a for a in acc_d], int(np.sum(ids_d[:, 0] == wids[:, 0])), len(wids),
