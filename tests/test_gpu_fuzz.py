@@ -17,3 +17,13 @@ def test_fuzz_slice():
     failures, worst = mod.main(n_cases=40, seed=5, verbose=False)
     assert failures == 0, worst
     assert worst["enc"] < 1e-4 and worst["score"] < 1e-12
+
+
+def test_fuzz_large_batches_slice():
+    """A fixed-seed slice of tools/fuzz_large_batches.py: the large-batch inference paths of round 6 (gate-split small-cell kernel,
+    device-side PAD-prefix bucketing) in every option combination -- same bits in the caller's row order -- and against the oracle."""
+    spec = importlib.util.spec_from_file_location("fuzz_large_batches", os.path.join(ROOT, "tools", "fuzz_large_batches.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    failures, worst = mod.main(n_cases=8, seed=3, verbose=False)
+    assert failures == 0 and worst < 1e-4, (failures, worst)

@@ -20,7 +20,18 @@ pmc() {  # name, counters, command...
   name=$1; ctr=$2; shift 2
   ( cd /tmp && timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$out/${name}_pmc_$(echo $ctr | tr ' ' '_' | cut -c1-24)" -o p -- "$@" > /dev/null 2>&1 )
 }
-if [ -n "${R5:-}" ]; then
+if [ -n "${R6:-}" ]; then
+  # round-6 set: the small-cell encoder (gate-split kernel against lstm_fwd_kernel<2,1,1>: times, MFMA-busy), configs[2] scoring and
+  # the two-pass path, the real-data legs with and without the device-side PAD-prefix bucketing
+  SSE_FWD_GS=1 run shapes_gs1 python "$root/tools/bench_shapes.py"
+  SSE_FWD_GS=0 run shapes_gs0 python "$root/tools/bench_shapes.py"
+  SSE_FWD_GS=1 pmc shapes_gs1 "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" python "$root/tools/bench_shapes.py"
+  SSE_FWD_GS=0 pmc shapes_gs0 "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" python "$root/tools/bench_shapes.py"
+  run c3 python "$root/tools/bench_c3.py"
+  run score env SSE_BENCH_PASSES=10 python "$root/tools/bench_score.py"
+  run score_16k python "$root/tools/bench_score.py" 16384 1250000 256
+  run train_default python "$root/tools/bench_train_default.py"
+elif [ -n "${R5:-}" ]; then
   # round-5 set: the text-CNN kernels (times, MFMA-busy, FETCH / WRITE), configs[2] scoring on the real rows, the any-shape path
   run cnn python "$root/tools/bench_cnn.py"
   pmc cnn "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" python "$root/tools/bench_cnn.py"
