@@ -396,7 +396,7 @@ hipError_t launch_pack_kT(const float *K, int row0, int nrows, int RT, int H, in
 // in HBM: the row numbers ordered by leading-PAD count so that every row tile of the matrix kernel can skip its whole common
 // prefix -- SHORTEST prefix first: the tiles with the most steps left are dispatched first and the short ones fill the tail
 // (longest-first left the T-step tiles for last: real crosslingual queries 0.85 -> 1.04 ms, profiles/r06_notes.txt).  Two launches, no host round trip:
-//   pad_lead_kernel   one wavefront per row (lanes over the time axis, ballot + ffs), lead[b] kept, a histogram over lead
+//   pad_lead_kernel   one thread per row (walks its row to the first token), lead[b] kept, a histogram over lead
 //                     through LDS; the LAST workgroup to finish (ticket counter) turns the histogram into bucket starts,
 //                     re-zeroes histogram + ticket for the next call, and stores the batch's statistics to `stat`
 //   pad_scatter_kernel  order[start[lead[b]]++] = b  (the order inside a bucket is whatever the atomics yield: every
@@ -410,21 +410,25 @@ __global__ void __launch_bounds__(256) pad_lead_kernel(const int32_t *__restrict
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int i = tid; i < T + 2; i += 256) lh[i] = 0;
   __syncthreads();
-  for (int b = (blockIdx.x * 4 + w); b < B; b += gridDim.x * 4) {
+  // one THREAD per row (second version).  The first had one wavefront per row on up to 1024 workgroups: a dense 16384-row batch
+  // then paid 1024 same-address histogram atomics + 1024 ticket atomics, 69 us (rocprofv3, profiles/r06_notes.txt).  A lane walks
+  // its own row until the first token: consecutive words of one cache line, at most T iterations of a wave whatever the mix;
+  // the wave's rows are counted into the LDS histogram one DISTINCT prefix length at a time (one LDS atomic per length per wave).
+  const int b = blockIdx.x * 256 + tid;
+  int l = -1;
+  if (b < B) {
     const int32_t *row = ids + (size_t)b * T;
-    int l = T;
-    for (int t0 = 0; t0 < T; t0 += 64) {
-      const int t = t0 + lane;
-      const unsigned long long m = __ballot(t < T && row[t] != 0);
-      if (m) {
-        l = t0 + __ffsll((long long)m) - 1;
-        break;
-      }
-    }
-    if (lane == 0) {
-      lead[b] = l;
-      atomicAdd(&lh[l + 1], 1);  // bucket l (no padding = bucket 0), shifted by one for the exclusive scan
-    }
+    l = 0;
+    while (l < T && row[l] == 0) ++l;
+    lead[b] = l;
+  }
+  unsigned long long todo = __ballot(l >= 0);
+  while (todo) {
+    const int first = __ffsll((long long)todo) - 1;
+    const int lv = __shfl(l, first);
+    const unsigned long long same = __ballot(l == lv) & todo;
+    if (lane == first) atomicAdd(&lh[lv + 1], __popcll(same));  // bucket lv (no padding = bucket 0), shifted by one for the exclusive scan
+    todo &= ~same;
   }
   __syncthreads();
   for (int i = tid; i < T + 2; i += 256)
@@ -481,11 +485,23 @@ __global__ void __launch_bounds__(256) pad_detect_kernel(const int32_t *__restri
   }
 }
 
+// (wave-aggregated: the rows of a wave that share a prefix length take their slots with ONE atomic -- real batches have a few
+// heavy buckets, a dense one a single bucket: 16384 same-address atomics took 188 us, rocprofv3, profiles/r06_notes.txt)
 __global__ void __launch_bounds__(256) pad_scatter_kernel(const int32_t *__restrict__ lead, int B, int T, int32_t *start,
                                                            int32_t *__restrict__ order) {
-  const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= B) return;
-  order[atomicAdd(&start[lead[b]], 1)] = b;
+  const int b = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  const int l = b < B ? lead[b] : -1;
+  unsigned long long todo = __ballot(l >= 0);
+  while (todo) {
+    const int first = __ffsll((long long)todo) - 1;
+    const int lv = __shfl(l, first);
+    const unsigned long long same = __ballot(l == lv) & todo;
+    int base = 0;
+    if (lane == first) base = atomicAdd(&start[lv], __popcll(same));
+    base = __shfl(base, first);
+    if (l == lv) order[base + __popcll(same & ((1ull << lane) - 1ull))] = b;
+    todo &= ~same;
+  }
 }
 
 // zeroed: int32 [SSE_PAD_SORT_MAX_T + 3] = hist [T + 2] ... | ticket (last word) -- zero on first use (the caller memsets the
@@ -501,7 +517,7 @@ hipError_t launch_pad_sort(const int32_t *ids, int B, int T, int32_t *zeroed, in
     return hipGetLastError();
   }
   int32_t *hist = zeroed, *ticket = zeroed + SSE_PAD_SORT_MAX_T + 2, *start = work, *lead = work + (T + 2);
-  const int grid = (B + 3) / 4 < 1024 ? (B + 3) / 4 : 1024;
+  const int grid = (B + 255) / 256;
   hipLaunchKernelGGL(pad_lead_kernel, dim3(grid), dim3(256), (size_t)(T + 2) * sizeof(int32_t), stream, ids, B, T, lead, hist,
                      ticket, start, stat_pinned, seq);
   hipLaunchKernelGGL(pad_scatter_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, lead, B, T, start, order);
