@@ -279,7 +279,8 @@ def reference_shapes_leg(sse_amd, torch, dev, rows=16384):
         tf = rows * flop / (ms * 1e-3) / 1e12
         out["shapes"].append({"shape": name, "mode": mode, "E": E2, "H": H2, "S": S2, "T": T2, "encode_ms": ms,
                               "seqs_per_s": rows / (ms * 1e-3), "algorithmic_mflop_per_seq": flop / 1e6,
-                              "roofline": {"kernel": "lstm_fwd_kernel", "bound": "mfma", "unit": "TFLOP/s", "achieved": tf,
+                              "roofline": {"kernel": "lstm_fwd_gs_kernel<%d> (gate-split, H <= 128 at 64-row tiles)" % ((H2 + 31) // 32),
+                                           "bound": "mfma", "unit": "TFLOP/s", "achieved": tf,
                                            "peak": PEAK_F32_MFMA_TFLOPS, "frac": tf / PEAK_F32_MFMA_TFLOPS}})
         m2.handle.close()
     return out
