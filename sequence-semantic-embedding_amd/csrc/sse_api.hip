@@ -1172,7 +1172,25 @@ int score_dev_locked(sse_handle *h, const float *q, int Q, int k, double *out_s,
   // ---- mid-size indexes under many queries: max-only sweep -> per-query threshold -> collect sweep -> float64 select (see
   // lane_max_threshold_kernel in score_topk.hip for the argument).  Everything is final after it: no certificates to follow up.
   if (bf && NQ == 4 && Q >= 1024 && h->idx_N >= h->score_two_pass_min_rows && h->idx_N <= h->score_two_pass_rows && !mirror) {
-    const int ns2 = std::min(nsplit, 16);  // (the threshold kernel takes up to 16 x 16 lane maxima per query)
+    // Splits of the two list-free sweeps: the list sweep's choice weighs list warm-up against rounds; without lists only the rounds
+    // count -- workgroups are one per CU (VGPRs), so QB x splits should sit just below a multiple of the CU count: 129 query blocks x 4
+    // splits = 2.02 rounds run as 3, x 16 = 8.06 run as 9.  At most 16 (the threshold kernel takes 16 x 16 lane maxima per query),
+    // at least 32 tiles per split.
+    int ns2 = std::min(nsplit, 16);
+    {
+      static const int force = getenv("SSE_TWO_PASS_SPLITS") ? atoi(getenv("SSE_TWO_PASS_SPLITS")) : 0;  // (env: measurement aid)
+      const int cus = h->cu_count > 0 ? h->cu_count : 256;
+      double best = 0.0;
+      for (int ns = 1; ns <= 16; ns *= 2) {
+        if (ns > 1 && NT / ns < 32) break;
+        const double r = (double)QB * ns / cus, eff = r / std::ceil(r);
+        if (eff > best + 0.02) {
+          best = eff;
+          ns2 = ns;
+        }
+      }
+      if (force == 1 || force == 2 || force == 4 || force == 8 || force == 16) ns2 = force;
+    }
     if (phase == SCORE_REST) return 0;
     h->two_pass_calls += 1;
     constexpr int MID_CAP = 512;  // rows one query may collect (typically 20 - 30); more: float64 brute force for that query
