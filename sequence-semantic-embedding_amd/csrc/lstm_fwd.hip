@@ -205,7 +205,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
   };
   float *red = smem + (size_t)(LIN ? 2 * RT * KG : RT * KGx + 2 * RT * KGh) * 256;  // [ROWS][NWR] (>= 8 floats)
   const int b0 = blockIdx.x * ROWS;
-  volatile int *pass_flag = reinterpret_cast<volatile int *>(red + 16);  // split3: [row tile] = steps whose i,j pass is parked
+  int *pass_flag = reinterpret_cast<int *>(red + 16);  /* LDS atomics, not volatile: see gs_flag_min4 in lstm_fwd_gs.hip */  // split3: [row tile] = steps whose i,j pass is parked
   if (tid < 8) pass_flag[tid] = 0;
 
   // --- x gather assignment: TPR threads per sequence row, 8 floats (one k-group) each.  Consecutive lanes take
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       }
       if (do_a && !do_b) {  // split3: publish the parked products of this step (LDS operations of a wave complete in order)
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-        if (lane == 0) pass_flag[fidx] = t + 1;
+        if (lane == 0) __hip_atomic_store(pass_flag + fidx, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       if (u == 0 && XD && have_next) {
         // x_{t+1}: its buffer was last read in step t-1, so it can be written as soon as the
@@ -516,7 +516,8 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmFwdArgs a) {
       if (do_b) gemm_pass<MT, LIN, SWAP>(wr, wvoff, wsoff + 2048, xa, ha, KGx, kend, g);
       FW_CLK(4)
       if (do_b && !do_a) {  // split3: the i,j pass of this (block, row tile) comes from the partner wave
-        while (pass_flag[fidx] < t + 1) __builtin_amdgcn_s_sleep(2);
+        while (__hip_atomic_load(pass_flag + fidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(2);
+        asm volatile("" ::: "memory");
       }
       FW_CLK(5)
 #pragma unroll

@@ -63,13 +63,26 @@ __device__ __forceinline__ f32x4 gs_wload(__amdgpu_buffer_rsrc_t r, int voff, in
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
+// Step flags in LDS.  Relaxed workgroup-scope ATOMICS on plain int pointers, not volatile accesses: the compiler keeps a volatile
+// access through a pointer computed from the dynamic LDS base in the GENERIC address space -- every flag poll was four
+// flat_load_dword sc0 sc1, each followed by s_waitcnt vmcnt(0) (which also drained the embedding prefetch in flight); the atomics
+// become ds_read_b32 / ds_write_b32 with one lgkmcnt wait (profiles/r06_notes.txt).
+__device__ __forceinline__ int gs_flag_min4(const int *f) {
+  const int f0 = __hip_atomic_load(f + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const int f1 = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const int f2 = __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const int f3 = __hip_atomic_load(f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return min(min(f0, f1), min(f2, f3));
+}
+__device__ __forceinline__ void gs_flag_set(int *f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 // slot of quad j of the activations of gate qw in the exchange area of a (group, block): the writer keeps its own quad
 __device__ __forceinline__ int gs_slot(int j, int qw) { return j - (j > qw ? 1 : 0); }
 
 // Q = this wave's gate and owned register quad (compile-time: the accumulator registers are indexed by it)
 template <int NB, int Q>
 __device__ __forceinline__ void gs_tail(const f32x16 (&acc)[NB], f32x4 (&c)[NB], float *ex /* exchange area of the group */,
-                                        float *hb /* h tile of the group */, volatile int *fl_act, volatile int *fl_h, int lane,
+                                        float *hb /* h tile of the group */, int *fl_act, int *fl_h, int lane,
                                         int step1 /* t + 1 */
 #ifdef SSE_GS_CLOCK
                                         , long long (&ck_)[8], long long &ck_t
@@ -89,14 +102,10 @@ __device__ __forceinline__ void gs_tail(const f32x16 (&acc)[NB], f32x4 (&c)[NB],
     }
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS operations of a wave complete in order, the flag follows the data
-  if (lane == 0) fl_act[Q] = step1;
+  if (lane == 0) gs_flag_set(fl_act + Q, step1);
   GS_CLK(4)
   // 2. wait for the other three gates of this group
-  for (;;) {
-    const int f0 = fl_act[0], f1 = fl_act[1], f2 = fl_act[2], f3 = fl_act[3];
-    if (min(min(f0, f1), min(f2, f3)) >= step1) break;
-    __builtin_amdgcn_s_sleep(1);
-  }
+  while (gs_flag_min4(fl_act) < step1) __builtin_amdgcn_s_sleep(1);
   asm volatile("" ::: "memory");
   GS_CLK(5)
   // 3. combine for the owned quad of every block (BasicLSTMCell, TF 1.x; the forget bias rides in the packed bias row)
@@ -120,7 +129,7 @@ __device__ __forceinline__ void gs_tail(const f32x16 (&acc)[NB], f32x4 (&c)[NB],
     *reinterpret_cast<f32x4 *>(hb + (4 * b + Q) * 256 + lane * 4) = hv;  // h_t, A-fragment order: k-group 4 b + Q
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);
-  if (lane == 0) fl_h[Q] = step1;
+  if (lane == 0) gs_flag_set(fl_h + Q, step1);
   GS_CLK(6)
 }
 
@@ -147,9 +156,9 @@ __global__ __launch_bounds__(GS_THREADS) void lstm_fwd_gs_kernel(LstmFwdArgs a) 
   float *xbase = smem;
   float *hb = smem + (size_t)4 * KGx * 256 + (size_t)g * KGl * 256;
   float *ex = smem + (size_t)4 * KGx * 256 + (size_t)2 * KGl * 256 + (size_t)g * 12 * NB * 256;
-  volatile int *flags = reinterpret_cast<volatile int *>(smem + (size_t)4 * KGx * 256 + (size_t)2 * KGl * 256 + (size_t)24 * NB * 256);
-  volatile int *fl_act = flags + g * 8, *fl_h = flags + g * 8 + 4;  // [group][activations | h][wave]
-  int *red = const_cast<int *>(flags) + 16;                            // [8 waves] prologue reductions
+  int *flags = reinterpret_cast<int *>(smem + (size_t)4 * KGx * 256 + (size_t)2 * KGl * 256 + (size_t)24 * NB * 256);
+  int *fl_act = flags + g * 8, *fl_h = flags + g * 8 + 4;  // [group][activations | h][wave]
+  int *red = flags + 16;                                   // [8 waves] prologue reductions
   auto xptr = [&](int buf) -> float * { return xbase + (size_t)((buf * 2 + g) * KGx) * 256; };
 
   // --- x gather assignment inside the group: 8 threads per sequence row, one k-group each (KGx <= 8)
@@ -222,12 +231,8 @@ __global__ __launch_bounds__(GS_THREADS) void lstm_fwd_gs_kernel(LstmFwdArgs a) 
   // group 1 starts when group 0 has published its first activations: from then on the two groups alternate between GEMM and
   // tail instead of running both in step (which would idle the matrix pipe during both tails)
   if (g == 1) {
-    volatile int *f0 = flags;  // group 0, activations
     int spins = 0;
-    for (;;) {
-      if (min(min(f0[0], f0[1]), min(f0[2], f0[3])) >= 1 || ++spins > 4096) break;
-      __builtin_amdgcn_s_sleep(8);
-    }
+    while (gs_flag_min4(flags) < 1 && ++spins <= 4096) __builtin_amdgcn_s_sleep(8);  // (group 0, activations)
   }
 
   constexpr int R = 3;
@@ -258,11 +263,7 @@ __global__ __launch_bounds__(GS_THREADS) void lstm_fwd_gs_kernel(LstmFwdArgs a) 
     GS_CLK(0)
     // h_{t-1} complete? (every wave of the group has published its quads of step t-1)
     if (t > t0) {
-      for (;;) {
-        const int f0 = fl_h[0], f1 = fl_h[1], f2 = fl_h[2], f3 = fl_h[3];
-        if (min(min(f0, f1), min(f2, f3)) >= t) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
+      while (gs_flag_min4(fl_h) < t) __builtin_amdgcn_s_sleep(1);
       asm volatile("" ::: "memory");
     }
 

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
   unsigned char *xbase = smem3;
   unsigned char *hbase = smem3 + (size_t)RT * KGX * 2048;
   float *red = reinterpret_cast<float *>(hbase + (size_t)2 * RT * KGH * 2048);
-  volatile int *pass_flag = reinterpret_cast<volatile int *>(red + 16);  // PSPLIT: [unit block] = steps whose i,j pass is parked
+  int *pass_flag = reinterpret_cast<int *>(red + 16);  /* LDS atomics, not volatile: see gs_flag_min4 in lstm_fwd_gs.hip */  // PSPLIT: [unit block] = steps whose i,j pass is parked
   if (tid < 4) pass_flag[tid] = 0;
   auto xptr = [&](int mt) -> unsigned char * { return xbase + (size_t)mt * KGX * 2048; };
   auto hptr = [&](int buf, int mt) -> unsigned char * { return hbase + (size_t)(buf * RT + mt) * KGH * 2048; };
@@ -350,11 +350,12 @@ __global__ __launch_bounds__(X3_THREADS) void lstm_fwd_x3_kernel(LstmX3Args a) {
       }
     if (do_a && !do_b) {  // publish the parked products of this step (LDS operations of a wave complete in order)
       __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-      if (lane == 0) pass_flag[w] = t + 1;
+      if (lane == 0) __hip_atomic_store(pass_flag + w, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     if (do_b && (TRAIN || w * 32 < a.H)) gemm(2, g);
     if (do_b && !do_a) {  // the i,j pass of this unit block comes from the partner wave
-      while (pass_flag[w] < t + 1) __builtin_amdgcn_s_sleep(2);
+      while (__hip_atomic_load(pass_flag + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(2);
+        asm volatile("" ::: "memory");
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
