@@ -166,14 +166,14 @@ __global__ __launch_bounds__(GS_THREADS) void lstm_fwd_gs_kernel(LstmFwdArgs a) 
   const int xr = tg & 31, xq = tg >> 5;
   const bool row_ok = (b0 + xr) < a.B;
   const int32_t *id_row = a.ids + (size_t)(row_ok ? (a.row_map ? a.row_map[b0 + xr] : b0 + xr) : 0) * T;
-  auto fetch_id = [&](int t) -> int {
-    int id = row_ok ? id_row[t] : 0;
+  auto check_id = [&](int id) -> int {
     if (id < 0 || id >= a.V) {
       atomicOr(a.err, 1);
       id = 0;
     }
     return id;
   };
+  auto fetch_id = [&](int t) -> int { return check_id(row_ok ? id_row[t] : 0); };
   auto x_store = [&](int buf, f32x4 lo, f32x4 hi) {
     float *dst = xptr(buf) + (size_t)xq * 256;
     *reinterpret_cast<f32x4 *>(dst + xr * 4) = lo;         // k%8 in 0..3 -> lane half 0
@@ -236,13 +236,18 @@ __global__ __launch_bounds__(GS_THREADS) void lstm_fwd_gs_kernel(LstmFwdArgs a) 
   }
 
   constexpr int R = 3;
+  // token ids travel TWO steps ahead: the id of step t + 1 is in a register when step t starts (its embedding row is requested at
+  // once, no load-to-load wait at the top of a step: that wait was 0.6 - 2.7 k cycles of every step), the id of t + 2 is requested
+  // here and looked at when the step ends
+  int id_next = (t0 + 1 < T) ? fetch_id(t0 + 1) : 0;
   GS_CLK_DECL
   for (int t = t0; t < T; ++t) {
     GS_CLK(7)
     const bool have_next = (t + 1) < T;
+    const int id_raw2 = (t + 2 < T && row_ok) ? id_row[t + 2] : 0;
     f32x4 nlo = {0, 0, 0, 0}, nhi = {0, 0, 0, 0};
     if (have_next) {
-      const int nid = fetch_id(t + 1);
+      const int nid = id_next;
       if (xq < KGx) {
         const float *src = a.emb + (size_t)nid * a.Ep + xq * 8;
         nlo = *reinterpret_cast<const f32x4 *>(src);
@@ -321,6 +326,7 @@ __global__ __launch_bounds__(GS_THREADS) void lstm_fwd_gs_kernel(LstmFwdArgs a) 
       case 2: gs_tail<NB, 2>(acc, c, ex, hb, fl_act, fl_h, lane, t + 1 GS_TAIL_EXTRA); break;
       default: gs_tail<NB, 3>(acc, c, ex, hb, fl_act, fl_h, lane, t + 1 GS_TAIL_EXTRA); break;
     }
+    id_next = check_id(id_raw2);
   }
 #ifdef SSE_GS_CLOCK
   if (blockIdx.x == 0 && lane == 0)
