@@ -3,7 +3,9 @@
 There is NO CPU fallback: if the library is missing or no HIP device is
 visible, loading / handle creation raises.
 """
+import atexit
 import ctypes as C
+import weakref
 import os
 import sys
 
@@ -138,12 +140,30 @@ class SSEError(RuntimeError):
     pass
 
 
+# Handles still alive when the interpreter exits are closed by an atexit hook, i.e. BEFORE module teardown and before the C-level
+# exit handlers: Handle.__del__ otherwise runs during interpreter finalisation, when the HIP runtime (and, under rocprofv3, the
+# profiler's intercept layer) may already be on its way out.
+_live_handles = weakref.WeakSet()
+
+
+def _close_live_handles():
+    for h in list(_live_handles):
+        try:
+            h.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_live_handles)
+
+
 class Handle(object):
     """Owner of one `sse_handle*`."""
 
     def __init__(self, cfg):
         self.lib = load_library()
         self._h = C.c_void_p()
+        _live_handles.add(self)
         self.index_gen = 0          # bumped by every index upload: lets holders of "their" index notice a replacement
         rc = self.lib.sse_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
