@@ -94,6 +94,11 @@ int sse_encode_dev(sse_handle *h, int side, const int32_t *ids_dev, int32_t B, i
  * skips its whole common prefix -- what sse_encode does with a host counting sort; outputs keep the caller's row order and
  * are bit-identical.  1 = adaptive (each eligible call measures its batch; rows are bucketed while the latest completed call
  * of that side saw padding, 32-row tiles while its mean prefix was >= T / 4), 2 = always, 0 = off.  Counter "pad_sorted_calls".
+ * "lstm_gate_split" (default 1): inference encodes of cell sizes <= 128 at 64-row tiles (batches above 8192 rows) run the
+ * gate-split kernel (one gate per wave, two phase-shifted 32-row groups per workgroup); bit-identical to 0.
+ * "score_two_pass_min_rows" / "score_two_pass_rows" (defaults 49152 / 524288): sse_score_topk* on an index of that many rows
+ * with >= 1024 queries, k <= 16 and bf16 candidates ranks by a max-only sweep -> per-query threshold -> collect sweep -> float64
+ * select instead of the list sweep: the same exact ids and score bits; max 0 = off.  Counter "score_two_pass_calls".
  * "lstm_small_rows" (default 1024): LSTM encodes of at most this many rows (a demo / web query, an evaluator batch of
  * 600, the tail batch of an index build) run on the few-sequences kernel -- one workgroup per 4 rows, gate GEMV on the
  * vector ALUs streaming the kernel matrix from L2 instead of ~38 us per step for a 32-row matrix tile; the same fp32
